@@ -1,0 +1,16 @@
+"""pytest config: registers the ``gpu`` marker and puts the product tree (the drop-in for the
+reference's ``src/`` root) and the repo root (for ``oracle``) on sys.path."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "fac-via-ppg_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

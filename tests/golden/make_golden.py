@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REFERENCE.
+
+Runs only in the dev container (needs /root/reference); the GPU box never sees the
+reference -- only the small .npz/.json files this script writes.  Harness shims follow
+SURVEY.md Appendix A: the reference hard-wires CUDA types and imports kaldi/textgrid/
+librosa, none of which exist here, so we
+  * register a synthetic ``common`` package pointing at src/common (skips __init__.py),
+  * stub ``librosa`` with the oracle's restatement (PARITY UNPINNED at that boundary),
+  * alias torch.cuda.{Float,Long,Half}Tensor to CPU types, ByteTensor to a bool ctor,
+  * make ``.cuda()`` the identity.
+Stochastic ops are made reproducible by INJECTION: ``torch.Tensor.normal_`` is replaced
+while WaveGlow.infer runs (z comes from facppg.synth.synthetic_z) and the reference's
+``F.dropout`` (prenet, model.py:134) multiplies by masks drawn from a seeded NumPy stream.
+
+Usage:  python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/src"
+sys.path.insert(0, os.path.join(ROOT, "fac-via-ppg_amd"))
+sys.path.insert(0, ROOT)
+
+from facppg import synth  # noqa: E402
+from oracle import dsp as odsp  # noqa: E402
+
+
+# ------------------------------------------------------------------ shims
+def install_shims():
+    sys.path.insert(0, REF)
+    for name in [m for m in sys.modules if m == "common" or m.startswith("common.") or
+                 m == "waveglow" or m.startswith("waveglow.")]:
+        del sys.modules[name]
+    pkg = types.ModuleType("common")
+    pkg.__path__ = [os.path.join(REF, "common")]
+    sys.modules["common"] = pkg
+    wg = types.ModuleType("waveglow")
+    wg.__path__ = [os.path.join(REF, "waveglow")]
+    sys.modules["waveglow"] = wg
+    lib = types.ModuleType("librosa")
+    lf = types.ModuleType("librosa.filters")
+    lu = types.ModuleType("librosa.util")
+    lf.mel = lambda sr, n_fft, n_mels=128, fmin=0.0, fmax=None, htk=False, norm=1: \
+        odsp.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+    lu.pad_center = lambda data, size, axis=-1: odsp.pad_center(data, size)
+    lu.tiny = odsp.tiny
+    lu.normalize = lambda S, norm=None: S
+    lib.filters, lib.util = lf, lu
+    sys.modules.update({"librosa": lib, "librosa.filters": lf, "librosa.util": lu})
+    torch.cuda.FloatTensor = torch.FloatTensor
+    torch.cuda.LongTensor = torch.LongTensor
+    torch.cuda.HalfTensor = torch.HalfTensor
+    torch.cuda.ByteTensor = lambda *s: torch.zeros(*s, dtype=torch.bool)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+
+
+class InjectNormal:
+    """Replace Tensor.normal_ so the n-th call copies the n-th injected tensor."""
+
+    def __init__(self, zs):
+        self.zs, self.i = list(zs), 0
+
+    def __enter__(self):
+        self.orig = torch.Tensor.normal_
+        inj = self
+
+        def fake(t, *a, **k):
+            z = inj.zs[inj.i]
+            inj.i += 1
+            assert tuple(t.shape) == tuple(z.shape), (t.shape, z.shape)
+            return t.copy_(z)
+        torch.Tensor.normal_ = fake
+        return self
+
+    def __exit__(self, *a):
+        torch.Tensor.normal_ = self.orig
+
+
+def masks_from_seed(seed, shape):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return (g.random(shape) < 0.5).astype(np.uint8)
+
+
+class InjectDropout:
+    """Replace model.F.dropout for training=True calls by x * mask * 2 with queued masks."""
+
+    def __init__(self, model_mod, masks):
+        self.mod, self.masks, self.i = model_mod, masks, 0
+
+    def __enter__(self):
+        self.orig = self.mod.F.dropout
+        inj = self
+
+        def fake(x, p=0.5, training=True, inplace=False):
+            if not training:
+                return x
+            assert p == 0.5
+            m = torch.from_numpy(inj.masks[inj.i].astype(np.float32))
+            inj.i += 1
+            assert tuple(m.shape) == tuple(x.shape), (m.shape, x.shape)
+            return x * m * 2.0
+        class _FProxy:
+            dropout = staticmethod(fake)
+
+            def __getattr__(self, k):
+                return getattr(torch.nn.functional, k)
+        self.mod.F = _FProxy()
+        return self
+
+    def __exit__(self, *a):
+        self.mod.F = torch.nn.functional
+
+
+def sha(t):
+    return hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest()[:16]
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print("wrote", name, os.path.getsize(path) // 1024, "KiB")
+
+
+# ------------------------------------------------------------------ generators
+def gen_hparams():
+    from common import hparams as rh
+    out = {"create_hparams": vars(rh.create_hparams()), "create_hparams_stage": vars(rh.create_hparams_stage())}
+    with open(os.path.join(HERE, "hparams.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote hparams.json")
+
+
+def ref_waveglow(cfg, seed=16807):
+    from waveglow import glow
+    m = glow.WaveGlow(**cfg)
+    m = glow.WaveGlow.remove_weightnorm(m)
+    missing = m.load_state_dict(synth.waveglow_state_dict(cfg, seed), strict=True)
+    m.eval()
+    return m
+
+
+def gen_waveglow():
+    for tag, hop, B, T in (("hop160", 160, 2, 20), ("hop256", 256, 1, 12)):
+        cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=hop)
+        m = ref_waveglow(cfg)
+        mel = synth.synthetic_mel(B, T, seed=1234)
+        L = T * hop // 8
+        zs = synth.synthetic_z(B, L, cfg, seed=4321)
+        with torch.no_grad(), InjectNormal(zs) as inj:
+            audio = m.infer(mel, sigma=0.6)
+            assert inj.i == 3
+        assert audio.shape == (B, T * hop)
+        # forward (training direction) KAT on the same weights: audio -> z, log_s, logdet
+        g = np.random.Generator(np.random.PCG64(99))
+        wav = torch.from_numpy(np.clip(g.standard_normal((B, T * hop), dtype=np.float32) * 0.1, -1, 1))
+        with torch.no_grad():
+            z, log_s, log_det = m((mel, wav))
+        save("waveglow_%s.npz" % tag, hop=hop, B=B, T=T, sigma=0.6, mel_seed=1234, z_seed=4321,
+             mel_sha=sha(mel.numpy()), z_sha=sha(np.concatenate([z_.numpy().ravel() for z_ in zs])),
+             audio=audio, fwd_audio_in=wav, fwd_z=z,
+             fwd_log_s_sum=np.array([float(x.double().sum()) for x in log_s]),
+             fwd_log_det=np.array([float(x) for x in log_det]))
+        if tag == "hop160":
+            # denoiser bias path: infer(zeros(1,80,88), sigma=0)  (denoiser.py:44-61)
+            from waveglow.denoiser import Denoiser
+            den = Denoiser(m, filter_length=1024, hop_length=160, win_length=1024, mode="zeros")
+            with torch.no_grad():
+                den_out = den(audio, strength=0.005)
+                den_out_strong = den(audio, strength=1.0)
+            save("denoiser_hop160.npz", bias_spec=den.bias_spec, audio_in=audio, out_0005=den_out,
+                 out_1=den_out_strong)
+
+
+def gen_stft():
+    from common.stft import STFT
+    from common.layers import TacotronSTFT
+    g = np.random.Generator(np.random.PCG64(5))
+    y = torch.from_numpy(np.clip(g.standard_normal((2, 4000), dtype=np.float32) * 0.3, -1, 1))
+    out = {"y": y}
+    for hop in (160, 256):
+        st = STFT(1024, hop, 1024)
+        mag, ph = st.transform(y)
+        rec = st.inverse(mag, ph)
+        out["mag_%d" % hop], out["phase_%d" % hop], out["rec_%d" % hop] = mag, ph, rec
+    ts = TacotronSTFT(1024, 160, 1024, 80, 16000, 0.0, 8000.0)
+    out["mel_16k"] = ts.mel_spectrogram(y)
+    out["mel_basis_16k"] = ts.mel_basis
+    ts2 = TacotronSTFT()  # library defaults: 22.05 kHz / hop 256 (layers.py:75-77)
+    out["mel_22k"] = ts2.mel_spectrogram(y)
+    save("stft.npz", **out)
+
+
+def gen_masks():
+    from common.utils import get_mask_from_lengths_window_and_time_step as ref_mask
+    cases, outs = [], {}
+    for lengths in ([30], [1], [5, 30, 17], [64, 3]):
+        for W in (20, 3):
+            for t in (0, 1, 2, 3, 10, 19, 20, 21, 29, 30, 45, 49, 50, 51, 63, 64, 90, 200):
+                m = ref_mask(torch.LongTensor(lengths), W, t)
+                key = "m_%d" % len(cases)
+                cases.append({"lengths": lengths, "W": W, "t": t, "key": key})
+                outs[key] = m.numpy().astype(np.uint8)
+    outs["cases"] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
+    save("attn_masks.npz", **outs)
+
+
+def gen_tacotron():
+    from common import hparams as rh
+    from common import model as rmodel
+    for tag, Tin, max_steps, gate_bias, n_sym in (("nostop", 30, 60, -10.0, 5816),
+                                                  ("stop", 24, 60, -0.1, 5816),
+                                                  ("mono40", 16, 16, -10.0, 40)):
+        hp = rh.create_hparams_stage(max_decoder_steps=max_steps, n_symbols=n_sym)
+        sd = synth.tacotron_state_dict(hp, seed=16807, gate_bias=gate_bias)
+        m = rmodel.Tacotron2(hp)
+        m.load_state_dict(sd, strict=True)
+        m.eval()
+        ppg = synth.synthetic_ppg(Tin, n_sym, seed=0, alpha=0.002 if n_sym > 100 else 0.1)
+        E, P = hp.symbols_embedding_dim, hp.prenet_dim
+        enc_masks = masks_from_seed(777, (2, 1, Tin, E))
+        dec_masks = masks_from_seed(778, (max_steps, 2, 1, P))
+        queue = [enc_masks[0], enc_masks[1]] + [dec_masks[t, j] for t in range(max_steps) for j in range(2)]
+        x = torch.from_numpy(ppg).float().transpose(0, 1).unsqueeze(0)
+        with torch.no_grad(), InjectDropout(rmodel, queue):
+            mel, mel_post, gate, align = m.inference(x)
+            memory = None
+        # encoder output alone (same masks) for stage-wise parity
+        with torch.no_grad(), InjectDropout(rmodel, queue[:2]):
+            memory = m.encoder.inference(x)
+        print(tag, "Tout =", mel.shape[2])
+        save("tacotron_%s.npz" % tag, Tin=Tin, max_steps=max_steps, gate_bias=gate_bias, n_symbols=n_sym,
+             ppg_seed=0, enc_mask_seed=777, dec_mask_seed=778, ppg_sha=sha(ppg),
+             memory=memory, mel=mel, mel_post=mel_post, gate=gate, align=align)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    install_shims()
+    gen_hparams()
+    gen_masks()
+    gen_stft()
+    gen_waveglow()
+    gen_tacotron()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""CPU: pin the oracle against the golden vectors captured from the reference itself
+(tests/golden/make_golden.py).  These are the vectors SURVEY.md section 8c calls for; the
+reference's own tests hold none for the hot path."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from helpers import golden, tacotron_case
+from facppg import synth
+from oracle import dsp, tacotron as otac, waveglow as owg
+
+
+@pytest.mark.parametrize("tag,hop", [("hop160", 160), ("hop256", 256)])
+def test_waveglow_infer_and_forward(tag, hop):
+    d = golden("waveglow_%s.npz" % tag)
+    B, T = int(d["B"]), int(d["T"])
+    cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=hop)
+    sd = synth.waveglow_state_dict(cfg)
+    mel = synth.synthetic_mel(B, T, seed=int(d["mel_seed"]))
+    zs = synth.synthetic_z(B, T * hop // 8, cfg, seed=int(d["z_seed"]))
+    with torch.no_grad():
+        audio = owg.infer(sd, cfg, mel, float(d["sigma"]), zs)
+        z, log_s, log_det = owg.forward(sd, cfg, mel, torch.from_numpy(d["fwd_audio_in"]))
+    assert audio.shape == (B, T * hop)                      # integer length: T*hop exactly
+    assert np.abs(audio.numpy() - d["audio"]).max() < 5e-5  # fp32 reassociation only
+    assert np.abs(z.numpy() - d["fwd_z"]).max() < 1e-5
+    assert np.allclose([float(x.double().sum()) for x in log_s], d["fwd_log_s_sum"], atol=1e-3)
+    # round trip (SURVEY section 4 KAT i): forward's z re-injected into infer gives the audio back
+    zf = z
+    zs_rt = [zf[:, 4:8], zf[:, 2:4], zf[:, 0:2]]
+    with torch.no_grad():
+        back = owg.infer(sd, cfg, mel, 1.0, zs_rt)
+    assert np.abs(back.numpy() - d["fwd_audio_in"]).max() < 2e-5
+
+
+def test_stft_mel_denoiser():
+    s = golden("stft.npz")
+    y = torch.from_numpy(s["y"])
+    for hop in (160, 256):
+        st = dsp.StftOracle(1024, hop, 1024)
+        mag, ph = st.transform(y)
+        assert mag.shape[2] == y.shape[1] // hop + 1        # frames = N//hop + 1
+        assert np.abs(mag.numpy() - s["mag_%d" % hop]).max() < 1e-5
+        rec = st.inverse(mag, ph)
+        assert rec.shape[2] == hop * (mag.shape[2] - 1)
+        assert np.abs(rec.numpy() - s["rec_%d" % hop]).max() < 1e-5
+    ts = dsp.TacotronStftOracle(1024, 160, 1024, 80, 16000, 0.0, 8000.0)
+    assert np.abs(ts.mel_basis.numpy() - s["mel_basis_16k"]).max() == 0
+    assert np.abs(ts.mel_spectrogram(y).numpy() - s["mel_16k"]).max() < 1e-5
+    assert np.abs(dsp.TacotronStftOracle().mel_spectrogram(y).numpy() - s["mel_22k"]).max() < 1e-5
+    # librosa documentation example: librosa.filters.mel(22050, 2048)[0, 1] == 0.016 (3 decimals)
+    assert abs(dsp.mel_filterbank(22050, 2048)[0, 1] - 0.016) < 5e-4
+    d = golden("denoiser_hop160.npz")
+    cfg = dict(synth.WAVEGLOW_CONFIG)
+    sd = synth.waveglow_state_dict(cfg)
+    L = 88 * 160 // 8
+    with torch.no_grad():
+        bias = owg.infer(sd, cfg, torch.zeros(1, 80, 88), 0.0,
+                         [torch.zeros(1, 4, L), torch.zeros(1, 2, L), torch.zeros(1, 2, L)])
+    den = dsp.DenoiserOracle(bias)
+    assert np.abs(den.bias_spec.numpy() - d["bias_spec"]).max() < 1e-4
+    x = torch.from_numpy(d["audio_in"])
+    assert np.abs(den(x, 0.005).numpy() - d["out_0005"]).max() < 1e-5
+    assert np.abs(den(x, 1.0).numpy() - d["out_1"]).max() < 1e-5
+
+
+def test_attention_window_mask_bit_exact():
+    d = golden("attn_masks.npz")
+    cases = json.loads(bytes(d["cases"]).decode())
+    assert len(cases) > 100
+    for c in cases:
+        m = otac.window_mask(c["lengths"], c["W"], c["t"]).numpy().astype(np.uint8)
+        assert np.array_equal(m, d[c["key"]]), c
+
+
+@pytest.mark.parametrize("tag", ["nostop", "stop", "mono40"])
+def test_tacotron_inference(tag):
+    d, hp, sd, ppg, em, dm = tacotron_case(tag)
+    x = torch.from_numpy(ppg).t().unsqueeze(0)
+    mel, mel_post, gate, align = otac.inference(
+        sd, hp, x, torch.from_numpy(em.astype(np.float32)), torch.from_numpy(dm.astype(np.float32)))
+    assert mel.shape == d["mel"].shape                      # Tout incl. the stopping frame
+    assert np.abs(mel.numpy() - d["mel"]).max() < 1e-5
+    assert np.abs(mel_post.numpy() - d["mel_post"]).max() < 1e-5
+    assert np.abs(gate.numpy() - d["gate"]).max() < 1e-5
+    assert np.abs(align.numpy() - d["align"]).max() < 1e-6
+
+
+def test_hparams_surface():
+    from common import hparams
+    with open(os.path.join(GOLDEN, "hparams.json")) as f:
+        ref = json.load(f)
+    assert vars(hparams.create_hparams()) == ref["create_hparams"]
+    assert vars(hparams.create_hparams_stage()) == ref["create_hparams_stage"]
+    assert hparams.create_hparams_stage(n_symbols=40).n_symbols == 40
+    with pytest.raises(ValueError, match="The hyper-parameter bogus is not supported."):
+        hparams.create_hparams_stage(bogus=1)
+    with pytest.raises(ValueError):
+        hparams.create_hparams(is_large_set=True)           # stage-only key
