@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Throughput bench of the PPG->wav hot path on MI355X (driver contract: see the task brief).
+
+A "step" is one WaveGlow.infer over one batch of synthetic mels = BASELINE.json configs[1]:
+batch 8, mel 80x1000, fp32, noise generated on the device, inputs resident in HBM.  The metric is
+BASELINE.json's: 22.05 kHz audio samples per second (hop 256), whole job over all ranks.
+With --gpus N > 1 it is launched under torch.distributed.run, one rank per GPU; utterance batches
+are independent, so each rank synthesises its own batch (weak scaling, no data-path collective;
+RCCL is used only for the barrier and the max-over-ranks of the elapsed time).
+
+Adds to the JSON line:
+  roofline      fp32-MFMA roofline of the dominant kernel (k_wn_layer): algorithmic FLOPs per
+                launch / its average launch duration measured live with hipEvents on the launch
+                stream during the timed steps (facppg_wg_last_layer_ms).
+  cpu_baseline  the CPU oracle (a port of the reference's PyTorch-CPU path) timed on this host's
+                cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "fac-via-ppg_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BATCH, FRAMES, HOP, SR = 8, 1000, 256, 22050
+
+
+def layer_flops_per_position(n_layers=8, C=256, ncond=640):
+    """Algorithmic FLOPs of one k_wn_layer launch per group position, averaged over a flow's
+    layers: in_layer 2*C*2C*3 + cond 2*ncond*2C + res_skip 2*C*2C (C last)."""
+    g1 = 2 * (3 * C + ncond) * 2 * C
+    return ((n_layers - 1) * (g1 + 2 * C * 2 * C) + (g1 + 2 * C * C)) / n_layers
+
+
+def cpu_baseline(cfg, sd):
+    """Oracle WaveGlow.infer on the host cores, bounded sample of the same workload."""
+    from facppg import synth
+    from oracle import waveglow as owg
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    Bc, Tc = 1, 150
+    mel = synth.synthetic_mel(Bc, Tc, seed=1234)
+    zs = synth.synthetic_z(Bc, Tc * HOP // 8, cfg, seed=4321)
+    sd = {k: v.float() for k, v in sd.items()}
+    times = []
+    with torch.no_grad():
+        owg.infer(sd, cfg, mel[:, :, :20], 0.6, [z[:, :, :20 * HOP // 8] for z in zs])   # warm-up
+        for _ in range(2):
+            t0 = time.perf_counter()
+            owg.infer(sd, cfg, mel, 0.6, zs)
+            times.append(time.perf_counter() - t0)
+    t = min(times)
+    return {"value": Bc * Tc * HOP / t, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "oracle WaveGlow.infer B=%d mel 80x%d hop=%d fp32 (%d samples), best of 2, torch-CPU %d threads"
+                      % (Bc, Tc, HOP, Bc * Tc * HOP, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from facppg import lib as flib, synth
+    from waveglow.glow import WaveGlow
+    cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=HOP)
+    sd = synth.waveglow_state_dict(cfg)
+    model = WaveGlow.remove_weightnorm(WaveGlow(**cfg))
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    mel = synth.synthetic_mel(BATCH, FRAMES, seed=1234 + rank).to(dev)
+    L = flib.load()
+
+    def step(i):
+        return model.infer(mel, sigma=0.6, seed=1000 + i)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    handle = model._handle(dev)
+    flib.check(L.facppg_wg_set_profiling(handle, 1))
+    layer_ms, layer_n = [], 0
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        audio = step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    ms = flib.ctypes.c_float()
+    n = flib.ctypes.c_int()
+    flib.check(L.facppg_wg_last_layer_ms(handle, flib.ctypes.byref(ms), flib.ctypes.byref(n)))
+    layer_ms, layer_n = ms.value, n.value
+    assert torch.isfinite(audio).all()
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    samples_per_step = world * BATCH * FRAMES * HOP
+    value = samples_per_step * args.steps / elapsed
+    positions = BATCH * FRAMES * HOP // 8
+    flops = layer_flops_per_position() * positions
+    achieved = flops / (layer_ms * 1e-3) / 1e12 if layer_ms > 0 else 0.0
+    out = {
+        "metric": "22.05 kHz audio samples/sec, WaveGlow.infer (mel->wav) of the PPG->wav path",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "WaveGlow.infer batch=%d, mel 80x%d, hop=%d (%d Hz), fp32, sigma=0.6, device Philox noise; "
+                               "seeded synthetic weights (no checkpoints ship with the reference)" % (BATCH, FRAMES, HOP, SR),
+                   "per_gpu_batch": BATCH, "global_batch": BATCH * world, "parallelism": "dp%d" % world},
+        "realtime_factor": value / SR,
+        "roofline": {"bound": "mfma", "kernel": "k_wn_layer", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "avg_launch_ms": layer_ms, "launches_timed": layer_n,
+                     "flops_per_launch": flops},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, sd)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

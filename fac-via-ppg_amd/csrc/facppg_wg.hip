@@ -1,0 +1,776 @@
+// WaveGlow.infer for MI355X (gfx950): hand-written HIP kernels + their C ABI.
+//
+// Replaces the reference's src/waveglow/glow.py:252-293 (WaveGlow.infer) and everything it
+// calls: WN.forward (:154-175), fused_add_tanh_sigmoid_multiply (:33-40),
+// Invertible1x1Conv reverse (:88-97), the upsample ConvTranspose1d + regroup (:253-259).
+//
+// Data layout in HBM (all fp32), per facppg_wg_infer call, inside the caller's workspace:
+//   L  = T*hop/8 group positions per utterance, Lr = round_up(L, 64), Lp = 128 + Lr + 128
+//   spect [B][640][Lr]   conditioning, channel = mel*8 + phase (glow.py:258-259)
+//   h0,h1 [B][256][Lp]   WN hidden state, ping-pong per layer; the 128-wide zero margins on
+//                        both sides ARE the dilated convolution's zero padding (dilation <= 128)
+//   skip  [B][256][Lr]   running sum of the skip outputs of a flow
+//   aud0,aud1 [B][8][Lr] the flow variable ("audio" in glow.py:272-290), ping-pong per flow
+// Positions are the contiguous axis, so a tile of 64 positions of one channel is one 256-byte
+// row: global loads are coalesced and the LDS image [k][64] is read conflict-free.
+//
+// Kernels (one launch each):
+//   k_upsample   mel -> spect                      (HBM-streaming + VALU)
+//   k_noise      Philox4x32-10 + Box-Muller -> z   (only when z is not injected)
+//   k_begin      sigma*z -> aud, start conv of the last flow -> h
+//   k_wn_layer   ONE fused WaveNet layer: dilated conv (3 taps) + 1x1 conditioning conv as a
+//                single [512 x 1408] x [1408 x 64] fp32 MFMA GEMM per tile, tanh*sigmoid gate,
+//                res/skip 1x1 conv as a second [512 x 256] x [256 x 64] MFMA GEMM, residual and
+//                skip updates in the epilogue.  This is >99 % of the FLOPs.
+//   k_flow_end   end 1x1 conv, affine-coupling inverse, inverse 1x1 conv, early-z concat, then
+//                either the next flow's start conv or the final group->time interleave.
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "facppg_common.h"
+
+namespace facppg {
+
+thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+namespace {
+
+constexpr int C = 256;        // WN channels (WN_config.n_channels)
+constexpr int TN = 64;        // positions per workgroup tile
+constexpr int HALO = 128;     // zero margin = max dilation 2^7
+constexpr int KCH = 64;       // K rows per LDS chunk
+constexpr int NCOND = 640;    // n_mel * n_group
+constexpr int K1 = 3 * C + NCOND;  // 1408
+constexpr int NG1 = K1 / 8;   // 176 k-groups of 8
+constexpr int NG2 = C / 8;    // 32
+constexpr int NCH1 = K1 / KCH;  // 22 chunks
+constexpr int MAXF = 32;      // max flows
+
+// ------------------------------------------------------------------------------------------
+// Weight packing (runs once in facppg_wg_create).
+// MFMA A-operand image: float4 index ((w*4 + rb)*NG + g)*64 + lane holds, for output row
+// rowmap(w, rb, lane&31) and kh = lane>>5, the four K entries 8g + 4kh + {0,1,2,3}.  A wave's
+// load of one (rb, g) is therefore 1 KiB contiguous.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int rowmap(int w, int rb, int i) { return (rb >> 1) * C + w * 64 + (rb & 1) * 32 + i; }
+
+__global__ void k_pack_w1(const float* __restrict__ in_w,    // [512][256][3]
+                          const float* __restrict__ cond_w,  // [512][640]
+                          float4* __restrict__ out) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
+  int total = 16 * NG1 * 64;
+  if (idx >= total) return;
+  int lane = idx & 63, g = (idx >> 6) % NG1, wr = (idx >> 6) / NG1;
+  int row = rowmap(wr >> 2, wr & 3, lane & 31);
+  float v[4];
+  for (int s = 0; s < 4; ++s) {
+    int kk = 8 * g + 4 * (lane >> 5) + s;
+    v[s] = kk < 3 * C ? in_w[(row * C + (kk % C)) * 3 + kk / C] : cond_w[row * NCOND + (kk - 3 * C)];
+  }
+  out[idx] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__global__ void k_pack_w2(const float* __restrict__ rs_w,  // [512 or 256][256]
+                          float4* __restrict__ out, int last) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int nrb = last ? 2 : 4;
+  int total = 4 * nrb * NG2 * 64;
+  if (idx >= total) return;
+  int lane = idx & 63, g = (idx >> 6) % NG2, wr = (idx >> 6) / NG2;
+  int w = wr / nrb, rb = wr % nrb;
+  int row = last ? w * 64 + rb * 32 + (lane & 31) : rowmap(w, rb, lane & 31);
+  float v[4];
+  for (int s = 0; s < 4; ++s) v[s] = rs_w[row * C + 8 * g + 4 * (lane >> 5) + s];
+  out[idx] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__global__ void k_add_bias(const float* a, const float* b, float* out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + b[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// k_wn_layer
+// ------------------------------------------------------------------------------------------
+struct WnArgs {
+  const float* h_in;
+  float* h_out;
+  const float* spect;
+  float* skip;
+  const float4* w1;
+  const float* b1;
+  const float4* w2;
+  const float* b2;
+  const int* t_valid;  // may be null
+  int T, hop8, Lp, Lr, dil, first;
+};
+
+template <int NRB>
+__device__ __forceinline__ void load_a(float4 (&a)[4], const float4* __restrict__ p, int rb_stride, int g) {
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) a[rb] = p[rb * rb_stride + g * 64];
+}
+
+// 4 K-steps (one k-group of 8) for NRB row blocks x 2 column blocks.
+template <int NRB>
+__device__ __forceinline__ void mfma_group(f32x16 (&acc)[4][2], const float4 (&a)[4], const float* lb, int g) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const float b0 = lb[(8 * g + s) * TN];
+    const float b1 = lb[(8 * g + s) * TN + 32];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      const float av = s == 0 ? a[rb].x : s == 1 ? a[rb].y : s == 2 ? a[rb].z : a[rb].w;
+      acc[rb][0] = mfma32x32x2(av, b0, acc[rb][0]);
+      acc[rb][1] = mfma32x32x2(av, b1, acc[rb][1]);
+    }
+  }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <bool LAST>
+__global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // 64 KiB: 2 x [64][64] staging, then acts [256][64]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 31, kh = lane >> 5;
+  const int b = blockIdx.y, t0 = blockIdx.x * TN;
+  const int Lb = (p.t_valid ? p.t_valid[b] : p.T) * p.hop8;
+  if (t0 >= Lb) return;
+
+  const float* hb = p.h_in + (size_t)b * C * p.Lp + HALO + t0 + lane;
+  const float* sb = p.spect + (size_t)b * NCOND * p.Lr + t0 + lane;
+
+  // accumulators start at the bias (in_layer.bias + cond_layer.bias, summed at pack time)
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb) {
+    const int base = (rb >> 1) * C + w * 64 + (rb & 1) * 32 + 4 * kh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 bv = *reinterpret_cast<const float4*>(p.b1 + base + 8 * q);
+      acc[rb][0][4 * q + 0] = bv.x; acc[rb][0][4 * q + 1] = bv.y; acc[rb][0][4 * q + 2] = bv.z; acc[rb][0][4 * q + 3] = bv.w;
+    }
+    acc[rb][1] = acc[rb][0];
+  }
+
+  float stg[16];
+  auto stage_load = [&](int c) {
+    const float* src;
+    int pitch;
+    if (c < 12) {
+      src = hb + (size_t)((c & 3) * 64 + w * 16) * p.Lp + ((c >> 2) - 1) * p.dil;
+      pitch = p.Lp;
+    } else {
+      src = sb + (size_t)((c - 12) * 64 + w * 16) * p.Lr;
+      pitch = p.Lr;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) stg[j] = src[(size_t)j * pitch];
+  };
+  auto stage_write = [&](int buf) {
+    float* dst = smem + buf * (KCH * TN) + (w * 16) * TN + lane;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dst[j * TN] = stg[j];
+  };
+
+  const float4* ap = p.w1 + (size_t)(w * 4) * NG1 * 64 + lane;
+  float4 a0[4], a1[4];
+  stage_load(0);
+  load_a<4>(a0, ap, NG1 * 64, 0);
+  stage_write(0);
+  __syncthreads();
+
+  for (int c = 0; c < NCH1; ++c) {
+    if (c + 1 < NCH1) stage_load(c + 1);
+    const float* lb = smem + (c & 1) * (KCH * TN) + (4 * kh) * TN + li;
+    const int G = c * 8;
+#pragma unroll
+    for (int g = 0; g < 8; g += 2) {
+      load_a<4>(a1, ap, NG1 * 64, G + g + 1);
+      mfma_group<4>(acc, a0, lb, g);
+      load_a<4>(a0, ap, NG1 * 64, G + g + 2);  // one padded group exists past the end
+      mfma_group<4>(acc, a1, lb, g + 1);
+    }
+    if (c + 1 < NCH1) stage_write((c + 1) & 1);
+    __syncthreads();
+  }
+
+  // gate: acts = tanh(pre[0:256]) * sigmoid(pre[256:512])  (glow.py:33-40) -> LDS [256][64]
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = tanhf(acc[rb][cb][r]) * sigmoidf_(acc[rb + 2][cb][r]);
+        const int ch = w * 64 + rb * 32 + 8 * (r >> 2) + (r & 3) + 4 * kh;
+        smem[ch * TN + cb * 32 + li] = v;
+      }
+  __syncthreads();
+
+  // res_skip 1x1 conv: [512 (256 if LAST)] x 256
+  constexpr int NRB2 = LAST ? 2 : 4;
+#pragma unroll
+  for (int rb = 0; rb < NRB2; ++rb) {
+    const int base = (LAST ? w * 64 + rb * 32 : (rb >> 1) * C + w * 64 + (rb & 1) * 32) + 4 * kh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 bv = *reinterpret_cast<const float4*>(p.b2 + base + 8 * q);
+      acc[rb][0][4 * q + 0] = bv.x; acc[rb][0][4 * q + 1] = bv.y; acc[rb][0][4 * q + 2] = bv.z; acc[rb][0][4 * q + 3] = bv.w;
+    }
+    acc[rb][1] = acc[rb][0];
+  }
+  {
+    const float4* ap2 = p.w2 + (size_t)(w * NRB2) * NG2 * 64 + lane;
+    const float* lb = smem + (4 * kh) * TN + li;
+    load_a<NRB2>(a0, ap2, NG2 * 64, 0);
+    for (int G = 0; G < NG2; G += 8) {
+#pragma unroll
+      for (int g = 0; g < 8; g += 2) {
+        load_a<NRB2>(a1, ap2, NG2 * 64, G + g + 1);
+        mfma_group<NRB2>(acc, a0, lb, G + g);
+        load_a<NRB2>(a0, ap2, NG2 * 64, G + g + 2);
+        mfma_group<NRB2>(acc, a1, lb, G + g + 1);
+      }
+    }
+  }
+
+  // epilogue: h_out = h_in + res (glow.py:165-166), skip (+)= skip part (glow.py:167-174)
+#pragma unroll
+  for (int rb = 0; rb < NRB2; ++rb) {
+    const bool is_res = !LAST && rb < 2;
+    const int chb = w * 64 + (rb & 1) * 32 + 4 * kh;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int pos = t0 + cb * 32 + li;
+      if (pos < Lb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ch = chb + 8 * (r >> 2) + (r & 3);
+          if (is_res) {
+            const size_t o = ((size_t)b * C + ch) * p.Lp + HALO + pos;
+            p.h_out[o] = p.h_in[o] + acc[rb][cb][r];
+          } else {
+            const size_t o = ((size_t)b * C + ch) * p.Lr + pos;
+            p.skip[o] = (p.first ? 0.0f : p.skip[o]) + acc[rb][cb][r];
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_upsample: ConvTranspose1d(n_mel, n_mel, K, stride=hop) + trim + regroup (glow.py:253-259)
+// out[m][n] = bias[m] + sum_{m'} sum_{t: 0 <= n - t*hop < K} mel[m'][t] * W[m'][m][n - t*hop]
+// One workgroup = (batch b, output channel m, block of QB frames).  Thread p owns the `hop`-phase
+// p: it keeps QB accumulators (one per frame q) so each weight it loads is reused QB times and
+// the mel values come from LDS as broadcasts.
+// ------------------------------------------------------------------------------------------
+constexpr int UP_QB = 32;
+constexpr int UP_MAXJ = 8;  // ceil(K / hop) <= 8  (hop >= 128 for K = 1024)
+
+__global__ __launch_bounds__(256) void k_upsample(const float* __restrict__ mel, const float* __restrict__ W,
+                                                  const float* __restrict__ bias, float* __restrict__ spect,
+                                                  const int* __restrict__ t_valid, int T, int n_mel, int hop,
+                                                  int ksize, int Lr) {
+  extern __shared__ float smel[];  // [n_mel][UP_QB + UP_MAXJ]
+  const int b = blockIdx.z, m = blockIdx.y, q0 = blockIdx.x * UP_QB;
+  const int Tb = t_valid ? t_valid[b] : T;
+  if (q0 >= Tb) return;
+  const int nj = (ksize + hop - 1) / hop;
+  const int SW = UP_QB + UP_MAXJ;
+  for (int i = threadIdx.x; i < n_mel * SW; i += blockDim.x) {
+    const int mp = i / SW, tt = i % SW;
+    const int t = q0 - (UP_MAXJ - 1) + tt;  // column tt <-> frame q0 - 7 + tt
+    smel[i] = (t >= 0 && t < Tb && tt < UP_QB + UP_MAXJ - 1) ? mel[((size_t)b * n_mel + mp) * T + t] : 0.0f;
+  }
+  __syncthreads();
+  for (int pp = threadIdx.x; pp < hop; pp += blockDim.x) {
+    float acc[UP_QB];
+    const float bv = bias[m];
+#pragma unroll
+    for (int q = 0; q < UP_QB; ++q) acc[q] = bv;
+    for (int j = 0; j < nj; ++j) {
+      const int k = pp + j * hop;
+      if (k < ksize) {
+        for (int mp = 0; mp < n_mel; ++mp) {
+          const float wv = W[((size_t)mp * n_mel + m) * ksize + k];
+          const float* sm = smel + mp * SW + (UP_MAXJ - 1) - j;  // frame q0 + q - j
+#pragma unroll
+          for (int q = 0; q < UP_QB; ++q) acc[q] = fmaf(sm[q], wv, acc[q]);
+        }
+      }
+    }
+    // n = (q0+q)*hop + pp -> channel m*8 + n%8, position n/8 ; frames >= Tb are not produced
+    const int hop8 = hop >> 3;
+    float* dst = spect + ((size_t)b * n_mel * 8 + m * 8 + (pp & 7)) * Lr + (pp >> 3);
+#pragma unroll
+    for (int q = 0; q < UP_QB; ++q)
+      if (q0 + q < Tb) dst[(size_t)(q0 + q) * hop8] = acc[q];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_noise: counter-based N(0,1) (Philox4x32-10, Box-Muller) replacing normal_() glow.py:266-289
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ void k_noise(float* __restrict__ z, size_t n, uint64_t seed) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // produces z[4i .. 4i+3]
+  if (4 * i >= n) return;
+  uint32_t r[4];
+  philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  float o[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u1 = ((float)(r[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
+    const float u2 = ((float)(r[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.28318530717958647692f * u2, &sn, &cs);
+    o[2 * h] = rad * cs; o[2 * h + 1] = rad * sn;
+  }
+  for (int j = 0; j < 4; ++j)
+    if (4 * i + j < n) z[4 * i + j] = o[j];
+}
+
+// ------------------------------------------------------------------------------------------
+// k_begin: audio = sigma * z0 (glow.py:261-270) and the start conv of the last flow (glow.py:156)
+// ------------------------------------------------------------------------------------------
+struct EdgeArgs {
+  const float* skip;       // [B][256][Lr]
+  const float* aud_in;     // [B][8][Lr]
+  float* aud_out;          // [B][8][Lr]
+  float* h_out;            // [B][256][Lp]
+  float* final_audio;      // [B][T*hop]
+  const float* z0;         // [B][c][L]  (k_begin)
+  const float* z_early;    // [B][n_early][L] or null
+  const float* end_w;      // [2H][256]
+  const float* end_b;      // [2H]
+  const float* winv;       // [2H][2H]
+  const float* start_w;    // next flow: [256][Hn]
+  const float* start_b;    // [256]
+  const int* t_valid;
+  float sigma;
+  int T, hop8, Lp, Lr, L, n_early, final_flow;
+};
+
+template <int HN>
+__device__ __forceinline__ void start_conv(const EdgeArgs& p, int b, int pos, const float* a0) {
+  float* dst = p.h_out + (size_t)b * C * p.Lp + HALO + pos;
+  for (int ch = 0; ch < C; ++ch) {
+    float v = p.start_b[ch];
+#pragma unroll
+    for (int j = 0; j < HN; ++j) v = fmaf(p.start_w[ch * HN + j], a0[j], v);
+    dst[(size_t)ch * p.Lp] = v;
+  }
+}
+
+template <int HN>
+__global__ __launch_bounds__(256) void k_begin(EdgeArgs p) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const int Lb = (p.t_valid ? p.t_valid[b] : p.T) * p.hop8;
+  if (pos >= Lb) return;
+  float a[2 * HN];
+#pragma unroll
+  for (int j = 0; j < 2 * HN; ++j) {
+    a[j] = p.sigma * p.z0[((size_t)b * 2 * HN + j) * p.L + pos];
+    p.aud_out[((size_t)b * 8 + j) * p.Lr + pos] = a[j];
+  }
+  start_conv<HN>(p, b, pos, a);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_flow_end<H, EARLY>: for a flow with n_half = H (glow.py:175, 278-290):
+//   out = end(skip) ; b = out[:H], s = out[H:] ; a1 = (a1 - b)/exp(s) ; audio = W^-1 [a0; a1]
+//   EARLY: audio = cat(sigma*z, audio) ; then next flow's start conv, or the final interleave
+// ------------------------------------------------------------------------------------------
+template <int H, bool EARLY>
+__global__ __launch_bounds__(256) void k_flow_end(EdgeArgs p) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const int Lb = (p.t_valid ? p.t_valid[b] : p.T) * p.hop8;
+  if (pos >= Lb) return;
+  constexpr int CC = 2 * H;
+  float o[CC];
+#pragma unroll
+  for (int j = 0; j < CC; ++j) o[j] = p.end_b[j];
+  const float* sk = p.skip + (size_t)b * C * p.Lr + pos;
+  for (int ch = 0; ch < C; ++ch) {
+    const float v = sk[(size_t)ch * p.Lr];
+#pragma unroll
+    for (int j = 0; j < CC; ++j) o[j] = fmaf(p.end_w[j * C + ch], v, o[j]);
+  }
+  float a[CC];
+#pragma unroll
+  for (int j = 0; j < CC; ++j) a[j] = p.aud_in[((size_t)b * 8 + j) * p.Lr + pos];
+#pragma unroll
+  for (int j = 0; j < H; ++j) a[H + j] = (a[H + j] - o[j]) / expf(o[H + j]);
+  constexpr int CN = EARLY ? CC + 2 : CC;
+  float y[CN];
+  if (EARLY) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) y[j] = p.sigma * p.z_early[((size_t)b * 2 + j) * p.L + pos];
+  }
+#pragma unroll
+  for (int i = 0; i < CC; ++i) {
+    float v = 0.0f;
+#pragma unroll
+    for (int j = 0; j < CC; ++j) v = fmaf(p.winv[i * CC + j], a[j], v);
+    y[(EARLY ? 2 : 0) + i] = v;
+  }
+  if (p.final_flow) {
+    // glow.py:292: [B, 8, L] -> permute -> [B, 8L]: sample n = 8*pos + channel
+    float* dst = p.final_audio + (size_t)b * p.T * p.hop8 * 8 + (size_t)pos * CN;
+#pragma unroll
+    for (int j = 0; j < CN; ++j) dst[j] = y[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < CN; ++j) p.aud_out[((size_t)b * 8 + j) * p.Lr + pos] = y[j];
+    start_conv<CN / 2>(p, b, pos, y);
+  }
+}
+
+}  // namespace
+}  // namespace facppg
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+using namespace facppg;
+
+struct facppg_wg {
+  facppg_wg_config cfg;
+  int device;
+  int n_rem[MAXF], n_half[MAXF], early[MAXF];
+  char* arena;  // one device allocation holding everything below
+  size_t arena_bytes;
+  float *up_w, *up_b;
+  float *start_w[MAXF], *start_b[MAXF], *end_w[MAXF], *end_b[MAXF], *winv[MAXF];
+  float4* w1[MAXF][8];
+  float4* w2[MAXF][8];
+  float *b1[MAXF][8], *b2[MAXF][8];
+  int profiling;
+  std::vector<hipEvent_t> ev;  // pairs around each k_wn_layer launch
+  int ev_used;
+};
+
+extern "C" int facppg_version(void) { return FACPPG_VERSION; }
+extern "C" const char* facppg_last_error(void) { return g_err; }
+
+static int wg_check_cfg(const facppg_wg_config* c) {
+  FACPPG_REQUIRE(c != nullptr, FACPPG_EINVAL, "config is NULL");
+  FACPPG_REQUIRE(c->wn_channels == C && c->wn_kernel_size == 3 && c->n_group == 8 && c->n_mel_channels * c->n_group == NCOND,
+                 FACPPG_EUNSUPPORTED,
+                 "kernels are built for WN n_channels=256, kernel_size=3, n_group=8, n_mel_channels=80 (got %d, %d, %d, %d)",
+                 c->wn_channels, c->wn_kernel_size, c->n_group, c->n_mel_channels);
+  FACPPG_REQUIRE(c->wn_layers >= 1 && c->wn_layers <= 8, FACPPG_EUNSUPPORTED, "wn_layers must be 1..8 (dilation <= 128)");
+  FACPPG_REQUIRE(c->n_flows >= 1 && c->n_flows <= MAXF, FACPPG_EUNSUPPORTED, "n_flows must be 1..%d", MAXF);
+  FACPPG_REQUIRE(c->hop_length > 0 && c->hop_length % c->n_group == 0, FACPPG_EUNSUPPORTED, "hop_length must be a positive multiple of n_group");
+  FACPPG_REQUIRE(c->upsample_kernel >= c->hop_length && (c->upsample_kernel + c->hop_length - 1) / c->hop_length <= UP_MAXJ,
+                 FACPPG_EUNSUPPORTED, "upsample kernel/hop ratio must be in [1, %d]", UP_MAXJ);
+  FACPPG_REQUIRE(c->n_early_size == 2 && c->n_early_every >= 1, FACPPG_EUNSUPPORTED, "n_early_size must be 2");
+  int n_half = c->n_group / 2, n_rem = c->n_group;
+  for (int k = 0; k < c->n_flows; ++k) {
+    if (k % c->n_early_every == 0 && k > 0) { n_half -= c->n_early_size / 2; n_rem -= c->n_early_size; }
+    FACPPG_REQUIRE(n_half >= 1, FACPPG_EUNSUPPORTED, "flow %d has no channels left", k);
+  }
+  return FACPPG_OK;
+}
+
+static void wg_flow_channels(const facppg_wg_config* c, int* n_rem, int* n_half, int* early) {
+  int h = c->n_group / 2, r = c->n_group;
+  for (int k = 0; k < c->n_flows; ++k) {
+    early[k] = (k % c->n_early_every == 0 && k > 0);
+    if (early[k]) { h -= c->n_early_size / 2; r -= c->n_early_size; }
+    n_rem[k] = r; n_half[k] = h;
+  }
+}
+
+extern "C" size_t facppg_wg_weight_count(const facppg_wg_config* c) {
+  if (wg_check_cfg(c) != FACPPG_OK) return 0;
+  int n_rem[MAXF], n_half[MAXF], early[MAXF];
+  wg_flow_channels(c, n_rem, n_half, early);
+  const size_t nm = c->n_mel_channels;
+  size_t n = nm * nm * c->upsample_kernel + nm;
+  for (int k = 0; k < c->n_flows; ++k) {
+    const size_t h = n_half[k], cc = 2 * h;
+    n += (size_t)C * h + C;
+    for (int i = 0; i < c->wn_layers; ++i) {
+      const size_t rs = i < c->wn_layers - 1 ? 2 * C : C;
+      n += (size_t)2 * C * C * 3 + 2 * C + (size_t)2 * C * NCOND + 2 * C + rs * C + rs;
+    }
+    n += cc * C + cc + cc * cc;
+  }
+  return n;
+}
+
+extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weights_dev, size_t n_floats, int device,
+                                void* stream_, facppg_wg** out) {
+  if (int rc = wg_check_cfg(cfg)) return rc;
+  FACPPG_REQUIRE(weights_dev && out, FACPPG_EINVAL, "weights_dev/out is NULL");
+  FACPPG_REQUIRE(n_floats == facppg_wg_weight_count(cfg), FACPPG_EINVAL, "weight blob has %zu floats, expected %zu", n_floats,
+                 facppg_wg_weight_count(cfg));
+  hipStream_t stream = (hipStream_t)stream_;
+  FACPPG_HIP_CHECK(hipSetDevice(device));
+  facppg_wg* h = new (std::nothrow) facppg_wg();
+  FACPPG_REQUIRE(h, FACPPG_EINVAL, "out of host memory");
+  h->cfg = *cfg; h->device = device; h->profiling = 0; h->ev_used = 0; h->arena = nullptr;
+  wg_flow_channels(cfg, h->n_rem, h->n_half, h->early);
+
+  // arena layout (bytes, 256-aligned pieces)
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t nm = cfg->n_mel_channels;
+  const size_t w1_bytes = (size_t)(16 * NG1 + 1) * 64 * sizeof(float4);
+  auto w2_bytes = [&](int last) { return (size_t)(4 * (last ? 2 : 4) * NG2 + 1) * 64 * sizeof(float4); };
+  struct Off { size_t start_w, start_b, end_w, end_b, winv, w1[8], w2[8], b1[8], b2[8]; } fo[MAXF];
+  const size_t o_up_w = take(nm * nm * cfg->upsample_kernel * 4), o_up_b = take(nm * 4);
+  for (int k = 0; k < cfg->n_flows; ++k) {
+    const size_t hh = h->n_half[k], cc = 2 * hh;
+    fo[k].start_w = take(C * hh * 4); fo[k].start_b = take(C * 4);
+    for (int i = 0; i < cfg->wn_layers; ++i) {
+      const int last = i == cfg->wn_layers - 1;
+      fo[k].w1[i] = take(w1_bytes); fo[k].b1[i] = take(2 * C * 4);
+      fo[k].w2[i] = take(w2_bytes(last)); fo[k].b2[i] = take(2 * C * 4);
+    }
+    fo[k].end_w = take(cc * C * 4); fo[k].end_b = take(cc * 4); fo[k].winv = take(cc * cc * 4);
+  }
+  h->arena_bytes = off;
+  if (hipMalloc((void**)&h->arena, off) != hipSuccess) {
+    set_error("hipMalloc(%zu) for packed weights failed", off);
+    delete h;
+    return FACPPG_EHIP;
+  }
+  auto fail = [&](int rc) { hipFree(h->arena); delete h; return rc; };
+#define WG_TRY(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t e__ = (expr);                                                             \
+    if (e__ != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(e__)); return fail(FACPPG_EHIP); } \
+  } while (0)
+  WG_TRY(hipMemsetAsync(h->arena, 0, off, stream));
+  auto F = [&](size_t o) { return (float*)(h->arena + o); };
+  auto cpy = [&](float* dst, const float* src, size_t n) { return hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, stream); };
+  const float* src = weights_dev;
+  h->up_w = F(o_up_w); h->up_b = F(o_up_b);
+  WG_TRY(cpy(h->up_w, src, nm * nm * cfg->upsample_kernel)); src += nm * nm * cfg->upsample_kernel;
+  WG_TRY(cpy(h->up_b, src, nm)); src += nm;
+  for (int k = 0; k < cfg->n_flows; ++k) {
+    const size_t hh = h->n_half[k], cc = 2 * hh;
+    h->start_w[k] = F(fo[k].start_w); h->start_b[k] = F(fo[k].start_b);
+    WG_TRY(cpy(h->start_w[k], src, C * hh)); src += C * hh;
+    WG_TRY(cpy(h->start_b[k], src, C)); src += C;
+    for (int i = 0; i < cfg->wn_layers; ++i) {
+      const int last = i == cfg->wn_layers - 1;
+      const float* in_w = src; src += (size_t)2 * C * C * 3;
+      const float* in_b = src; src += 2 * C;
+      const float* cond_w = src; src += (size_t)2 * C * NCOND;
+      const float* cond_b = src; src += 2 * C;
+      const size_t rs = last ? C : 2 * C;
+      const float* rs_w = src; src += rs * C;
+      const float* rs_b = src; src += rs;
+      h->w1[k][i] = (float4*)(h->arena + fo[k].w1[i]); h->b1[k][i] = F(fo[k].b1[i]);
+      h->w2[k][i] = (float4*)(h->arena + fo[k].w2[i]); h->b2[k][i] = F(fo[k].b2[i]);
+      const int n1 = 16 * NG1 * 64, n2 = 4 * (last ? 2 : 4) * NG2 * 64;
+      k_pack_w1<<<(n1 + 255) / 256, 256, 0, stream>>>(in_w, cond_w, h->w1[k][i]);
+      k_pack_w2<<<(n2 + 255) / 256, 256, 0, stream>>>(rs_w, h->w2[k][i], last);
+      k_add_bias<<<2, 256, 0, stream>>>(in_b, cond_b, h->b1[k][i], 2 * C);
+      WG_TRY(cpy(h->b2[k][i], rs_b, rs));
+    }
+    h->end_w[k] = F(fo[k].end_w); h->end_b[k] = F(fo[k].end_b); h->winv[k] = F(fo[k].winv);
+    WG_TRY(cpy(h->end_w[k], src, cc * C)); src += cc * C;
+    WG_TRY(cpy(h->end_b[k], src, cc)); src += cc;
+    WG_TRY(cpy(h->winv[k], src, cc * cc)); src += cc * cc;
+  }
+  WG_TRY(hipGetLastError());
+  WG_TRY(hipStreamSynchronize(stream));
+  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+#undef WG_TRY
+  *out = h;
+  return FACPPG_OK;
+}
+
+extern "C" void facppg_wg_destroy(facppg_wg* h) {
+  if (!h) return;
+  for (hipEvent_t e : h->ev) hipEventDestroy(e);
+  hipFree(h->arena);
+  delete h;
+}
+
+namespace {
+struct WsLayout {
+  int L, Lr, Lp;
+  size_t spect, h0, h1, skip, aud0, aud1, z, total;
+};
+WsLayout ws_layout(const facppg_wg_config& c, int B, int T) {
+  WsLayout w;
+  w.L = T * (c.hop_length / 8);
+  w.Lr = round_up(w.L, TN);
+  w.Lp = HALO + w.Lr + HALO;
+  size_t off = 0;
+  auto take = [&](size_t floats) { size_t o = off; off += (floats * 4 + 255) / 256 * 256; return o; };
+  w.h0 = take((size_t)B * C * w.Lp);
+  w.h1 = take((size_t)B * C * w.Lp);
+  w.spect = take((size_t)B * NCOND * w.Lr);
+  w.skip = take((size_t)B * C * w.Lr);
+  w.aud0 = take((size_t)B * 8 * w.Lr);
+  w.aud1 = take((size_t)B * 8 * w.Lr);
+  w.z = take((size_t)B * 8 * w.L + 4);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t facppg_wg_workspace_bytes(const facppg_wg* h, int B, int T) {
+  if (!h || B <= 0 || T <= 0) return 0;
+  return ws_layout(h->cfg, B, T).total;
+}
+
+extern "C" int facppg_wg_set_profiling(facppg_wg* h, int enable) {
+  FACPPG_REQUIRE(h, FACPPG_EINVAL, "handle is NULL");
+  h->profiling = enable ? 1 : 0;
+  return FACPPG_OK;
+}
+
+extern "C" int facppg_wg_last_layer_ms(facppg_wg* h, float* avg_ms, int* n_launches) {
+  FACPPG_REQUIRE(h && avg_ms && n_launches, FACPPG_EINVAL, "NULL argument");
+  double tot = 0;
+  for (int i = 0; i + 1 < h->ev_used; i += 2) {
+    float ms = 0;
+    FACPPG_HIP_CHECK(hipEventSynchronize(h->ev[i + 1]));
+    FACPPG_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+    tot += ms;
+  }
+  *n_launches = h->ev_used / 2;
+  *avg_ms = *n_launches ? (float)(tot / *n_launches) : 0.0f;
+  return FACPPG_OK;
+}
+
+template <int H>
+static void launch_flow_end(bool early, dim3 grid, hipStream_t s, const EdgeArgs& a) {
+  if (early) k_flow_end<H, true><<<grid, 256, 0, s>>>(a);
+  else k_flow_end<H, false><<<grid, 256, 0, s>>>(a);
+}
+
+extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t* T_valid_dev, const float* z_dev,
+                               uint64_t seed, float sigma, int B, int T, float* audio_dev, void* ws_, size_t ws_bytes,
+                               void* stream_) {
+  FACPPG_REQUIRE(h && mel_dev && audio_dev && ws_, FACPPG_EINVAL, "NULL argument");
+  FACPPG_REQUIRE(B > 0 && T > 0, FACPPG_EINVAL, "B and T must be positive (got %d, %d)", B, T);
+  const facppg_wg_config& c = h->cfg;
+  const WsLayout w = ws_layout(c, B, T);
+  FACPPG_REQUIRE(ws_bytes >= w.total, FACPPG_EWORKSPACE, "workspace has %zu bytes, need %zu", ws_bytes, w.total);
+  FACPPG_REQUIRE(B <= 65535, FACPPG_EINVAL, "B too large");
+  hipStream_t s = (hipStream_t)stream_;
+  char* ws = (char*)ws_;
+  float* hbuf[2] = {(float*)(ws + w.h0), (float*)(ws + w.h1)};
+  float* spect = (float*)(ws + w.spect);
+  float* skip = (float*)(ws + w.skip);
+  float* aud[2] = {(float*)(ws + w.aud0), (float*)(ws + w.aud1)};
+  float* zbuf = (float*)(ws + w.z);
+  const int hop8 = c.hop_length / 8;
+  const int nf = c.n_flows;
+
+  // zero margins of h (the conv zero padding) and everything a ragged tile may read
+  FACPPG_HIP_CHECK(hipMemsetAsync(ws + w.h0, 0, (size_t)B * C * w.Lp * 4 * 2, s));
+  if (w.Lr != w.L || T_valid_dev) FACPPG_HIP_CHECK(hipMemsetAsync(spect, 0, (size_t)B * NCOND * w.Lr * 4, s));
+
+  const float* z = z_dev;
+  const size_t zn = (size_t)B * 8 * w.L;
+  {
+    // total noise channels = n_remaining(last flow) + n_early_size * (#early flows) = n_group
+    int tot = h->n_rem[nf - 1];
+    for (int k = 0; k < nf; ++k) tot += h->early[k] ? c.n_early_size : 0;
+    FACPPG_REQUIRE(tot == 8, FACPPG_EUNSUPPORTED, "noise channel count %d != n_group", tot);
+  }
+  if (!z) {
+    k_noise<<<(unsigned)((zn / 4 + 255) / 256 + 1), 256, 0, s>>>(zbuf, zn, seed);
+    z = zbuf;
+  }
+  {
+    dim3 g((T + UP_QB - 1) / UP_QB, c.n_mel_channels, B);
+    const size_t sm = (size_t)c.n_mel_channels * (UP_QB + UP_MAXJ) * 4;
+    k_upsample<<<g, 256, sm, s>>>(mel_dev, h->up_w, h->up_b, spect, T_valid_dev, T, c.n_mel_channels, c.hop_length,
+                                  c.upsample_kernel, w.Lr);
+  }
+  EdgeArgs e;
+  memset(&e, 0, sizeof(e));
+  e.skip = skip; e.t_valid = T_valid_dev; e.sigma = sigma; e.T = T; e.hop8 = hop8; e.Lp = w.Lp; e.Lr = w.Lr; e.L = w.L;
+  e.final_audio = audio_dev;
+  const dim3 egrid((w.L + 255) / 256, B);
+  int ai = 0, hi = 0;  // current audio / h buffer
+  {
+    const int k = nf - 1;
+    e.z0 = z; e.aud_out = aud[ai]; e.h_out = hbuf[hi]; e.start_w = h->start_w[k]; e.start_b = h->start_b[k];
+    switch (h->n_half[k]) {
+      case 1: k_begin<1><<<egrid, 256, 0, s>>>(e); break;
+      case 2: k_begin<2><<<egrid, 256, 0, s>>>(e); break;
+      case 3: k_begin<3><<<egrid, 256, 0, s>>>(e); break;
+      case 4: k_begin<4><<<egrid, 256, 0, s>>>(e); break;
+      default: FACPPG_REQUIRE(false, FACPPG_EUNSUPPORTED, "n_half %d", h->n_half[k]);
+    }
+  }
+  size_t z_off = (size_t)B * h->n_rem[nf - 1] * w.L;
+  if (h->profiling) {
+    const size_t need = (size_t)2 * nf * c.wn_layers;
+    while (h->ev.size() < need) {
+      hipEvent_t ev;
+      FACPPG_HIP_CHECK(hipEventCreate(&ev));
+      h->ev.push_back(ev);
+    }
+  }
+  h->ev_used = 0;
+  const dim3 lgrid(w.Lr / TN, B);
+  for (int k = nf - 1; k >= 0; --k) {
+    for (int i = 0; i < c.wn_layers; ++i) {
+      WnArgs a;
+      a.h_in = hbuf[hi]; a.h_out = hbuf[hi ^ 1]; a.spect = spect; a.skip = skip;
+      a.w1 = h->w1[k][i]; a.b1 = h->b1[k][i]; a.w2 = h->w2[k][i]; a.b2 = h->b2[k][i];
+      a.t_valid = T_valid_dev; a.T = T; a.hop8 = hop8; a.Lp = w.Lp; a.Lr = w.Lr; a.dil = 1 << i; a.first = (i == 0);
+      const bool last = i == c.wn_layers - 1;
+      if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
+      if (last) k_wn_layer<true><<<lgrid, 256, 65536, s>>>(a);
+      else { k_wn_layer<false><<<lgrid, 256, 65536, s>>>(a); hi ^= 1; }
+      if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
+    }
+    e.aud_in = aud[ai]; e.aud_out = aud[ai ^ 1]; e.h_out = hbuf[hi];
+    e.end_w = h->end_w[k]; e.end_b = h->end_b[k]; e.winv = h->winv[k];
+    e.final_flow = (k == 0);
+    e.z_early = nullptr;
+    if (h->early[k]) { e.z_early = z + z_off; z_off += (size_t)B * c.n_early_size * w.L; }
+    if (k > 0) { e.start_w = h->start_w[k - 1]; e.start_b = h->start_b[k - 1]; }
+    const int cn = 2 * h->n_half[k] + (h->early[k] ? 2 : 0);
+    if (k > 0) FACPPG_REQUIRE(cn == 2 * h->n_half[k - 1], FACPPG_EUNSUPPORTED, "flow %d channel mismatch", k);
+    else FACPPG_REQUIRE(cn == 8, FACPPG_EUNSUPPORTED, "final flow must yield n_group channels");
+    switch (h->n_half[k]) {
+      case 1: launch_flow_end<1>(h->early[k], egrid, s, e); break;
+      case 2: launch_flow_end<2>(h->early[k], egrid, s, e); break;
+      case 3: launch_flow_end<3>(h->early[k], egrid, s, e); break;
+      case 4: launch_flow_end<4>(h->early[k], egrid, s, e); break;
+      default: FACPPG_REQUIRE(false, FACPPG_EUNSUPPORTED, "n_half %d", h->n_half[k]);
+    }
+    ai ^= 1;
+  }
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}

@@ -1,0 +1,86 @@
+"""ctypes binding of libfacppg_hip.so (C ABI: include/facppg.h).
+
+The library is the product: if it is missing, or there is no GPU, the synthesis path raises --
+there is no CPU fallback (the CPU restatement lives in oracle/ and is test infrastructure).
+``import torch`` happens before ``CDLL`` on purpose: libfacppg_hip.so needs ``libamdhip64.so.7``
+and must bind to the copy PyTorch-ROCm already loaded, so that torch's streams and device
+pointers are valid inside the kernels' launches.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfacppg_hip.so")
+
+_lib = None
+
+
+class FacppgError(RuntimeError):
+    pass
+
+
+class WgConfig(ctypes.Structure):
+    """facppg_wg_config (include/facppg.h)."""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "n_mel_channels", "hop_length", "n_flows", "n_group", "n_early_every", "n_early_size",
+        "wn_layers", "wn_channels", "wn_kernel_size", "upsample_kernel")]
+
+
+def _declare(lib):
+    c = ctypes
+    vp, i32, u64, f32, sz = c.c_void_p, c.c_int32, c.c_uint64, c.c_float, c.c_size_t
+    sigs = {
+        "facppg_version": (c.c_int, []),
+        "facppg_last_error": (c.c_char_p, []),
+        "facppg_wg_weight_count": (sz, [c.POINTER(WgConfig)]),
+        "facppg_wg_create": (c.c_int, [c.POINTER(WgConfig), vp, sz, c.c_int, vp, c.POINTER(vp)]),
+        "facppg_wg_destroy": (None, [vp]),
+        "facppg_wg_workspace_bytes": (sz, [vp, c.c_int, c.c_int]),
+        "facppg_wg_infer": (c.c_int, [vp, vp, vp, vp, u64, f32, c.c_int, c.c_int, vp, vp, sz, vp]),
+        "facppg_wg_set_profiling": (c.c_int, [vp, c.c_int]),
+        "facppg_wg_last_layer_ms": (c.c_int, [vp, c.POINTER(f32), c.POINTER(c.c_int)]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)      # AttributeError here = header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    return sigs
+
+
+def exported_symbols():
+    """Names include/facppg.h declares and the binding uses (checked by the CPU tests)."""
+    return sorted(_declare(load()))
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise FacppgError(
+                "%s is not built. Build it with `python -c \"import __graft_entry__ as g; g.build()\"` "
+                "(or `make -C fac-via-ppg_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        _declare(lib)
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise FacppgError("libfacppg_hip: error %d: %s" % (rc, load().facppg_last_error().decode()))
+
+
+def require_cuda(t, what):
+    if not (torch.is_tensor(t) and t.is_cuda):
+        raise FacppgError(
+            "%s must be a GPU tensor: this build runs only on the HIP kernels of libfacppg_hip.so "
+            "(MI355X / gfx950); there is no CPU path." % what)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def current_stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,268 @@
+"""WaveGlow vocoder -- drop-in for the reference's ``waveglow.glow`` (src/waveglow/glow.py).
+
+Same classes, constructor arguments, parameter/state-dict layout and checkpoint behaviour as
+the reference (checkpoints pickle ``waveglow.glow.WaveGlow`` objects, train_waveglow.py:56-64,
+so the qualified names matter), but ``WaveGlow.infer`` does not run torch ops: it hands raw
+device pointers to ``facppg_wg_infer`` in libfacppg_hip.so (include/facppg.h), whose fused
+gfx950 kernels implement glow.py:252-293.  The ``torch.nn`` modules below are parameter
+containers only; there is no CPU path.
+
+Extensions over the reference signature (all optional, defaults = reference behaviour):
+  ``infer(spect, sigma=1.0, z=None, lengths=None, seed=None)``
+    z        the three N(0,1) draws of glow.py:261-270,285-290 (list of tensors in call order, or
+             one flat tensor); None -> generated on the device (Philox) from ``seed``
+    lengths  per-utterance valid frame counts for padded batches: utterance b is synthesised
+             exactly as a batch-1 call on spect[b, :, :lengths[b]] would be
+"""
+import torch
+
+from facppg import lib as _lib
+
+
+def fused_add_tanh_sigmoid_multiply(input_a, input_b, n_channels):
+    """glow.py:33-40.  In the HIP path this is the epilogue of the first GEMM of k_wn_layer;
+    the standalone function is kept for API compatibility on tensors the caller already has."""
+    n = int(n_channels[0])
+    in_act = input_a + input_b
+    return torch.tanh(in_act[:, :n, :]) * torch.sigmoid(in_act[:, n:, :])
+
+
+class WaveGlowLoss(torch.nn.Module):
+    """glow.py:43-59 (training loss; a scalar reduction of the flow outputs)."""
+
+    def __init__(self, sigma=1.0):
+        super(WaveGlowLoss, self).__init__()
+        self.sigma = sigma
+
+    def forward(self, model_output):
+        z, log_s_list, log_det_W_list = model_output
+        log_s_total = sum(torch.sum(ls) for ls in log_s_list)
+        log_det_total = sum(log_det_W_list)
+        loss = torch.sum(z * z) / (2 * self.sigma * self.sigma) - log_s_total - log_det_total
+        return loss / (z.size(0) * z.size(1) * z.size(2))
+
+
+def _effective_weight(conv):
+    """Weight of a conv whether or not weight-norm is still attached (Denoiser is handed a model
+    that still carries weight_g/weight_v, generate_synthesis.py:58-61)."""
+    if hasattr(conv, "weight_g"):
+        return torch._weight_norm(conv.weight_v, conv.weight_g, 0)
+    return conv.weight
+
+
+class Invertible1x1Conv(torch.nn.Module):
+    """glow.py:62-102: parameter container for the c x c mixing matrix.  In inference the
+    inverse matrix is applied inside k_flow_end (fused with the affine coupling)."""
+
+    def __init__(self, c):
+        super(Invertible1x1Conv, self).__init__()
+        self.conv = torch.nn.Conv1d(c, c, kernel_size=1, stride=1, padding=0, bias=False)
+        W = torch.linalg.qr(torch.randn(c, c))[0]        # random orthonormal init
+        if torch.det(W) < 0:
+            W[:, 0] = -1 * W[:, 0]                       # det = +1
+        self.conv.weight.data = W.view(c, c, 1).contiguous()
+
+    def inverse_matrix(self):
+        """W^-1 as the reference computes and caches it (glow.py:88-95)."""
+        if not hasattr(self, "W_inverse"):
+            W = self.conv.weight.squeeze(-1)
+            self.W_inverse = W.float().inverse()[..., None]
+        return self.W_inverse.squeeze(-1)
+
+    def forward(self, z, reverse=False):
+        raise NotImplementedError(
+            "Invertible1x1Conv is fused into libfacppg_hip's flow kernels; call WaveGlow.infer")
+
+
+class WN(torch.nn.Module):
+    """glow.py:105-175: parameter container with the reference's layer layout."""
+
+    def __init__(self, n_in_channels, n_mel_channels, n_layers, n_channels, kernel_size):
+        super(WN, self).__init__()
+        assert kernel_size % 2 == 1
+        assert n_channels % 2 == 0
+        self.n_layers = n_layers
+        self.n_channels = n_channels
+        self.in_layers = torch.nn.ModuleList()
+        self.res_skip_layers = torch.nn.ModuleList()
+        self.cond_layers = torch.nn.ModuleList()
+        wn = torch.nn.utils.weight_norm
+        self.start = wn(torch.nn.Conv1d(n_in_channels, n_channels, 1), name='weight')
+        end = torch.nn.Conv1d(n_channels, 2 * n_in_channels, 1)
+        end.weight.data.zero_()                          # coupling starts as identity
+        end.bias.data.zero_()
+        self.end = end
+        for i in range(n_layers):
+            dilation = 2 ** i
+            padding = (kernel_size * dilation - dilation) // 2
+            self.in_layers.append(wn(torch.nn.Conv1d(
+                n_channels, 2 * n_channels, kernel_size, dilation=dilation, padding=padding), name='weight'))
+            self.cond_layers.append(wn(torch.nn.Conv1d(n_mel_channels, 2 * n_channels, 1), name='weight'))
+            rs = 2 * n_channels if i < n_layers - 1 else n_channels
+            self.res_skip_layers.append(wn(torch.nn.Conv1d(n_channels, rs, 1), name='weight'))
+
+    def forward(self, forward_input):
+        raise NotImplementedError("WN is fused into libfacppg_hip's k_wn_layer; call WaveGlow.infer")
+
+
+class WaveGlow(torch.nn.Module):
+    """glow.py:178-303."""
+
+    def __init__(self, n_mel_channels, hop_length, n_flows, n_group, n_early_every,
+                 n_early_size, WN_config):
+        super(WaveGlow, self).__init__()
+        self.upsample = torch.nn.ConvTranspose1d(n_mel_channels, n_mel_channels, 1024, stride=hop_length)
+        assert n_group % 2 == 0
+        self.n_flows = n_flows
+        self.n_group = n_group
+        self.n_early_every = n_early_every
+        self.n_early_size = n_early_size
+        self.WN = torch.nn.ModuleList()
+        self.convinv = torch.nn.ModuleList()
+        n_half = n_group // 2
+        n_remaining_channels = n_group
+        for k in range(n_flows):
+            if k % self.n_early_every == 0 and k > 0:
+                n_half = n_half - self.n_early_size // 2
+                n_remaining_channels = n_remaining_channels - self.n_early_size
+            self.convinv.append(Invertible1x1Conv(n_remaining_channels))
+            self.WN.append(WN(n_half, n_mel_channels * n_group, **WN_config))
+        self.n_remaining_channels = n_remaining_channels
+
+    # ---------------------------------------------------------------- HIP handle management
+    def _config(self):
+        cfg = _lib.WgConfig()
+        cfg.n_mel_channels = self.upsample.in_channels
+        cfg.hop_length = self.upsample.stride[0]
+        cfg.n_flows, cfg.n_group = self.n_flows, self.n_group
+        cfg.n_early_every, cfg.n_early_size = self.n_early_every, self.n_early_size
+        cfg.wn_layers = self.WN[0].n_layers
+        cfg.wn_channels = self.WN[0].n_channels
+        cfg.wn_kernel_size = self.WN[0].in_layers[0].kernel_size[0]
+        cfg.upsample_kernel = self.upsample.kernel_size[0]
+        return cfg
+
+    def _flat_weights(self):
+        """The plain weight blob in the order include/facppg.h documents."""
+        parts = [self.upsample.weight, self.upsample.bias]
+        for k in range(self.n_flows):
+            wn = self.WN[k]
+            parts += [_effective_weight(wn.start), wn.start.bias]
+            for i in range(wn.n_layers):
+                parts += [_effective_weight(wn.in_layers[i]), wn.in_layers[i].bias,
+                          _effective_weight(wn.cond_layers[i]), wn.cond_layers[i].bias,
+                          _effective_weight(wn.res_skip_layers[i]), wn.res_skip_layers[i].bias]
+            parts += [wn.end.weight, wn.end.bias, self.convinv[k].inverse_matrix()]
+        return torch.cat([p.detach().float().reshape(-1) for p in parts])
+
+    def _release(self):
+        h = self.__dict__.pop("_facppg_handle", None)
+        if h is not None:
+            _lib.load().facppg_wg_destroy(h[0])
+        self.__dict__.pop("_facppg_ws", None)
+
+    def _handle(self, device):
+        h = self.__dict__.get("_facppg_handle")
+        if h is not None and h[1] == device:
+            return h[0]
+        self._release()
+        L = _lib.load()
+        cfg = self._config()
+        blob = self._flat_weights().to(device).contiguous()
+        if blob.numel() != L.facppg_wg_weight_count(cfg):
+            raise _lib.FacppgError("weight blob has %d values, library expects %d (unsupported config: %s)" % (
+                blob.numel(), L.facppg_wg_weight_count(cfg), L.facppg_last_error().decode()))
+        out = _lib.ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(L.facppg_wg_create(cfg, _lib.ptr(blob), blob.numel(), device.index,
+                                          _lib.current_stream(device), _lib.ctypes.byref(out)))
+        self.__dict__["_facppg_handle"] = (out, device)
+        return out
+
+    def _apply(self, fn, *a, **k):                       # .cuda()/.to()/.float(): weights moved
+        self._release()
+        return super(WaveGlow, self)._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._release()
+        for c in self.convinv:
+            c.__dict__.pop("W_inverse", None)
+        return super(WaveGlow, self).load_state_dict(*a, **k)
+
+    def __getstate__(self):                              # never pickle device handles
+        d = dict(self.__dict__)
+        d.pop("_facppg_handle", None)
+        d.pop("_facppg_ws", None)
+        return d
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- the hot path
+    def forward(self, forward_input):
+        raise NotImplementedError(
+            "WaveGlow.forward (training direction, glow.py:208-250) is the next row of the scope "
+            "table (SURVEY.md 8f.1); this build implements the synthesis path WaveGlow.infer")
+
+    def infer(self, spect, sigma=1.0, z=None, lengths=None, seed=None):
+        """mel [B, n_mel, T] (GPU, fp32) -> audio [B, T*hop]   (glow.py:252-293)."""
+        _lib.require_cuda(spect, "WaveGlow.infer: spect")
+        if spect.dtype != torch.float32:
+            raise _lib.FacppgError("WaveGlow.infer: fp32 only (the reference's fp16 branch is not built)")
+        L = _lib.load()
+        dev = spect.device
+        spect = spect.contiguous()
+        B, _, T = spect.shape
+        hop = self.upsample.stride[0]
+        h = self._handle(dev)
+        nbytes = L.facppg_wg_workspace_bytes(h, B, T)
+        ws = self.__dict__.get("_facppg_ws")
+        if ws is None or ws.numel() < nbytes or ws.device != dev:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self.__dict__["_facppg_ws"] = ws
+        zt = None
+        if z is not None:
+            if isinstance(z, (list, tuple)):
+                z = torch.cat([t.to(dev).float().reshape(-1) for t in z])
+            zt = z.to(dev).float().contiguous()
+            if zt.numel() != B * self.n_group * (T * hop // self.n_group):
+                raise _lib.FacppgError("z has %d values, expected B*n_group*L = %d" % (
+                    zt.numel(), B * self.n_group * (T * hop // self.n_group)))
+        lt = None
+        if lengths is not None:
+            lt = torch.as_tensor(lengths).to(device=dev, dtype=torch.int32).contiguous()
+            if lt.numel() != B or int(lt.max()) > T or int(lt.min()) < 1:
+                raise _lib.FacppgError("lengths must be B values in [1, T]")
+        if seed is None:
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        audio = torch.zeros(B, T * hop, dtype=torch.float32, device=dev) if lt is not None else \
+            torch.empty(B, T * hop, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.facppg_wg_infer(h, _lib.ptr(spect), _lib.ptr(lt), _lib.ptr(zt),
+                                         seed & 0xFFFFFFFFFFFFFFFF, float(sigma), B, T, _lib.ptr(audio),
+                                         _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)))
+        return audio
+
+    @staticmethod
+    def remove_weightnorm(model):
+        """glow.py:295-303: fold g*v/||v|| into plain weights (load-time only)."""
+        waveglow = model
+        for wn in waveglow.WN:
+            wn.start = torch.nn.utils.remove_weight_norm(wn.start)
+            wn.in_layers = remove(wn.in_layers)
+            wn.cond_layers = remove(wn.cond_layers)
+            wn.res_skip_layers = remove(wn.res_skip_layers)
+        if hasattr(waveglow, "_release"):
+            waveglow._release()
+        return waveglow
+
+
+def remove(conv_list):
+    """glow.py:306-311"""
+    out = torch.nn.ModuleList()
+    for conv in conv_list:
+        out.append(torch.nn.utils.remove_weight_norm(conv))
+    return out

@@ -1,0 +1,55 @@
+"""CPU: the C-ABI library loads and exports every symbol include/facppg.h declares; argument
+validation that needs no device works; the product refuses to run without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+from facppg import lib as flib
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "facppg.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(facppg_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = flib.load()
+    names = _header_symbols()
+    assert len(names) >= 9
+    for n in names:
+        assert hasattr(L, n), "libfacppg_hip.so does not export %s" % n
+    assert sorted(flib.exported_symbols()) == [n for n in names if n in flib.exported_symbols()]
+    assert L.facppg_version() == 100
+
+
+def test_single_hip_runtime():
+    flib.load()
+    maps = open("/proc/self/maps").read()
+    libs = set(l.split()[-1] for l in maps.splitlines() if "libamdhip64" in l)
+    assert len(libs) == 1, libs          # must share PyTorch's HIP runtime
+
+
+def test_config_validation_without_device():
+    L = flib.load()
+    cfg = flib.WgConfig(80, 160, 12, 8, 4, 2, 8, 256, 3, 1024)
+    n = L.facppg_wg_weight_count(cfg)
+    from facppg import synth
+    assert n == sum(v.numel() for v in synth.waveglow_state_dict().values())
+    bad = flib.WgConfig(80, 160, 12, 8, 4, 2, 8, 128, 3, 1024)
+    assert L.facppg_wg_weight_count(bad) == 0
+    assert b"n_channels=256" in L.facppg_last_error()
+    assert L.facppg_wg_workspace_bytes(None, 1, 1) == 0
+
+
+def test_no_cpu_fallback():
+    from waveglow.glow import WaveGlow
+    from facppg import synth
+    cfg = dict(synth.WAVEGLOW_CONFIG, n_flows=1)
+    m = WaveGlow(**cfg)
+    with pytest.raises(flib.FacppgError, match="no CPU path"):
+        m.infer(torch.zeros(1, 80, 4))
