@@ -39,27 +39,47 @@ def layer_flops_per_position(n_layers=8, C=256, ncond=640):
     return ((n_layers - 1) * (g1 + 2 * C * 2 * C) + (g1 + 2 * C * C)) / n_layers
 
 
-def cpu_baseline(cfg, sd):
-    """Oracle WaveGlow.infer on the host cores, bounded sample of the same workload."""
+def cpu_baseline_worker(threads, frames):
+    """Oracle WaveGlow.infer (a port of the reference's PyTorch-CPU path, validated against the
+    reference's golden vectors) on `threads` host cores; prints one JSON line."""
     from facppg import synth
     from oracle import waveglow as owg
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    Bc, Tc = 1, 150
-    mel = synth.synthetic_mel(Bc, Tc, seed=1234)
-    zs = synth.synthetic_z(Bc, Tc * HOP // 8, cfg, seed=4321)
-    sd = {k: v.float() for k, v in sd.items()}
-    times = []
+    torch.set_num_threads(threads)
+    cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=HOP)
+    sd = synth.waveglow_state_dict(cfg)
+    mel = synth.synthetic_mel(1, frames, seed=1234)
+    zs = synth.synthetic_z(1, frames * HOP // 8, cfg, seed=4321)
     with torch.no_grad():
         owg.infer(sd, cfg, mel[:, :, :20], 0.6, [z[:, :, :20 * HOP // 8] for z in zs])   # warm-up
-        for _ in range(2):
-            t0 = time.perf_counter()
-            owg.infer(sd, cfg, mel, 0.6, zs)
-            times.append(time.perf_counter() - t0)
-    t = min(times)
-    return {"value": Bc * Tc * HOP / t, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "oracle WaveGlow.infer B=%d mel 80x%d hop=%d fp32 (%d samples), best of 2, torch-CPU %d threads"
-                      % (Bc, Tc, HOP, Bc * Tc * HOP, cores)}
+        t0 = time.perf_counter()
+        owg.infer(sd, cfg, mel, 0.6, zs)
+        t = time.perf_counter() - t0
+    print(json.dumps({"threads": threads, "frames": frames, "seconds": t, "value": frames * HOP / t}))
+
+
+def cpu_baseline(log):
+    """Bounded CPU sample in subprocesses (a 256-thread oneDNN run of these small convs is
+    pathologically slow, so a few thread counts are tried under a timeout and the best is reported)."""
+    import subprocess
+    frames, best = 600, None
+    for threads in (16, 32):
+        if threads > (os.cpu_count() or 1):
+            continue
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(threads), str(frames)],
+                               capture_output=True, text=True, timeout=120)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            log("cpu baseline: %d threads -> %.0f samples/s (%.1f s)" % (threads, d["value"], d["seconds"]))
+            if best is None or d["value"] > best["value"]:
+                best = d
+        except Exception as e:  # timeout or parse failure: report what we have
+            log("cpu baseline with %d threads failed: %r" % (threads, e))
+    if best is None:
+        return None
+    return {"value": best["value"], "unit": "samples/s", "cores": best["threads"], "kind": "port",
+            "host_cpus": os.cpu_count(),
+            "sample": "oracle (torch-CPU fp32 port of the reference path) WaveGlow.infer B=1 mel 80x%d hop=%d = %d samples, "
+                      "%.1f s on %d threads (best of 16/32 threads)" % (frames, HOP, frames * HOP, best["seconds"], best["threads"])}
 
 
 def main():
@@ -68,8 +88,12 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", nargs=2, type=int, metavar=("THREADS", "FRAMES"), help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker(*args.cpu_baseline_worker)
 
+    t_start = time.perf_counter()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,8 +124,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def log(msg):
+        if rank == 0:
+            print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
+    log("model ready; warmup")
     for i in range(args.warmup):
         step(i)
+    torch.cuda.synchronize(dev)
+    log("warmup done")
     handle = model._handle(dev)
     flib.check(L.facppg_wg_set_profiling(handle, 1))
     layer_ms, layer_n = [], 0
@@ -111,6 +142,7 @@ def main():
         audio = step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
+    log("timed region done: %.3f s" % elapsed)
     ms = flib.ctypes.c_float()
     n = flib.ctypes.c_int()
     flib.check(L.facppg_wg_last_layer_ms(handle, flib.ctypes.byref(ms), flib.ctypes.byref(n)))
@@ -141,7 +173,7 @@ def main():
                      "flops_per_launch": flops},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, sd)
+        out["cpu_baseline"] = cpu_baseline(log)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
