@@ -1,0 +1,275 @@
+"""Tacotron2-style PPG -> mel model -- drop-in for src/common/model.py.
+
+The module tree (names, parameter shapes, state-dict keys: SURVEY.md Appendix B) equals the
+reference's so ``load_state_dict(torch.load(ckpt)['state_dict'])`` works unchanged
+(generate_synthesis.py:82).  The modules hold parameters only; ``Tacotron2.inference`` packs
+them once into a ``facppg_taco`` handle and runs the encoder GEMMs, the BiLSTM kernel, the
+persistent decoder kernel and the postnet GEMMs of csrc/facppg_taco.hip through the C ABI.
+There is no CPU path.
+
+Extensions over the reference signature (defaults reproduce it):
+  ``inference(inputs, lengths=None, dropout_masks=None, seed=None)``
+    lengths        valid PPG frames per utterance for a padded batch; every utterance is decoded
+                   exactly as its own batch-1 run (the reference only supports batch 1,
+                   model.py:524-528)
+    dropout_masks  (enc [2, B, Tin, E], dec [steps, 2, B, prenet_dim]) keep-masks in {0,1} for the
+                   prenets' always-on dropout (model.py:132-135); None -> drawn on the device
+"""
+import torch
+from torch import nn
+
+from common.layers import ConvNorm, LinearNorm
+from facppg import lib as _lib
+
+
+class LocationLayer(nn.Module):
+    """model.py:44-60"""
+
+    def __init__(self, attention_n_filters, attention_kernel_size, attention_dim):
+        super(LocationLayer, self).__init__()
+        self.location_conv = ConvNorm(2, attention_n_filters, kernel_size=attention_kernel_size,
+                                      padding=(attention_kernel_size - 1) // 2, bias=False, stride=1, dilation=1)
+        self.location_dense = LinearNorm(attention_n_filters, attention_dim, bias=False, w_init_gain='tanh')
+
+
+class Attention(nn.Module):
+    """model.py:63-121 (location-sensitive attention); evaluated inside k_decoder."""
+
+    def __init__(self, attention_rnn_dim, embedding_dim, attention_dim, attention_location_n_filters,
+                 attention_location_kernel_size):
+        super(Attention, self).__init__()
+        self.query_layer = LinearNorm(attention_rnn_dim, attention_dim, bias=False, w_init_gain='tanh')
+        self.memory_layer = LinearNorm(embedding_dim, attention_dim, bias=False, w_init_gain='tanh')
+        self.v = LinearNorm(attention_dim, 1, bias=False)
+        self.location_layer = LocationLayer(attention_location_n_filters, attention_location_kernel_size, attention_dim)
+        self.score_mask_value = -float("inf")
+        self.not_so_small_mask = -1000
+
+
+class Prenet(nn.Module):
+    """model.py:124-135: bias-free Linear + ReLU + dropout(p=0.5, ALWAYS on) per layer."""
+
+    def __init__(self, in_dim, sizes):
+        super(Prenet, self).__init__()
+        in_sizes = [in_dim] + sizes[:-1]
+        self.layers = nn.ModuleList([LinearNorm(i, o, bias=False) for i, o in zip(in_sizes, sizes)])
+
+
+class Postnet(nn.Module):
+    """model.py:138-184: five 1-D convolutions (k=5) with BatchNorm, tanh on all but the last."""
+
+    def __init__(self, hparams):
+        super(Postnet, self).__init__()
+        nf, pe, pk = hparams.n_acoustic_feat_dims, hparams.postnet_embedding_dim, hparams.postnet_kernel_size
+        dims = [nf] + [pe] * (hparams.postnet_n_convolutions - 1) + [nf]
+        self.convolutions = nn.ModuleList()
+        for j in range(hparams.postnet_n_convolutions):
+            last = j == hparams.postnet_n_convolutions - 1
+            self.convolutions.append(nn.Sequential(
+                ConvNorm(dims[j], dims[j + 1], kernel_size=pk, stride=1, padding=(pk - 1) // 2, dilation=1,
+                         w_init_gain='linear' if last else 'tanh'),
+                nn.BatchNorm1d(dims[j + 1])))
+
+
+class Encoder(nn.Module):
+    """model.py:187-249: prenet, conv bank (conv+BN+ReLU), bidirectional LSTM."""
+
+    def __init__(self, hparams):
+        super(Encoder, self).__init__()
+        E = hparams.encoder_embedding_dim
+        self.prenet = Prenet(hparams.n_symbols, [hparams.symbols_embedding_dim, hparams.symbols_embedding_dim])
+        ks = hparams.encoder_kernel_size
+        self.convolutions = nn.ModuleList([
+            nn.Sequential(ConvNorm(E, E, kernel_size=ks, stride=1, padding=(ks - 1) // 2, dilation=1, w_init_gain='relu'),
+                          nn.BatchNorm1d(E))
+            for _ in range(hparams.encoder_n_convolutions)])
+        self.lstm = nn.LSTM(E, E // 2, 1, batch_first=True, bidirectional=True)
+
+
+class Decoder(nn.Module):
+    """model.py:252-535"""
+
+    def __init__(self, hparams):
+        super(Decoder, self).__init__()
+        self.n_acoustic_feat_dims = hparams.n_acoustic_feat_dims
+        self.encoder_embedding_dim = hparams.encoder_embedding_dim
+        self.attention_rnn_dim = hparams.attention_rnn_dim
+        self.decoder_rnn_dim = hparams.decoder_rnn_dim
+        self.prenet_dim = hparams.prenet_dim
+        self.max_decoder_steps = hparams.max_decoder_steps
+        self.gate_threshold = hparams.gate_threshold
+        self.p_attention_dropout = hparams.p_attention_dropout
+        self.p_decoder_dropout = hparams.p_decoder_dropout
+        self.attention_window_size = hparams.attention_window_size
+        self.prenet = Prenet(hparams.n_acoustic_feat_dims, [hparams.prenet_dim, hparams.prenet_dim])
+        self.attention_rnn = nn.LSTMCell(hparams.prenet_dim + hparams.encoder_embedding_dim, hparams.attention_rnn_dim)
+        self.attention_layer = Attention(hparams.attention_rnn_dim, hparams.encoder_embedding_dim, hparams.attention_dim,
+                                         hparams.attention_location_n_filters, hparams.attention_location_kernel_size)
+        self.decoder_rnn = nn.LSTMCell(hparams.attention_rnn_dim + hparams.encoder_embedding_dim, hparams.decoder_rnn_dim, 1)
+        self.linear_projection = LinearNorm(hparams.decoder_rnn_dim + hparams.encoder_embedding_dim,
+                                            hparams.n_acoustic_feat_dims)
+        self.gate_layer = LinearNorm(hparams.decoder_rnn_dim + hparams.encoder_embedding_dim, 1, bias=True,
+                                     w_init_gain='sigmoid')
+
+
+class Tacotron2(nn.Module):
+    """model.py:538-610"""
+
+    def __init__(self, hparams):
+        super(Tacotron2, self).__init__()
+        self.mask_padding = hparams.mask_padding
+        self.fp16_run = hparams.fp16_run
+        self.n_acoustic_feat_dims = hparams.n_acoustic_feat_dims
+        self.encoder = Encoder(hparams)
+        self.decoder = Decoder(hparams)
+        self.postnet = Postnet(hparams)
+        self._hp = {k: getattr(hparams, k) for k in (
+            "n_symbols", "symbols_embedding_dim", "encoder_kernel_size", "encoder_n_convolutions", "encoder_embedding_dim",
+            "n_acoustic_feat_dims", "prenet_dim", "attention_rnn_dim", "decoder_rnn_dim", "attention_dim",
+            "attention_location_n_filters", "attention_location_kernel_size", "attention_window_size",
+            "postnet_embedding_dim", "postnet_kernel_size", "postnet_n_convolutions", "gate_threshold")}
+
+    # ---------------------------------------------------------------- HIP handle
+    def _config(self):
+        c = _lib.TacoConfig()
+        for k, v in self._hp.items():
+            if k == "attention_window_size":
+                v = -1 if v is None else int(v)
+            setattr(c, k, v)
+        c.gate_threshold = float(self.decoder.gate_threshold)
+        c.bn_eps = float(self.postnet.convolutions[0][1].eps)
+        return c
+
+    def _flat_weights(self):
+        """Plain weight blob in the order include/facppg.h documents."""
+        sd = self.state_dict()
+        keys = ["encoder.prenet.layers.0.linear_layer.weight", "encoder.prenet.layers.1.linear_layer.weight"]
+        for j in range(len(self.encoder.convolutions)):
+            p = "encoder.convolutions.%d." % j
+            keys += [p + "0.conv.weight", p + "0.conv.bias", p + "1.weight", p + "1.bias", p + "1.running_mean", p + "1.running_var"]
+        for sfx in ("", "_reverse"):
+            keys += ["encoder.lstm.%s_l0%s" % (n, sfx) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        keys += ["decoder.prenet.layers.0.linear_layer.weight", "decoder.prenet.layers.1.linear_layer.weight"]
+        keys += ["decoder.attention_rnn." + n for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        a = "decoder.attention_layer."
+        keys += [a + "query_layer.linear_layer.weight", a + "memory_layer.linear_layer.weight", a + "v.linear_layer.weight",
+                 a + "location_layer.location_conv.conv.weight", a + "location_layer.location_dense.linear_layer.weight"]
+        keys += ["decoder.decoder_rnn." + n for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        keys += ["decoder.linear_projection.linear_layer.weight", "decoder.linear_projection.linear_layer.bias",
+                 "decoder.gate_layer.linear_layer.weight", "decoder.gate_layer.linear_layer.bias"]
+        for j in range(len(self.postnet.convolutions)):
+            p = "postnet.convolutions.%d." % j
+            keys += [p + "0.conv.weight", p + "0.conv.bias", p + "1.weight", p + "1.bias", p + "1.running_mean", p + "1.running_var"]
+        return torch.cat([sd[k].detach().float().reshape(-1) for k in keys])
+
+    def _release(self):
+        h = self.__dict__.pop("_facppg_handle", None)
+        if h is not None:
+            _lib.load().facppg_taco_destroy(h[0])
+
+    def _handle(self, dev):
+        h = self.__dict__.get("_facppg_handle")
+        if h is not None and h[1] == dev:
+            return h[0]
+        self._release()
+        L = _lib.load()
+        cfg = self._config()
+        blob = self._flat_weights().to(dev).contiguous()
+        if blob.numel() != L.facppg_taco_weight_count(cfg):
+            raise _lib.FacppgError("weight blob has %d values, library expects %d: %s" % (
+                blob.numel(), L.facppg_taco_weight_count(cfg), L.facppg_last_error().decode()))
+        out = _lib.ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            _lib.check(L.facppg_taco_create(cfg, _lib.ptr(blob), blob.numel(), dev.index, _lib.current_stream(dev),
+                                            _lib.ctypes.byref(out)))
+        self.__dict__["_facppg_handle"] = (out, dev)
+        return out
+
+    def _apply(self, fn, *a, **k):
+        self._release()
+        return super(Tacotron2, self)._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._release()
+        return super(Tacotron2, self).load_state_dict(*a, **k)
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_facppg_handle", None)
+        return d
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- reference surface
+    def parse_input(self, inputs):
+        if self.fp16_run:
+            raise _lib.FacppgError("fp16_run is not built (the reference's README.md:53 says FP16 does not work either)")
+        return inputs
+
+    def parse_output(self, outputs, output_lengths=None):
+        return outputs
+
+    def forward(self, inputs):
+        raise NotImplementedError("teacher-forced training of the PPG->mel model is out of scope (SURVEY.md section 2)")
+
+    def inference(self, inputs, lengths=None, dropout_masks=None, seed=None):
+        """inputs [B, n_symbols, Tin] (GPU fp32) -> [mel, mel_post, gate, alignments]
+        = [B,80,Tout], [B,80,Tout], [B,Tout,1], [B,Tout,Tin]  (model.py:597-610).  For B > 1 the
+        outputs are zero beyond each utterance's own Tout, kept in ``self.last_output_lengths``."""
+        inputs = self.parse_input(inputs)
+        _lib.require_cuda(inputs, "Tacotron2.inference: inputs")
+        L = _lib.load()
+        dev = inputs.device
+        x = inputs.float().contiguous()
+        B, D, Tin = x.shape
+        hp = self._hp
+        if D != hp["n_symbols"]:
+            raise _lib.FacppgError("inputs have %d symbols, model was built for %d" % (D, hp["n_symbols"]))
+        h = self._handle(dev)
+        lt = None
+        if lengths is not None:
+            lt = torch.as_tensor(lengths).to(device=dev, dtype=torch.int32).contiguous()
+            if lt.numel() != B or int(lt.max()) > Tin or int(lt.min()) < 1:
+                raise _lib.FacppgError("lengths must be B values in [1, Tin]")
+        if seed is None:
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        seed &= 0xFFFFFFFFFFFFFFFF
+        enc_m = dec_m = None
+        steps = int(self.decoder.max_decoder_steps)
+        E, P, NF, AD = hp["encoder_embedding_dim"], hp["prenet_dim"], hp["n_acoustic_feat_dims"], hp["attention_dim"]
+        if dropout_masks is not None:
+            em, dm = dropout_masks
+            enc_m = torch.as_tensor(em).to(dev).to(torch.uint8).reshape(2, B, Tin, E).permute(0, 1, 3, 2).contiguous()
+            dec_m = torch.as_tensor(dm).to(dev).to(torch.uint8).contiguous()
+            if dec_m.numel() != steps * 2 * B * P:
+                raise _lib.FacppgError("decoder masks must be [max_decoder_steps, 2, B, prenet_dim]")
+        ws = torch.empty(max(L.facppg_taco_workspace_bytes(h, B, Tin), L.facppg_taco_decode_workspace_bytes(h, B, steps)),
+                         dtype=torch.uint8, device=dev)
+        memory = torch.zeros(B, Tin, E, device=dev)
+        pm = torch.zeros(B, Tin, AD, device=dev)
+        mel = torch.zeros(B, NF, steps, device=dev)
+        gate = torch.zeros(B, steps, device=dev)
+        align = torch.zeros(B, steps, Tin, device=dev)
+        out_len = torch.zeros(B, dtype=torch.int32, device=dev)
+        st = _lib.current_stream(dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.facppg_taco_encode(h, _lib.ptr(x), _lib.ptr(lt), _lib.ptr(enc_m), seed, B, Tin, _lib.ptr(memory),
+                                            _lib.ptr(pm), _lib.ptr(ws), ws.numel(), st))
+            _lib.check(L.facppg_taco_decode(h, _lib.ptr(memory), _lib.ptr(pm), _lib.ptr(lt), _lib.ptr(dec_m), seed, B, Tin,
+                                            steps, _lib.ptr(mel), _lib.ptr(gate), _lib.ptr(align), _lib.ptr(out_len),
+                                            _lib.ptr(ws), ws.numel(), st))
+            out_len_host = out_len.cpu()                       # the path's single device->host sync
+            Tout = int(out_len_host.max())
+            if Tout == steps and bool((out_len_host == steps).any()):
+                print("Warning! Reached max decoder steps")     # model.py:527
+            mel_post = torch.zeros_like(mel)
+            ws2 = torch.empty(L.facppg_taco_postnet_workspace_bytes(h, B, Tout), dtype=torch.uint8, device=dev)
+            _lib.check(L.facppg_taco_postnet(h, _lib.ptr(mel), _lib.ptr(out_len), B, Tout, steps, _lib.ptr(mel_post),
+                                             _lib.ptr(ws2), ws2.numel(), st))
+        self.last_output_lengths = out_len_host.to(torch.long)
+        self.last_memory = memory
+        return self.parse_output([mel[:, :, :Tout], mel_post[:, :, :Tout], gate[:, :Tout].unsqueeze(-1), align[:, :Tout]])

@@ -1,0 +1,143 @@
+// Generic exact-fp32 MFMA tapped GEMM (see facppg_gemm.h).  One workgroup = 4 waves computes a
+// 128 (rows) x 64 (columns) tile: wave w owns rows 32w..32w+31 (one MFMA row block) and both
+// 32-column blocks.  The activation operand is staged through LDS in [64 k-rows][64 columns]
+// chunks (double buffered, register-staged so the global loads of chunk c+1 fly under the MFMAs
+// of chunk c); the weight operand streams straight from its packed image into registers.
+#include "facppg_gemm.h"
+
+namespace facppg {
+namespace {
+
+constexpr int TN = 64, KCH = 64;
+
+__global__ void k_pack_a(const float* __restrict__ src, float4* __restrict__ dst, int M, int Cin, int taps, int KG) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int MB = (M + 31) / 32;
+  if (idx >= MB * (KG + 1) * 64) return;
+  const int lane = idx & 63, g = (idx >> 6) % (KG + 1), mb = (idx >> 6) / (KG + 1);
+  const int m = mb * 32 + (lane & 31), K = Cin * taps;
+  float v[4];
+  for (int s = 0; s < 4; ++s) {
+    const int k = 8 * g + 4 * (lane >> 5) + s;
+    const int tap = k / Cin, c = k - tap * Cin;
+    v[s] = (m < M && k < K && g < KG) ? src[((size_t)m * Cin + c) * taps + tap] : 0.0f;
+  }
+  dst[idx] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+struct KArgs {
+  GemmArgs g;
+  int KG;  // k-groups of 8 (Kpad / 8)
+};
+
+__global__ __launch_bounds__(256) void k_gemm(KArgs ka) {
+  const GemmArgs& p = ka.g;
+  __shared__ __attribute__((aligned(16))) float smem[2 * KCH * TN];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
+  const int b = blockIdx.z, n0 = blockIdx.x * TN;
+  const int Nb = p.n_valid ? min(p.N, p.n_valid[b] * p.n_valid_mul + p.n_valid_add) : p.N;
+  if (n0 >= Nb) return;
+  const int mb = blockIdx.y * 4 + w;
+  const int MB = (p.M + 31) / 32;
+  const bool active = mb < MB;
+  const int K = p.Cin * p.taps;
+  const int nch = ka.KG / 8;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; }
+
+  const float* xb = p.X + (size_t)b * p.x_bs;
+  const int col = n0 + lane;
+  float stg[16];
+  auto stage_load = [&](int c) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int kk = c * KCH + w * 16 + j;
+      const int tap = kk / p.Cin, ch = kk - tap * p.Cin;
+      const int sc = col + (tap - p.pad) * p.dil;
+      stg[j] = (kk < K && sc >= 0 && sc < Nb) ? xb[(size_t)ch * p.ldx + sc] : 0.0f;
+    }
+  };
+  auto stage_write = [&](int buf) {
+    float* dst = smem + buf * (KCH * TN) + (w * 16) * TN + lane;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dst[j * TN] = stg[j];
+  };
+
+  const float4* ap = p.A + (size_t)(active ? mb : 0) * (ka.KG + 1) * 64 + lane;
+  float4 a0, a1;
+  stage_load(0);
+  a0 = ap[0];
+  stage_write(0);
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+    if (c + 1 < nch) stage_load(c + 1);
+    const float* lb = smem + (c & 1) * (KCH * TN) + (4 * kh) * TN + li;
+    const int G = c * 8;
+#pragma unroll
+    for (int g = 0; g < 8; g += 2) {
+      a1 = ap[(G + g + 1) * 64];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float av = s == 0 ? a0.x : s == 1 ? a0.y : s == 2 ? a0.z : a0.w;
+        acc[0] = mfma32x32x2(av, lb[(8 * g + s) * TN], acc[0]);
+        acc[1] = mfma32x32x2(av, lb[(8 * g + s) * TN + 32], acc[1]);
+      }
+      a0 = ap[(G + g + 2) * 64];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float av = s == 0 ? a1.x : s == 1 ? a1.y : s == 2 ? a1.z : a1.w;
+        acc[0] = mfma32x32x2(av, lb[(8 * (g + 1) + s) * TN], acc[0]);
+        acc[1] = mfma32x32x2(av, lb[(8 * (g + 1) + s) * TN + 32], acc[1]);
+      }
+    }
+    if (c + 1 < nch) stage_write((c + 1) & 1);
+    __syncthreads();
+  }
+  if (!active) return;
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int n = n0 + cb * 32 + li;
+    if (n >= Nb) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mb * 32 + 8 * (r >> 2) + (r & 3) + 4 * kh;
+      if (m >= p.M) continue;
+      float v = acc[cb][r];
+      if (p.bias) v += p.bias[m];
+      if (p.scale) v = v * p.scale[m] + p.shift[m];
+      if (p.act == ACT_RELU) v = fmaxf(v, 0.0f);
+      else if (p.act == ACT_TANH) v = tanhf(v);
+      else if (p.act == ACT_LOG_CLAMP) v = logf(fmaxf(v, 1e-5f));
+      if (p.mask) v = v * (float)p.mask[(size_t)b * p.mask_bs + (size_t)m * p.ldmask + n] * 2.0f;
+      if (p.res) v += p.res[(size_t)b * p.res_bs + (size_t)m * p.ldres + n];
+      if (p.c_transposed) p.C[(size_t)b * p.c_bs + (size_t)n * p.ldc + m] = v;
+      else p.C[(size_t)b * p.c_bs + (size_t)m * p.ldc + n] = v;
+    }
+  }
+}
+
+}  // namespace
+
+int pack_a(const float* src, int M, int Cin, int taps, float4* dst, hipStream_t s) {
+  const int KG = gemm_kpad(Cin * taps) / 8;
+  const int total = (round_up(M, 32) / 32) * (KG + 1) * 64;
+  k_pack_a<<<(total + 255) / 256, 256, 0, s>>>(src, dst, M, Cin, taps, KG);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+int gemm_launch(const GemmArgs& a, hipStream_t s) {
+  FACPPG_REQUIRE(a.A && a.X && a.C && a.M > 0 && a.N > 0 && a.Cin > 0 && a.taps > 0 && a.B > 0, FACPPG_EINVAL,
+                 "gemm_launch: bad arguments");
+  KArgs ka;
+  ka.g = a;
+  ka.KG = gemm_kpad(a.Cin * a.taps) / 8;
+  dim3 grid((a.N + TN - 1) / TN, (round_up(a.M, 32) / 32 + 3) / 4, a.B);
+  k_gemm<<<grid, 256, 0, s>>>(ka);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+}  // namespace facppg

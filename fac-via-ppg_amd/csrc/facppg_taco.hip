@@ -1,0 +1,712 @@
+// Tacotron2-style PPG -> mel inference on gfx950: encoder, autoregressive decoder, postnet.
+//
+// Replaces src/common/model.py of the reference: Prenet (:124-135), Encoder.inference (:237-249),
+// LocationLayer/Attention (:44-121), Decoder.inference/decode (:489-535, :387-442), Postnet
+// (:138-184), Tacotron2.inference (:597-610) and the attention window mask
+// get_mask_from_lengths_window_and_time_step (src/common/utils.py:46-78).
+//
+// Layout: activations are channel-major [B][C][T] (time contiguous), so every Linear/Conv1d of
+// the encoder and postnet is one exact-fp32 MFMA tapped GEMM (facppg_gemm) with the bias, eval
+// BatchNorm (as per-row scale/shift), ReLU/tanh, dropout mask and residual fused in its epilogue.
+// The two sequential parts run as persistent workgroups, one per (utterance[, direction]):
+//   k_bilstm   the encoder BiLSTM recurrence (input projections were one GEMM for all t)
+//   k_decoder  the whole autoregressive loop: no host round trip per frame (the reference syncs the
+//              host at least twice per frame: the stop test model.py:524 and the Python mask builder),
+//              the stop decision is taken on the device and the attention is evaluated only on
+//              the +-window positions the reference's mask keeps (<= 2W+1 of Tin).
+// Recurrent weights are stored K-major ([k][rows], rows padded to 4) so a thread streams float4
+// columns with fully coalesced 16-byte loads; a 1200x1200 step is 900 threads x 400 loads.
+#include <cstring>
+#include <new>
+
+#include "facppg_gemm.h"
+
+using namespace facppg;
+
+struct facppg_taco {
+  facppg_taco_config c;
+  int device;
+  char* arena;
+  // encoder
+  float4 *pre0, *pre1, *conv[8], *wih;
+  float *conv_b[8], *conv_scale[8], *conv_shift[8];
+  float *whh_t[2], *lstm_b;        // [2][H][4H] k-major, bias [2][4H]
+  float4* mem_w;                   // memory_layer packed
+  // decoder (k-major, rows padded to a multiple of 4)
+  float *dp0_t, *dp1_t, *att_t, *att_b, *dec_t, *dec_b, *q_t, *proj_t, *proj_b;
+  float *loc_conv, *loc_dense, *v;
+  // postnet
+  float4* post[8];
+  float *post_b[8], *post_scale[8], *post_shift[8];
+};
+
+namespace {
+
+constexpr int NT = 1024;  // threads of the persistent kernels
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// dst[k_off + k][Rp] = src[r][k]  (k-major transpose with row padding)
+__global__ void k_transpose_pad(const float* __restrict__ src, float* __restrict__ dst, int R, int K, int Rp, int k_off) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * Rp) return;
+  const int k = i / Rp, r = i % Rp;
+  dst[(size_t)(k_off + k) * Rp + r] = r < R ? src[(size_t)r * K + k] : 0.0f;
+}
+__global__ void k_add2(const float* a, const float* b, float* o, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a[i] + b[i];
+}
+__global__ void k_bn_fold(const float* w, const float* b, const float* mean, const float* var, float eps, float* scale,
+                          float* shift, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float s = w[i] / sqrtf(var[i] + eps);
+    scale[i] = s;
+    shift[i] = b[i] - mean[i] * s;
+  }
+}
+
+// Philox-free cheap keep-mask: one 64-bit SplitMix hash per element (p = 0.5 Bernoulli).
+__global__ void k_random_mask(uint8_t* __restrict__ out, size_t n, uint64_t seed) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (i + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  out[i] = (uint8_t)((z >> 40) & 1);
+}
+
+// partial matvec: part[ks][Rp] = sum_{k in split ks} WT[k][Rp] * v[k]; thread = (slot of 4 rows, k split)
+__device__ __forceinline__ void matvec_part(const float* __restrict__ WT, int K, int Rp, int KS, const float* v, float* part,
+                                            int tid) {
+  const int ns = Rp >> 2;
+  const int slot = tid % ns, ks = tid / ns;
+  if (ks >= KS) return;
+  const int k0 = (int)((long)ks * K / KS), k1 = (int)((long)(ks + 1) * K / KS);
+  const float4* w = reinterpret_cast<const float4*>(WT) + slot;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int k = k0; k < k1; ++k) {
+    const float4 wv = w[(size_t)k * ns];
+    const float vk = v[k];
+    acc.x = fmaf(wv.x, vk, acc.x); acc.y = fmaf(wv.y, vk, acc.y);
+    acc.z = fmaf(wv.z, vk, acc.z); acc.w = fmaf(wv.w, vk, acc.w);
+  }
+  reinterpret_cast<float4*>(part)[ks * ns + slot] = acc;
+}
+__device__ __forceinline__ int pick_ks(int Rp, int K) {
+  int ks = NT / (Rp >> 2);
+  if (ks > K) ks = K;
+  return ks < 1 ? 1 : ks;
+}
+__device__ __forceinline__ float part_sum(const float* part, int Rp, int KS, int r) {
+  float s = 0.0f;
+  for (int i = 0; i < KS; ++i) s += part[i * Rp + r];
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// Encoder BiLSTM recurrence (nn.LSTM, gate order i,f,g,o; model.py:211-213, 246-247).
+// xproj[b][t][dir*4H + row] = W_ih x_t + b_ih + b_hh (from the GEMM).  grid = (2, B).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_bilstm(const float* __restrict__ xproj, const float* __restrict__ whh_t0,
+                                               const float* __restrict__ whh_t1, const int* __restrict__ lengths, int Tin, int H,
+                                               float* __restrict__ mem_tm /*[B][Tin][2H]*/, float* __restrict__ mem_cm /*[B][2H][Tin]*/) {
+  extern __shared__ float sm[];
+  const int dir = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int R = 4 * H;
+  float* hv = sm;             // [H]
+  float* cv = hv + H;         // [H]
+  float* part = cv + H;       // [KS][R]
+  const float* WT = dir ? whh_t1 : whh_t0;
+  const int len = lengths ? lengths[b] : Tin;
+  const int KS = pick_ks(R, H);
+  for (int i = tid; i < H; i += NT) { hv[i] = 0.0f; cv[i] = 0.0f; }
+  __syncthreads();
+  for (int s = 0; s < len; ++s) {
+    const int t = dir ? len - 1 - s : s;
+    matvec_part(WT, H, R, KS, hv, part, tid);
+    __syncthreads();
+    if (tid < H) {
+      const float* xp = xproj + ((size_t)b * Tin + t) * (2 * R) + dir * R;
+      const float gi = part_sum(part, R, KS, tid) + xp[tid];
+      const float gf = part_sum(part, R, KS, H + tid) + xp[H + tid];
+      const float gg = part_sum(part, R, KS, 2 * H + tid) + xp[2 * H + tid];
+      const float go = part_sum(part, R, KS, 3 * H + tid) + xp[3 * H + tid];
+      const float c = sigm(gf) * cv[tid] + sigm(gi) * tanhf(gg);
+      const float h = sigm(go) * tanhf(c);
+      cv[tid] = c; hv[tid] = h;
+      mem_tm[((size_t)b * Tin + t) * (2 * H) + dir * H + tid] = h;
+      mem_cm[((size_t)b * 2 * H + dir * H + tid) * Tin + t] = h;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Decoder loop.  grid = B, block = 1024.
+// ------------------------------------------------------------------------------------------
+struct DecArgs {
+  const float *dp0_t, *dp1_t, *att_t, *att_b, *dec_t, *dec_b, *q_t, *proj_t, *proj_b, *loc_conv, *loc_dense, *v;
+  const float* memory;   // [B][Tin][E]
+  const float* pm;       // [B][Tin][AD]
+  const int* lengths;    // [B] or null
+  const uint8_t* masks;  // [steps][2][B][P]
+  float* mel;            // [B][NF][max_steps]
+  float* gate;           // [B][max_steps]
+  float* align;          // [B][max_steps][Tin] or null
+  int* out_len;          // [B]
+  int B, Tin, E, P, A, D, AD, NF, NFIL, KSZ, window, max_steps;
+  float gate_thr;
+};
+
+__global__ __launch_bounds__(NT) void k_decoder(DecArgs p) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int len = p.lengths ? p.lengths[b] : p.Tin;
+  const int G = 4 * p.A;                 // LSTM gate rows (A == D checked on the host)
+  const int KA = p.P + p.E + p.A;        // attention LSTM input: [prenet | ctx | ah]
+  const int KD = p.A + p.E + p.D;        // decoder LSTM input:   [ah | ctx | dh]
+  const int KP = p.D + p.E;              // projection input:     [dh | ctx]
+  const int ADp = round_up(p.AD, 4), NFp = round_up(p.NF + 1, 4), Pp = round_up(p.P, 4);
+  // LDS carve
+  float* in_att = sm;                    // [KA]
+  float* in_dec = in_att + KA;           // [KD]
+  float* in_proj = in_dec + KD;          // [KP]
+  float* ac = in_proj + KP;              // [A]
+  float* dc = ac + p.A;                  // [D]
+  float* xin = dc + p.D;                 // [NF] previous frame
+  float* p1 = xin + round_up(p.NF, 4);   // [P]
+  float* pq = p1 + Pp;                   // [ADp]
+  float* part = pq + ADp;                // [4096]
+  float* feat = part + 4096;             // [64][NFIL]
+  float* lconv = feat + 64 * p.NFIL;     // [NFIL*2*KSZ]
+  float* ldense = lconv + round_up(p.NFIL * 2 * p.KSZ, 4);  // [AD][NFIL]
+  float* vv = ldense + p.AD * p.NFIL;    // [AD]
+  float* wprev = vv + ADp;               // [Tin]
+  float* wcum = wprev + p.Tin;           // [Tin]
+  float* en = wcum + p.Tin;              // [Tin] energies -> new weights
+  __shared__ int s_stop;
+
+  for (int i = tid; i < KA + KD + KP + p.A + p.D + round_up(p.NF, 4) + Pp + ADp; i += NT) sm[i] = 0.0f;
+  for (int i = tid; i < p.NFIL * 2 * p.KSZ; i += NT) lconv[i] = p.loc_conv[i];
+  for (int i = tid; i < p.AD * p.NFIL; i += NT) ldense[i] = p.loc_dense[i];
+  for (int i = tid; i < p.AD; i += NT) vv[i] = p.v[i];
+  for (int i = tid; i < 3 * p.Tin; i += NT) wprev[i] = 0.0f;
+  if (tid == 0) s_stop = 0;
+  __syncthreads();
+
+  const float* mem = p.memory + (size_t)b * p.Tin * p.E;
+  const float* pm = p.pm + (size_t)b * p.Tin * p.AD;
+  float* ah = in_att + p.P + p.E;   // attention hidden lives inside in_att; copied into in_dec[0:A]
+  float* ctx_a = in_att + p.P;      // context copy for the attention LSTM
+  float* dh = in_dec + p.A + p.E;   // decoder hidden lives inside in_dec; copied into in_proj[0:D]
+
+  int t = 0;
+  for (;; ++t) {
+    const uint8_t* mk = p.masks + ((size_t)t * 2 * p.B + b) * p.P;
+    // ---- prenet layer 0: relu(W0 x) * mask * 2   (model.py:132-135)
+    {
+      const int KS = pick_ks(Pp, p.NF);
+      matvec_part(p.dp0_t, p.NF, Pp, KS, xin, part, tid);
+      __syncthreads();
+      if (tid < p.P) p1[tid] = fmaxf(part_sum(part, Pp, KS, tid), 0.0f) * (float)mk[tid] * 2.0f;
+      __syncthreads();
+    }
+    // ---- prenet layer 1 -> in_att[0:P]
+    {
+      const int KS = pick_ks(Pp, p.P);
+      matvec_part(p.dp1_t, p.P, Pp, KS, p1, part, tid);
+      __syncthreads();
+      if (tid < p.P) in_att[tid] = fmaxf(part_sum(part, Pp, KS, tid), 0.0f) * (float)mk[(size_t)p.B * p.P + tid] * 2.0f;
+      __syncthreads();
+    }
+    // ---- attention LSTMCell on [prenet | ctx | ah]   (model.py:400-403)
+    {
+      const int KS = pick_ks(G, KA);
+      matvec_part(p.att_t, KA, G, KS, in_att, part, tid);
+      __syncthreads();
+      float hnew = 0.0f;
+      if (tid < p.A) {
+        const float gi = part_sum(part, G, KS, tid) + p.att_b[tid];
+        const float gf = part_sum(part, G, KS, p.A + tid) + p.att_b[p.A + tid];
+        const float gg = part_sum(part, G, KS, 2 * p.A + tid) + p.att_b[2 * p.A + tid];
+        const float go = part_sum(part, G, KS, 3 * p.A + tid) + p.att_b[3 * p.A + tid];
+        const float c = sigm(gf) * ac[tid] + sigm(gi) * tanhf(gg);
+        ac[tid] = c;
+        hnew = sigm(go) * tanhf(c);
+      }
+      __syncthreads();   // all reads of the old ah (inside in_att) are done
+      if (tid < p.A) { ah[tid] = hnew; in_dec[tid] = hnew; }
+      __syncthreads();
+    }
+    // ---- attention (model.py:63-121) on the window the reference's mask keeps (utils.py:64-77)
+    int lo = 0, hi = len - 1;
+    if (p.window >= 0) {
+      lo = min(max(0, t - p.window), len - 1);
+      hi = min(t + p.window, len - 1);
+    }
+    {
+      const int KS = pick_ks(ADp, p.A);
+      matvec_part(p.q_t, p.A, ADp, KS, ah, part, tid);
+      __syncthreads();
+      if (tid < p.AD) pq[tid] = part_sum(part, ADp, KS, tid);
+      __syncthreads();
+    }
+    const int half = (p.KSZ - 1) / 2;
+    for (int c0 = lo; c0 <= hi; c0 += 64) {
+      const int nc = min(64, hi - c0 + 1);
+      // location conv features feat[i][f] = sum_{c,k} Wc[f][c][k] * wcat[c][pos + k - half]
+      for (int i = tid; i < nc * p.NFIL; i += NT) {
+        const int pi = i / p.NFIL, f = i % p.NFIL, pos = c0 + pi;
+        float s = 0.0f;
+        for (int k = 0; k < p.KSZ; ++k) {
+          const int q = pos + k - half;
+          if (q >= 0 && q < p.Tin) {
+            s = fmaf(lconv[(f * 2 + 0) * p.KSZ + k], wprev[q], s);
+            s = fmaf(lconv[(f * 2 + 1) * p.KSZ + k], wcum[q], s);
+          }
+        }
+        feat[pi * p.NFIL + f] = s;
+      }
+      __syncthreads();
+      // energies: one wave per position
+      for (int pi = wave; pi < nc; pi += NT / 64) {
+        const int pos = c0 + pi;
+        float e = 0.0f;
+        for (int a = lane; a < p.AD; a += 64) {
+          float pa = 0.0f;
+          for (int f = 0; f < p.NFIL; ++f) pa = fmaf(ldense[a * p.NFIL + f], feat[pi * p.NFIL + f], pa);
+          e = fmaf(vv[a], tanhf(pq[a] + pa + pm[(size_t)pos * p.AD + a]), e);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+        if (lane == 0) en[pos] = e;
+      }
+      __syncthreads();
+    }
+    // softmax over [lo, hi] (everything else is masked to -inf => weight 0), wave 0
+    if (wave == 0) {
+      float mx = -INFINITY;
+      for (int q = lo + lane; q <= hi; q += 64) mx = fmaxf(mx, en[q]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      float sum = 0.0f;
+      for (int q = lo + lane; q <= hi; q += 64) {
+        const float ex = expf(en[q] - mx);
+        en[q] = ex;
+        sum += ex;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      for (int q = lo + lane; q <= hi; q += 64) en[q] = en[q] / sum;
+    }
+    __syncthreads();
+    // new weights: w = en on the window, 0 elsewhere; cum += w; context = w . memory
+    for (int q = tid; q < p.Tin; q += NT) {
+      const float wv = (q >= lo && q <= hi) ? en[q] : 0.0f;
+      wprev[q] = wv;
+      wcum[q] += wv;
+      if (p.align) p.align[((size_t)b * p.max_steps + t) * p.Tin + q] = wv;
+    }
+    if (tid < p.E) {
+      float s = 0.0f;
+      for (int q = lo; q <= hi; ++q) s = fmaf(en[q], mem[(size_t)q * p.E + tid], s);
+      ctx_a[tid] = s; in_dec[p.A + tid] = s; in_proj[p.D + tid] = s;
+    }
+    __syncthreads();
+    // ---- decoder LSTMCell on [ah | ctx | dh]   (model.py:425-428)
+    {
+      const int KS = pick_ks(G, KD);
+      matvec_part(p.dec_t, KD, G, KS, in_dec, part, tid);
+      __syncthreads();
+      float hnew = 0.0f;
+      if (tid < p.D) {
+        const float gi = part_sum(part, G, KS, tid) + p.dec_b[tid];
+        const float gf = part_sum(part, G, KS, p.D + tid) + p.dec_b[p.D + tid];
+        const float gg = part_sum(part, G, KS, 2 * p.D + tid) + p.dec_b[2 * p.D + tid];
+        const float go = part_sum(part, G, KS, 3 * p.D + tid) + p.dec_b[3 * p.D + tid];
+        const float c = sigm(gf) * dc[tid] + sigm(gi) * tanhf(gg);
+        dc[tid] = c;
+        hnew = sigm(go) * tanhf(c);
+      }
+      __syncthreads();
+      if (tid < p.D) { dh[tid] = hnew; in_proj[tid] = hnew; }
+      __syncthreads();
+    }
+    // ---- linear projection + gate on [dh | ctx]   (model.py:436-441)
+    {
+      const int KS = pick_ks(NFp, KP);
+      matvec_part(p.proj_t, KP, NFp, KS, in_proj, part, tid);
+      __syncthreads();
+      if (tid <= p.NF) {
+        const float v = part_sum(part, NFp, KS, tid) + p.proj_b[tid];
+        if (tid < p.NF) {
+          xin[tid] = v;
+          p.mel[((size_t)b * p.NF + tid) * p.max_steps + t] = v;
+        } else {
+          p.gate[(size_t)b * p.max_steps + t] = v;
+          // stop rule (model.py:524-528): the stopping frame is kept
+          if (sigm(v) > p.gate_thr || t + 1 == p.max_steps) s_stop = 1;
+        }
+      }
+      __syncthreads();
+    }
+    if (s_stop) break;
+  }
+  if (tid == 0) p.out_len[b] = t + 1;
+}
+
+// ------------------------------------------------------------------------------------------
+struct TWs {
+  size_t a0, a1, xproj, mem_cm, mask, total;
+};
+TWs tws_layout(const facppg_taco_config& c, int B, int Tin) {
+  TWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t E = c.encoder_embedding_dim > c.symbols_embedding_dim ? c.encoder_embedding_dim : c.symbols_embedding_dim;
+  w.a0 = take((size_t)B * E * Tin * 4);
+  w.a1 = take((size_t)B * E * Tin * 4);
+  w.xproj = take((size_t)B * Tin * 4 * c.encoder_embedding_dim * 4);   // [B][Tin][2*4H], 4H = 2E
+  w.mem_cm = take((size_t)B * c.encoder_embedding_dim * Tin * 4);
+  w.mask = take((size_t)2 * B * c.symbols_embedding_dim * Tin);
+  w.total = off;
+  return w;
+}
+
+}  // namespace
+
+static int taco_check(const facppg_taco_config* c) {
+  FACPPG_REQUIRE(c, FACPPG_EINVAL, "config is NULL");
+  FACPPG_REQUIRE(c->n_symbols > 0 && c->symbols_embedding_dim > 0 && c->encoder_embedding_dim > 0 && c->encoder_embedding_dim % 2 == 0,
+                 FACPPG_EINVAL, "bad encoder dims");
+  FACPPG_REQUIRE(c->symbols_embedding_dim == c->encoder_embedding_dim, FACPPG_EUNSUPPORTED,
+                 "symbols_embedding_dim must equal encoder_embedding_dim (prenet feeds the conv bank)");
+  FACPPG_REQUIRE(c->encoder_n_convolutions >= 0 && c->encoder_n_convolutions <= 8 && c->postnet_n_convolutions >= 2 &&
+                     c->postnet_n_convolutions <= 8 && c->encoder_kernel_size % 2 == 1 && c->postnet_kernel_size % 2 == 1,
+                 FACPPG_EUNSUPPORTED, "conv stack sizes out of range");
+  FACPPG_REQUIRE(c->attention_rnn_dim == c->decoder_rnn_dim && c->attention_rnn_dim % 4 == 0 && 4 * c->attention_rnn_dim <= 4096,
+                 FACPPG_EUNSUPPORTED, "attention_rnn_dim must equal decoder_rnn_dim, be a multiple of 4 and <= 1024");
+  FACPPG_REQUIRE(c->encoder_embedding_dim <= NT && c->prenet_dim <= NT && c->attention_dim <= NT && c->n_acoustic_feat_dims < NT &&
+                     (2 * c->encoder_embedding_dim) % 4 == 0,
+                 FACPPG_EUNSUPPORTED, "decoder dims exceed the 1024-thread workgroup");
+  FACPPG_REQUIRE(c->attention_location_kernel_size % 2 == 1 && c->attention_location_n_filters > 0, FACPPG_EUNSUPPORTED,
+                 "attention_location_kernel_size must be odd");
+  return FACPPG_OK;
+}
+
+static size_t taco_count(const facppg_taco_config* c) {
+  const size_t S = c->symbols_embedding_dim, E = c->encoder_embedding_dim, H = E / 2, K = c->encoder_kernel_size;
+  const size_t P = c->prenet_dim, A = c->attention_rnn_dim, D = c->decoder_rnn_dim, AD = c->attention_dim, NF = c->n_acoustic_feat_dims;
+  size_t n = S * c->n_symbols + S * S;
+  n += (size_t)c->encoder_n_convolutions * (E * E * K + 5 * E);
+  n += 2 * (4 * H * E + 4 * H * H + 8 * H);
+  n += P * NF + P * P;
+  n += 4 * A * (P + E) + 4 * A * A + 8 * A;
+  n += AD * A + AD * E + AD + (size_t)c->attention_location_n_filters * 2 * c->attention_location_kernel_size +
+       AD * c->attention_location_n_filters;
+  n += 4 * D * (A + E) + 4 * D * D + 8 * D;
+  n += NF * (D + E) + NF + (D + E) + 1;
+  const size_t PE = c->postnet_embedding_dim, PK = c->postnet_kernel_size;
+  for (int j = 0; j < c->postnet_n_convolutions; ++j) {
+    const size_t ci = j == 0 ? NF : PE, co = j == c->postnet_n_convolutions - 1 ? NF : PE;
+    n += co * ci * PK + 5 * co;
+  }
+  return n;
+}
+
+extern "C" size_t facppg_taco_weight_count(const facppg_taco_config* c) {
+  if (taco_check(c) != FACPPG_OK) return 0;
+  return taco_count(c);
+}
+
+extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* wsrc, size_t n_floats, int device, void* stream_,
+                                  facppg_taco** out) {
+  if (int rc = taco_check(cfg)) return rc;
+  FACPPG_REQUIRE(wsrc && out, FACPPG_EINVAL, "NULL argument");
+  FACPPG_REQUIRE(n_floats == taco_count(cfg), FACPPG_EINVAL, "weight blob has %zu floats, expected %zu", n_floats, taco_count(cfg));
+  hipStream_t s = (hipStream_t)stream_;
+  FACPPG_HIP_CHECK(hipSetDevice(device));
+  facppg_taco* h = new (std::nothrow) facppg_taco();
+  FACPPG_REQUIRE(h, FACPPG_EINVAL, "out of host memory");
+  h->c = *cfg; h->device = device;
+  const facppg_taco_config& c = *cfg;
+  const int S = c.symbols_embedding_dim, E = c.encoder_embedding_dim, H = E / 2, K = c.encoder_kernel_size;
+  const int P = c.prenet_dim, A = c.attention_rnn_dim, D = c.decoder_rnn_dim, AD = c.attention_dim, NF = c.n_acoustic_feat_dims;
+  const int NFIL = c.attention_location_n_filters, KSZ = c.attention_location_kernel_size;
+  const int PE = c.postnet_embedding_dim, PK = c.postnet_kernel_size;
+  const int Pp = round_up(P, 4), ADp = round_up(AD, 4), NFp = round_up(NF + 1, 4), G = 4 * A;
+
+  // pass 1: sizes
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  struct { size_t pre0, pre1, conv[8], conv_b[8], conv_sc[8], conv_sh[8], wih, whh[2], lstm_b, mem_w, dp0, dp1, att, att_b, dec, dec_b, q,
+           proj, proj_b, lc, ld, v, post[8], post_b[8], post_sc[8], post_sh[8]; } o;
+  o.pre0 = take(packed_a_float4s(S, c.n_symbols) * 16);
+  o.pre1 = take(packed_a_float4s(S, S) * 16);
+  for (int j = 0; j < c.encoder_n_convolutions; ++j) {
+    o.conv[j] = take(packed_a_float4s(E, E * K) * 16);
+    o.conv_b[j] = take(E * 4); o.conv_sc[j] = take(E * 4); o.conv_sh[j] = take(E * 4);
+  }
+  o.wih = take(packed_a_float4s(8 * H, E) * 16);
+  o.whh[0] = take((size_t)H * 4 * H * 4); o.whh[1] = take((size_t)H * 4 * H * 4);
+  o.lstm_b = take((size_t)8 * H * 4);
+  o.mem_w = take(packed_a_float4s(AD, E) * 16);
+  o.dp0 = take((size_t)NF * Pp * 4); o.dp1 = take((size_t)P * Pp * 4);
+  o.att = take((size_t)(P + E + A) * G * 4); o.att_b = take((size_t)G * 4);
+  o.dec = take((size_t)(A + E + D) * G * 4); o.dec_b = take((size_t)G * 4);
+  o.q = take((size_t)A * ADp * 4);
+  o.proj = take((size_t)(D + E) * NFp * 4); o.proj_b = take((size_t)NFp * 4);
+  o.lc = take((size_t)NFIL * 2 * KSZ * 4); o.ld = take((size_t)AD * NFIL * 4); o.v = take((size_t)AD * 4);
+  for (int j = 0; j < c.postnet_n_convolutions; ++j) {
+    const int ci = j == 0 ? NF : PE, co = j == c.postnet_n_convolutions - 1 ? NF : PE;
+    o.post[j] = take(packed_a_float4s(co, ci * PK) * 16);
+    o.post_b[j] = take(co * 4); o.post_sc[j] = take(co * 4); o.post_sh[j] = take(co * 4);
+  }
+  if (hipMalloc((void**)&h->arena, off) != hipSuccess) {
+    set_error("hipMalloc(%zu) failed", off);
+    delete h;
+    return FACPPG_EHIP;
+  }
+  int rc = FACPPG_OK;
+  auto F = [&](size_t x) { return (float*)(h->arena + x); };
+  auto F4 = [&](size_t x) { return (float4*)(h->arena + x); };
+  auto hipok = [&](hipError_t e) { if (e != hipSuccess && !rc) { set_error("HIP error in facppg_taco_create: %s", hipGetErrorString(e)); rc = FACPPG_EHIP; } };
+  auto cpy = [&](float* dst, const float* src, size_t n) { hipok(hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, s)); };
+  auto tr = [&](const float* src, float* dst, int R, int Kk, int Rp, int k_off) {
+    const int n = Kk * Rp;
+    k_transpose_pad<<<(n + 255) / 256, 256, 0, s>>>(src, dst, R, Kk, Rp, k_off);
+  };
+  auto bn = [&](const float*& src, int n, float* sc, float* sh) {
+    k_bn_fold<<<(n + 255) / 256, 256, 0, s>>>(src, src + n, src + 2 * n, src + 3 * n, c.bn_eps, sc, sh, n);
+    src += 4 * (size_t)n;
+  };
+  hipok(hipMemsetAsync(h->arena, 0, off, s));
+  const float* src = wsrc;
+  h->pre0 = F4(o.pre0); h->pre1 = F4(o.pre1);
+  if (!rc) rc = pack_a(src, S, c.n_symbols, 1, h->pre0, s); src += (size_t)S * c.n_symbols;
+  if (!rc) rc = pack_a(src, S, S, 1, h->pre1, s); src += (size_t)S * S;
+  for (int j = 0; j < c.encoder_n_convolutions; ++j) {
+    h->conv[j] = F4(o.conv[j]); h->conv_b[j] = F(o.conv_b[j]); h->conv_scale[j] = F(o.conv_sc[j]); h->conv_shift[j] = F(o.conv_sh[j]);
+    if (!rc) rc = pack_a(src, E, E, K, h->conv[j], s); src += (size_t)E * E * K;
+    cpy(h->conv_b[j], src, E); src += E;
+    bn(src, E, h->conv_scale[j], h->conv_shift[j]);
+  }
+  // LSTM: both directions' W_ih stacked into one [8H][E] GEMM operand
+  h->wih = F4(o.wih); h->whh_t[0] = F(o.whh[0]); h->whh_t[1] = F(o.whh[1]); h->lstm_b = F(o.lstm_b);
+  {
+    float* tmp = nullptr;
+    hipok(hipMalloc((void**)&tmp, (size_t)8 * H * E * 4));
+    for (int d = 0; d < 2 && !rc; ++d) {
+      const float* wih = src; src += (size_t)4 * H * E;
+      const float* whh = src; src += (size_t)4 * H * H;
+      const float* bih = src; src += 4 * H;
+      const float* bhh = src; src += 4 * H;
+      cpy(tmp + (size_t)d * 4 * H * E, wih, (size_t)4 * H * E);
+      tr(whh, h->whh_t[d], 4 * H, H, 4 * H, 0);
+      k_add2<<<(4 * H + 255) / 256, 256, 0, s>>>(bih, bhh, h->lstm_b + d * 4 * H, 4 * H);
+    }
+    if (!rc) rc = pack_a(tmp, 8 * H, E, 1, h->wih, s);
+    hipok(hipStreamSynchronize(s));
+    (void)hipFree(tmp);
+  }
+  // decoder
+  h->dp0_t = F(o.dp0); h->dp1_t = F(o.dp1); h->att_t = F(o.att); h->att_b = F(o.att_b); h->dec_t = F(o.dec); h->dec_b = F(o.dec_b);
+  h->q_t = F(o.q); h->proj_t = F(o.proj); h->proj_b = F(o.proj_b); h->loc_conv = F(o.lc); h->loc_dense = F(o.ld); h->v = F(o.v);
+  h->mem_w = F4(o.mem_w);
+  tr(src, h->dp0_t, P, NF, Pp, 0); src += (size_t)P * NF;
+  tr(src, h->dp1_t, P, P, Pp, 0); src += (size_t)P * P;
+  tr(src, h->att_t, G, P + E, G, 0); src += (size_t)G * (P + E);
+  tr(src, h->att_t, G, A, G, P + E); src += (size_t)G * A;
+  k_add2<<<(G + 255) / 256, 256, 0, s>>>(src, src + G, h->att_b, G); src += 2 * (size_t)G;
+  tr(src, h->q_t, AD, A, ADp, 0); src += (size_t)AD * A;
+  if (!rc) rc = pack_a(src, AD, E, 1, h->mem_w, s); src += (size_t)AD * E;
+  cpy(h->v, src, AD); src += AD;
+  cpy(h->loc_conv, src, (size_t)NFIL * 2 * KSZ); src += (size_t)NFIL * 2 * KSZ;
+  cpy(h->loc_dense, src, (size_t)AD * NFIL); src += (size_t)AD * NFIL;
+  tr(src, h->dec_t, G, A + E, G, 0); src += (size_t)G * (A + E);
+  tr(src, h->dec_t, G, D, G, A + E); src += (size_t)G * D;
+  k_add2<<<(G + 255) / 256, 256, 0, s>>>(src, src + G, h->dec_b, G); src += 2 * (size_t)G;
+  // projection rows 0..NF-1, gate row NF, K-major [D+E][NFp]
+  {
+    const float* pw = src; src += (size_t)NF * (D + E);
+    const float* pb = src; src += NF;
+    const float* gw = src; src += (D + E);
+    const float* gb = src; src += 1;
+    tr(pw, h->proj_t, NF, D + E, NFp, 0);
+    // gate weights into column NF: a [1][D+E] matrix transposed with row offset -> strided copy
+    hipok(hipMemcpy2DAsync(h->proj_t + NF, (size_t)NFp * 4, gw, 4, 4, D + E, hipMemcpyDeviceToDevice, s));
+    cpy(h->proj_b, pb, NF);
+    cpy(h->proj_b + NF, gb, 1);
+  }
+  for (int j = 0; j < c.postnet_n_convolutions; ++j) {
+    const int ci = j == 0 ? NF : PE, co = j == c.postnet_n_convolutions - 1 ? NF : PE;
+    h->post[j] = F4(o.post[j]); h->post_b[j] = F(o.post_b[j]); h->post_scale[j] = F(o.post_sc[j]); h->post_shift[j] = F(o.post_sh[j]);
+    if (!rc) rc = pack_a(src, co, ci, PK, h->post[j], s); src += (size_t)co * ci * PK;
+    cpy(h->post_b[j], src, co); src += co;
+    bn(src, co, h->post_scale[j], h->post_shift[j]);
+  }
+  hipok(hipGetLastError());
+  hipok(hipStreamSynchronize(s));
+  if (!rc && (size_t)(src - wsrc) != n_floats) { set_error("internal: consumed %zu of %zu weights", (size_t)(src - wsrc), n_floats); rc = FACPPG_EINVAL; }
+  if (rc) {
+    (void)hipFree(h->arena);
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return FACPPG_OK;
+}
+
+extern "C" void facppg_taco_destroy(facppg_taco* h) {
+  if (!h) return;
+  (void)hipFree(h->arena);
+  delete h;
+}
+
+extern "C" size_t facppg_taco_workspace_bytes(const facppg_taco* h, int B, int Tin) {
+  if (!h || B <= 0 || Tin <= 0) return 0;
+  return tws_layout(h->c, B, Tin).total;
+}
+
+// Encoder.inference (model.py:237-249) + Attention.memory_layer (model.py:334).
+extern "C" int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const int32_t* lengths_dev, const uint8_t* masks_dev,
+                                  uint64_t seed, int B, int Tin, float* memory_dev, float* pm_dev, void* ws_, size_t ws_bytes,
+                                  void* stream_) {
+  FACPPG_REQUIRE(h && ppg_dev && memory_dev && pm_dev && ws_, FACPPG_EINVAL, "NULL argument");
+  FACPPG_REQUIRE(B > 0 && Tin > 0 && B <= 65535, FACPPG_EINVAL, "bad B/Tin");
+  const facppg_taco_config& c = h->c;
+  const TWs w = tws_layout(c, B, Tin);
+  FACPPG_REQUIRE(ws_bytes >= w.total, FACPPG_EWORKSPACE, "workspace has %zu bytes, need %zu", ws_bytes, w.total);
+  hipStream_t s = (hipStream_t)stream_;
+  char* ws = (char*)ws_;
+  float* a0 = (float*)(ws + w.a0);
+  float* a1 = (float*)(ws + w.a1);
+  float* xproj = (float*)(ws + w.xproj);
+  float* mem_cm = (float*)(ws + w.mem_cm);
+  const int S = c.symbols_embedding_dim, E = c.encoder_embedding_dim, H = E / 2;
+  const uint8_t* masks = masks_dev;
+  if (!masks) {
+    uint8_t* m = (uint8_t*)(ws + w.mask);
+    const size_t n = (size_t)2 * B * S * Tin;
+    k_random_mask<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(m, n, seed);
+    masks = m;
+  }
+  GemmArgs g;
+  g.B = B; g.N = Tin; g.n_valid = lengths_dev;
+  // prenet: 2 x (Linear no bias, ReLU, dropout p=.5 always on)  model.py:124-135
+  g.A = h->pre0; g.M = S; g.Cin = c.n_symbols; g.X = ppg_dev; g.x_bs = (long)c.n_symbols * Tin; g.ldx = Tin; g.act = ACT_RELU;
+  g.mask = masks; g.mask_bs = (long)S * Tin; g.ldmask = Tin; g.C = a0; g.c_bs = (long)S * Tin; g.ldc = Tin;
+  if (int rc = gemm_launch(g, s)) return rc;
+  g.A = h->pre1; g.Cin = S; g.X = a0; g.x_bs = (long)S * Tin; g.mask = masks + (size_t)B * S * Tin; g.C = a1;
+  if (int rc = gemm_launch(g, s)) return rc;
+  // conv bank: conv k + BN(eval) + ReLU  model.py:241-242
+  float* cur = a1;
+  float* nxt = a0;
+  g.mask = nullptr;
+  for (int j = 0; j < c.encoder_n_convolutions; ++j) {
+    g.A = h->conv[j]; g.M = E; g.Cin = E; g.taps = c.encoder_kernel_size; g.pad = (c.encoder_kernel_size - 1) / 2; g.X = cur;
+    g.x_bs = (long)E * Tin; g.bias = h->conv_b[j]; g.scale = h->conv_scale[j]; g.shift = h->conv_shift[j]; g.C = nxt;
+    g.c_bs = (long)E * Tin;
+    if (int rc = gemm_launch(g, s)) return rc;
+    float* t = cur; cur = nxt; nxt = t;
+  }
+  // LSTM input projections for both directions, time-major out [B][Tin][8H]
+  GemmArgs p;
+  p.B = B; p.N = Tin; p.n_valid = lengths_dev; p.A = h->wih; p.M = 8 * H; p.Cin = E; p.X = cur; p.x_bs = (long)E * Tin; p.ldx = Tin;
+  p.bias = h->lstm_b; p.C = xproj; p.c_bs = (long)Tin * 8 * H; p.ldc = 8 * H; p.c_transposed = 1;
+  if (int rc = gemm_launch(p, s)) return rc;
+  {
+    const int KS = NT / H < H ? NT / H : H;
+    const size_t smem = (size_t)(2 * H + (KS > 0 ? KS : 1) * 4 * H) * 4;
+    k_bilstm<<<dim3(2, B), NT, smem, s>>>(xproj, h->whh_t[0], h->whh_t[1], lengths_dev, Tin, H, memory_dev, mem_cm);
+  }
+  // processed_memory = memory_layer(memory), time-major [B][Tin][AD]
+  GemmArgs m;
+  m.B = B; m.N = Tin; m.n_valid = lengths_dev; m.A = h->mem_w; m.M = c.attention_dim; m.Cin = E; m.X = mem_cm; m.x_bs = (long)E * Tin;
+  m.ldx = Tin; m.C = pm_dev; m.c_bs = (long)Tin * c.attention_dim; m.ldc = c.attention_dim; m.c_transposed = 1;
+  if (int rc = gemm_launch(m, s)) return rc;
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+// Decoder.inference (model.py:489-535).
+extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const float* pm_dev, const int32_t* lengths_dev,
+                                  const uint8_t* masks_dev, uint64_t seed, int B, int Tin, int max_steps, float* mel_dev,
+                                  float* gate_dev, float* align_dev, int32_t* out_lengths_dev, void* ws_, size_t ws_bytes,
+                                  void* stream_) {
+  FACPPG_REQUIRE(h && memory_dev && pm_dev && mel_dev && gate_dev && out_lengths_dev, FACPPG_EINVAL, "NULL argument");
+  FACPPG_REQUIRE(B > 0 && Tin > 0 && max_steps > 0, FACPPG_EINVAL, "bad B/Tin/max_steps");
+  FACPPG_REQUIRE(Tin <= 8192, FACPPG_EUNSUPPORTED, "Tin > 8192 does not fit the decoder's LDS state");
+  const facppg_taco_config& c = h->c;
+  hipStream_t s = (hipStream_t)stream_;
+  const uint8_t* masks = masks_dev;
+  const size_t nmask = (size_t)max_steps * 2 * B * c.prenet_dim;
+  if (!masks) {
+    FACPPG_REQUIRE(ws_ && ws_bytes >= nmask, FACPPG_EWORKSPACE, "decode needs %zu workspace bytes for dropout masks", nmask);
+    k_random_mask<<<(unsigned)((nmask + 255) / 256), 256, 0, s>>>((uint8_t*)ws_, nmask, seed ^ 0xD1B54A32D192ED03ull);
+    masks = (const uint8_t*)ws_;
+  }
+  DecArgs a;
+  a.dp0_t = h->dp0_t; a.dp1_t = h->dp1_t; a.att_t = h->att_t; a.att_b = h->att_b; a.dec_t = h->dec_t; a.dec_b = h->dec_b;
+  a.q_t = h->q_t; a.proj_t = h->proj_t; a.proj_b = h->proj_b; a.loc_conv = h->loc_conv; a.loc_dense = h->loc_dense; a.v = h->v;
+  a.memory = memory_dev; a.pm = pm_dev; a.lengths = lengths_dev; a.masks = masks; a.mel = mel_dev; a.gate = gate_dev;
+  a.align = align_dev; a.out_len = out_lengths_dev;
+  a.B = B; a.Tin = Tin; a.E = c.encoder_embedding_dim; a.P = c.prenet_dim; a.A = c.attention_rnn_dim; a.D = c.decoder_rnn_dim;
+  a.AD = c.attention_dim; a.NF = c.n_acoustic_feat_dims; a.NFIL = c.attention_location_n_filters;
+  a.KSZ = c.attention_location_kernel_size; a.window = c.attention_window_size; a.max_steps = max_steps;
+  a.gate_thr = c.gate_threshold;
+  const int KA = a.P + a.E + a.A, KD = a.A + a.E + a.D, KP = a.D + a.E;
+  const size_t fl = (size_t)KA + KD + KP + a.A + a.D + round_up(a.NF, 4) + round_up(a.P, 4) + round_up(a.AD, 4) + 4096 +
+                    64 * a.NFIL + round_up(a.NFIL * 2 * a.KSZ, 4) + (size_t)a.AD * a.NFIL + round_up(a.AD, 4) + 3 * (size_t)Tin;
+  const size_t smem = fl * 4;
+  FACPPG_REQUIRE(smem <= 160 * 1024 - 64, FACPPG_EUNSUPPORTED, "decoder state (%zu bytes) exceeds LDS", smem);
+  FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_decoder, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  k_decoder<<<B, NT, smem, s>>>(a);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+// Postnet + residual (model.py:178-184, 604-605): mel_post = mel + postnet(mel).
+extern "C" int facppg_taco_postnet(facppg_taco* h, const float* mel_dev, const int32_t* out_lengths_dev, int B, int T, int ld,
+                                   float* mel_post_dev, void* ws_, size_t ws_bytes, void* stream_) {
+  FACPPG_REQUIRE(h && mel_dev && mel_post_dev && ws_, FACPPG_EINVAL, "NULL argument");
+  FACPPG_REQUIRE(B > 0 && T > 0 && ld >= T, FACPPG_EINVAL, "bad B/T/ld");
+  const facppg_taco_config& c = h->c;
+  const int PE = c.postnet_embedding_dim, NF = c.n_acoustic_feat_dims, n = c.postnet_n_convolutions;
+  const size_t need = (size_t)2 * B * PE * T * 4;
+  FACPPG_REQUIRE(ws_bytes >= need, FACPPG_EWORKSPACE, "workspace has %zu bytes, need %zu", ws_bytes, need);
+  hipStream_t s = (hipStream_t)stream_;
+  float* buf[2] = {(float*)ws_, (float*)ws_ + (size_t)B * PE * T};
+  const float* cur = mel_dev;
+  long cur_bs = (long)NF * ld;
+  int cur_ld = ld;
+  for (int j = 0; j < n; ++j) {
+    const int ci = j == 0 ? NF : PE, co = j == n - 1 ? NF : PE;
+    GemmArgs g;
+    g.B = B; g.N = T; g.n_valid = out_lengths_dev; g.A = h->post[j]; g.M = co; g.Cin = ci; g.taps = c.postnet_kernel_size;
+    g.pad = (c.postnet_kernel_size - 1) / 2; g.X = cur; g.x_bs = cur_bs; g.ldx = cur_ld; g.bias = h->post_b[j];
+    g.scale = h->post_scale[j]; g.shift = h->post_shift[j];
+    if (j < n - 1) {
+      g.act = ACT_TANH; g.C = buf[j & 1]; g.c_bs = (long)PE * T; g.ldc = T;
+    } else {
+      g.res = mel_dev; g.res_bs = (long)NF * ld; g.ldres = ld; g.C = mel_post_dev; g.c_bs = (long)NF * ld; g.ldc = ld;
+    }
+    if (int rc = gemm_launch(g, s)) return rc;
+    cur = g.C; cur_bs = g.c_bs; cur_ld = g.ldc;
+  }
+  return FACPPG_OK;
+}
+
+extern "C" size_t facppg_taco_postnet_workspace_bytes(const facppg_taco* h, int B, int T) {
+  if (!h || B <= 0 || T <= 0) return 0;
+  return (size_t)2 * B * h->c.postnet_embedding_dim * T * 4;
+}
+
+extern "C" size_t facppg_taco_decode_workspace_bytes(const facppg_taco* h, int B, int max_steps) {
+  if (!h || B <= 0 || max_steps <= 0) return 0;
+  return (size_t)max_steps * 2 * B * h->c.prenet_dim;
+}

@@ -28,6 +28,16 @@ class WgConfig(ctypes.Structure):
         "wn_layers", "wn_channels", "wn_kernel_size", "upsample_kernel")]
 
 
+class TacoConfig(ctypes.Structure):
+    """facppg_taco_config (include/facppg.h)."""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "n_symbols", "symbols_embedding_dim", "encoder_kernel_size", "encoder_n_convolutions", "encoder_embedding_dim",
+        "n_acoustic_feat_dims", "prenet_dim", "attention_rnn_dim", "decoder_rnn_dim", "attention_dim",
+        "attention_location_n_filters", "attention_location_kernel_size", "attention_window_size",
+        "postnet_embedding_dim", "postnet_kernel_size", "postnet_n_convolutions")] + \
+        [("gate_threshold", ctypes.c_float), ("bn_eps", ctypes.c_float)]
+
+
 def _declare(lib):
     c = ctypes
     vp, i32, u64, f32, sz = c.c_void_p, c.c_int32, c.c_uint64, c.c_float, c.c_size_t
@@ -41,6 +51,22 @@ def _declare(lib):
         "facppg_wg_infer": (c.c_int, [vp, vp, vp, vp, u64, f32, c.c_int, c.c_int, vp, vp, sz, vp]),
         "facppg_wg_set_profiling": (c.c_int, [vp, c.c_int]),
         "facppg_wg_last_layer_ms": (c.c_int, [vp, c.POINTER(f32), c.POINTER(c.c_int)]),
+        "facppg_stft_create": (c.c_int, [c.c_int, c.c_int, vp, vp, vp, vp, c.c_int, c.c_int, vp, c.POINTER(vp)]),
+        "facppg_stft_destroy": (None, [vp]),
+        "facppg_stft_workspace_bytes": (sz, [vp, c.c_int, c.c_int]),
+        "facppg_stft_transform": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, vp, vp, vp, sz, vp]),
+        "facppg_stft_inverse": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, vp, vp, sz, vp]),
+        "facppg_stft_mel": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, vp, vp, sz, vp]),
+        "facppg_denoise": (c.c_int, [vp, vp, vp, vp, f32, c.c_int, c.c_int, vp, vp, sz, vp]),
+        "facppg_taco_weight_count": (sz, [c.POINTER(TacoConfig)]),
+        "facppg_taco_create": (c.c_int, [c.POINTER(TacoConfig), vp, sz, c.c_int, vp, c.POINTER(vp)]),
+        "facppg_taco_destroy": (None, [vp]),
+        "facppg_taco_workspace_bytes": (sz, [vp, c.c_int, c.c_int]),
+        "facppg_taco_decode_workspace_bytes": (sz, [vp, c.c_int, c.c_int]),
+        "facppg_taco_postnet_workspace_bytes": (sz, [vp, c.c_int, c.c_int]),
+        "facppg_taco_encode": (c.c_int, [vp, vp, vp, vp, u64, c.c_int, c.c_int, vp, vp, vp, sz, vp]),
+        "facppg_taco_decode": (c.c_int, [vp, vp, vp, vp, vp, u64, c.c_int, c.c_int, c.c_int, vp, vp, vp, vp, vp, sz, vp]),
+        "facppg_taco_postnet": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, c.c_int, vp, vp, sz, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch

@@ -119,13 +119,13 @@ def tacotron_state_dict(hp, seed=16807, gate_bias=-10.0):
     for j in range(hp.encoder_n_convolutions):
         p = "encoder.convolutions.%d." % j
         K = hp.encoder_kernel_size
-        sd[p + "0.conv.weight"] = _normal(seed, p + "w", (E, E, K), 2.0 / np.sqrt(E * K))
+        sd[p + "0.conv.weight"] = _normal(seed, p + "w", (E, E, K), 1.5 / np.sqrt(E * K))
         sd[p + "0.conv.bias"] = _normal(seed, p + "b", (E,), 0.01)
         _bn(sd, seed, p + "1.", E)
     H = E // 2
     for sfx in ("", "_reverse"):
-        sd["encoder.lstm.weight_ih_l0" + sfx] = _normal(seed, "enc.lstm.wih" + sfx, (4 * H, E), 2.5 / np.sqrt(E))
-        sd["encoder.lstm.weight_hh_l0" + sfx] = _normal(seed, "enc.lstm.whh" + sfx, (4 * H, H), 1.5 / np.sqrt(H))
+        sd["encoder.lstm.weight_ih_l0" + sfx] = _normal(seed, "enc.lstm.wih" + sfx, (4 * H, E), 1.5 / np.sqrt(E))
+        sd["encoder.lstm.weight_hh_l0" + sfx] = _normal(seed, "enc.lstm.whh" + sfx, (4 * H, H), 0.8 / np.sqrt(H))
         sd["encoder.lstm.bias_ih_l0" + sfx] = _normal(seed, "enc.lstm.bih" + sfx, (4 * H,), 0.01)
         sd["encoder.lstm.bias_hh_l0" + sfx] = _normal(seed, "enc.lstm.bhh" + sfx, (4 * H,), 0.01)
     A, D, P = hp.attention_rnn_dim, hp.decoder_rnn_dim, hp.prenet_dim
@@ -133,19 +133,19 @@ def tacotron_state_dict(hp, seed=16807, gate_bias=-10.0):
     lin("decoder.prenet.layers.0", P, nf, gain=2.0)
     lin("decoder.prenet.layers.1", P, P, gain=2.0)
     for nm_, idim, hdim in (("attention_rnn", P + E, A), ("decoder_rnn", A + E, D)):
-        sd["decoder.%s.weight_ih" % nm_] = _normal(seed, nm_ + ".wih", (4 * hdim, idim), 2.5 / np.sqrt(idim))
-        sd["decoder.%s.weight_hh" % nm_] = _normal(seed, nm_ + ".whh", (4 * hdim, hdim), 1.5 / np.sqrt(hdim))
+        sd["decoder.%s.weight_ih" % nm_] = _normal(seed, nm_ + ".wih", (4 * hdim, idim), 1.2 / np.sqrt(idim))
+        sd["decoder.%s.weight_hh" % nm_] = _normal(seed, nm_ + ".whh", (4 * hdim, hdim), 0.7 / np.sqrt(hdim))
         sd["decoder.%s.bias_ih" % nm_] = _normal(seed, nm_ + ".bih", (4 * hdim,), 0.01)
         sd["decoder.%s.bias_hh" % nm_] = _normal(seed, nm_ + ".bhh", (4 * hdim,), 0.01)
     ad = hp.attention_dim
     lin("decoder.attention_layer.query_layer", ad, A, gain=2.0)
     lin("decoder.attention_layer.memory_layer", ad, E, gain=3.0)
-    lin("decoder.attention_layer.v", 1, ad, gain=6.0)
+    lin("decoder.attention_layer.v", 1, ad, gain=3.0)
     nfil, ksz = hp.attention_location_n_filters, hp.attention_location_kernel_size
     sd["decoder.attention_layer.location_layer.location_conv.conv.weight"] = _normal(
         seed, "loc.conv", (nfil, 2, ksz), 1.0 / np.sqrt(2 * ksz))
     lin("decoder.attention_layer.location_layer.location_dense", ad, nfil, gain=3.0)
-    lin("decoder.linear_projection", nf, D + E, bias=True, gain=3.0)
+    lin("decoder.linear_projection", nf, D + E, bias=True, gain=2.0)
     lin("decoder.gate_layer", 1, D + E, bias=True)
     sd["decoder.gate_layer.linear_layer.bias"] = torch.tensor([gate_bias], dtype=torch.float32)
     pe, pk, pn = hp.postnet_embedding_dim, hp.postnet_kernel_size, hp.postnet_n_convolutions

@@ -109,6 +109,119 @@ int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t* T_valid_d
 int facppg_wg_set_profiling(facppg_wg* h, int enable);
 int facppg_wg_last_layer_ms(facppg_wg* h, float* avg_ms, int* n_launches);
 
+/* ------------------------------------------------------------------------------------
+ * STFT / mel analysis / denoiser (src/common/stft.py, src/common/layers.py,
+ * src/waveglow/denoiser.py)
+ * ---------------------------------------------------------------------------------- */
+typedef struct facppg_stft facppg_stft;
+
+/* Replaces STFT.__init__ (stft.py:46-77) [+ TacotronSTFT.__init__ layers.py:75-87 when a mel
+ * basis is given].  The caller supplies the constant tables (built on the host exactly as the
+ * reference builds them) as device arrays:
+ *   fwd_basis_dev   [filter_length+2][filter_length]  windowed DFT basis (real rows, then imag rows)
+ *   inv_basis_t_dev [filter_length][filter_length+2]  TRANSPOSE of the windowed pinv basis
+ *   win_sq_dev      [filter_length]  squared, centre-padded window (audio_processing.py:79-82)
+ *   mel_basis_dev   [n_mel][filter_length/2+1] or NULL
+ * Synchronises `stream` before returning. */
+int facppg_stft_create(int filter_length, int hop_length, const float* fwd_basis_dev,
+                       const float* inv_basis_t_dev, const float* win_sq_dev,
+                       const float* mel_basis_dev, int n_mel, int device, void* stream,
+                       facppg_stft** out);
+void facppg_stft_destroy(facppg_stft* h);
+size_t facppg_stft_workspace_bytes(const facppg_stft* h, int B, int N);
+
+/* Replaces STFT.transform (stft.py:79-107): audio [B][N] -> magnitude, phase
+ * [B][filter_length/2+1][N/hop+1] (phase_dev may be NULL).  n_valid_dev: NULL or [B] sample
+ * counts <= N for padded batches (reflect padding is applied at each utterance's own end). */
+int facppg_stft_transform(facppg_stft* h, const float* audio_dev, const int32_t* n_valid_dev,
+                          int B, int N, float* mag_dev, float* phase_dev, void* workspace_dev,
+                          size_t workspace_bytes, void* stream);
+/* Replaces STFT.inverse (stft.py:109-138): magnitude, phase [B][cutoff][F] -> [B][hop*(F-1)]. */
+int facppg_stft_inverse(facppg_stft* h, const float* mag_dev, const float* phase_dev, int B,
+                        int F, float* out_dev, void* workspace_dev, size_t workspace_bytes,
+                        void* stream);
+/* Replaces TacotronSTFT.mel_spectrogram (layers.py:96-112) without its host-side range assert:
+ * audio [B][N] in [-1,1] -> log(clamp(mel_basis . |STFT|, 1e-5)) [B][n_mel][N/hop+1]. */
+int facppg_stft_mel(facppg_stft* h, const float* audio_dev, const int32_t* n_valid_dev, int B,
+                    int N, float* mel_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+/* Replaces Denoiser.forward (denoiser.py:63-68): STFT, magnitude - bias_spec*strength clamped
+ * at 0, inverse STFT with the original phase.  bias_spec_dev [filter_length/2+1];
+ * out [B][hop*(N/hop)]. */
+int facppg_denoise(facppg_stft* h, const float* audio_dev, const int32_t* n_valid_dev,
+                   const float* bias_spec_dev, float strength, int B, int N, float* out_dev,
+                   void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Tacotron2-style PPG -> mel model (src/common/model.py)
+ * ---------------------------------------------------------------------------------- */
+/* The model hyper-parameters of create_hparams_stage() (hparams.py:161-241). */
+typedef struct facppg_taco_config {
+  int32_t n_symbols;                      /* 5816 (full PPG) or 40 (monophone) */
+  int32_t symbols_embedding_dim;          /* 600 */
+  int32_t encoder_kernel_size;            /* 5 */
+  int32_t encoder_n_convolutions;         /* 3 */
+  int32_t encoder_embedding_dim;          /* 600 */
+  int32_t n_acoustic_feat_dims;           /* 80 */
+  int32_t prenet_dim;                     /* 300 */
+  int32_t attention_rnn_dim;              /* 300 */
+  int32_t decoder_rnn_dim;                /* 300 */
+  int32_t attention_dim;                  /* 150 */
+  int32_t attention_location_n_filters;   /* 32 */
+  int32_t attention_location_kernel_size; /* 31 */
+  int32_t attention_window_size;          /* 20; -1 = None (no window) */
+  int32_t postnet_embedding_dim;          /* 512 */
+  int32_t postnet_kernel_size;            /* 5 */
+  int32_t postnet_n_convolutions;         /* 5 */
+  float gate_threshold;                   /* 0.5 */
+  float bn_eps;                           /* 1e-5 (torch BatchNorm1d default) */
+} facppg_taco_config;
+
+typedef struct facppg_taco facppg_taco;
+
+/* fp32 values in the plain weight blob, flattened in THIS order (names: SURVEY.md Appendix B):
+ *   encoder.prenet.layers.{0,1}.linear_layer.weight
+ *   encoder.convolutions.j: conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var
+ *   encoder.lstm: weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0, then the same four *_reverse
+ *   decoder.prenet.layers.{0,1}.linear_layer.weight
+ *   decoder.attention_rnn: weight_ih, weight_hh, bias_ih, bias_hh
+ *   decoder.attention_layer: query_layer.W, memory_layer.W, v.W, location_conv.W, location_dense.W
+ *   decoder.decoder_rnn: weight_ih, weight_hh, bias_ih, bias_hh
+ *   decoder.linear_projection: W, b ; decoder.gate_layer: W, b
+ *   postnet.convolutions.j: conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var */
+size_t facppg_taco_weight_count(const facppg_taco_config* cfg);
+/* Replaces Tacotron2.__init__ + load_state_dict's weight preparation (model.py:539-546). */
+int facppg_taco_create(const facppg_taco_config* cfg, const float* weights_dev, size_t n_floats,
+                       int device, void* stream, facppg_taco** out);
+void facppg_taco_destroy(facppg_taco* h);
+size_t facppg_taco_workspace_bytes(const facppg_taco* h, int B, int Tin);
+size_t facppg_taco_decode_workspace_bytes(const facppg_taco* h, int B, int max_steps);
+size_t facppg_taco_postnet_workspace_bytes(const facppg_taco* h, int B, int T);
+
+/* Replaces Encoder.inference (model.py:237-249) and the memory_layer projection
+ * (model.py:334).  ppg_dev [B][n_symbols][Tin]; lengths_dev NULL or [B] valid frame counts
+ * (each utterance is encoded exactly as its own batch-1 run); masks_dev NULL (dropout keep-masks
+ * are drawn on the device from `seed`) or uint8 {0,1} [2][B][symbols_embedding_dim][Tin]
+ * (the prenet's two always-on p=0.5 dropouts, model.py:132-135).
+ * Outputs: memory_dev [B][Tin][E] and processed-memory pm_dev [B][Tin][attention_dim]. */
+int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const int32_t* lengths_dev,
+                       const uint8_t* masks_dev, uint64_t seed, int B, int Tin, float* memory_dev,
+                       float* pm_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+/* Replaces Decoder.inference (model.py:489-535) including the attention window mask
+ * (utils.py:46-78) and the stop rule (sigmoid(gate) > gate_threshold after appending the frame,
+ * else stop at max_steps).  masks_dev NULL or uint8 [max_steps][2][B][prenet_dim].
+ * Outputs: mel_dev [B][n_feat][max_steps], gate_dev [B][max_steps], align_dev NULL or
+ * [B][max_steps][Tin], out_lengths_dev [B] (= Tout per utterance; columns beyond it untouched). */
+int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const float* pm_dev,
+                       const int32_t* lengths_dev, const uint8_t* masks_dev, uint64_t seed, int B,
+                       int Tin, int max_steps, float* mel_dev, float* gate_dev, float* align_dev,
+                       int32_t* out_lengths_dev, void* workspace_dev, size_t workspace_bytes,
+                       void* stream);
+/* Replaces Postnet.forward + the residual add (model.py:178-184, 604-605):
+ * mel_dev [B][n_feat][ld] (first T columns used) -> mel_post_dev, same layout. */
+int facppg_taco_postnet(facppg_taco* h, const float* mel_dev, const int32_t* out_lengths_dev,
+                        int B, int T, int ld, float* mel_post_dev, void* workspace_dev,
+                        size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -219,7 +219,7 @@ def gen_tacotron():
     from common import hparams as rh
     from common import model as rmodel
     for tag, Tin, max_steps, gate_bias, n_sym in (("nostop", 30, 60, -10.0, 5816),
-                                                  ("stop", 24, 60, -0.1, 5816),
+                                                  ("stop", 24, 60, -0.08, 5816),
                                                   ("mono40", 16, 16, -10.0, 40)):
         hp = rh.create_hparams_stage(max_decoder_steps=max_steps, n_symbols=n_sym)
         sd = synth.tacotron_state_dict(hp, seed=16807, gate_bias=gate_bias)

@@ -1,0 +1,72 @@
+"""GPU parity: Tacotron2.inference (encoder GEMMs + BiLSTM kernel + persistent decoder kernel +
+postnet GEMMs) vs the reference's golden vectors with the same injected dropout masks.
+Tolerances (north_star): mel <= 1e-4 abs; Tout (stop decision incl. the stopping frame) exact."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import tacotron_case
+
+pytestmark = pytest.mark.gpu
+
+
+def build(hp, sd):
+    from script.train_ppg2mel import load_model
+    m = load_model(hp)
+    m.load_state_dict(sd, strict=True)
+    return m.eval()
+
+
+@pytest.mark.parametrize("tag", ["nostop", "stop", "mono40"])
+def test_inference_matches_reference_golden(tag):
+    d, hp, sd, ppg, em, dm = tacotron_case(tag)
+    m = build(hp, sd)
+    x = torch.from_numpy(ppg).t().unsqueeze(0).cuda()
+    mel, mel_post, gate, align = m.inference(x, dropout_masks=(em, dm))
+    assert mel.shape == d["mel"].shape, (mel.shape, d["mel"].shape)       # Tout exact
+    assert gate.shape == d["gate"].shape and align.shape == d["align"].shape
+    e_mem = np.abs(m.last_memory.cpu().numpy() - d["memory"]).max()
+    e_mel = np.abs(mel.cpu().numpy() - d["mel"]).max()
+    e_post = np.abs(mel_post.cpu().numpy() - d["mel_post"]).max()
+    e_al = np.abs(align.cpu().numpy() - d["align"]).max()
+    e_gate = np.abs(gate.cpu().numpy() - d["gate"]).max()
+    print(tag, "memory %.2e mel %.2e mel_post %.2e align %.2e gate %.2e" % (e_mem, e_mel, e_post, e_al, e_gate))
+    assert e_mem <= 1e-4 and e_mel <= 1e-4 and e_post <= 1e-4 and e_al <= 1e-4 and e_gate <= 1e-4
+
+
+def test_get_inference_surface_and_clip():
+    from common.utils import get_inference
+    d, hp, sd, ppg, em, dm = tacotron_case("mono40")
+    m = build(hp, sd)
+    torch.manual_seed(0)
+    out = get_inference(ppg, m)                     # device-drawn dropout: shape/finite only
+    assert out.shape == (1, 80, 16) and torch.isfinite(out).all()
+    Tin = ppg.shape[0]
+    clipped = get_inference(ppg, m, is_clip=True)   # [10 : Tin-10] on the OUTPUT axis (utils.py:171-172)
+    assert clipped.shape[2] == max(0, min(16, Tin - 10) - 10)
+
+
+def test_padded_batch_equals_independent_runs():
+    """Batched semantics the reference never defined (batch-1 only): identical to B independent
+    batch-1 runs, including each utterance's own stop step."""
+    d, hp, sd, ppg, em, dm = tacotron_case("stop")
+    m = build(hp, sd)
+    lens = [24, 9, 17]
+    B, Tin, steps = len(lens), max(lens), int(d["max_steps"])
+    g = np.random.Generator(np.random.PCG64(21))
+    x = torch.zeros(B, ppg.shape[1], Tin)
+    from facppg import synth
+    for b, n in enumerate(lens):
+        x[b, :, :n] = torch.from_numpy(synth.synthetic_ppg(n, ppg.shape[1], seed=40 + b)).t()
+    emb = (g.random((2, B, Tin, 600)) < 0.5).astype(np.uint8)
+    dmb = (g.random((steps, 2, B, 300)) < 0.5).astype(np.uint8)
+    mel, mel_post, gate, align = m.inference(x.cuda(), lengths=lens, dropout_masks=(emb, dmb))
+    out_lens = m.last_output_lengths.tolist()
+    for b, n in enumerate(lens):
+        sm, sp, sg, sa = m.inference(x[b:b + 1, :, :n].contiguous().cuda(),
+                                     dropout_masks=(emb[:, b:b + 1, :n], dmb[:, :, b:b + 1]))
+        To = sm.shape[2]
+        assert To == out_lens[b]
+        assert torch.equal(sm[0], mel[b, :, :To]) and torch.equal(sp[0], mel_post[b, :, :To])
+        assert torch.equal(sa[0], align[b, :To, :n])
+        assert torch.count_nonzero(mel_post[b, :, To:]) == 0
