@@ -1,0 +1,23 @@
+"""``get_ppg`` hook of the reference's src/common/data_utils.py:55-59.
+
+The reference computes the PPG of a wav with PyKaldi; that front-end is upstream of the hot path
+and out of scope here.  This build reads a precomputed PPG ([Tin, n_symbols] float array, 10 ms
+frame shift, rows = posteriors): either the given path itself is a ``.npy`` file or a sibling
+``<wav>.ppg.npy`` exists next to the wav.
+"""
+import os
+
+import numpy as np
+
+
+def get_ppg(wav_path, deps=None, is_fmllr=False):
+    candidates = [wav_path] if wav_path.endswith(".npy") else [wav_path + ".ppg.npy", os.path.splitext(wav_path)[0] + ".ppg.npy"]
+    for c in candidates:
+        if os.path.isfile(c):
+            ppg = np.load(c)
+            if ppg.ndim != 2:
+                raise ValueError("PPG file %s must hold a [Tin, n_symbols] array, got shape %s" % (c, ppg.shape))
+            return ppg.astype(np.float32)
+    raise NotImplementedError(
+        "PPG extraction from audio (Kaldi nnet3 acoustic model) is upstream of the synthesis hot path and not part "
+        "of this build; provide a precomputed PPG as %s" % " or ".join(candidates))

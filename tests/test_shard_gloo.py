@@ -1,0 +1,73 @@
+"""CPU, world_size 2, gloo: the N>1 data path of offline corpus synthesis -- length-balanced
+partition, flat weight broadcast, and the ragged gather of audio to rank 0 -- with a stand-in
+synthesiser (the HIP path itself needs a GPU)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from facppg import shard
+
+
+def test_partition_covers_every_utterance_once_and_balances():
+    g = np.random.Generator(np.random.PCG64(11))
+    lengths = (100 + g.integers(0, 301, size=1024)).tolist()
+    parts = shard.partition(lengths, 8)
+    flat = sorted(i for p in parts for i in p)
+    assert flat == list(range(1024))
+    sums = [sum(lengths[i] for i in p) for p in parts]
+    assert max(sums) - min(sums) <= max(lengths)           # round-robin on sorted lengths
+    assert all(len(p) == 128 for p in parts)
+    for p in parts:                                         # each shard stays length-sorted
+        assert [lengths[i] for i in p] == sorted((lengths[i] for i in p), reverse=True)
+    assert shard.partition([], 4) == [[], [], [], []]
+    assert shard.partition([5], 4) == [[0], [], [], []]     # fewer utterances than ranks
+    assert shard.batches(list(range(5)), None, 2) == [[0, 1], [2, 3], [4]]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, lengths, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # rank 0 owns the weights; everyone else receives them in one flat broadcast
+        w = [torch.arange(6, dtype=torch.float32).view(2, 3) * (1 if rank == 0 else 0), torch.ones(4) * (rank == 0)]
+        w = shard.broadcast_state(w, src=0)
+        assert torch.equal(w[0], torch.arange(6, dtype=torch.float32).view(2, 3)) and w[1].sum() == 4
+        mine = shard.partition(lengths, world)[rank]
+        # stand-in synthesiser: utterance i -> ramp of its own length tagged with its id
+        wavs = [torch.arange(lengths[i], dtype=torch.float32) + 1000 * i for i in mine]
+        got = shard.gather_ragged(wavs, mine, dst=0)
+        if rank == 0:
+            ok = sorted(got) == list(range(len(lengths))) and all(
+                torch.equal(got[i], torch.arange(lengths[i], dtype=torch.float32) + 1000 * i) for i in got)
+            q.put(ok)
+        else:
+            assert got is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lengths", [[7, 3, 12, 5, 9], [4], [6, 6, 6, 6]])
+def test_gather_ragged_world2_gloo(lengths):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, lengths, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) is True
