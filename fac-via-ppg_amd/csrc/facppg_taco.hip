@@ -16,6 +16,9 @@
 //              the +-window positions the reference's mask keeps (<= 2W+1 of Tin).
 // Recurrent weights are stored K-major ([k][rows], rows padded to 4) so a thread streams float4
 // columns with fully coalesced 16-byte loads; a 1200x1200 step is 900 threads x 400 loads.
+#include <hip/hip_cooperative_groups.h>
+
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -35,6 +38,8 @@ struct facppg_taco {
   // decoder (k-major, rows padded to a multiple of 4)
   float *dp0_t, *dp1_t, *att_t, *att_b, *dec_t, *dec_b, *q_t, *proj_t, *proj_b;
   float *loc_conv, *loc_dense, *v;
+  float *att_coop, *dec_coop;      // per-workgroup LSTM slices [NWG][K][4U] for k_decoder_coop
+  int coop_U, coop_nwg;
   // postnet
   float4* post[8];
   float *post_b[8], *post_scale[8], *post_shift[8];
@@ -42,7 +47,8 @@ struct facppg_taco {
 
 namespace {
 
-constexpr int NT = 1024;  // threads of the persistent kernels
+constexpr int NT = 1024;  // threads of the persistent kernels (16 waves; the context/energy code assumes 16)
+constexpr int ACH = 4 * (NT / 64);  // attention positions per chunk: 4 per wave
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -65,6 +71,16 @@ __global__ void k_bn_fold(const float* w, const float* b, const float* mean, con
     scale[i] = s;
     shift[i] = b[i] - mean[i] * s;
   }
+}
+
+// coop slices: dst[wg][k][g*U + j] = src_t[k][g*A + wg*U + j]  (0 beyond A)
+__global__ void k_pack_coop(const float* __restrict__ src_t, float* __restrict__ dst, int K, int A, int U, int NWG) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int SC = 4 * U;
+  if (i >= (size_t)NWG * K * SC) return;
+  const int col = (int)(i % SC), k = (int)((i / SC) % K), wg = (int)(i / ((size_t)SC * K));
+  const int u = wg * U + col % U;
+  dst[i] = u < A ? src_t[(size_t)k * 4 * A + (col / U) * A + u] : 0.0f;
 }
 
 // Philox-free cheap keep-mask: one 64-bit SplitMix hash per element (p = 0.5 Bernoulli).
@@ -103,6 +119,7 @@ __device__ __forceinline__ int pick_ks(int Rp, int K) {
 }
 __device__ __forceinline__ float part_sum(const float* part, int Rp, int KS, int r) {
   float s = 0.0f;
+#pragma unroll 8
   for (int i = 0; i < KS; ++i) s += part[i * Rp + r];
   return s;
 }
@@ -146,10 +163,22 @@ __global__ __launch_bounds__(NT) void k_bilstm(const float* __restrict__ xproj, 
 }
 
 // ------------------------------------------------------------------------------------------
-// Decoder loop.  grid = B, block = 1024.
+// Decoder.  Two launch shapes share the per-step building blocks below:
+//   k_decoder       one workgroup per utterance (throughput mode: large batches; B workgroups)
+//   k_decoder_coop  NWG workgroups per utterance (latency mode: small batches).  Every workgroup
+//                   redundantly runs the small parts of a step (projection, prenet, attention) and
+//                   owns U of the LSTM units of both LSTMCells: it streams only its 4U-row slice
+//                   of the two 1200x1200 recurrent matrices (packed per workgroup, L2 resident)
+//                   and the hidden vectors are exchanged through global memory with two grid
+//                   barriers per frame.  Because the redundant parts are computed with identical
+//                   code on identical data, every workgroup takes the same stop decision.
 // ------------------------------------------------------------------------------------------
 struct DecArgs {
   const float *dp0_t, *dp1_t, *att_t, *att_b, *dec_t, *dec_b, *q_t, *proj_t, *proj_b, *loc_conv, *loc_dense, *v;
+  const float *att_coop, *dec_coop;  // [NWG][K][4U] slices (coop mode)
+  float* xchg;           // [B][2][A] hidden-state exchange (coop mode)
+  int* fin;              // [B] finished flags (coop mode)
+  long long* prof;       // optional [8] phase cycle counters (debug; FACPPG_DECODER_PROF=1)
   const float* memory;   // [B][Tin][E]
   const float* pm;       // [B][Tin][AD]
   const int* lengths;    // [B] or null
@@ -158,205 +187,429 @@ struct DecArgs {
   float* gate;           // [B][max_steps]
   float* align;          // [B][max_steps][Tin] or null
   int* out_len;          // [B]
-  int B, Tin, E, P, A, D, AD, NF, NFIL, KSZ, window, max_steps;
+  int B, Tin, E, P, A, D, AD, NF, NFIL, KSZ, window, max_steps, U;
   float gate_thr;
 };
 
+struct DecLds {
+  float *in_att, *in_dec, *in_proj, *ac, *dc, *xin, *p1, *pq, *part, *feat, *lconv, *ldense, *vv, *wprev, *wcum, *en;
+  int KA, KD, KP, ADp, NFp, Pp, G;
+};
+
+__host__ __device__ inline size_t dec_lds_floats(int P, int E, int A, int D, int NF, int AD, int NFIL, int KSZ, int Tin) {
+  return (size_t)(P + E + A) + (A + E + D) + (D + E) + A + D + round_up(NF, 4) + round_up(P, 4) + round_up(AD, 4) + 4096 +
+         64 * NFIL + round_up(NFIL * 2 * KSZ, 4) + (size_t)AD * NFIL + round_up(AD, 4) + 3 * (size_t)Tin;
+}
+
+__device__ __forceinline__ void dec_carve(const DecArgs& p, float* sm, DecLds& L) {
+  L.G = 4 * p.A;
+  L.KA = p.P + p.E + p.A;   // attention LSTM input: [prenet | ctx | ah]
+  L.KD = p.A + p.E + p.D;   // decoder LSTM input:   [ah | ctx | dh]
+  L.KP = p.D + p.E;         // projection input:     [dh | ctx]
+  L.ADp = round_up(p.AD, 4); L.NFp = round_up(p.NF + 1, 4); L.Pp = round_up(p.P, 4);
+  L.in_att = sm;
+  L.in_dec = L.in_att + L.KA;
+  L.in_proj = L.in_dec + L.KD;
+  L.ac = L.in_proj + L.KP;
+  L.dc = L.ac + p.A;
+  L.xin = L.dc + p.D;
+  L.p1 = L.xin + round_up(p.NF, 4);
+  L.pq = L.p1 + L.Pp;
+  L.part = L.pq + L.ADp;
+  L.feat = L.part + 4096;
+  L.lconv = L.feat + 64 * p.NFIL;
+  L.ldense = L.lconv + round_up(p.NFIL * 2 * p.KSZ, 4);
+  L.vv = L.ldense + p.AD * p.NFIL;
+  L.wprev = L.vv + L.ADp;
+  L.wcum = L.wprev + p.Tin;
+  L.en = L.wcum + p.Tin;
+}
+
+__device__ __forceinline__ void dec_init(const DecArgs& p, const DecLds& L, float* sm, int tid) {
+  for (int i = tid; i < L.KA + L.KD + L.KP + p.A + p.D + round_up(p.NF, 4) + L.Pp + L.ADp; i += NT) sm[i] = 0.0f;
+  for (int i = tid; i < p.NFIL * 2 * p.KSZ; i += NT) L.lconv[i] = p.loc_conv[i];
+  for (int i = tid; i < p.AD * p.NFIL; i += NT) L.ldense[(i % p.NFIL) * p.AD + i / p.NFIL] = p.loc_dense[i];  // [f][a]
+  for (int i = tid; i < p.AD; i += NT) L.vv[i] = p.v[i];
+  for (int i = tid; i < 3 * p.Tin; i += NT) L.wprev[i] = 0.0f;
+}
+
+// prenet: 2 x (Linear no bias, ReLU, dropout p=0.5 always on)  xin -> in_att[0:P]   (model.py:132-135)
+__device__ __forceinline__ void dec_prenet(const DecArgs& p, const DecLds& L, int t, int b, int tid) {
+  const uint8_t* mk = p.masks + ((size_t)t * 2 * p.B + b) * p.P;
+  {
+    const int KS = pick_ks(L.Pp, p.NF);
+    matvec_part(p.dp0_t, p.NF, L.Pp, KS, L.xin, L.part, tid);
+    __syncthreads();
+    if (tid < p.P) L.p1[tid] = fmaxf(part_sum(L.part, L.Pp, KS, tid), 0.0f) * (float)mk[tid] * 2.0f;
+    __syncthreads();
+  }
+  {
+    const int KS = pick_ks(L.Pp, p.P);
+    matvec_part(p.dp1_t, p.P, L.Pp, KS, L.p1, L.part, tid);
+    __syncthreads();
+    if (tid < p.P) L.in_att[tid] = fmaxf(part_sum(L.part, L.Pp, KS, tid), 0.0f) * (float)mk[(size_t)p.B * p.P + tid] * 2.0f;
+    __syncthreads();
+  }
+}
+
+// LSTMCell pointwise for unit `u` from the four gate pre-activations (gate order i,f,g,o)
+__device__ __forceinline__ float lstm_point(float gi, float gf, float gg, float go, float* c) {
+  const float cn = sigm(gf) * (*c) + sigm(gi) * tanhf(gg);
+  *c = cn;
+  return sigm(go) * tanhf(cn);
+}
+
+// Location-sensitive attention (model.py:63-121) evaluated on the index range the reference's
+// window mask keeps (utils.py:64-77).  Reads ah from in_att[P+E:], updates wprev/wcum and writes
+// the context into in_att[P:], in_dec[A:], in_proj[D:].
+__device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L, const float* mem, const float* pm, int len,
+                                              int t, int b, int tid, bool write_out) {
+  const int lane = tid & 63, wave = tid >> 6;
+  long long atk = clock64();
+#define APROF(slot)                                                     \
+  if (p.prof && write_out && b == 0 && tid == 0) {                       \
+    const long long now = clock64();                                     \
+    p.prof[slot] += now - atk;                                           \
+    atk = now;                                                           \
+  }
+  const float* ah = L.in_att + p.P + p.E;
+  int lo = 0, hi = len - 1;
+  if (p.window >= 0) {
+    lo = min(max(0, t - p.window), len - 1);
+    hi = min(t + p.window, len - 1);
+  }
+  {
+    const int KS = pick_ks(L.ADp, p.A);
+    matvec_part(p.q_t, p.A, L.ADp, KS, ah, L.part, tid);
+    __syncthreads();
+    if (tid < p.AD) L.pq[tid] = part_sum(L.part, L.ADp, KS, tid);
+    __syncthreads();
+  }
+  APROF(8)
+  const int half = (p.KSZ - 1) / 2;
+  for (int c0 = lo; c0 <= hi; c0 += ACH) {
+    const int nc = min(ACH, hi - c0 + 1);
+    // location conv features feat[i][f] = sum_{c,k} Wc[f][c][k] * wcat[c][pos + k - half]
+    for (int i = tid; i < nc * p.NFIL; i += NT) {
+      const int pi = i / p.NFIL, f = i % p.NFIL, pos = c0 + pi;
+      float s = 0.0f;
+#pragma unroll 8
+      for (int k = 0; k < p.KSZ; ++k) {
+        const int q = pos + k - half;
+        if (q >= 0 && q < p.Tin) {
+          s = fmaf(L.lconv[(f * 2 + 0) * p.KSZ + k], L.wprev[q], s);
+          s = fmaf(L.lconv[(f * 2 + 1) * p.KSZ + k], L.wcum[q], s);
+        }
+      }
+      L.feat[pi * p.NFIL + f] = s;
+    }
+    __syncthreads();
+    APROF(9)
+    // energies: one wave per position (<= 4 per wave per 64-chunk); the processed-memory rows are
+    // fetched up front so their L2 latency is paid once, not once per use
+    {
+      float pmv[4][3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pi = wave + j * (NT / 64);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int a = lane + 64 * r;
+          pmv[j][r] = (pi < nc && a < p.AD) ? pm[(size_t)(c0 + pi) * p.AD + a] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pi = wave + j * (NT / 64);
+        if (pi < nc) {
+          float e = 0.0f;
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const int a = lane + 64 * r;
+            if (a < p.AD) {
+              float pa = 0.0f;
+#pragma unroll 8
+              for (int f = 0; f < p.NFIL; ++f) pa = fmaf(L.ldense[f * p.AD + a], L.feat[pi * p.NFIL + f], pa);
+              e = fmaf(L.vv[a], tanhf(L.pq[a] + pa + pmv[j][r]), e);
+            }
+          }
+          for (int a = lane + 192; a < p.AD; a += 64) {   // attention_dim > 192 (not the reference's 150)
+            float pa = 0.0f;
+            for (int f = 0; f < p.NFIL; ++f) pa = fmaf(L.ldense[f * p.AD + a], L.feat[pi * p.NFIL + f], pa);
+            e = fmaf(L.vv[a], tanhf(L.pq[a] + pa + pm[(size_t)(c0 + pi) * p.AD + a]), e);
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+          if (lane == 0) L.en[c0 + pi] = e;
+        }
+      }
+    }
+    __syncthreads();
+    APROF(10)
+  }
+  if (wave == 0) {   // softmax over [lo, hi]; everything else is masked to -inf => weight 0
+    float mx = -INFINITY;
+    for (int q = lo + lane; q <= hi; q += 64) mx = fmaxf(mx, L.en[q]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.0f;
+    for (int q = lo + lane; q <= hi; q += 64) {
+      const float ex = expf(L.en[q] - mx);
+      L.en[q] = ex;
+      sum += ex;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    for (int q = lo + lane; q <= hi; q += 64) L.en[q] = L.en[q] / sum;
+  }
+  __syncthreads();
+  APROF(11)
+  for (int q = tid; q < p.Tin; q += NT) {
+    const float wv = (q >= lo && q <= hi) ? L.en[q] : 0.0f;
+    L.wprev[q] = wv;
+    L.wcum[q] += wv;
+    if (write_out && p.align) p.align[((size_t)b * p.max_steps + t) * p.Tin + q] = wv;
+  }
+  APROF(12)
+  // context = sum_q w[q] * memory[q][:].  Positions are dealt to 8 waves so the window's global
+  // loads are independent and in flight together; the 8 partial vectors meet in LDS (part+feat are
+  // free here) and are summed in a FIXED order: the result must be bitwise reproducible, because
+  // in coop mode every workgroup recomputes it and must reach the same stop decision.
+  {
+    constexpr int CW = 8;    // position groups (waves w and w+8 share a group, splitting the channels)
+    constexpr int QU = 3;    // positions per wave issued together (2 rounds cover the 41-wide window)
+    constexpr int CR = 6;    // 64-channel rounds per half (E <= 768)
+    float* cpart = L.part;   // [CW][E]  (part + feat = 6144 floats >= 8 * E for E <= 768)
+    static_assert(NT / 64 == 2 * CW, "context code deals positions to 8 wave pairs");
+    const int grp = wave & (CW - 1), halfsel = wave / CW;
+    float accv[CR];
+#pragma unroll
+    for (int r = 0; r < CR; ++r) accv[r] = 0.0f;
+    for (int qb = lo + grp; qb <= hi; qb += CW * QU) {
+      float mv[QU][CR];
+#pragma unroll
+      for (int j = 0; j < QU; ++j) {
+        const int q = qb + j * CW;
+#pragma unroll
+        for (int r = 0; r < CR; ++r) {
+          const int c = lane + 64 * (halfsel * CR + r);
+          mv[j][r] = (q <= hi && c < p.E) ? mem[(size_t)q * p.E + c] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < QU; ++j) {
+        const int q = qb + j * CW;
+        const float wq = q <= hi ? L.en[q] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < CR; ++r) accv[r] = fmaf(wq, mv[j][r], accv[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < CR; ++r) {
+      const int c = lane + 64 * (halfsel * CR + r);
+      if (c < p.E) cpart[grp * p.E + c] = accv[r];
+    }
+    __syncthreads();
+    for (int i = tid; i < p.E; i += NT) {
+      float s = 0.0f;
+#pragma unroll
+      for (int j = 0; j < CW; ++j) s += cpart[j * p.E + i];
+      L.in_att[p.P + i] = s; L.in_dec[p.A + i] = s; L.in_proj[p.D + i] = s;
+    }
+    __syncthreads();
+  }
+  APROF(13)
+#undef APROF
+}
+
+// linear projection + gate on [dh | ctx] (model.py:436-441) for frame index t; returns the stop
+// decision (model.py:524-528: the stopping frame is kept) through *s_stop.
+__device__ __forceinline__ void dec_project(const DecArgs& p, const DecLds& L, int t, int b, int tid, bool write_out,
+                                            int* s_stop) {
+  const int KS = pick_ks(L.NFp, L.KP);
+  matvec_part(p.proj_t, L.KP, L.NFp, KS, L.in_proj, L.part, tid);
+  __syncthreads();
+  if (tid <= p.NF) {
+    const float v = part_sum(L.part, L.NFp, KS, tid) + p.proj_b[tid];
+    if (tid < p.NF) {
+      L.xin[tid] = v;
+      if (write_out) p.mel[((size_t)b * p.NF + tid) * p.max_steps + t] = v;
+    } else {
+      if (write_out) p.gate[(size_t)b * p.max_steps + t] = v;
+      if (sigm(v) > p.gate_thr || t + 1 == p.max_steps) *s_stop = 1;
+    }
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(NT) void k_decoder(DecArgs p) {
   extern __shared__ float sm[];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int len = p.lengths ? p.lengths[b] : p.Tin;
-  const int G = 4 * p.A;                 // LSTM gate rows (A == D checked on the host)
-  const int KA = p.P + p.E + p.A;        // attention LSTM input: [prenet | ctx | ah]
-  const int KD = p.A + p.E + p.D;        // decoder LSTM input:   [ah | ctx | dh]
-  const int KP = p.D + p.E;              // projection input:     [dh | ctx]
-  const int ADp = round_up(p.AD, 4), NFp = round_up(p.NF + 1, 4), Pp = round_up(p.P, 4);
-  // LDS carve
-  float* in_att = sm;                    // [KA]
-  float* in_dec = in_att + KA;           // [KD]
-  float* in_proj = in_dec + KD;          // [KP]
-  float* ac = in_proj + KP;              // [A]
-  float* dc = ac + p.A;                  // [D]
-  float* xin = dc + p.D;                 // [NF] previous frame
-  float* p1 = xin + round_up(p.NF, 4);   // [P]
-  float* pq = p1 + Pp;                   // [ADp]
-  float* part = pq + ADp;                // [4096]
-  float* feat = part + 4096;             // [64][NFIL]
-  float* lconv = feat + 64 * p.NFIL;     // [NFIL*2*KSZ]
-  float* ldense = lconv + round_up(p.NFIL * 2 * p.KSZ, 4);  // [AD][NFIL]
-  float* vv = ldense + p.AD * p.NFIL;    // [AD]
-  float* wprev = vv + ADp;               // [Tin]
-  float* wcum = wprev + p.Tin;           // [Tin]
-  float* en = wcum + p.Tin;              // [Tin] energies -> new weights
   __shared__ int s_stop;
-
-  for (int i = tid; i < KA + KD + KP + p.A + p.D + round_up(p.NF, 4) + Pp + ADp; i += NT) sm[i] = 0.0f;
-  for (int i = tid; i < p.NFIL * 2 * p.KSZ; i += NT) lconv[i] = p.loc_conv[i];
-  for (int i = tid; i < p.AD * p.NFIL; i += NT) ldense[i] = p.loc_dense[i];
-  for (int i = tid; i < p.AD; i += NT) vv[i] = p.v[i];
-  for (int i = tid; i < 3 * p.Tin; i += NT) wprev[i] = 0.0f;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int len = p.lengths ? p.lengths[b] : p.Tin;
+  DecLds L;
+  dec_carve(p, sm, L);
+  dec_init(p, L, sm, tid);
   if (tid == 0) s_stop = 0;
   __syncthreads();
-
   const float* mem = p.memory + (size_t)b * p.Tin * p.E;
   const float* pm = p.pm + (size_t)b * p.Tin * p.AD;
-  float* ah = in_att + p.P + p.E;   // attention hidden lives inside in_att; copied into in_dec[0:A]
-  float* ctx_a = in_att + p.P;      // context copy for the attention LSTM
-  float* dh = in_dec + p.A + p.E;   // decoder hidden lives inside in_dec; copied into in_proj[0:D]
-
+  float* ah = L.in_att + p.P + p.E;   // attention hidden lives inside in_att; copied into in_dec[0:A]
+  float* dh = L.in_dec + p.A + p.E;   // decoder hidden lives inside in_dec; copied into in_proj[0:D]
   int t = 0;
   for (;; ++t) {
-    const uint8_t* mk = p.masks + ((size_t)t * 2 * p.B + b) * p.P;
-    // ---- prenet layer 0: relu(W0 x) * mask * 2   (model.py:132-135)
-    {
-      const int KS = pick_ks(Pp, p.NF);
-      matvec_part(p.dp0_t, p.NF, Pp, KS, xin, part, tid);
-      __syncthreads();
-      if (tid < p.P) p1[tid] = fmaxf(part_sum(part, Pp, KS, tid), 0.0f) * (float)mk[tid] * 2.0f;
-      __syncthreads();
-    }
-    // ---- prenet layer 1 -> in_att[0:P]
-    {
-      const int KS = pick_ks(Pp, p.P);
-      matvec_part(p.dp1_t, p.P, Pp, KS, p1, part, tid);
-      __syncthreads();
-      if (tid < p.P) in_att[tid] = fmaxf(part_sum(part, Pp, KS, tid), 0.0f) * (float)mk[(size_t)p.B * p.P + tid] * 2.0f;
-      __syncthreads();
-    }
-    // ---- attention LSTMCell on [prenet | ctx | ah]   (model.py:400-403)
-    {
-      const int KS = pick_ks(G, KA);
-      matvec_part(p.att_t, KA, G, KS, in_att, part, tid);
+    dec_prenet(p, L, t, b, tid);
+    {  // attention LSTMCell on [prenet | ctx | ah]   (model.py:400-403)
+      const int KS = pick_ks(L.G, L.KA);
+      matvec_part(p.att_t, L.KA, L.G, KS, L.in_att, L.part, tid);
       __syncthreads();
       float hnew = 0.0f;
-      if (tid < p.A) {
-        const float gi = part_sum(part, G, KS, tid) + p.att_b[tid];
-        const float gf = part_sum(part, G, KS, p.A + tid) + p.att_b[p.A + tid];
-        const float gg = part_sum(part, G, KS, 2 * p.A + tid) + p.att_b[2 * p.A + tid];
-        const float go = part_sum(part, G, KS, 3 * p.A + tid) + p.att_b[3 * p.A + tid];
-        const float c = sigm(gf) * ac[tid] + sigm(gi) * tanhf(gg);
-        ac[tid] = c;
-        hnew = sigm(go) * tanhf(c);
-      }
+      if (tid < p.A)
+        hnew = lstm_point(part_sum(L.part, L.G, KS, tid) + p.att_b[tid], part_sum(L.part, L.G, KS, p.A + tid) + p.att_b[p.A + tid],
+                          part_sum(L.part, L.G, KS, 2 * p.A + tid) + p.att_b[2 * p.A + tid],
+                          part_sum(L.part, L.G, KS, 3 * p.A + tid) + p.att_b[3 * p.A + tid], &L.ac[tid]);
       __syncthreads();   // all reads of the old ah (inside in_att) are done
-      if (tid < p.A) { ah[tid] = hnew; in_dec[tid] = hnew; }
+      if (tid < p.A) { ah[tid] = hnew; L.in_dec[tid] = hnew; }
       __syncthreads();
     }
-    // ---- attention (model.py:63-121) on the window the reference's mask keeps (utils.py:64-77)
-    int lo = 0, hi = len - 1;
-    if (p.window >= 0) {
-      lo = min(max(0, t - p.window), len - 1);
-      hi = min(t + p.window, len - 1);
-    }
-    {
-      const int KS = pick_ks(ADp, p.A);
-      matvec_part(p.q_t, p.A, ADp, KS, ah, part, tid);
-      __syncthreads();
-      if (tid < p.AD) pq[tid] = part_sum(part, ADp, KS, tid);
-      __syncthreads();
-    }
-    const int half = (p.KSZ - 1) / 2;
-    for (int c0 = lo; c0 <= hi; c0 += 64) {
-      const int nc = min(64, hi - c0 + 1);
-      // location conv features feat[i][f] = sum_{c,k} Wc[f][c][k] * wcat[c][pos + k - half]
-      for (int i = tid; i < nc * p.NFIL; i += NT) {
-        const int pi = i / p.NFIL, f = i % p.NFIL, pos = c0 + pi;
-        float s = 0.0f;
-        for (int k = 0; k < p.KSZ; ++k) {
-          const int q = pos + k - half;
-          if (q >= 0 && q < p.Tin) {
-            s = fmaf(lconv[(f * 2 + 0) * p.KSZ + k], wprev[q], s);
-            s = fmaf(lconv[(f * 2 + 1) * p.KSZ + k], wcum[q], s);
-          }
-        }
-        feat[pi * p.NFIL + f] = s;
-      }
-      __syncthreads();
-      // energies: one wave per position
-      for (int pi = wave; pi < nc; pi += NT / 64) {
-        const int pos = c0 + pi;
-        float e = 0.0f;
-        for (int a = lane; a < p.AD; a += 64) {
-          float pa = 0.0f;
-          for (int f = 0; f < p.NFIL; ++f) pa = fmaf(ldense[a * p.NFIL + f], feat[pi * p.NFIL + f], pa);
-          e = fmaf(vv[a], tanhf(pq[a] + pa + pm[(size_t)pos * p.AD + a]), e);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
-        if (lane == 0) en[pos] = e;
-      }
-      __syncthreads();
-    }
-    // softmax over [lo, hi] (everything else is masked to -inf => weight 0), wave 0
-    if (wave == 0) {
-      float mx = -INFINITY;
-      for (int q = lo + lane; q <= hi; q += 64) mx = fmaxf(mx, en[q]);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-      float sum = 0.0f;
-      for (int q = lo + lane; q <= hi; q += 64) {
-        const float ex = expf(en[q] - mx);
-        en[q] = ex;
-        sum += ex;
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-      for (int q = lo + lane; q <= hi; q += 64) en[q] = en[q] / sum;
-    }
-    __syncthreads();
-    // new weights: w = en on the window, 0 elsewhere; cum += w; context = w . memory
-    for (int q = tid; q < p.Tin; q += NT) {
-      const float wv = (q >= lo && q <= hi) ? en[q] : 0.0f;
-      wprev[q] = wv;
-      wcum[q] += wv;
-      if (p.align) p.align[((size_t)b * p.max_steps + t) * p.Tin + q] = wv;
-    }
-    if (tid < p.E) {
-      float s = 0.0f;
-      for (int q = lo; q <= hi; ++q) s = fmaf(en[q], mem[(size_t)q * p.E + tid], s);
-      ctx_a[tid] = s; in_dec[p.A + tid] = s; in_proj[p.D + tid] = s;
-    }
-    __syncthreads();
-    // ---- decoder LSTMCell on [ah | ctx | dh]   (model.py:425-428)
-    {
-      const int KS = pick_ks(G, KD);
-      matvec_part(p.dec_t, KD, G, KS, in_dec, part, tid);
+    dec_attention(p, L, mem, pm, len, t, b, tid, true);
+    {  // decoder LSTMCell on [ah | ctx | dh]   (model.py:425-428)
+      const int KS = pick_ks(L.G, L.KD);
+      matvec_part(p.dec_t, L.KD, L.G, KS, L.in_dec, L.part, tid);
       __syncthreads();
       float hnew = 0.0f;
-      if (tid < p.D) {
-        const float gi = part_sum(part, G, KS, tid) + p.dec_b[tid];
-        const float gf = part_sum(part, G, KS, p.D + tid) + p.dec_b[p.D + tid];
-        const float gg = part_sum(part, G, KS, 2 * p.D + tid) + p.dec_b[2 * p.D + tid];
-        const float go = part_sum(part, G, KS, 3 * p.D + tid) + p.dec_b[3 * p.D + tid];
-        const float c = sigm(gf) * dc[tid] + sigm(gi) * tanhf(gg);
-        dc[tid] = c;
-        hnew = sigm(go) * tanhf(c);
-      }
+      if (tid < p.D)
+        hnew = lstm_point(part_sum(L.part, L.G, KS, tid) + p.dec_b[tid], part_sum(L.part, L.G, KS, p.D + tid) + p.dec_b[p.D + tid],
+                          part_sum(L.part, L.G, KS, 2 * p.D + tid) + p.dec_b[2 * p.D + tid],
+                          part_sum(L.part, L.G, KS, 3 * p.D + tid) + p.dec_b[3 * p.D + tid], &L.dc[tid]);
       __syncthreads();
-      if (tid < p.D) { dh[tid] = hnew; in_proj[tid] = hnew; }
+      if (tid < p.D) { dh[tid] = hnew; L.in_proj[tid] = hnew; }
       __syncthreads();
     }
-    // ---- linear projection + gate on [dh | ctx]   (model.py:436-441)
-    {
-      const int KS = pick_ks(NFp, KP);
-      matvec_part(p.proj_t, KP, NFp, KS, in_proj, part, tid);
-      __syncthreads();
-      if (tid <= p.NF) {
-        const float v = part_sum(part, NFp, KS, tid) + p.proj_b[tid];
-        if (tid < p.NF) {
-          xin[tid] = v;
-          p.mel[((size_t)b * p.NF + tid) * p.max_steps + t] = v;
-        } else {
-          p.gate[(size_t)b * p.max_steps + t] = v;
-          // stop rule (model.py:524-528): the stopping frame is kept
-          if (sigm(v) > p.gate_thr || t + 1 == p.max_steps) s_stop = 1;
-        }
-      }
-      __syncthreads();
-    }
+    dec_project(p, L, t, b, tid, true, &s_stop);
     if (s_stop) break;
   }
   if (tid == 0) p.out_len[b] = t + 1;
+}
+
+// One LSTMCell slice in coop mode: this workgroup's 4U gate rows (columns g*U + j of the packed
+// slice) over the full input vector; returns the new hidden value of unit j in thread j < U.
+__device__ __forceinline__ void coop_lstm_slice(const float* __restrict__ Wslice, const float* __restrict__ bias, int K, int U,
+                                                int A, int unit0, const float* in, float* part, float* cstate, float* xchg_out,
+                                                int tid) {
+  const int SC = 4 * U, KS = NT / SC;
+  const int col = tid % SC, ks = tid / SC;
+  if (ks < KS) {
+    const int k0 = (int)((long)ks * K / KS), k1 = (int)((long)(ks + 1) * K / KS);
+    const float* w = Wslice + col;
+    float acc = 0.0f;
+#pragma unroll 16
+    for (int k = k0; k < k1; ++k) acc = fmaf(w[(size_t)k * SC], in[k], acc);
+    part[ks * SC + col] = acc;
+  }
+  __syncthreads();
+  if (tid < SC) {
+    float s = 0.0f;
+#pragma unroll 8
+    for (int i = 0; i < KS; ++i) s += part[i * SC + tid];
+    const int u = unit0 + tid % U;
+    part[NT + tid] = s + (u < A ? bias[(tid / U) * A + u] : 0.0f);
+  }
+  __syncthreads();
+  if (tid < U && unit0 + tid < A) {
+    const float* gs = part + NT;
+    const float h = lstm_point(gs[tid], gs[U + tid], gs[2 * U + tid], gs[3 * U + tid], &cstate[tid]);
+    __hip_atomic_store(xchg_out + unit0 + tid, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(NT) void k_decoder_coop(DecArgs p) {
+  namespace cg = cooperative_groups;
+  cg::grid_group grid = cg::this_grid();
+  extern __shared__ float sm[];
+  __shared__ int s_stop, s_all;
+  __shared__ float c_att[64], c_dec[64];
+  const int wg = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const bool leader = wg == 0;
+  const int len = p.lengths ? p.lengths[b] : p.Tin;
+  DecLds L;
+  dec_carve(p, sm, L);
+  dec_init(p, L, sm, tid);
+  if (tid == 0) s_stop = 0;
+  if (tid < 64) { c_att[tid] = 0.0f; c_dec[tid] = 0.0f; }
+  __syncthreads();
+  const float* mem = p.memory + (size_t)b * p.Tin * p.E;
+  const float* pm = p.pm + (size_t)b * p.Tin * p.AD;
+  float* ah = L.in_att + p.P + p.E;
+  float* dh = L.in_dec + p.A + p.E;
+  float* xa = p.xchg + (size_t)b * 2 * p.A;
+  float* xd = xa + p.A;
+  const int SC = 4 * p.U, unit0 = wg * p.U;
+  const float* att_slice = p.att_coop + (size_t)wg * L.KA * SC;
+  const float* dec_slice = p.dec_coop + (size_t)wg * L.KD * SC;
+  bool fin = false;
+  int n_out = 0;
+  long long tk = clock64();
+#define PROF(slot)                                                        \
+  if (p.prof && leader && b == 0 && tid == 0) {                           \
+    const long long now = clock64();                                      \
+    p.prof[slot] += now - tk;                                             \
+    tk = now;                                                             \
+  }
+  for (int t = 0;; ++t) {
+    if (!fin) {
+      if (t > 0) {   // finish frame t-1: projection, gate, stop decision (identical in every workgroup)
+        dec_project(p, L, t - 1, b, tid, leader, &s_stop);
+        if (s_stop) {
+          fin = true;
+          n_out = t;
+          if (leader && tid == 0) {
+            p.out_len[b] = t;
+            __hip_atomic_store(p.fin + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+      PROF(0)
+      if (!fin) {
+        dec_prenet(p, L, t, b, tid);
+        PROF(1)
+        coop_lstm_slice(att_slice, p.att_b, L.KA, p.U, p.A, unit0, L.in_att, L.part, c_att, xa, tid);
+        PROF(2)
+      }
+    }
+    grid.sync();
+    PROF(3)
+    if (tid == 0) {
+      int all = 1;
+      for (int i = 0; i < p.B; ++i) all &= __hip_atomic_load(p.fin + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_all = all;
+    }
+    __syncthreads();
+    if (s_all) break;
+    if (!fin) {
+      for (int i = tid; i < p.A; i += NT) {
+        const float h = __hip_atomic_load(xa + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ah[i] = h; L.in_dec[i] = h;
+      }
+      __syncthreads();
+      PROF(4)
+      dec_attention(p, L, mem, pm, len, t, b, tid, leader);
+      PROF(5)
+      coop_lstm_slice(dec_slice, p.dec_b, L.KD, p.U, p.D, unit0, L.in_dec, L.part, c_dec, xd, tid);
+      PROF(6)
+    }
+    grid.sync();
+    PROF(7)
+    if (!fin) {
+      for (int i = tid; i < p.D; i += NT) {
+        const float h = __hip_atomic_load(xd + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dh[i] = h; L.in_proj[i] = h;
+      }
+      __syncthreads();
+    }
+  }
+  (void)n_out;
+#undef PROF
 }
 
 // ------------------------------------------------------------------------------------------
@@ -390,7 +643,7 @@ static int taco_check(const facppg_taco_config* c) {
                  FACPPG_EUNSUPPORTED, "conv stack sizes out of range");
   FACPPG_REQUIRE(c->attention_rnn_dim == c->decoder_rnn_dim && c->attention_rnn_dim % 4 == 0 && 4 * c->attention_rnn_dim <= 4096,
                  FACPPG_EUNSUPPORTED, "attention_rnn_dim must equal decoder_rnn_dim, be a multiple of 4 and <= 1024");
-  FACPPG_REQUIRE(c->encoder_embedding_dim <= NT && c->prenet_dim <= NT && c->attention_dim <= NT && c->n_acoustic_feat_dims < NT &&
+  FACPPG_REQUIRE(c->encoder_embedding_dim <= 768 && c->prenet_dim <= NT && c->attention_dim <= NT && c->n_acoustic_feat_dims < NT &&
                      (2 * c->encoder_embedding_dim) % 4 == 0,
                  FACPPG_EUNSUPPORTED, "decoder dims exceed the 1024-thread workgroup");
   FACPPG_REQUIRE(c->attention_location_kernel_size % 2 == 1 && c->attention_location_n_filters > 0, FACPPG_EUNSUPPORTED,
@@ -444,7 +697,7 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   struct { size_t pre0, pre1, conv[8], conv_b[8], conv_sc[8], conv_sh[8], wih, whh[2], lstm_b, mem_w, dp0, dp1, att, att_b, dec, dec_b, q,
-           proj, proj_b, lc, ld, v, post[8], post_b[8], post_sc[8], post_sh[8]; } o;
+           proj, proj_b, lc, ld, v, attc, decc, post[8], post_b[8], post_sc[8], post_sh[8]; } o;
   o.pre0 = take(packed_a_float4s(S, c.n_symbols) * 16);
   o.pre1 = take(packed_a_float4s(S, S) * 16);
   for (int j = 0; j < c.encoder_n_convolutions; ++j) {
@@ -460,6 +713,8 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
   o.dec = take((size_t)(A + E + D) * G * 4); o.dec_b = take((size_t)G * 4);
   o.q = take((size_t)A * ADp * 4);
   o.proj = take((size_t)(D + E) * NFp * 4); o.proj_b = take((size_t)NFp * 4);
+  const int CU_ = 8, NWG_ = (A + CU_ - 1) / CU_;
+  o.attc = take((size_t)NWG_ * (P + E + A) * 4 * CU_ * 4); o.decc = take((size_t)NWG_ * (A + E + D) * 4 * CU_ * 4);
   o.lc = take((size_t)NFIL * 2 * KSZ * 4); o.ld = take((size_t)AD * NFIL * 4); o.v = take((size_t)AD * 4);
   for (int j = 0; j < c.postnet_n_convolutions; ++j) {
     const int ci = j == 0 ? NF : PE, co = j == c.postnet_n_convolutions - 1 ? NF : PE;
@@ -530,6 +785,12 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
   tr(src, h->dec_t, G, A + E, G, 0); src += (size_t)G * (A + E);
   tr(src, h->dec_t, G, D, G, A + E); src += (size_t)G * D;
   k_add2<<<(G + 255) / 256, 256, 0, s>>>(src, src + G, h->dec_b, G); src += 2 * (size_t)G;
+  h->att_coop = F(o.attc); h->dec_coop = F(o.decc); h->coop_U = CU_; h->coop_nwg = NWG_;
+  {
+    const size_t na = (size_t)NWG_ * (P + E + A) * 4 * CU_, nd = (size_t)NWG_ * (A + E + D) * 4 * CU_;
+    k_pack_coop<<<(unsigned)((na + 255) / 256), 256, 0, s>>>(h->att_t, h->att_coop, P + E + A, A, CU_, NWG_);
+    k_pack_coop<<<(unsigned)((nd + 255) / 256), 256, 0, s>>>(h->dec_t, h->dec_coop, A + E + D, D, CU_, NWG_);
+  }
   // projection rows 0..NF-1, gate row NF, K-major [D+E][NFp]
   {
     const float* pw = src; src += (size_t)NF * (D + E);
@@ -633,39 +894,77 @@ extern "C" int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const in
   return FACPPG_OK;
 }
 
+namespace {
+struct DecWs { size_t mask, xchg, fin, prof, total; };
+DecWs dec_ws(const facppg_taco_config& c, int B, int max_steps) {
+  DecWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  w.mask = take((size_t)max_steps * 2 * B * c.prenet_dim);
+  w.xchg = take((size_t)B * 2 * c.attention_rnn_dim * 4);
+  w.fin = take((size_t)B * 4);
+  w.prof = take(16 * 8);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
 // Decoder.inference (model.py:489-535).
 extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const float* pm_dev, const int32_t* lengths_dev,
                                   const uint8_t* masks_dev, uint64_t seed, int B, int Tin, int max_steps, float* mel_dev,
                                   float* gate_dev, float* align_dev, int32_t* out_lengths_dev, void* ws_, size_t ws_bytes,
                                   void* stream_) {
-  FACPPG_REQUIRE(h && memory_dev && pm_dev && mel_dev && gate_dev && out_lengths_dev, FACPPG_EINVAL, "NULL argument");
+  FACPPG_REQUIRE(h && memory_dev && pm_dev && mel_dev && gate_dev && out_lengths_dev && ws_, FACPPG_EINVAL, "NULL argument");
   FACPPG_REQUIRE(B > 0 && Tin > 0 && max_steps > 0, FACPPG_EINVAL, "bad B/Tin/max_steps");
   FACPPG_REQUIRE(Tin <= 8192, FACPPG_EUNSUPPORTED, "Tin > 8192 does not fit the decoder's LDS state");
   const facppg_taco_config& c = h->c;
   hipStream_t s = (hipStream_t)stream_;
+  const DecWs w = dec_ws(c, B, max_steps);
+  FACPPG_REQUIRE(ws_bytes >= w.total, FACPPG_EWORKSPACE, "decode workspace has %zu bytes, need %zu", ws_bytes, w.total);
+  char* ws = (char*)ws_;
   const uint8_t* masks = masks_dev;
   const size_t nmask = (size_t)max_steps * 2 * B * c.prenet_dim;
   if (!masks) {
-    FACPPG_REQUIRE(ws_ && ws_bytes >= nmask, FACPPG_EWORKSPACE, "decode needs %zu workspace bytes for dropout masks", nmask);
-    k_random_mask<<<(unsigned)((nmask + 255) / 256), 256, 0, s>>>((uint8_t*)ws_, nmask, seed ^ 0xD1B54A32D192ED03ull);
-    masks = (const uint8_t*)ws_;
+    k_random_mask<<<(unsigned)((nmask + 255) / 256), 256, 0, s>>>((uint8_t*)(ws + w.mask), nmask, seed ^ 0xD1B54A32D192ED03ull);
+    masks = (const uint8_t*)(ws + w.mask);
   }
   DecArgs a;
   a.dp0_t = h->dp0_t; a.dp1_t = h->dp1_t; a.att_t = h->att_t; a.att_b = h->att_b; a.dec_t = h->dec_t; a.dec_b = h->dec_b;
   a.q_t = h->q_t; a.proj_t = h->proj_t; a.proj_b = h->proj_b; a.loc_conv = h->loc_conv; a.loc_dense = h->loc_dense; a.v = h->v;
+  a.att_coop = h->att_coop; a.dec_coop = h->dec_coop; a.xchg = (float*)(ws + w.xchg); a.fin = (int*)(ws + w.fin); a.U = h->coop_U;
+  a.prof = getenv("FACPPG_DECODER_PROF") ? (long long*)(ws + w.prof) : nullptr;
   a.memory = memory_dev; a.pm = pm_dev; a.lengths = lengths_dev; a.masks = masks; a.mel = mel_dev; a.gate = gate_dev;
   a.align = align_dev; a.out_len = out_lengths_dev;
   a.B = B; a.Tin = Tin; a.E = c.encoder_embedding_dim; a.P = c.prenet_dim; a.A = c.attention_rnn_dim; a.D = c.decoder_rnn_dim;
   a.AD = c.attention_dim; a.NF = c.n_acoustic_feat_dims; a.NFIL = c.attention_location_n_filters;
   a.KSZ = c.attention_location_kernel_size; a.window = c.attention_window_size; a.max_steps = max_steps;
   a.gate_thr = c.gate_threshold;
-  const int KA = a.P + a.E + a.A, KD = a.A + a.E + a.D, KP = a.D + a.E;
-  const size_t fl = (size_t)KA + KD + KP + a.A + a.D + round_up(a.NF, 4) + round_up(a.P, 4) + round_up(a.AD, 4) + 4096 +
-                    64 * a.NFIL + round_up(a.NFIL * 2 * a.KSZ, 4) + (size_t)a.AD * a.NFIL + round_up(a.AD, 4) + 3 * (size_t)Tin;
-  const size_t smem = fl * 4;
-  FACPPG_REQUIRE(smem <= 160 * 1024 - 64, FACPPG_EUNSUPPORTED, "decoder state (%zu bytes) exceeds LDS", smem);
-  FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_decoder, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  k_decoder<<<B, NT, smem, s>>>(a);
+  const size_t smem = dec_lds_floats(a.P, a.E, a.A, a.D, a.NF, a.AD, a.NFIL, a.KSZ, Tin) * 4;
+  FACPPG_REQUIRE(smem <= 160 * 1024 - 1024, FACPPG_EUNSUPPORTED, "decoder state (%zu bytes) exceeds LDS", smem);
+  // latency mode (few utterances): NWG cooperating workgroups per utterance; throughput mode: one each
+  const char* mode = getenv("FACPPG_DECODER_MODE");
+  bool coop = (long)B * h->coop_nwg <= 240;
+  if (mode && !strcmp(mode, "single")) coop = false;
+  if (mode && !strcmp(mode, "coop")) {
+    FACPPG_REQUIRE((long)B * h->coop_nwg <= 240, FACPPG_EUNSUPPORTED, "coop decoder needs B*%d <= 240 resident workgroups", h->coop_nwg);
+    coop = true;
+  }
+  if (coop) {
+    FACPPG_HIP_CHECK(hipMemsetAsync(ws + w.xchg, 0, w.total - w.xchg, s));
+    FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_decoder_coop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    void* args[] = {(void*)&a};
+    FACPPG_HIP_CHECK(hipLaunchCooperativeKernel((const void*)k_decoder_coop, dim3(h->coop_nwg, B), dim3(NT), args, smem, s));
+    if (a.prof) {
+      long long pr[16];
+      FACPPG_HIP_CHECK(hipMemcpyAsync(pr, a.prof, sizeof(pr), hipMemcpyDeviceToHost, s));
+      FACPPG_HIP_CHECK(hipStreamSynchronize(s));
+      fprintf(stderr, "[facppg decoder prof, shader cycles] project %lld prenet %lld att_slice %lld sync1 %lld gather %lld attention %lld dec_slice %lld sync2 %lld | att: query %lld feat %lld energy %lld softmax %lld update %lld context %lld\n",
+              pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7], pr[8], pr[9], pr[10], pr[11], pr[12], pr[13]);
+    }
+  } else {
+    FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_decoder, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    k_decoder<<<B, NT, smem, s>>>(a);
+  }
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
 }
@@ -708,5 +1007,5 @@ extern "C" size_t facppg_taco_postnet_workspace_bytes(const facppg_taco* h, int 
 
 extern "C" size_t facppg_taco_decode_workspace_bytes(const facppg_taco* h, int B, int max_steps) {
   if (!h || B <= 0 || max_steps <= 0) return 0;
-  return (size_t)max_steps * 2 * B * h->c.prenet_dim;
+  return dec_ws(h->c, B, max_steps).total;
 }

@@ -119,38 +119,44 @@ __device__ __forceinline__ void load_a(float4 (&a)[4], const float4* __restrict_
   for (int rb = 0; rb < NRB; ++rb) a[rb] = p[rb * rb_stride + g * 64];
 }
 
-// 4 K-steps (one k-group of 8) for NRB row blocks x 2 column blocks.
-template <int NRB>
-__device__ __forceinline__ void mfma_group(f32x16 (&acc)[4][2], const float4 (&a)[4], const float* lb, int g) {
+// 4 K-steps (one k-group of 8) for NRB row blocks x NCB column blocks; LDS image [k][32*NCB].
+template <int NRB, int NCB>
+__device__ __forceinline__ void mfma_group(f32x16 (&acc)[4][NCB], const float4 (&a)[4], const float* lb, int g) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const float b0 = lb[(8 * g + s) * TN];
-    const float b1 = lb[(8 * g + s) * TN + 32];
+    float bv[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) bv[cb] = lb[(8 * g + s) * (32 * NCB) + 32 * cb];
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) {
       const float av = s == 0 ? a[rb].x : s == 1 ? a[rb].y : s == 2 ? a[rb].z : a[rb].w;
-      acc[rb][0] = mfma32x32x2(av, b0, acc[rb][0]);
-      acc[rb][1] = mfma32x32x2(av, b1, acc[rb][1]);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mfma32x32x2(av, bv[cb], acc[rb][cb]);
     }
   }
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <bool LAST>
-__global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // 64 KiB: 2 x [64][64] staging, then acts [256][64]
+template <bool LAST, int NCB>
+__global__ __launch_bounds__(256, NCB == 1 ? 3 : 2) void k_wn_layer(WnArgs p) {
+  // LDS: 2 staging buffers [64 k][TNt] then the gated activations [256][TNt] (aliased)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int TNt = 32 * NCB;          // positions per tile: 64 (throughput) or 32 (small problems)
+  constexpr int RPL = 64 / TNt;          // k-rows covered by one wave-wide staging load
+  constexpr int NSTG = 16 / RPL;         // staging loads per wave per chunk
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int li = lane & 31, kh = lane >> 5;
-  const int b = blockIdx.y, t0 = blockIdx.x * TN;
+  const int b = blockIdx.y, t0 = blockIdx.x * TNt;
   const int Lb = (p.t_valid ? p.t_valid[b] : p.T) * p.hop8;
   if (t0 >= Lb) return;
+  const int srow = lane / TNt, scol = lane % TNt;   // this lane's slot inside a staging load
 
-  const float* hb = p.h_in + (size_t)b * C * p.Lp + HALO + t0 + lane;
-  const float* sb = p.spect + (size_t)b * NCOND * p.Lr + t0 + lane;
+  const float* hb = p.h_in + (size_t)b * C * p.Lp + HALO + t0 + scol;
+  const float* sb = p.spect + (size_t)b * NCOND * p.Lr + t0 + scol;
 
   // accumulators start at the bias (in_layer.bias + cond_layer.bias, summed at pack time)
-  f32x16 acc[4][2];
+  f32x16 acc[4][NCB];
 #pragma unroll
   for (int rb = 0; rb < 4; ++rb) {
     const int base = (rb >> 1) * C + w * 64 + (rb & 1) * 32 + 4 * kh;
@@ -159,61 +165,66 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
       const float4 bv = *reinterpret_cast<const float4*>(p.b1 + base + 8 * q);
       acc[rb][0][4 * q + 0] = bv.x; acc[rb][0][4 * q + 1] = bv.y; acc[rb][0][4 * q + 2] = bv.z; acc[rb][0][4 * q + 3] = bv.w;
     }
-    acc[rb][1] = acc[rb][0];
+#pragma unroll
+    for (int cb = 1; cb < NCB; ++cb) acc[rb][cb] = acc[rb][0];
   }
 
-  float stg[16];
+  float stg[NSTG];
   auto stage_load = [&](int c) {
     const float* src;
     int pitch;
     if (c < 12) {
-      src = hb + (size_t)((c & 3) * 64 + w * 16) * p.Lp + ((c >> 2) - 1) * p.dil;
+      src = hb + (size_t)((c & 3) * 64 + w * 16 + srow) * p.Lp + ((c >> 2) - 1) * p.dil;
       pitch = p.Lp;
     } else {
-      src = sb + (size_t)((c - 12) * 64 + w * 16) * p.Lr;
+      src = sb + (size_t)((c - 12) * 64 + w * 16 + srow) * p.Lr;
       pitch = p.Lr;
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) stg[j] = src[(size_t)j * pitch];
+    for (int j = 0; j < NSTG; ++j) stg[j] = src[(size_t)(j * RPL) * pitch];
   };
   auto stage_write = [&](int buf) {
-    float* dst = smem + buf * (KCH * TN) + (w * 16) * TN + lane;
+    float* dst = smem + buf * (KCH * TNt) + (w * 16) * TNt + lane;   // (row srow, col scol) = + lane
 #pragma unroll
-    for (int j = 0; j < 16; ++j) dst[j * TN] = stg[j];
+    for (int j = 0; j < NSTG; ++j) dst[j * 64] = stg[j];
   };
 
+  // A operand: a ring of RING register sets, prefetched PD = RING-1 k-groups (PD*16*NCB MFMAs)
+  // ahead.  The 64-wide tile runs 2 waves/SIMD (the other wave hides L2 latency) and keeps PD = 1;
+  // the 32-wide tile is used when there is ~1 wave/SIMD, so it prefetches 3 groups ahead.
+  constexpr int RING = NCB == 1 ? 4 : 2;
   const float4* ap = p.w1 + (size_t)(w * 4) * NG1 * 64 + lane;
-  float4 a0[4], a1[4];
+  float4 ar[RING][4];
   stage_load(0);
-  load_a<4>(a0, ap, NG1 * 64, 0);
+#pragma unroll
+  for (int i = 0; i < RING - 1; ++i) load_a<4>(ar[i], ap, NG1 * 64, i);
   stage_write(0);
   __syncthreads();
 
   for (int c = 0; c < NCH1; ++c) {
     if (c + 1 < NCH1) stage_load(c + 1);
-    const float* lb = smem + (c & 1) * (KCH * TN) + (4 * kh) * TN + li;
+    const float* lb = smem + (c & 1) * (KCH * TNt) + (4 * kh) * TNt + li;
     const int G = c * 8;
 #pragma unroll
-    for (int g = 0; g < 8; g += 2) {
-      load_a<4>(a1, ap, NG1 * 64, G + g + 1);
-      mfma_group<4>(acc, a0, lb, g);
-      load_a<4>(a0, ap, NG1 * 64, G + g + 2);  // one padded group exists past the end
-      mfma_group<4>(acc, a1, lb, g + 1);
+    for (int g = 0; g < 8; ++g) {
+      // padded groups exist past the end of the packed image (RING-1 of them)
+      load_a<4>(ar[(g + RING - 1) % RING], ap, NG1 * 64, G + g + RING - 1);
+      mfma_group<4, NCB>(acc, ar[g % RING], lb, g);
     }
     if (c + 1 < NCH1) stage_write((c + 1) & 1);
     __syncthreads();
   }
 
-  // gate: acts = tanh(pre[0:256]) * sigmoid(pre[256:512])  (glow.py:33-40) -> LDS [256][64]
+  // gate: acts = tanh(pre[0:256]) * sigmoid(pre[256:512])  (glow.py:33-40) -> LDS [256][TNt]
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = tanhf(acc[rb][cb][r]) * sigmoidf_(acc[rb + 2][cb][r]);
         const int ch = w * 64 + rb * 32 + 8 * (r >> 2) + (r & 3) + 4 * kh;
-        smem[ch * TN + cb * 32 + li] = v;
+        smem[ch * TNt + cb * 32 + li] = v;
       }
   __syncthreads();
 
@@ -227,19 +238,19 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
       const float4 bv = *reinterpret_cast<const float4*>(p.b2 + base + 8 * q);
       acc[rb][0][4 * q + 0] = bv.x; acc[rb][0][4 * q + 1] = bv.y; acc[rb][0][4 * q + 2] = bv.z; acc[rb][0][4 * q + 3] = bv.w;
     }
-    acc[rb][1] = acc[rb][0];
+#pragma unroll
+    for (int cb = 1; cb < NCB; ++cb) acc[rb][cb] = acc[rb][0];
   }
   {
     const float4* ap2 = p.w2 + (size_t)(w * NRB2) * NG2 * 64 + lane;
-    const float* lb = smem + (4 * kh) * TN + li;
-    load_a<NRB2>(a0, ap2, NG2 * 64, 0);
+    const float* lb = smem + (4 * kh) * TNt + li;
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i) load_a<NRB2>(ar[i], ap2, NG2 * 64, i);
     for (int G = 0; G < NG2; G += 8) {
 #pragma unroll
-      for (int g = 0; g < 8; g += 2) {
-        load_a<NRB2>(a1, ap2, NG2 * 64, G + g + 1);
-        mfma_group<NRB2>(acc, a0, lb, G + g);
-        load_a<NRB2>(a0, ap2, NG2 * 64, G + g + 2);
-        mfma_group<NRB2>(acc, a1, lb, G + g + 1);
+      for (int g = 0; g < 8; ++g) {
+        load_a<NRB2>(ar[(g + RING - 1) % RING], ap2, NG2 * 64, G + g + RING - 1);
+        mfma_group<NRB2, NCB>(acc, ar[g % RING], lb, G + g);
       }
     }
   }
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
     const bool is_res = !LAST && rb < 2;
     const int chb = w * 64 + (rb & 1) * 32 + 4 * kh;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < NCB; ++cb) {
       const int pos = t0 + cb * 32 + li;
       if (pos < Lb) {
 #pragma unroll
@@ -541,8 +552,8 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t nm = cfg->n_mel_channels;
-  const size_t w1_bytes = (size_t)(16 * NG1 + 1) * 64 * sizeof(float4);
-  auto w2_bytes = [&](int last) { return (size_t)(4 * (last ? 2 : 4) * NG2 + 1) * 64 * sizeof(float4); };
+  const size_t w1_bytes = (size_t)(16 * NG1 + 4) * 64 * sizeof(float4);
+  auto w2_bytes = [&](int last) { return (size_t)(4 * (last ? 2 : 4) * NG2 + 4) * 64 * sizeof(float4); };
   struct Off { size_t start_w, start_b, end_w, end_b, winv, w1[8], w2[8], b1[8], b2[8]; } fo[MAXF];
   const size_t o_up_w = take(nm * nm * cfg->upsample_kernel * 4), o_up_b = take(nm * 4);
   for (int k = 0; k < cfg->n_flows; ++k) {
@@ -603,8 +614,8 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   }
   WG_TRY(hipGetLastError());
   WG_TRY(hipStreamSynchronize(stream));
-  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
 #undef WG_TRY
   *out = h;
   return FACPPG_OK;
@@ -740,7 +751,10 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
     }
   }
   h->ev_used = 0;
-  const dim3 lgrid(w.Lr / TN, B);
+  // tile width: 64 positions per workgroup for throughput; 32 when the launch would not fill
+  // the chip's 512 workgroup slots 1.5 times (single short utterances), halving the per-layer latency
+  const bool narrow = (long)(w.Lr / TN) * B < 768;
+  const dim3 lgrid(narrow ? w.Lr / 32 : w.Lr / TN, B);
   for (int k = nf - 1; k >= 0; --k) {
     for (int i = 0; i < c.wn_layers; ++i) {
       WnArgs a;
@@ -749,8 +763,14 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
       a.t_valid = T_valid_dev; a.T = T; a.hop8 = hop8; a.Lp = w.Lp; a.Lr = w.Lr; a.dil = 1 << i; a.first = (i == 0);
       const bool last = i == c.wn_layers - 1;
       if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
-      if (last) k_wn_layer<true><<<lgrid, 256, 65536, s>>>(a);
-      else { k_wn_layer<false><<<lgrid, 256, 65536, s>>>(a); hi ^= 1; }
+      if (narrow) {
+        if (last) k_wn_layer<true, 1><<<lgrid, 256, 32768, s>>>(a);
+        else k_wn_layer<false, 1><<<lgrid, 256, 32768, s>>>(a);
+      } else {
+        if (last) k_wn_layer<true, 2><<<lgrid, 256, 65536, s>>>(a);
+        else k_wn_layer<false, 2><<<lgrid, 256, 65536, s>>>(a);
+      }
+      if (!last) hi ^= 1;
       if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
     }
     e.aud_in = aud[ai]; e.aud_out = aud[ai ^ 1]; e.h_out = hbuf[hi];

@@ -17,8 +17,12 @@ def build(hp, sd):
     return m.eval()
 
 
+@pytest.mark.parametrize("mode", ["coop", "single"])
 @pytest.mark.parametrize("tag", ["nostop", "stop", "mono40"])
-def test_inference_matches_reference_golden(tag):
+def test_inference_matches_reference_golden(tag, mode, monkeypatch):
+    """Both decoder launch shapes: 'coop' (38 cooperating workgroups per utterance, latency mode)
+    and 'single' (one workgroup per utterance, throughput mode)."""
+    monkeypatch.setenv("FACPPG_DECODER_MODE", mode)
     d, hp, sd, ppg, em, dm = tacotron_case(tag)
     m = build(hp, sd)
     x = torch.from_numpy(ppg).t().unsqueeze(0).cuda()
@@ -30,7 +34,7 @@ def test_inference_matches_reference_golden(tag):
     e_post = np.abs(mel_post.cpu().numpy() - d["mel_post"]).max()
     e_al = np.abs(align.cpu().numpy() - d["align"]).max()
     e_gate = np.abs(gate.cpu().numpy() - d["gate"]).max()
-    print(tag, "memory %.2e mel %.2e mel_post %.2e align %.2e gate %.2e" % (e_mem, e_mel, e_post, e_al, e_gate))
+    print(tag, mode, "memory %.2e mel %.2e mel_post %.2e align %.2e gate %.2e" % (e_mem, e_mel, e_post, e_al, e_gate))
     assert e_mem <= 1e-4 and e_mel <= 1e-4 and e_post <= 1e-4 and e_al <= 1e-4 and e_gate <= 1e-4
 
 
@@ -46,9 +50,11 @@ def test_get_inference_surface_and_clip():
     assert clipped.shape[2] == max(0, min(16, Tin - 10) - 10)
 
 
-def test_padded_batch_equals_independent_runs():
+@pytest.mark.parametrize("mode", ["coop", "single"])
+def test_padded_batch_equals_independent_runs(mode, monkeypatch):
     """Batched semantics the reference never defined (batch-1 only): identical to B independent
     batch-1 runs, including each utterance's own stop step."""
+    monkeypatch.setenv("FACPPG_DECODER_MODE", mode)
     d, hp, sd, ppg, em, dm = tacotron_case("stop")
     m = build(hp, sd)
     lens = [24, 9, 17]
