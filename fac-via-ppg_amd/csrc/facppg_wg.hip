@@ -25,8 +25,10 @@
 //   k_flow_end   end 1x1 conv, affine-coupling inverse, inverse 1x1 conv, early-z concat, then
 //                either the next flow's start conv or the final group->time interleave.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "facppg_common.h"
@@ -119,27 +121,44 @@ __device__ __forceinline__ void load_a(float4 (&a)[4], const float4* __restrict_
   for (int rb = 0; rb < NRB; ++rb) a[rb] = p[rb * rb_stride + g * 64];
 }
 
-// 4 K-steps (one k-group of 8) for NRB row blocks x NCB column blocks; LDS image [k][32*NCB].
+// B operand of one k-group (4 K-steps x NCB column blocks) from the LDS image [k][32*NCB].
+template <int NCB>
+__device__ __forceinline__ void load_b(float (&bv)[4][NCB], const float* lb, int g) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) bv[s][cb] = lb[(8 * g + s) * (32 * NCB) + 32 * cb];
+}
+
+// 4 K-steps (one k-group of 8) for NRB row blocks x NCB column blocks.
 template <int NRB, int NCB>
-__device__ __forceinline__ void mfma_group(f32x16 (&acc)[4][NCB], const float4 (&a)[4], const float* lb, int g) {
+__device__ __forceinline__ void mfma_group(f32x16 (&acc)[4][NCB], const float4 (&a)[4], const float (&bv)[4][NCB]) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    float bv[NCB];
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) bv[cb] = lb[(8 * g + s) * (32 * NCB) + 32 * cb];
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) {
       const float av = s == 0 ? a[rb].x : s == 1 ? a[rb].y : s == 2 ? a[rb].z : a[rb].w;
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mfma32x32x2(av, bv[cb], acc[rb][cb]);
+      for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mfma32x32x2(av, bv[s][cb], acc[rb][cb]);
     }
   }
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// tanh(a) * sigmoid(b) with two hardware exponentials and one reciprocal:
+//   (1 - e^-2a) / ((1 + e^-2a) (1 + e^-b)).  tanh saturates to +-1 in fp32 beyond |a| > 9.02, so
+// clamping a to +-15 keeps e^-2a finite without changing the result; e^-b -> inf gives 0 as it must.
+// Relative error ~1e-6 (v_exp_f32 / v_rcp_f32 are 1-ulp), i.e. fp32-roundoff class for this path;
+// the libm tanhf/expf pair it replaces cost ~150 VALU instructions per element (16 % of the kernel).
+__device__ __forceinline__ float gate_tanh_sigmoid(float a, float b) {
+  const float ea = __expf(-2.0f * fminf(fmaxf(a, -15.0f), 15.0f));
+  const float eb = __expf(-b);
+  return __fdividef(1.0f - ea, (1.0f + ea) * (1.0f + eb));
+}
+
 template <bool LAST, int NCB>
-__global__ __launch_bounds__(256, NCB == 1 ? 3 : 2) void k_wn_layer(WnArgs p) {
+__global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   // LDS: 2 staging buffers [64 k][TNt] then the gated activations [256][TNt] (aliased)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TNt = 32 * NCB;          // positions per tile: 64 (throughput) or 32 (small problems)
@@ -169,6 +188,11 @@ __global__ __launch_bounds__(256, NCB == 1 ? 3 : 2) void k_wn_layer(WnArgs p) {
     for (int cb = 1; cb < NCB; ++cb) acc[rb][cb] = acc[rb][0];
   }
 
+#if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 4)
+  const float4* wave_a_ptr = p.w1 + lane;   // ablation: every wave streams the same rows (L1 hits)
+#else
+  const float4* wave_a_ptr = p.w1 + (size_t)(w * 4) * NG1 * 64 + lane;
+#endif
   float stg[NSTG];
   auto stage_load = [&](int c) {
     const float* src;
@@ -189,11 +213,15 @@ __global__ __launch_bounds__(256, NCB == 1 ? 3 : 2) void k_wn_layer(WnArgs p) {
     for (int j = 0; j < NSTG; ++j) dst[j * 64] = stg[j];
   };
 
-  // A operand: a ring of RING register sets, prefetched PD = RING-1 k-groups (PD*16*NCB MFMAs)
-  // ahead.  The 64-wide tile runs 2 waves/SIMD (the other wave hides L2 latency) and keeps PD = 1;
-  // the 32-wide tile is used when there is ~1 wave/SIMD, so it prefetches 3 groups ahead.
-  constexpr int RING = NCB == 1 ? 4 : 2;
-  const float4* ap = p.w1 + (size_t)(w * 4) * NG1 * 64 + lane;
+  // A operand: a ring of RING register sets, prefetched PD = RING-1 k-groups ahead.  vmcnt retires
+  // IN ORDER, so a wait on an A load also waits for every older load -- including the activation
+  // staging loads, which come from HBM (2-3 us) while the weights come from L2.  With PD = 1 every
+  // chunk stalled ~1 us on that; PD >= 2 gives the staging loads 3+ k-groups (>= 6144 cycles) to
+  // land before the first younger A load is needed.  RING = 3 needs the group loop unrolled by
+  // lcm(8, 3) = 24 groups = 3 chunks; 22 chunks = 7 x 3 + 1 and 168 % 3 == 0 keeps the phase static.
+  constexpr int RING = NCB == 1 ? 4 : 3;
+  constexpr int CPI = RING == 3 ? 3 : 1;   // chunks per unrolled iteration
+  const float4* ap = wave_a_ptr;
   float4 ar[RING][4];
   stage_load(0);
 #pragma unroll
@@ -201,18 +229,58 @@ __global__ __launch_bounds__(256, NCB == 1 ? 3 : 2) void k_wn_layer(WnArgs p) {
   stage_write(0);
   __syncthreads();
 
-  for (int c = 0; c < NCH1; ++c) {
-    if (c + 1 < NCH1) stage_load(c + 1);
+  // One chunk = 64 K-rows = 8 k-groups.  No branch may sit between the staging loads and the
+  // MFMAs that follow: hipcc's waitcnt pass merges the two paths and then waits for the staging
+  // loads (vmcnt of the shorter path) at the very first A use -- an HBM round trip per chunk.
+  // So the staging load is unconditional (the last chunk re-stages itself, harmlessly) and the
+  // tail chunk is peeled instead of guarded.
+  auto do_chunk = [&](int c, auto jc) {
+    constexpr int j = decltype(jc)::value;
+    stage_load(c + 1 < NCH1 ? c + 1 : c);
     const float* lb = smem + (c & 1) * (KCH * TNt) + (4 * kh) * TNt + li;
     const int G = c * 8;
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
+      const int gi = j * 8 + g;   // position inside the unrolled iteration (ring phase is static)
       // padded groups exist past the end of the packed image (RING-1 of them)
-      load_a<4>(ar[(g + RING - 1) % RING], ap, NG1 * 64, G + g + RING - 1);
-      mfma_group<4, NCB>(acc, ar[g % RING], lb, g);
+      load_a<4>(ar[(gi + RING - 1) % RING], ap, NG1 * 64, G + g + RING - 1);
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch PD groups ahead (hipcc sinks it otherwise)
+      float bq[4][NCB];
+      load_b<NCB>(bq, lb, g);
+      mfma_group<4, NCB>(acc, ar[gi % RING], bq);
     }
-    if (c + 1 < NCH1) stage_write((c + 1) & 1);
+#if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 8)
+    asm volatile("" ::"v"(stg[0]));   // ablation: no LDS staging write, no barrier
+#else
+    stage_write((c + 1) & 1);
     __syncthreads();
+#endif
+  };
+  if constexpr (CPI == 3) {
+    static_assert(NCH1 % 3 == 1, "peeling below assumes 22 chunks");
+    for (int c0 = 0; c0 + 3 <= NCH1; c0 += 3) {
+      do_chunk(c0, std::integral_constant<int, 0>{});
+      do_chunk(c0 + 1, std::integral_constant<int, 1>{});
+      do_chunk(c0 + 2, std::integral_constant<int, 2>{});
+    }
+    do_chunk(NCH1 - 1, std::integral_constant<int, 0>{});
+  } else {
+    for (int c = 0; c < NCH1; ++c) do_chunk(c, std::integral_constant<int, 0>{});
+  }
+
+  // residual inputs h_in[ch][pos] for this lane's res rows are fetched BEFORE the gate so their
+  // latency hides under its VALU work; they seed the second GEMM's accumulators (bias + h_in), which
+  // makes the residual add free and takes the loads out of the epilogue
+  float hres[LAST ? 1 : 2][NCB][16];
+  if constexpr (!LAST) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const float* src = p.h_in + ((size_t)b * C + w * 64 + rb * 32 + 4 * kh) * p.Lp + HALO + t0 + cb * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hres[rb][cb][r] = src[(size_t)(8 * (r >> 2) + (r & 3)) * p.Lp];
+      }
   }
 
   // gate: acts = tanh(pre[0:256]) * sigmoid(pre[256:512])  (glow.py:33-40) -> LDS [256][TNt]
@@ -222,13 +290,17 @@ __global__ __launch_bounds__(256, NCB == 1 ? 3 : 2) void k_wn_layer(WnArgs p) {
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = tanhf(acc[rb][cb][r]) * sigmoidf_(acc[rb + 2][cb][r]);
+#if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 1)
+        const float v = fminf(fmaxf(acc[rb][cb][r], -1.f), 1.f) * fminf(fmaxf(acc[rb + 2][cb][r], 0.f), 1.f);   // ablation: no transcendentals
+#else
+        const float v = gate_tanh_sigmoid(acc[rb][cb][r], acc[rb + 2][cb][r]);
+#endif
         const int ch = w * 64 + rb * 32 + 8 * (r >> 2) + (r & 3) + 4 * kh;
         smem[ch * TNt + cb * 32 + li] = v;
       }
   __syncthreads();
 
-  // res_skip 1x1 conv: [512 (256 if LAST)] x 256
+  // res_skip 1x1 conv: [512 (256 if LAST)] x 256; accumulators start at bias (+ h_in for res rows)
   constexpr int NRB2 = LAST ? 2 : 4;
 #pragma unroll
   for (int rb = 0; rb < NRB2; ++rb) {
@@ -240,18 +312,54 @@ __global__ __launch_bounds__(256, NCB == 1 ? 3 : 2) void k_wn_layer(WnArgs p) {
     }
 #pragma unroll
     for (int cb = 1; cb < NCB; ++cb) acc[rb][cb] = acc[rb][0];
+    if constexpr (!LAST) {
+      if (rb < 2) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[rb][cb][r] += hres[rb][cb][r];
+      }
+    }
   }
+  // running skip sum of this lane's skip rows: fetched now (into the registers hres just freed) so
+  // the read-modify-write's load latency hides under the second GEMM instead of the epilogue.  Only
+  // A loads issued AFTER these can be delayed by them (in-order vmcnt), and those are needed two
+  // k-groups later.
+  float sk[2][NCB][16];
   {
     const float4* ap2 = p.w2 + (size_t)(w * NRB2) * NG2 * 64 + lane;
     const float* lb = smem + (4 * kh) * TNt + li;
 #pragma unroll
     for (int i = 0; i < RING - 1; ++i) load_a<NRB2>(ar[i], ap2, NG2 * 64, i);
-    for (int G = 0; G < NG2; G += 8) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const float* src = p.skip + ((size_t)b * C + w * 64 + rb * 32 + 4 * kh) * p.Lr + t0 + cb * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sk[rb][cb][r] = src[(size_t)(8 * (r >> 2) + (r & 3)) * p.Lr];
+      }
+    constexpr int NCH2 = NG2 / 8;
+    auto do_chunk2 = [&](int c, auto jc) {
+      constexpr int j = decltype(jc)::value;
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
-        load_a<NRB2>(ar[(g + RING - 1) % RING], ap2, NG2 * 64, G + g + RING - 1);
-        mfma_group<NRB2, NCB>(acc, ar[g % RING], lb, G + g);
+        const int gi = j * 8 + g;
+        load_a<NRB2>(ar[(gi + RING - 1) % RING], ap2, NG2 * 64, c * 8 + g + RING - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        float bq[4][NCB];
+        load_b<NCB>(bq, lb, c * 8 + g);
+        mfma_group<NRB2, NCB>(acc, ar[gi % RING], bq);
       }
+    };
+    if constexpr (CPI == 3) {
+      static_assert(NCH2 == 4, "peeling below assumes 4 chunks");
+      do_chunk2(0, std::integral_constant<int, 0>{});
+      do_chunk2(1, std::integral_constant<int, 1>{});
+      do_chunk2(2, std::integral_constant<int, 2>{});
+      do_chunk2(3, std::integral_constant<int, 0>{});
+    } else {
+      for (int c = 0; c < NCH2; ++c) do_chunk2(c, std::integral_constant<int, 0>{});
     }
   }
 
@@ -269,10 +377,10 @@ __global__ __launch_bounds__(256, NCB == 1 ? 3 : 2) void k_wn_layer(WnArgs p) {
           const int ch = chb + 8 * (r >> 2) + (r & 3);
           if (is_res) {
             const size_t o = ((size_t)b * C + ch) * p.Lp + HALO + pos;
-            p.h_out[o] = p.h_in[o] + acc[rb][cb][r];
+            p.h_out[o] = acc[rb][cb][r];   // bias + h_in + res (h_in was folded into the accumulator)
           } else {
             const size_t o = ((size_t)b * C + ch) * p.Lr + pos;
-            p.skip[o] = (p.first ? 0.0f : p.skip[o]) + acc[rb][cb][r];
+            p.skip[o] = (p.first ? 0.0f : sk[rb & 1][cb][r]) + acc[rb][cb][r];
           }
         }
       }
@@ -614,8 +722,8 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   }
   WG_TRY(hipGetLastError());
   WG_TRY(hipStreamSynchronize(stream));
-  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef WG_TRY
   *out = h;
   return FACPPG_OK;
@@ -767,8 +875,9 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
         if (last) k_wn_layer<true, 1><<<lgrid, 256, 32768, s>>>(a);
         else k_wn_layer<false, 1><<<lgrid, 256, 32768, s>>>(a);
       } else {
-        if (last) k_wn_layer<true, 2><<<lgrid, 256, 65536, s>>>(a);
-        else k_wn_layer<false, 2><<<lgrid, 256, 65536, s>>>(a);
+        static const int lds_bytes = getenv("FACPPG_WN_LDS") ? atoi(getenv("FACPPG_WN_LDS")) : 65536;   // tuning knob: > 80 KiB forces 1 workgroup/CU
+        if (last) k_wn_layer<true, 2><<<lgrid, 256, lds_bytes, s>>>(a);
+        else k_wn_layer<false, 2><<<lgrid, 256, lds_bytes, s>>>(a);
       }
       if (!last) hi ^= 1;
       if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
