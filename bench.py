@@ -97,18 +97,30 @@ def end_to_end_batch1(dev, waveglow, log):
     taco.eval()
     den = Denoiser(waveglow, hop_length=HOP, mode="zeros")
     ppgs = [synth.synthetic_ppg(frames, 5816, seed=0)]
+    import contextlib
     times = []
-    for i in range(4):
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        wavs, tout = pipeline.synthesize(ppgs, taco, waveglow, den, sigma=0.6, strength=0.005, seed=i, return_device=True)
-        torch.cuda.synchronize(dev)
-        times.append(time.perf_counter() - t0)
+    with contextlib.redirect_stdout(sys.stderr):     # the model prints the reference's "Reached max decoder steps"
+        for i in range(4):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            wavs, tout = pipeline.synthesize(ppgs, taco, waveglow, den, sigma=0.6, strength=0.005, seed=i, return_device=True)
+            torch.cuda.synchronize(dev)
+            times.append(time.perf_counter() - t0)
     t = min(times[1:])
     n = tout[0] * HOP
     log("end-to-end batch=1: %d frames -> %d samples in %.2f ms" % (tout[0], n, t * 1e3))
     return {"workload": "PPG [200 x 5816] -> mel -> wav, hop=%d, batch=1 (Tacotron2 + WaveGlow + Denoiser)" % HOP,
             "ms": t * 1e3, "samples_per_s": n / t, "realtime_factor": n / t / SR}
+
+
+def pmc_traffic():
+    """HBM bytes per k_wn_layer launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc.json; FETCH_SIZE doubled per the gfx950 correction, calibrated on k_flow_end)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
+            return json.load(f)["k_wn_layer"]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def main():
@@ -117,6 +129,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the secondary batch-1 end-to-end measurement")
     ap.add_argument("--cpu-baseline-worker", nargs=2, type=int, metavar=("THREADS", "FRAMES"), help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -197,11 +210,11 @@ def main():
                    "per_gpu_batch": BATCH, "global_batch": BATCH * world, "parallelism": "dp%d" % world},
         "realtime_factor": value / SR,
         "roofline": {"bound": "mfma", "kernel": "k_wn_layer", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(),
                      "avg_launch_ms": layer_ms, "launches_timed": layer_n,
                      "flops_per_launch": flops},
     }
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_e2e:
         out["end_to_end_batch1"] = end_to_end_batch1(dev, model, log)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(log)

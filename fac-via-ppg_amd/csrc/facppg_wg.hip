@@ -321,24 +321,11 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
       }
     }
   }
-  // running skip sum of this lane's skip rows: fetched now (into the registers hres just freed) so
-  // the read-modify-write's load latency hides under the second GEMM instead of the epilogue.  Only
-  // A loads issued AFTER these can be delayed by them (in-order vmcnt), and those are needed two
-  // k-groups later.
-  float sk[2][NCB][16];
   {
     const float4* ap2 = p.w2 + (size_t)(w * NRB2) * NG2 * 64 + lane;
     const float* lb = smem + (4 * kh) * TNt + li;
 #pragma unroll
     for (int i = 0; i < RING - 1; ++i) load_a<NRB2>(ar[i], ap2, NG2 * 64, i);
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        const float* src = p.skip + ((size_t)b * C + w * 64 + rb * 32 + 4 * kh) * p.Lr + t0 + cb * 32 + li;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sk[rb][cb][r] = src[(size_t)(8 * (r >> 2) + (r & 3)) * p.Lr];
-      }
     constexpr int NCH2 = NG2 / 8;
     auto do_chunk2 = [&](int c, auto jc) {
       constexpr int j = decltype(jc)::value;
@@ -380,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
             p.h_out[o] = acc[rb][cb][r];   // bias + h_in + res (h_in was folded into the accumulator)
           } else {
             const size_t o = ((size_t)b * C + ch) * p.Lr + pos;
-            p.skip[o] = (p.first ? 0.0f : sk[rb & 1][cb][r]) + acc[rb][cb][r];
+            p.skip[o] = (p.first ? 0.0f : p.skip[o]) + acc[rb][cb][r];
           }
         }
       }
