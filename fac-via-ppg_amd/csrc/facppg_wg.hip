@@ -388,7 +388,7 @@ constexpr int UP_MAXJ = 8;  // ceil(K / hop) <= 8  (hop >= 128 for K = 1024)
 __global__ __launch_bounds__(256) void k_upsample(const float* __restrict__ mel, const float* __restrict__ W,
                                                   const float* __restrict__ bias, float* __restrict__ spect,
                                                   const int* __restrict__ t_valid, int T, int n_mel, int hop,
-                                                  int ksize, int Lr) {
+                                                  int ksize, int Lr, int n_limit) {
   extern __shared__ float smel[];  // [n_mel][UP_QB + UP_MAXJ]
   const int b = blockIdx.z, m = blockIdx.y, q0 = blockIdx.x * UP_QB;
   const int Tb = t_valid ? t_valid[b] : T;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void k_upsample(const float* __restrict__ mel,
     float* dst = spect + ((size_t)b * n_mel * 8 + m * 8 + (pp & 7)) * Lr + (pp >> 3);
 #pragma unroll
     for (int q = 0; q < UP_QB; ++q)
-      if (q0 + q < Tb) dst[(size_t)(q0 + q) * hop8] = acc[q];
+      if (q0 + q < Tb && (q0 + q) * hop + pp < n_limit) dst[(size_t)(q0 + q) * hop8] = acc[q];
   }
 }
 
@@ -556,6 +556,101 @@ __global__ __launch_bounds__(256) void k_flow_end(EdgeArgs p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Training direction (WaveGlow.forward, glow.py:208-250): audio -> z.  The WN stacks are the same
+// k_wn_layer launches; only the flow edges differ:
+//   k_fwd_begin      regroup audio [B][N] -> 8 channels (glow.py:224), W_0 mix, start conv of flow 0
+//   k_fwd_flow_end   end conv, log_s/b split, a1 = exp(log_s)*a1 + b (glow.py:241-246), then for
+//                    the next flow: early-output split (glow.py:230-232), W mix, start conv
+// ------------------------------------------------------------------------------------------
+struct FwdArgs {
+  const float* skip;
+  const float* aud_in;
+  float* aud_out;
+  float* h_out;
+  const float* audio;     // [B][N] (k_fwd_begin)
+  float* z_out;           // [B][8][L]
+  float* log_s_out;       // [B][H][L] of this flow
+  const float* end_w;
+  const float* end_b;
+  const float* w_next;    // [CN][CN] mixing matrix of the next flow (or flow 0)
+  const float* start_w;   // next flow's start conv
+  const float* start_b;
+  int N, hop8, Lp, Lr, L, z_row;   // z_row: first z channel the early / final outputs go to
+};
+
+__device__ __forceinline__ void fwd_start(const FwdArgs& p, int b, int pos, const float* a0, int HN) {
+  float* dst = p.h_out + (size_t)b * C * p.Lp + HALO + pos;
+  for (int ch = 0; ch < C; ++ch) {
+    float v = p.start_b[ch];
+    for (int j = 0; j < HN; ++j) v = fmaf(p.start_w[ch * HN + j], a0[j], v);
+    dst[(size_t)ch * p.Lp] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fwd_begin(FwdArgs p) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (pos >= p.L) return;
+  float a[8], y[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = p.audio[(size_t)b * p.N + (size_t)pos * 8 + j];   // unfold(1, 8, 8)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float v = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v = fmaf(p.w_next[i * 8 + j], a[j], v);
+    y[i] = v;
+    p.aud_out[((size_t)b * 8 + i) * p.Lr + pos] = v;
+  }
+  fwd_start(p, b, pos, y, 4);
+}
+
+template <int H, bool EARLY_NEXT, bool LASTFLOW>
+__global__ __launch_bounds__(256) void k_fwd_flow_end(FwdArgs p) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (pos >= p.L) return;
+  constexpr int CC = 2 * H;
+  float o[CC];
+#pragma unroll
+  for (int j = 0; j < CC; ++j) o[j] = p.end_b[j];
+  const float* sk = p.skip + (size_t)b * C * p.Lr + pos;
+  for (int ch = 0; ch < C; ++ch) {
+    const float v = sk[(size_t)ch * p.Lr];
+#pragma unroll
+    for (int j = 0; j < CC; ++j) o[j] = fmaf(p.end_w[j * C + ch], v, o[j]);
+  }
+  float a[CC];
+#pragma unroll
+  for (int j = 0; j < CC; ++j) a[j] = p.aud_in[((size_t)b * 8 + j) * p.Lr + pos];
+#pragma unroll
+  for (int j = 0; j < H; ++j) {
+    a[H + j] = expf(o[H + j]) * a[H + j] + o[j];
+    p.log_s_out[((size_t)b * H + j) * p.L + pos] = o[H + j];
+  }
+  if constexpr (LASTFLOW) {
+#pragma unroll
+    for (int j = 0; j < CC; ++j) p.z_out[((size_t)b * 8 + p.z_row + j) * p.L + pos] = a[j];
+  } else {
+    constexpr int CN = EARLY_NEXT ? CC - 2 : CC;
+    constexpr int OFF = EARLY_NEXT ? 2 : 0;
+    if constexpr (EARLY_NEXT) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) p.z_out[((size_t)b * 8 + p.z_row + j) * p.L + pos] = a[j];
+    }
+    float y[CN > 0 ? CN : 1];
+#pragma unroll
+    for (int i = 0; i < CN; ++i) {
+      float v = 0.0f;
+#pragma unroll
+      for (int j = 0; j < CN; ++j) v = fmaf(p.w_next[i * CN + j], a[OFF + j], v);
+      y[i] = v;
+      p.aud_out[((size_t)b * 8 + i) * p.Lr + pos] = v;
+    }
+    fwd_start(p, b, pos, y, CN / 2);
+  }
+}
+
 }  // namespace
 }  // namespace facppg
 
@@ -571,7 +666,7 @@ struct facppg_wg {
   char* arena;  // one device allocation holding everything below
   size_t arena_bytes;
   float *up_w, *up_b;
-  float *start_w[MAXF], *start_b[MAXF], *end_w[MAXF], *end_b[MAXF], *winv[MAXF];
+  float *start_w[MAXF], *start_b[MAXF], *end_w[MAXF], *end_b[MAXF], *winv[MAXF], *wfwd[MAXF];
   float4* w1[MAXF][8];
   float4* w2[MAXF][8];
   float *b1[MAXF][8], *b2[MAXF][8];
@@ -625,7 +720,7 @@ extern "C" size_t facppg_wg_weight_count(const facppg_wg_config* c) {
       const size_t rs = i < c->wn_layers - 1 ? 2 * C : C;
       n += (size_t)2 * C * C * 3 + 2 * C + (size_t)2 * C * NCOND + 2 * C + rs * C + rs;
     }
-    n += cc * C + cc + cc * cc;
+    n += cc * C + cc + 2 * cc * cc;
   }
   return n;
 }
@@ -649,7 +744,7 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   const size_t nm = cfg->n_mel_channels;
   const size_t w1_bytes = (size_t)(16 * NG1 + 4) * 64 * sizeof(float4);
   auto w2_bytes = [&](int last) { return (size_t)(4 * (last ? 2 : 4) * NG2 + 4) * 64 * sizeof(float4); };
-  struct Off { size_t start_w, start_b, end_w, end_b, winv, w1[8], w2[8], b1[8], b2[8]; } fo[MAXF];
+  struct Off { size_t start_w, start_b, end_w, end_b, winv, wfwd, w1[8], w2[8], b1[8], b2[8]; } fo[MAXF];
   const size_t o_up_w = take(nm * nm * cfg->upsample_kernel * 4), o_up_b = take(nm * 4);
   for (int k = 0; k < cfg->n_flows; ++k) {
     const size_t hh = h->n_half[k], cc = 2 * hh;
@@ -659,7 +754,7 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
       fo[k].w1[i] = take(w1_bytes); fo[k].b1[i] = take(2 * C * 4);
       fo[k].w2[i] = take(w2_bytes(last)); fo[k].b2[i] = take(2 * C * 4);
     }
-    fo[k].end_w = take(cc * C * 4); fo[k].end_b = take(cc * 4); fo[k].winv = take(cc * cc * 4);
+    fo[k].end_w = take(cc * C * 4); fo[k].end_b = take(cc * 4); fo[k].winv = take(cc * cc * 4); fo[k].wfwd = take(cc * cc * 4);
   }
   h->arena_bytes = off;
   if (hipMalloc((void**)&h->arena, off) != hipSuccess) {
@@ -706,6 +801,8 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
     WG_TRY(cpy(h->end_w[k], src, cc * C)); src += cc * C;
     WG_TRY(cpy(h->end_b[k], src, cc)); src += cc;
     WG_TRY(cpy(h->winv[k], src, cc * cc)); src += cc * cc;
+    h->wfwd[k] = F(fo[k].wfwd);
+    WG_TRY(cpy(h->wfwd[k], src, cc * cc)); src += cc * cc;
   }
   WG_TRY(hipGetLastError());
   WG_TRY(hipStreamSynchronize(stream));
@@ -817,7 +914,7 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
     dim3 g((T + UP_QB - 1) / UP_QB, c.n_mel_channels, B);
     const size_t sm = (size_t)c.n_mel_channels * (UP_QB + UP_MAXJ) * 4;
     k_upsample<<<g, 256, sm, s>>>(mel_dev, h->up_w, h->up_b, spect, T_valid_dev, T, c.n_mel_channels, c.hop_length,
-                                  c.upsample_kernel, w.Lr);
+                                  c.upsample_kernel, w.Lr, T * c.hop_length);
   }
   EdgeArgs e;
   memset(&e, 0, sizeof(e));
@@ -883,6 +980,101 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
       case 2: launch_flow_end<2>(h->early[k], egrid, s, e); break;
       case 3: launch_flow_end<3>(h->early[k], egrid, s, e); break;
       case 4: launch_flow_end<4>(h->early[k], egrid, s, e); break;
+      default: FACPPG_REQUIRE(false, FACPPG_EUNSUPPORTED, "n_half %d", h->n_half[k]);
+    }
+    ai ^= 1;
+  }
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+template <int H>
+static void launch_fwd_end(bool early_next, bool lastflow, dim3 grid, hipStream_t s, const FwdArgs& a) {
+  if (lastflow) k_fwd_flow_end<H, false, true><<<grid, 256, 0, s>>>(a);
+  else if (early_next) k_fwd_flow_end<H, true, false><<<grid, 256, 0, s>>>(a);
+  else k_fwd_flow_end<H, false, false><<<grid, 256, 0, s>>>(a);
+}
+
+extern "C" size_t facppg_wg_log_s_count(const facppg_wg* h, int B, int N) {
+  if (!h || B <= 0 || N <= 0) return 0;
+  size_t n = 0;
+  for (int k = 0; k < h->cfg.n_flows; ++k) n += (size_t)B * h->n_half[k] * (N / 8);
+  return n;
+}
+
+extern "C" int facppg_wg_forward(facppg_wg* h, const float* mel_dev, const float* audio_dev, int B, int F, int N, float* z_dev,
+                                 float* log_s_dev, void* ws_, size_t ws_bytes, void* stream_) {
+  FACPPG_REQUIRE(h && mel_dev && audio_dev && z_dev && log_s_dev && ws_, FACPPG_EINVAL, "NULL argument");
+  const facppg_wg_config& c = h->cfg;
+  FACPPG_REQUIRE(B > 0 && F > 0 && N > 0 && N % 8 == 0, FACPPG_EINVAL, "need B, F > 0 and N a positive multiple of n_group");
+  FACPPG_REQUIRE((F - 1) * c.hop_length + c.upsample_kernel >= N, FACPPG_EINVAL,
+                 "upsampled mel (%d frames) is shorter than the audio (%d samples)  (glow.py:216)", F, N);
+  FACPPG_REQUIRE(h->n_half[0] == 4, FACPPG_EUNSUPPORTED, "forward expects n_group = 8");
+  // workspace: same layout as infer for T' frames covering N samples
+  const int Tq = (N + c.hop_length - 1) / c.hop_length;
+  WsLayout w = ws_layout(c, B, Tq);
+  const int L = N / 8;
+  FACPPG_REQUIRE(ws_bytes >= w.total, FACPPG_EWORKSPACE, "workspace has %zu bytes, need %zu (facppg_wg_workspace_bytes(B, ceil(N/hop)))",
+                 ws_bytes, w.total);
+  hipStream_t s = (hipStream_t)stream_;
+  char* ws = (char*)ws_;
+  float* hbuf[2] = {(float*)(ws + w.h0), (float*)(ws + w.h1)};
+  float* spect = (float*)(ws + w.spect);
+  float* skip = (float*)(ws + w.skip);
+  float* aud[2] = {(float*)(ws + w.aud0), (float*)(ws + w.aud1)};
+  const int hop8 = c.hop_length / 8, nf = c.n_flows;
+  FACPPG_HIP_CHECK(hipMemsetAsync(ws + w.h0, 0, (size_t)B * C * w.Lp * 4 * 2, s));
+  FACPPG_HIP_CHECK(hipMemsetAsync(spect, 0, (size_t)B * NCOND * w.Lr * 4, s));
+  {
+    // spect = upsample(mel)[:, :, :N] regrouped (glow.py:214-222); mel frames beyond those that reach n < N add nothing
+    dim3 g((F + UP_QB - 1) / UP_QB, c.n_mel_channels, B);
+    const size_t sm = (size_t)c.n_mel_channels * (UP_QB + UP_MAXJ) * 4;
+    // frames q >= Tq would write positions >= N: they are cut by n_limit; frames < F contribute via their taps
+    k_upsample<<<g, 256, sm, s>>>(mel_dev, h->up_w, h->up_b, spect, nullptr, F, c.n_mel_channels, c.hop_length,
+                                  c.upsample_kernel, w.Lr, N);
+  }
+  FwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.skip = skip; a.audio = audio_dev; a.z_out = z_dev; a.N = N; a.hop8 = hop8; a.Lp = w.Lp; a.Lr = w.Lr; a.L = L;
+  const dim3 egrid((L + 255) / 256, B);
+  int ai = 0, hi = 0;
+  a.aud_out = aud[ai]; a.h_out = hbuf[hi]; a.w_next = h->wfwd[0]; a.start_w = h->start_w[0]; a.start_b = h->start_b[0];
+  k_fwd_begin<<<egrid, 256, 0, s>>>(a);
+  // layers see T = Tq frames; positions >= L are masked through t_valid-free Lb = Tq*hop8 >= L: use exact L via T/hop8
+  const bool narrow = (long)(w.Lr / TN) * B < 768;
+  const dim3 lgrid(narrow ? w.Lr / 32 : w.Lr / TN, B);
+  size_t ls_off = 0;
+  int z_row = 0;
+  for (int k = 0; k < nf; ++k) {
+    for (int i = 0; i < c.wn_layers; ++i) {
+      WnArgs la;
+      la.h_in = hbuf[hi]; la.h_out = hbuf[hi ^ 1]; la.spect = spect; la.skip = skip;
+      la.w1 = h->w1[k][i]; la.b1 = h->b1[k][i]; la.w2 = h->w2[k][i]; la.b2 = h->b2[k][i];
+      la.t_valid = nullptr; la.T = L; la.hop8 = 1;   // Lb = T * hop8 = L exactly
+      la.Lp = w.Lp; la.Lr = w.Lr; la.dil = 1 << i; la.first = (i == 0);
+      const bool last = i == c.wn_layers - 1;
+      if (narrow) {
+        if (last) k_wn_layer<true, 1><<<lgrid, 256, 32768, s>>>(la);
+        else k_wn_layer<false, 1><<<lgrid, 256, 32768, s>>>(la);
+      } else {
+        if (last) k_wn_layer<true, 2><<<lgrid, 256, 65536, s>>>(la);
+        else k_wn_layer<false, 2><<<lgrid, 256, 65536, s>>>(la);
+      }
+      if (!last) hi ^= 1;
+    }
+    const bool lastflow = k == nf - 1;
+    const bool early_next = !lastflow && h->early[k + 1];
+    a.aud_in = aud[ai]; a.aud_out = aud[ai ^ 1]; a.h_out = hbuf[hi];
+    a.end_w = h->end_w[k]; a.end_b = h->end_b[k];
+    a.log_s_out = log_s_dev + ls_off;
+    ls_off += (size_t)B * h->n_half[k] * L;
+    a.z_row = z_row;
+    if (early_next) z_row += 2;
+    if (!lastflow) { a.w_next = h->wfwd[k + 1]; a.start_w = h->start_w[k + 1]; a.start_b = h->start_b[k + 1]; }
+    switch (h->n_half[k]) {
+      case 2: launch_fwd_end<2>(early_next, lastflow, egrid, s, a); break;
+      case 3: launch_fwd_end<3>(early_next, lastflow, egrid, s, a); break;
+      case 4: launch_fwd_end<4>(early_next, lastflow, egrid, s, a); break;
       default: FACPPG_REQUIRE(false, FACPPG_EUNSUPPORTED, "n_half %d", h->n_half[k]);
     }
     ai ^= 1;

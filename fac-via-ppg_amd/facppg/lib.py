@@ -49,6 +49,8 @@ def _declare(lib):
         "facppg_wg_destroy": (None, [vp]),
         "facppg_wg_workspace_bytes": (sz, [vp, c.c_int, c.c_int]),
         "facppg_wg_infer": (c.c_int, [vp, vp, vp, vp, u64, f32, c.c_int, c.c_int, vp, vp, sz, vp]),
+        "facppg_wg_log_s_count": (sz, [vp, c.c_int, c.c_int]),
+        "facppg_wg_forward": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, c.c_int, vp, vp, vp, sz, vp]),
         "facppg_wg_set_profiling": (c.c_int, [vp, c.c_int]),
         "facppg_wg_last_layer_ms": (c.c_int, [vp, c.POINTER(f32), c.POINTER(c.c_int)]),
         "facppg_stft_create": (c.c_int, [c.c_int, c.c_int, vp, vp, vp, vp, c.c_int, c.c_int, vp, c.POINTER(vp)]),

@@ -152,7 +152,7 @@ class WaveGlow(torch.nn.Module):
                 parts += [_effective_weight(wn.in_layers[i]), wn.in_layers[i].bias,
                           _effective_weight(wn.cond_layers[i]), wn.cond_layers[i].bias,
                           _effective_weight(wn.res_skip_layers[i]), wn.res_skip_layers[i].bias]
-            parts += [wn.end.weight, wn.end.bias, self.convinv[k].inverse_matrix()]
+            parts += [wn.end.weight, wn.end.bias, self.convinv[k].inverse_matrix(), self.convinv[k].conv.weight.squeeze(-1)]
         return torch.cat([p.detach().float().reshape(-1) for p in parts])
 
     def _release(self):
@@ -203,9 +203,40 @@ class WaveGlow(torch.nn.Module):
 
     # ---------------------------------------------------------------- the hot path
     def forward(self, forward_input):
-        raise NotImplementedError(
-            "WaveGlow.forward (training direction, glow.py:208-250) is the next row of the scope "
-            "table (SURVEY.md 8f.1); this build implements the synthesis path WaveGlow.infer")
+        """(mel [B, n_mel, F], audio [B, N]) -> (z [B, n_group, N/n_group], log_s_list, log_det_W_list)
+        -- the training direction, glow.py:208-250, on the HIP kernels (no autograd: the backward
+        pass / training step is the next row of the scope table)."""
+        spect, audio = forward_input
+        _lib.require_cuda(spect, "WaveGlow.forward: spect")
+        _lib.require_cuda(audio, "WaveGlow.forward: audio")
+        L = _lib.load()
+        dev = spect.device
+        spect = spect.float().contiguous()
+        audio = audio.float().contiguous()
+        B, _, F = spect.shape
+        N = audio.shape[1]
+        hop = self.upsample.stride[0]
+        h = self._handle(dev)
+        nbytes = L.facppg_wg_workspace_bytes(h, B, (N + hop - 1) // hop)
+        ws = self.__dict__.get("_facppg_ws")
+        if ws is None or ws.numel() < nbytes or ws.device != dev:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self.__dict__["_facppg_ws"] = ws
+        Lg = N // self.n_group
+        z = torch.empty(B, self.n_group, Lg, device=dev)
+        log_s_flat = torch.empty(L.facppg_wg_log_s_count(h, B, N), device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.facppg_wg_forward(h, _lib.ptr(spect), _lib.ptr(audio), B, F, N, _lib.ptr(z), _lib.ptr(log_s_flat),
+                                           _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)))
+        log_s_list, log_det_W_list, off = [], [], 0
+        for k in range(self.n_flows):
+            hk = self.convinv[k].conv.weight.shape[0] // 2
+            n = B * hk * Lg
+            log_s_list.append(log_s_flat[off:off + n].view(B, hk, Lg))
+            off += n
+            W = self.convinv[k].conv.weight.squeeze(-1).float()
+            log_det_W_list.append(B * Lg * torch.logdet(W))          # glow.py:100
+        return z, log_s_list, log_det_W_list
 
     def infer(self, spect, sigma=1.0, z=None, lengths=None, seed=None):
         """mel [B, n_mel, T] (GPU, fp32) -> audio [B, T*hop]   (glow.py:252-293)."""

@@ -71,6 +71,7 @@ typedef struct facppg_wg facppg_wg;
  *       WN.k.res_skip_layers.i.weight [2C or C (last i)][C], .bias
  *     WN.k.end.weight [c_k][C], WN.k.end.bias [c_k]
  *     convinv.k  W_inverse [c_k][c_k]   (= conv.weight.squeeze().inverse(), glow.py:88-95)
+ *     convinv.k  W [c_k][c_k]           (conv.weight.squeeze(), used by the training direction)
  */
 size_t facppg_wg_weight_count(const facppg_wg_config* cfg);
 
@@ -106,6 +107,21 @@ int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t* T_valid_d
  * the most recent facppg_wg_infer on this handle, measured with hipEvents on the stream the
  * kernels ran on when profiling was enabled with facppg_wg_set_profiling(h, 1).  Synchronises
  * the recorded events.  *n_launches receives the number of launches averaged. */
+/* Replaces: WaveGlow.forward((spect, audio)) (glow.py:208-250), the training direction
+ * audio -> z: upsample + crop to the audio length, 8-sample regroup, per flow the forward 1x1
+ * mixing conv, WN, and a1 = exp(log_s)*a1 + b, with early outputs split off every n_early_every
+ * flows.
+ *   mel_dev [B][n_mel][F], audio_dev [B][N] (N a multiple of n_group; (F-1)*hop + kernel >= N)
+ *   z_dev   [B][n_group][N/n_group]   = cat(early outputs..., final) along channels (glow.py:249)
+ *   log_s_dev  the per-flow log_s tensors [B][h_k][N/n_group], flow 0 first, concatenated flat
+ *              (facppg_wg_log_s_count values); log|det W_k| is a property of the weights alone and
+ *              is left to the caller (glow.py:100).
+ * Workspace: facppg_wg_workspace_bytes(h, B, ceil(N / hop)). */
+size_t facppg_wg_log_s_count(const facppg_wg* h, int B, int N);
+int facppg_wg_forward(facppg_wg* h, const float* mel_dev, const float* audio_dev, int B, int F,
+                      int N, float* z_dev, float* log_s_dev, void* workspace_dev,
+                      size_t workspace_bytes, void* stream);
+
 int facppg_wg_set_profiling(facppg_wg* h, int enable);
 int facppg_wg_last_layer_ms(facppg_wg* h, float* avg_ms, int* n_launches);
 

@@ -39,7 +39,9 @@ def test_config_validation_without_device():
     cfg = flib.WgConfig(80, 160, 12, 8, 4, 2, 8, 256, 3, 1024)
     n = L.facppg_wg_weight_count(cfg)
     from facppg import synth
-    assert n == sum(v.numel() for v in synth.waveglow_state_dict().values())
+    sd = synth.waveglow_state_dict()
+    # the blob carries every state-dict tensor plus W_inverse next to each convinv W
+    assert n == sum(v.numel() for v in sd.values()) + sum(v.numel() for k, v in sd.items() if k.startswith("convinv"))
     bad = flib.WgConfig(80, 160, 12, 8, 4, 2, 8, 128, 3, 1024)
     assert L.facppg_wg_weight_count(bad) == 0
     assert b"n_channels=256" in L.facppg_last_error()

@@ -104,3 +104,33 @@ def test_full_size_properties():
     e = (hip - ref).numpy()
     print("T=200 rms err", rms(e), "max", np.abs(e).max())
     assert rms(e) <= RMS_TOL
+
+
+@pytest.mark.parametrize("tag,hop", [("hop160", 160), ("hop256", 256)])
+def test_forward_matches_reference_golden_and_inverts(tag, hop, model160):
+    """Training direction audio -> z (WaveGlow.forward, glow.py:208-250) vs the reference's golden
+    z / sum(log_s) / logdet, the loss value, and the flow-invertibility KAT: infer with the
+    forward's z re-injected returns the audio (KAT i)."""
+    from waveglow.glow import WaveGlowLoss
+    d = golden("waveglow_%s.npz" % tag)
+    B, T = int(d["B"]), int(d["T"])
+    m, cfg = model160 if hop == 160 else make_model(hop)
+    mel = synth.synthetic_mel(B, T, seed=int(d["mel_seed"])).cuda()
+    wav = torch.from_numpy(d["fwd_audio_in"]).cuda()
+    z, log_s, log_det = m((mel, wav))
+    assert z.shape == (B, 8, T * hop // 8) and len(log_s) == 12 and [x.shape[1] for x in log_s] == [4] * 4 + [3] * 4 + [2] * 4
+    ez = np.abs(z.cpu().numpy() - d["fwd_z"]).max()
+    sums = np.array([float(x.double().sum()) for x in log_s])
+    print("forward z max err %.2e, log_s sum err %.2e" % (ez, np.abs(sums - d["fwd_log_s_sum"]).max()))
+    assert ez <= 1e-4
+    assert np.allclose(sums, d["fwd_log_s_sum"], atol=2e-3)
+    assert np.allclose([float(x) for x in log_det], d["fwd_log_det"], atol=1e-3)
+    loss = WaveGlowLoss(sigma=0.7071)((z, log_s, log_det))
+    from oracle import waveglow as owg
+    ref_loss = owg.loss(torch.from_numpy(d["fwd_z"]), [torch.tensor(v) for v in d["fwd_log_s_sum"]],
+                        [torch.tensor(v) for v in d["fwd_log_det"]], sigma=0.7071)
+    assert abs(float(loss) - float(ref_loss)) <= 1e-4 * max(1.0, abs(float(ref_loss)))
+    back = m.infer(mel, sigma=1.0, z=[z[:, 4:8].contiguous(), z[:, 2:4].contiguous(), z[:, 0:2].contiguous()])
+    e = (back - wav).cpu().numpy()
+    print("round trip rms err", rms(e))
+    assert rms(e) <= 1e-4
