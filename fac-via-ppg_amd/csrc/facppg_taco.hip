@@ -38,8 +38,10 @@ struct facppg_taco {
   // decoder (k-major, rows padded to a multiple of 4)
   float *dp0_t, *dp1_t, *att_t, *att_b, *dec_t, *dec_b, *q_t, *proj_t, *proj_b;
   float *loc_conv, *loc_dense, *v;
-  float *att_coop, *dec_coop;      // per-workgroup LSTM slices [NWG][K][4U] for k_decoder_coop
-  int coop_U, coop_nwg;
+  // per-workgroup LSTM slices [NWG][K][4U] for k_decoder_coop, packed for three slice widths:
+  // U = 8 (38 workgroups/utterance, B <= 6), 20 (15, B <= 16), 40 (8, B <= 30)
+  float *att_coop[3], *dec_coop[3];
+  int coop_U[3], coop_nwg[3];
   // postnet
   float4* post[8];
   float *post_b[8], *post_scale[8], *post_shift[8];
@@ -528,7 +530,7 @@ __global__ __launch_bounds__(NT) void k_decoder_coop(DecArgs p) {
   cg::grid_group grid = cg::this_grid();
   extern __shared__ float sm[];
   __shared__ int s_stop, s_all;
-  __shared__ float c_att[64], c_dec[64];
+  __shared__ float c_att[64], c_dec[64];   // U <= 64 units per workgroup
   const int wg = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const bool leader = wg == 0;
   const int len = p.lengths ? p.lengths[b] : p.Tin;
@@ -697,7 +699,7 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   struct { size_t pre0, pre1, conv[8], conv_b[8], conv_sc[8], conv_sh[8], wih, whh[2], lstm_b, mem_w, dp0, dp1, att, att_b, dec, dec_b, q,
-           proj, proj_b, lc, ld, v, attc, decc, post[8], post_b[8], post_sc[8], post_sh[8]; } o;
+           proj, proj_b, lc, ld, v, attc[3], decc[3], post[8], post_b[8], post_sc[8], post_sh[8]; } o;
   o.pre0 = take(packed_a_float4s(S, c.n_symbols) * 16);
   o.pre1 = take(packed_a_float4s(S, S) * 16);
   for (int j = 0; j < c.encoder_n_convolutions; ++j) {
@@ -713,8 +715,11 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
   o.dec = take((size_t)(A + E + D) * G * 4); o.dec_b = take((size_t)G * 4);
   o.q = take((size_t)A * ADp * 4);
   o.proj = take((size_t)(D + E) * NFp * 4); o.proj_b = take((size_t)NFp * 4);
-  const int CU_ = 8, NWG_ = (A + CU_ - 1) / CU_;
-  o.attc = take((size_t)NWG_ * (P + E + A) * 4 * CU_ * 4); o.decc = take((size_t)NWG_ * (A + E + D) * 4 * CU_ * 4);
+  const int CUs[3] = {8, 20, 40};
+  for (int v = 0; v < 3; ++v) {
+    const int nwg = (A + CUs[v] - 1) / CUs[v];
+    o.attc[v] = take((size_t)nwg * (P + E + A) * 4 * CUs[v] * 4); o.decc[v] = take((size_t)nwg * (A + E + D) * 4 * CUs[v] * 4);
+  }
   o.lc = take((size_t)NFIL * 2 * KSZ * 4); o.ld = take((size_t)AD * NFIL * 4); o.v = take((size_t)AD * 4);
   for (int j = 0; j < c.postnet_n_convolutions; ++j) {
     const int ci = j == 0 ? NF : PE, co = j == c.postnet_n_convolutions - 1 ? NF : PE;
@@ -785,11 +790,12 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
   tr(src, h->dec_t, G, A + E, G, 0); src += (size_t)G * (A + E);
   tr(src, h->dec_t, G, D, G, A + E); src += (size_t)G * D;
   k_add2<<<(G + 255) / 256, 256, 0, s>>>(src, src + G, h->dec_b, G); src += 2 * (size_t)G;
-  h->att_coop = F(o.attc); h->dec_coop = F(o.decc); h->coop_U = CU_; h->coop_nwg = NWG_;
-  {
-    const size_t na = (size_t)NWG_ * (P + E + A) * 4 * CU_, nd = (size_t)NWG_ * (A + E + D) * 4 * CU_;
-    k_pack_coop<<<(unsigned)((na + 255) / 256), 256, 0, s>>>(h->att_t, h->att_coop, P + E + A, A, CU_, NWG_);
-    k_pack_coop<<<(unsigned)((nd + 255) / 256), 256, 0, s>>>(h->dec_t, h->dec_coop, A + E + D, D, CU_, NWG_);
+  for (int v = 0; v < 3; ++v) {
+    const int U = CUs[v], nwg = (A + U - 1) / U;
+    h->att_coop[v] = F(o.attc[v]); h->dec_coop[v] = F(o.decc[v]); h->coop_U[v] = U; h->coop_nwg[v] = nwg;
+    const size_t na = (size_t)nwg * (P + E + A) * 4 * U, nd = (size_t)nwg * (A + E + D) * 4 * U;
+    k_pack_coop<<<(unsigned)((na + 255) / 256), 256, 0, s>>>(h->att_t, h->att_coop[v], P + E + A, A, U, nwg);
+    k_pack_coop<<<(unsigned)((nd + 255) / 256), 256, 0, s>>>(h->dec_t, h->dec_coop[v], A + E + D, D, U, nwg);
   }
   // projection rows 0..NF-1, gate row NF, K-major [D+E][NFp]
   {
@@ -931,7 +937,7 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
   DecArgs a;
   a.dp0_t = h->dp0_t; a.dp1_t = h->dp1_t; a.att_t = h->att_t; a.att_b = h->att_b; a.dec_t = h->dec_t; a.dec_b = h->dec_b;
   a.q_t = h->q_t; a.proj_t = h->proj_t; a.proj_b = h->proj_b; a.loc_conv = h->loc_conv; a.loc_dense = h->loc_dense; a.v = h->v;
-  a.att_coop = h->att_coop; a.dec_coop = h->dec_coop; a.xchg = (float*)(ws + w.xchg); a.fin = (int*)(ws + w.fin); a.U = h->coop_U;
+  a.xchg = (float*)(ws + w.xchg); a.fin = (int*)(ws + w.fin);
   a.prof = getenv("FACPPG_DECODER_PROF") ? (long long*)(ws + w.prof) : nullptr;
   a.memory = memory_dev; a.pm = pm_dev; a.lengths = lengths_dev; a.masks = masks; a.mel = mel_dev; a.gate = gate_dev;
   a.align = align_dev; a.out_len = out_lengths_dev;
@@ -942,18 +948,22 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
   const size_t smem = dec_lds_floats(a.P, a.E, a.A, a.D, a.NF, a.AD, a.NFIL, a.KSZ, Tin) * 4;
   FACPPG_REQUIRE(smem <= 160 * 1024 - 1024, FACPPG_EUNSUPPORTED, "decoder state (%zu bytes) exceeds LDS", smem);
   // latency mode (few utterances): NWG cooperating workgroups per utterance; throughput mode: one each
+  // slice width: the narrowest (most workgroups per utterance) that keeps B * NWG <= 240 resident
   const char* mode = getenv("FACPPG_DECODER_MODE");
-  bool coop = (long)B * h->coop_nwg <= 240;
+  int variant = -1;
+  for (int v = 0; v < 3 && variant < 0; ++v)
+    if ((long)B * h->coop_nwg[v] <= 240) variant = v;
+  bool coop = variant >= 0;
   if (mode && !strcmp(mode, "single")) coop = false;
-  if (mode && !strcmp(mode, "coop")) {
-    FACPPG_REQUIRE((long)B * h->coop_nwg <= 240, FACPPG_EUNSUPPORTED, "coop decoder needs B*%d <= 240 resident workgroups", h->coop_nwg);
-    coop = true;
+  if (mode && !strcmp(mode, "coop")) FACPPG_REQUIRE(coop, FACPPG_EUNSUPPORTED, "coop decoder needs B <= 30");
+  if (coop) {
+    a.att_coop = h->att_coop[variant]; a.dec_coop = h->dec_coop[variant]; a.U = h->coop_U[variant];
   }
   if (coop) {
     FACPPG_HIP_CHECK(hipMemsetAsync(ws + w.xchg, 0, w.total - w.xchg, s));
     FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_decoder_coop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     void* args[] = {(void*)&a};
-    FACPPG_HIP_CHECK(hipLaunchCooperativeKernel((const void*)k_decoder_coop, dim3(h->coop_nwg, B), dim3(NT), args, smem, s));
+    FACPPG_HIP_CHECK(hipLaunchCooperativeKernel((const void*)k_decoder_coop, dim3(h->coop_nwg[variant], B), dim3(NT), args, smem, s));
     if (a.prof) {
       long long pr[16];
       FACPPG_HIP_CHECK(hipMemcpyAsync(pr, a.prof, sizeof(pr), hipMemcpyDeviceToHost, s));

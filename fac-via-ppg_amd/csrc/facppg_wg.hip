@@ -244,10 +244,18 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
       const int gi = j * 8 + g;   // position inside the unrolled iteration (ring phase is static)
       // padded groups exist past the end of the packed image (RING-1 of them)
       load_a<4>(ar[(gi + RING - 1) % RING], ap, NG1 * 64, G + g + RING - 1);
+#ifndef FACPPG_WN_NOSCHEDBAR
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch PD groups ahead (hipcc sinks it otherwise)
+#endif
       float bq[4][NCB];
       load_b<NCB>(bq, lb, g);
+#ifdef FACPPG_WN_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
       mfma_group<4, NCB>(acc, ar[gi % RING], bq);
+#ifdef FACPPG_WN_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
 #if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 8)
     asm volatile("" ::"v"(stg[0]));   // ablation: no LDS staging write, no barrier
