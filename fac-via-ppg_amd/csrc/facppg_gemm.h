@@ -23,6 +23,8 @@ inline size_t packed_a_float4s(int M, int K) { return (size_t)(round_up(M, 32) /
 
 // src element (m, c, tap) at src[(m * Cin + c) * taps + tap]  (torch Conv1d / Linear weight layout)
 int pack_a(const float* src, int M, int Cin, int taps, float4* dst, hipStream_t s);
+// general form: element (m, c, tap) at src[off + m*sm + c*sc + tap*st] (transposed / tap-reversed views)
+int pack_a_strided(const float* src, int M, int Cin, int taps, long sm, long sc, long st, long off, float4* dst, hipStream_t s);
 
 struct GemmArgs {
   const float4* A = nullptr;  // packed weights
@@ -49,6 +51,11 @@ struct GemmArgs {
   long c_bs = 0;
   int ldc = 0;
   int c_transposed = 0;           // 1: store C[b][n][m] (address n*ldc + m)
+  // gate backward (training): v = d(acts)[m][n]; with T = tanh(pre_t), S = sigmoid(pre_s) saved by the
+  // forward at gate_ts[b][m][n] / gate_ts[b][M+m][n]: C[m] = v*S*(1-T^2), C[M+m] = v*T*S*(1-S)
+  const float* gate_ts = nullptr;
+  long gate_bs = 0;
+  int ldgate = 0;
   int B = 1;
 };
 

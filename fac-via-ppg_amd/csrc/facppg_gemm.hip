@@ -10,7 +10,8 @@ namespace {
 
 constexpr int TN = 64, KCH = 64;
 
-__global__ void k_pack_a(const float* __restrict__ src, float4* __restrict__ dst, int M, int Cin, int taps, int KG) {
+__global__ void k_pack_a(const float* __restrict__ src, float4* __restrict__ dst, int M, int Cin, int taps, int KG, long sm,
+                         long sc, long st, long off) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int MB = (M + 31) / 32;
   if (idx >= MB * (KG + 1) * 64) return;
@@ -20,7 +21,7 @@ __global__ void k_pack_a(const float* __restrict__ src, float4* __restrict__ dst
   for (int s = 0; s < 4; ++s) {
     const int k = 8 * g + 4 * (lane >> 5) + s;
     const int tap = k / Cin, c = k - tap * Cin;
-    v[s] = (m < M && k < K && g < KG) ? src[((size_t)m * Cin + c) * taps + tap] : 0.0f;
+    v[s] = (m < M && k < K && g < KG) ? src[off + m * sm + c * sc + tap * st] : 0.0f;
   }
   dst[idx] = make_float4(v[0], v[1], v[2], v[3]);
 }
@@ -112,7 +113,12 @@ __global__ __launch_bounds__(256) void k_gemm(KArgs ka) {
       else if (p.act == ACT_LOG_CLAMP) v = logf(fmaxf(v, 1e-5f));
       if (p.mask) v = v * (float)p.mask[(size_t)b * p.mask_bs + (size_t)m * p.ldmask + n] * 2.0f;
       if (p.res) v += p.res[(size_t)b * p.res_bs + (size_t)m * p.ldres + n];
-      if (p.c_transposed) p.C[(size_t)b * p.c_bs + (size_t)n * p.ldc + m] = v;
+      if (p.gate_ts) {
+        const float T = p.gate_ts[(size_t)b * p.gate_bs + (size_t)m * p.ldgate + n];
+        const float S = p.gate_ts[(size_t)b * p.gate_bs + (size_t)(p.M + m) * p.ldgate + n];
+        p.C[(size_t)b * p.c_bs + (size_t)m * p.ldc + n] = v * S * (1.0f - T * T);
+        p.C[(size_t)b * p.c_bs + (size_t)(p.M + m) * p.ldc + n] = v * T * S * (1.0f - S);
+      } else if (p.c_transposed) p.C[(size_t)b * p.c_bs + (size_t)n * p.ldc + m] = v;
       else p.C[(size_t)b * p.c_bs + (size_t)m * p.ldc + n] = v;
     }
   }
@@ -120,12 +126,16 @@ __global__ __launch_bounds__(256) void k_gemm(KArgs ka) {
 
 }  // namespace
 
-int pack_a(const float* src, int M, int Cin, int taps, float4* dst, hipStream_t s) {
+int pack_a_strided(const float* src, int M, int Cin, int taps, long sm, long sc, long st, long off, float4* dst, hipStream_t s) {
   const int KG = gemm_kpad(Cin * taps) / 8;
   const int total = (round_up(M, 32) / 32) * (KG + 1) * 64;
-  k_pack_a<<<(total + 255) / 256, 256, 0, s>>>(src, dst, M, Cin, taps, KG);
+  k_pack_a<<<(total + 255) / 256, 256, 0, s>>>(src, dst, M, Cin, taps, KG, sm, sc, st, off);
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
+}
+
+int pack_a(const float* src, int M, int Cin, int taps, float4* dst, hipStream_t s) {
+  return pack_a_strided(src, M, Cin, taps, (long)Cin * taps, taps, 1, 0, dst, s);
 }
 
 int gemm_launch(const GemmArgs& a, hipStream_t s) {

@@ -31,7 +31,7 @@
 #include <type_traits>
 #include <vector>
 
-#include "facppg_common.h"
+#include "facppg_gemm.h"
 
 namespace facppg {
 
@@ -113,6 +113,7 @@ struct WnArgs {
   const float* b2;
   const int* t_valid;  // may be null
   int T, hop8, Lp, Lr, dil, first;
+  float* save_ts;      // training: [B][512][Lr] tanh / sigmoid halves of the gate (SAVE variant)
 };
 
 template <int NRB>
@@ -157,7 +158,7 @@ __device__ __forceinline__ float gate_tanh_sigmoid(float a, float b) {
   return __fdividef(1.0f - ea, (1.0f + ea) * (1.0f + eb));
 }
 
-template <bool LAST, int NCB>
+template <bool LAST, int NCB, bool SAVE = false>
 __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   // LDS: 2 staging buffers [64 k][TNt] then the gated activations [256][TNt] (aliased)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -299,11 +300,24 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
 #if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 1)
+        const int ch = w * 64 + rb * 32 + 8 * (r >> 2) + (r & 3) + 4 * kh;
         const float v = fminf(fmaxf(acc[rb][cb][r], -1.f), 1.f) * fminf(fmaxf(acc[rb + 2][cb][r], 0.f), 1.f);   // ablation: no transcendentals
 #else
-        const float v = gate_tanh_sigmoid(acc[rb][cb][r], acc[rb + 2][cb][r]);
-#endif
+        float v;
         const int ch = w * 64 + rb * 32 + 8 * (r >> 2) + (r & 3) + 4 * kh;
+        if constexpr (SAVE) {   // training: keep tanh and sigmoid separately for the gate's backward
+          const float ea = __expf(-2.0f * fminf(fmaxf(acc[rb][cb][r], -15.0f), 15.0f));
+          const float T = __fdividef(1.0f - ea, 1.0f + ea), S = __fdividef(1.0f, 1.0f + __expf(-acc[rb + 2][cb][r]));
+          v = T * S;
+          const int pos = t0 + cb * 32 + li;
+          if (pos < Lb) {
+            p.save_ts[((size_t)b * 2 * C + ch) * p.Lr + pos] = T;
+            p.save_ts[((size_t)b * 2 * C + C + ch) * p.Lr + pos] = S;
+          }
+        } else {
+          v = gate_tanh_sigmoid(acc[rb][cb][r], acc[rb + 2][cb][r]);
+        }
+#endif
         smem[ch * TNt + cb * 32 + li] = v;
       }
   __syncthreads();
@@ -961,6 +975,7 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
       a.h_in = hbuf[hi]; a.h_out = hbuf[hi ^ 1]; a.spect = spect; a.skip = skip;
       a.w1 = h->w1[k][i]; a.b1 = h->b1[k][i]; a.w2 = h->w2[k][i]; a.b2 = h->b2[k][i];
       a.t_valid = T_valid_dev; a.T = T; a.hop8 = hop8; a.Lp = w.Lp; a.Lr = w.Lr; a.dil = 1 << i; a.first = (i == 0);
+      a.save_ts = nullptr;
       const bool last = i == c.wn_layers - 1;
       if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
       if (narrow) {
@@ -1059,7 +1074,7 @@ extern "C" int facppg_wg_forward(facppg_wg* h, const float* mel_dev, const float
       la.h_in = hbuf[hi]; la.h_out = hbuf[hi ^ 1]; la.spect = spect; la.skip = skip;
       la.w1 = h->w1[k][i]; la.b1 = h->b1[k][i]; la.w2 = h->w2[k][i]; la.b2 = h->b2[k][i];
       la.t_valid = nullptr; la.T = L; la.hop8 = 1;   // Lb = T * hop8 = L exactly
-      la.Lp = w.Lp; la.Lr = w.Lr; la.dil = 1 << i; la.first = (i == 0);
+      la.Lp = w.Lp; la.Lr = w.Lr; la.dil = 1 << i; la.first = (i == 0); la.save_ts = nullptr;
       const bool last = i == c.wn_layers - 1;
       if (narrow) {
         if (last) k_wn_layer<true, 1><<<lgrid, 256, 32768, s>>>(la);
@@ -1087,6 +1102,234 @@ extern "C" int facppg_wg_forward(facppg_wg* h, const float* mel_dev, const float
     }
     ai ^= 1;
   }
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+// ==========================================================================================
+// WN training primitives (WaveGlow training step): the WN stack of ONE flow
+// with activations saved, and its backward w.r.t. data.  Weights change every optimiser step and
+// are weight-normed on the host side, so these take PLAIN effective weights and pack them per call
+// into the caller's workspace.  Weight gradients are plain [M x N].[N x K] matrix products over the
+// saved tensors and are left to the caller's BLAS (rocBLAS through torch.matmul).
+// ==========================================================================================
+namespace {
+using namespace facppg;
+
+__global__ void k_wn_start(const float* __restrict__ a0, const float* __restrict__ w, const float* __restrict__ bias,
+                           float* __restrict__ h0, int nh, int L, int Lp) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (pos >= L) return;
+  float a[8];
+  for (int j = 0; j < nh; ++j) a[j] = a0[((size_t)b * nh + j) * L + pos];
+  float* dst = h0 + (size_t)b * C * Lp + HALO + pos;
+  for (int ch = 0; ch < C; ++ch) {
+    float v = bias[ch];
+    for (int j = 0; j < nh; ++j) v = fmaf(w[ch * nh + j], a[j], v);
+    dst[(size_t)ch * Lp] = v;
+  }
+}
+
+__global__ void k_wn_end(const float* __restrict__ skip, const float* __restrict__ w, const float* __restrict__ bias,
+                         float* __restrict__ out, int nout, int L, int Lr) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (pos >= L) return;
+  float o[8];
+  for (int j = 0; j < nout; ++j) o[j] = bias[j];
+  const float* sk = skip + (size_t)b * C * Lr + pos;
+  for (int ch = 0; ch < C; ++ch) {
+    const float v = sk[(size_t)ch * Lr];
+    for (int j = 0; j < nout; ++j) o[j] = fmaf(w[j * C + ch], v, o[j]);
+  }
+  for (int j = 0; j < nout; ++j) out[((size_t)b * nout + j) * L + pos] = o[j];
+}
+
+// dskip[b][ch][pos] = sum_j Wend[j][ch] * dout[b][j][pos]
+__global__ void k_wn_end_bwd(const float* __restrict__ dout, const float* __restrict__ w, float* __restrict__ dskip, int nout,
+                             int L, int Lr) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (pos >= L) return;
+  float d[8];
+  for (int j = 0; j < nout; ++j) d[j] = dout[((size_t)b * nout + j) * L + pos];
+  float* dst = dskip + (size_t)b * C * Lr + pos;
+  for (int ch = 0; ch < C; ++ch) {
+    float v = 0.0f;
+    for (int j = 0; j < nout; ++j) v = fmaf(w[j * C + ch], d[j], v);
+    dst[(size_t)ch * Lr] = v;
+  }
+}
+
+// da0[b][j][pos] = sum_ch Wstart[ch][j] * dh0[b][ch][pos]
+__global__ void k_wn_start_bwd(const float* __restrict__ dh0, const float* __restrict__ w, float* __restrict__ da0, int nh, int L,
+                               int Lr) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (pos >= L) return;
+  float d[8];
+  for (int j = 0; j < nh; ++j) d[j] = 0.0f;
+  const float* src = dh0 + (size_t)b * C * Lr + pos;
+  for (int ch = 0; ch < C; ++ch) {
+    const float v = src[(size_t)ch * Lr];
+    for (int j = 0; j < nh; ++j) d[j] = fmaf(w[ch * nh + j], v, d[j]);
+  }
+  for (int j = 0; j < nh; ++j) da0[((size_t)b * nh + j) * L + pos] = d[j];
+}
+
+struct WnTrainWs {
+  size_t w1[8], b1[8], w2[8], total;                     // forward operands
+  size_t rs_a[8], rs_b[8], in_t[8], cond_t[8], tmp;      // backward operands ([K][M] transposes) + dacts temp
+};
+WnTrainWs wn_train_ws(int n_layers, int B, int Lr) {
+  WnTrainWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  for (int i = 0; i < n_layers; ++i) {
+    w.w1[i] = take((size_t)(16 * NG1 + 4) * 64 * sizeof(float4));
+    w.b1[i] = take(2 * C * 4);
+    w.w2[i] = take((size_t)(16 * NG2 + 4) * 64 * sizeof(float4));
+    w.rs_a[i] = take(packed_a_float4s(C, C) * 16);
+    w.rs_b[i] = take(packed_a_float4s(C, C) * 16);
+    w.in_t[i] = take(packed_a_float4s(C, 2 * C * 3) * 16);
+    w.cond_t[i] = take(packed_a_float4s(NCOND, 2 * C) * 16);
+  }
+  w.tmp = take((size_t)B * C * Lr * 4);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t facppg_wn_train_workspace_bytes(int n_layers, int B, int L) {
+  if (n_layers < 1 || n_layers > 8 || B <= 0 || L <= 0) return 0;
+  return wn_train_ws(n_layers, B, round_up(L, TN)).total;
+}
+
+static int wn_check(const facppg_wn_weights* w, int n_in, int n_layers, int B, int L) {
+  FACPPG_REQUIRE(w && w->start_w && w->start_b && w->end_w && w->end_b, FACPPG_EINVAL, "NULL weight pointer");
+  FACPPG_REQUIRE(n_in >= 1 && n_in <= 4 && n_layers >= 1 && n_layers <= 8 && B > 0 && B <= 65535 && L > 0, FACPPG_EINVAL,
+                 "bad n_in/n_layers/B/L");
+  for (int i = 0; i < n_layers; ++i)
+    FACPPG_REQUIRE(w->in_w[i] && w->in_b[i] && w->cond_w[i] && w->cond_b[i] && w->rs_w[i] && w->rs_b[i], FACPPG_EINVAL,
+                   "NULL weight pointer (layer %d)", i);
+  return FACPPG_OK;
+}
+
+// Replaces: WN.forward (glow.py:154-175) in training, keeping what its backward needs:
+//   h_all  [n_layers+1][B][256][Lp]  layer inputs (zero margins = conv padding), Lp = 128 + Lr + 128
+//   ts_all [n_layers][B][512][Lr]    tanh / sigmoid halves of each gate
+//   skip   [B][256][Lr]              total skip sum (input of the end conv)
+// a0 [B][n_in][L], spect_pad [B][640][Lr] (columns >= L must be readable), out [B][2*n_in][L].
+extern "C" int facppg_wn_forward_save(const facppg_wn_weights* wts, int n_in, int n_layers, const float* a0_dev,
+                                      const float* spect_pad_dev, int B, int L, float* out_dev, float* h_all_dev,
+                                      float* ts_all_dev, float* skip_dev, void* ws_, size_t ws_bytes, void* stream_) {
+  if (int rc = wn_check(wts, n_in, n_layers, B, L)) return rc;
+  FACPPG_REQUIRE(a0_dev && spect_pad_dev && out_dev && h_all_dev && ts_all_dev && skip_dev && ws_, FACPPG_EINVAL, "NULL argument");
+  const int Lr = round_up(L, TN), Lp = HALO + Lr + HALO;
+  const WnTrainWs w = wn_train_ws(n_layers, B, Lr);
+  FACPPG_REQUIRE(ws_bytes >= w.total, FACPPG_EWORKSPACE, "workspace has %zu bytes, need %zu", ws_bytes, w.total);
+  hipStream_t s = (hipStream_t)stream_;
+  char* ws = (char*)ws_;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wn_layer<false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wn_layer<true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    attr_set = true;
+  }
+  const size_t hsz = (size_t)B * C * Lp;
+  FACPPG_HIP_CHECK(hipMemsetAsync(h_all_dev, 0, hsz * (n_layers + 1) * 4, s));   // zero margins / tail columns
+  for (int i = 0; i < n_layers; ++i) {
+    const int last = i == n_layers - 1;
+    const int n1 = 16 * NG1 * 64, n2 = 4 * (last ? 2 : 4) * NG2 * 64;
+    k_pack_w1<<<(n1 + 255) / 256, 256, 0, s>>>(wts->in_w[i], wts->cond_w[i], (float4*)(ws + w.w1[i]));
+    k_pack_w2<<<(n2 + 255) / 256, 256, 0, s>>>(wts->rs_w[i], (float4*)(ws + w.w2[i]), last);
+    k_add_bias<<<2, 256, 0, s>>>(wts->in_b[i], wts->cond_b[i], (float*)(ws + w.b1[i]), 2 * C);
+  }
+  const dim3 egrid((L + 255) / 256, B);
+  k_wn_start<<<egrid, 256, 0, s>>>(a0_dev, wts->start_w, wts->start_b, h_all_dev, n_in, L, Lp);
+  const dim3 lgrid(Lr / TN, B);
+  for (int i = 0; i < n_layers; ++i) {
+    WnArgs a;
+    a.h_in = h_all_dev + hsz * i; a.h_out = h_all_dev + hsz * (i + 1); a.spect = spect_pad_dev; a.skip = skip_dev;
+    a.w1 = (const float4*)(ws + w.w1[i]); a.b1 = (const float*)(ws + w.b1[i]); a.w2 = (const float4*)(ws + w.w2[i]);
+    a.b2 = wts->rs_b[i]; a.t_valid = nullptr; a.T = L; a.hop8 = 1; a.Lp = Lp; a.Lr = Lr; a.dil = 1 << i; a.first = (i == 0);
+    a.save_ts = ts_all_dev + (size_t)B * 2 * C * Lr * i;
+    if (i == n_layers - 1) k_wn_layer<true, 2, true><<<lgrid, 256, 65536, s>>>(a);
+    else k_wn_layer<false, 2, true><<<lgrid, 256, 65536, s>>>(a);
+  }
+  k_wn_end<<<egrid, 256, 0, s>>>(skip_dev, wts->end_w, wts->end_b, out_dev, 2 * n_in, L, Lr);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+// Backward of WN.forward w.r.t. data, layer by layer in reverse (all exact-fp32 MFMA GEMMs):
+//   dskip = Wend^T dout
+//   d(acts_i) = Wrs_i^T [dh_{i+1}; dskip]          (+ gate derivative in the GEMM epilogue -> dpre_i)
+//   dh_i = dh_{i+1} + sum_taps Win_i[:, :, tap]^T dpre_i (shifted)   (transposed dilated conv)
+//   dspect += Wcond_i^T dpre_i ;  da0 = Wstart^T dh_0
+// Outputs kept for the caller's weight-gradient products: dpre_all [n_layers][B][512][Lr],
+// dh_all [n_layers+1][B][256][Lr] (dh_all[n_layers] = 0), dskip [B][256][Lr]; dspect [B][640][Lr], da0 [B][n_in][L].
+extern "C" int facppg_wn_backward_data(const facppg_wn_weights* wts, int n_in, int n_layers, const float* dout_dev,
+                                       const float* ts_all_dev, int B, int L, float* dpre_all_dev, float* dh_all_dev,
+                                       float* dskip_dev, float* dspect_dev, float* da0_dev, void* ws_, size_t ws_bytes,
+                                       void* stream_) {
+  if (int rc = wn_check(wts, n_in, n_layers, B, L)) return rc;
+  FACPPG_REQUIRE(dout_dev && ts_all_dev && dpre_all_dev && dh_all_dev && dskip_dev && dspect_dev && da0_dev && ws_, FACPPG_EINVAL,
+                 "NULL argument");
+  const int Lr = round_up(L, TN);
+  const WnTrainWs w = wn_train_ws(n_layers, B, Lr);
+  FACPPG_REQUIRE(ws_bytes >= w.total, FACPPG_EWORKSPACE, "workspace has %zu bytes, need %zu", ws_bytes, w.total);
+  hipStream_t s = (hipStream_t)stream_;
+  char* ws = (char*)ws_;
+  float* tmp = (float*)(ws + w.tmp);
+  const size_t dh_sz = (size_t)B * C * Lr, dp_sz = (size_t)B * 2 * C * Lr;
+  for (int i = 0; i < n_layers; ++i) {
+    const int last = i == n_layers - 1;
+    // Wrs_i [512 or 256][256]: A_a[m][c] = Wrs[c][m] (res rows), A_b[m][c] = Wrs[256 + c][m] (skip rows)
+    if (!last) {
+      if (int rc = pack_a_strided(wts->rs_w[i], C, C, 1, 1, C, 0, 0, (float4*)(ws + w.rs_a[i]), s)) return rc;
+      if (int rc = pack_a_strided(wts->rs_w[i], C, C, 1, 1, C, 0, (long)C * C, (float4*)(ws + w.rs_b[i]), s)) return rc;
+    } else {
+      if (int rc = pack_a_strided(wts->rs_w[i], C, C, 1, 1, C, 0, 0, (float4*)(ws + w.rs_b[i]), s)) return rc;
+    }
+    // Win_i [512][256][3] -> A[m = cin][c = cout][tap'] = Win[c][m][2 - tap']
+    if (int rc = pack_a_strided(wts->in_w[i], C, 2 * C, 3, 3, (long)C * 3, -1, 2, (float4*)(ws + w.in_t[i]), s)) return rc;
+    // Wcond_i [512][640] -> A[m = cond channel][c = cout]
+    if (int rc = pack_a_strided(wts->cond_w[i], NCOND, 2 * C, 1, 1, NCOND, 0, 0, (float4*)(ws + w.cond_t[i]), s)) return rc;
+  }
+  const dim3 egrid((L + 255) / 256, B);
+  FACPPG_HIP_CHECK(hipMemsetAsync(dskip_dev, 0, dh_sz * 4, s));
+  FACPPG_HIP_CHECK(hipMemsetAsync(dh_all_dev, 0, dh_sz * (n_layers + 1) * 4, s));
+  k_wn_end_bwd<<<egrid, 256, 0, s>>>(dout_dev, wts->end_w, dskip_dev, 2 * n_in, L, Lr);
+  for (int i = n_layers - 1; i >= 0; --i) {
+    const int last = i == n_layers - 1;
+    float* dpre = dpre_all_dev + dp_sz * i;
+    const float* dh_next = dh_all_dev + dh_sz * (i + 1);
+    float* dh = dh_all_dev + dh_sz * i;
+    GemmArgs g;
+    g.B = B; g.N = L; g.M = C; g.Cin = C; g.ldx = Lr; g.x_bs = (long)C * Lr;
+    const float* res = nullptr;
+    if (!last) {   // tmp = Wrs_res^T dh_{i+1}
+      g.A = (const float4*)(ws + w.rs_a[i]); g.X = dh_next; g.C = tmp; g.c_bs = (long)C * Lr; g.ldc = Lr;
+      if (int rc = gemm_launch(g, s)) return rc;
+      res = tmp;
+    }
+    // dpre_i = gate'( Wrs_skip^T dskip (+ tmp) )
+    g.A = (const float4*)(ws + w.rs_b[i]); g.X = dskip_dev; g.res = res; g.res_bs = (long)C * Lr; g.ldres = Lr;
+    g.gate_ts = ts_all_dev + dp_sz * i; g.gate_bs = (long)2 * C * Lr; g.ldgate = Lr;
+    g.C = dpre; g.c_bs = (long)2 * C * Lr; g.ldc = Lr;
+    if (int rc = gemm_launch(g, s)) return rc;
+    // dh_i = dh_{i+1} + Win^T (*) dpre_i   (taps reversed, same dilation)
+    GemmArgs t;
+    t.B = B; t.N = L; t.M = C; t.Cin = 2 * C; t.taps = 3; t.pad = 1; t.dil = 1 << i; t.A = (const float4*)(ws + w.in_t[i]);
+    t.X = dpre; t.x_bs = (long)2 * C * Lr; t.ldx = Lr; t.res = last ? nullptr : dh_next; t.res_bs = (long)C * Lr; t.ldres = Lr;
+    t.C = dh; t.c_bs = (long)C * Lr; t.ldc = Lr;
+    if (int rc = gemm_launch(t, s)) return rc;
+    // dspect (+)= Wcond^T dpre_i
+    GemmArgs cgm;
+    cgm.B = B; cgm.N = L; cgm.M = NCOND; cgm.Cin = 2 * C; cgm.A = (const float4*)(ws + w.cond_t[i]); cgm.X = dpre;
+    cgm.x_bs = (long)2 * C * Lr; cgm.ldx = Lr; cgm.res = last ? nullptr : dspect_dev; cgm.res_bs = (long)NCOND * Lr; cgm.ldres = Lr;
+    cgm.C = dspect_dev; cgm.c_bs = (long)NCOND * Lr; cgm.ldc = Lr;
+    if (int rc = gemm_launch(cgm, s)) return rc;
+  }
+  k_wn_start_bwd<<<egrid, 256, 0, s>>>(dh_all_dev, wts->start_w, da0_dev, n_in, L, Lr);
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
 }

@@ -38,6 +38,15 @@ class TacoConfig(ctypes.Structure):
         [("gate_threshold", ctypes.c_float), ("bn_eps", ctypes.c_float)]
 
 
+class WnWeights(ctypes.Structure):
+    """facppg_wn_weights (include/facppg.h)."""
+    _fields_ = [("start_w", ctypes.c_void_p), ("start_b", ctypes.c_void_p),
+                ("in_w", ctypes.c_void_p * 8), ("in_b", ctypes.c_void_p * 8),
+                ("cond_w", ctypes.c_void_p * 8), ("cond_b", ctypes.c_void_p * 8),
+                ("rs_w", ctypes.c_void_p * 8), ("rs_b", ctypes.c_void_p * 8),
+                ("end_w", ctypes.c_void_p), ("end_b", ctypes.c_void_p)]
+
+
 def _declare(lib):
     c = ctypes
     vp, i32, u64, f32, sz = c.c_void_p, c.c_int32, c.c_uint64, c.c_float, c.c_size_t
@@ -51,6 +60,11 @@ def _declare(lib):
         "facppg_wg_infer": (c.c_int, [vp, vp, vp, vp, u64, f32, c.c_int, c.c_int, vp, vp, sz, vp]),
         "facppg_wg_log_s_count": (sz, [vp, c.c_int, c.c_int]),
         "facppg_wg_forward": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, c.c_int, vp, vp, vp, sz, vp]),
+        "facppg_wn_train_workspace_bytes": (sz, [c.c_int, c.c_int, c.c_int]),
+        "facppg_wn_forward_save": (c.c_int, [c.POINTER(WnWeights), c.c_int, c.c_int, vp, vp, c.c_int, c.c_int, vp, vp, vp, vp,
+                                             vp, sz, vp]),
+        "facppg_wn_backward_data": (c.c_int, [c.POINTER(WnWeights), c.c_int, c.c_int, vp, vp, c.c_int, c.c_int, vp, vp, vp, vp,
+                                              vp, vp, sz, vp]),
         "facppg_wg_set_profiling": (c.c_int, [vp, c.c_int]),
         "facppg_wg_last_layer_ms": (c.c_int, [vp, c.POINTER(f32), c.POINTER(c.c_int)]),
         "facppg_stft_create": (c.c_int, [c.c_int, c.c_int, vp, vp, vp, vp, c.c_int, c.c_int, vp, c.POINTER(vp)]),

@@ -50,6 +50,94 @@ def _effective_weight(conv):
     return conv.weight
 
 
+_TN, _HALO = 64, 128   # tile width / zero margin of the HIP layouts (csrc/facppg_wg.hip)
+
+
+class _WNFunction(torch.autograd.Function):
+    """One flow's WN stack (glow.py:154-175) as an autograd node on the HIP kernels.
+
+    forward  = facppg_wn_forward_save: the fused k_wn_layer launches, keeping layer inputs and the
+               tanh/sigmoid halves of each gate;
+    backward = facppg_wn_backward_data for everything that flows through the data (transposed
+               dilated convs, gate derivative, conditioning gradient: exact-fp32 MFMA GEMMs) plus
+               the weight gradients, which are plain [M x N].[N x K] products over the saved tensors
+               and go to rocBLAS through torch.
+    Inputs: a0 [B, n_in, L], spect_pad [B, 640, Lr], then start.w, start.b, per layer
+    (in.w, in.b, cond.w, cond.b, res_skip.w, res_skip.b), end.w, end.b -- plain effective weights."""
+
+    @staticmethod
+    def _weights_struct(ws):
+        n_layers = (len(ws) - 4) // 6
+        st = _lib.WnWeights()
+        st.start_w, st.start_b = ws[0].data_ptr(), ws[1].data_ptr()
+        for i in range(n_layers):
+            q = ws[2 + 6 * i: 8 + 6 * i]
+            st.in_w[i], st.in_b[i], st.cond_w[i], st.cond_b[i], st.rs_w[i], st.rs_b[i] = [t.data_ptr() for t in q]
+        st.end_w, st.end_b = ws[-2].data_ptr(), ws[-1].data_ptr()
+        return st, n_layers
+
+    @staticmethod
+    def forward(ctx, a0, spect_pad, *weights):
+        L = _lib.load()
+        dev = a0.device
+        a0 = a0.contiguous()
+        ws_t = [w.detach().float().contiguous() for w in weights]
+        st, n_layers = _WNFunction._weights_struct(ws_t)
+        B, n_in, Lg = a0.shape
+        Lr = spect_pad.shape[2]
+        Lp = _HALO + Lr + _HALO
+        out = torch.empty(B, 2 * n_in, Lg, device=dev)
+        h_all = torch.empty(n_layers + 1, B, 256, Lp, device=dev)
+        ts_all = torch.empty(n_layers, B, 512, Lr, device=dev)
+        skip = torch.empty(B, 256, Lr, device=dev)
+        work = torch.empty(L.facppg_wn_train_workspace_bytes(n_layers, B, Lg), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.facppg_wn_forward_save(st, n_in, n_layers, _lib.ptr(a0), _lib.ptr(spect_pad), B, Lg, _lib.ptr(out),
+                                                _lib.ptr(h_all), _lib.ptr(ts_all), _lib.ptr(skip), _lib.ptr(work), work.numel(),
+                                                _lib.current_stream(dev)))
+        ctx.save_for_backward(a0, spect_pad, h_all, ts_all, skip, *ws_t)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.load()
+        a0, spect_pad, h_all, ts_all, skip, *ws_t = ctx.saved_tensors
+        dev = a0.device
+        st, n_layers = _WNFunction._weights_struct(ws_t)
+        B, n_in, Lg = a0.shape
+        Lr = spect_pad.shape[2]
+        dout = dout.contiguous().float()
+        dpre_all = torch.empty(n_layers, B, 512, Lr, device=dev)
+        dh_all = torch.empty(n_layers + 1, B, 256, Lr, device=dev)
+        dskip = torch.empty(B, 256, Lr, device=dev)
+        dspect = torch.zeros(B, spect_pad.shape[1], Lr, device=dev)
+        da0 = torch.empty_like(a0)
+        work = torch.empty(L.facppg_wn_train_workspace_bytes(n_layers, B, Lg), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.facppg_wn_backward_data(st, n_in, n_layers, _lib.ptr(dout), _lib.ptr(ts_all), B, Lg, _lib.ptr(dpre_all),
+                                                 _lib.ptr(dh_all), _lib.ptr(dskip), _lib.ptr(dspect), _lib.ptr(da0),
+                                                 _lib.ptr(work), work.numel(), _lib.current_stream(dev)))
+
+        def outer(a, b):                      # sum over batch and positions of a[:, m, n] * b[:, k, n]
+            return torch.einsum('bmn,bkn->mk', a, b)
+
+        sp = spect_pad[:, :, :Lg]
+        grads = [outer(dh_all[0][:, :, :Lg], a0).unsqueeze(-1), dh_all[0][:, :, :Lg].sum((0, 2))]
+        dsk = dskip[:, :, :Lg]
+        for i in range(n_layers):
+            acts = ts_all[i][:, :256, :Lg] * ts_all[i][:, 256:, :Lg]
+            dpre = dpre_all[i][:, :, :Lg]
+            d = 2 ** i
+            d_in = torch.stack([outer(dpre, h_all[i][:, :, _HALO + (tap - 1) * d:_HALO + (tap - 1) * d + Lg])
+                                for tap in range(3)], dim=2)
+            db = dpre.sum((0, 2))
+            drs = torch.cat((dh_all[i + 1][:, :, :Lg], dsk), 1) if i < n_layers - 1 else dsk
+            grads += [d_in, db, outer(dpre, sp).unsqueeze(-1), db, outer(drs, acts).unsqueeze(-1), drs.sum((0, 2))]
+        grads += [outer(dout, skip[:, :, :Lg]).unsqueeze(-1), dout.sum((0, 2))]
+        grads = [g.reshape(w.shape) for g, w in zip(grads, ws_t)]
+        return (da0, dspect, *grads)
+
+
 class Invertible1x1Conv(torch.nn.Module):
     """glow.py:62-102: parameter container for the c x c mixing matrix.  In inference the
     inverse matrix is applied inside k_flow_end (fused with the affine coupling)."""
@@ -202,13 +290,57 @@ class WaveGlow(torch.nn.Module):
             pass
 
     # ---------------------------------------------------------------- the hot path
+    def _wn_weights(self, k):
+        wn = self.WN[k]
+        ws = [_effective_weight(wn.start), wn.start.bias]
+        for i in range(wn.n_layers):
+            ws += [_effective_weight(wn.in_layers[i]), wn.in_layers[i].bias, _effective_weight(wn.cond_layers[i]),
+                   wn.cond_layers[i].bias, _effective_weight(wn.res_skip_layers[i]), wn.res_skip_layers[i].bias]
+        return ws + [wn.end.weight, wn.end.bias]
+
+    def _forward_autograd(self, spect, audio):
+        """Training forward with a differentiable graph (train_waveglow.py:126-133).  Per flow the WN
+        stack -- >99 % of the work -- is one HIP autograd node (_WNFunction); the flow edges
+        (c <= 8 channels per position: 1x1 mixing conv and its logdet, affine coupling, early
+        split) and the 0.4 %-of-FLOPs upsampling conv stay as torch ops so autograd links them."""
+        F = torch.nn.functional
+        g = self.n_group
+        spect = F.conv_transpose1d(spect, self.upsample.weight, self.upsample.bias, stride=self.upsample.stride[0])
+        assert spect.size(2) >= audio.size(1)
+        spect = spect[:, :, :audio.size(1)]
+        spect = spect.unfold(2, g, g).permute(0, 2, 1, 3)
+        spect = spect.contiguous().view(spect.size(0), spect.size(1), -1).permute(0, 2, 1)
+        Lg = spect.size(2)
+        spect_pad = F.pad(spect, (0, -(-Lg // _TN) * _TN - Lg)).contiguous()
+        audio = audio.unfold(1, g, g).permute(0, 2, 1)
+        output_audio, log_s_list, log_det_W_list = [], [], []
+        for k in range(self.n_flows):
+            if k % self.n_early_every == 0 and k > 0:
+                output_audio.append(audio[:, :self.n_early_size, :])
+                audio = audio[:, self.n_early_size:, :]
+            W = self.convinv[k].conv.weight.squeeze(-1)
+            log_det_W_list.append(audio.size(0) * audio.size(2) * torch.logdet(W))
+            audio = F.conv1d(audio, W.unsqueeze(-1))
+            n_half = audio.size(1) // 2
+            audio_0, audio_1 = audio[:, :n_half, :], audio[:, n_half:, :]
+            output = _WNFunction.apply(audio_0.contiguous(), spect_pad, *self._wn_weights(k))
+            log_s, b = output[:, n_half:, :], output[:, :n_half, :]
+            audio_1 = torch.exp(log_s) * audio_1 + b
+            log_s_list.append(log_s)
+            audio = torch.cat([audio_0, audio_1], 1)
+        output_audio.append(audio)
+        return torch.cat(output_audio, 1), log_s_list, log_det_W_list
+
     def forward(self, forward_input):
         """(mel [B, n_mel, F], audio [B, N]) -> (z [B, n_group, N/n_group], log_s_list, log_det_W_list)
-        -- the training direction, glow.py:208-250, on the HIP kernels (no autograd: the backward
-        pass / training step is the next row of the scope table)."""
+        -- the training direction, glow.py:208-250.  With gradients enabled this builds an autograd
+        graph whose heavy nodes run on the HIP kernels (see _forward_autograd); under no_grad it is one
+        fused facppg_wg_forward call."""
         spect, audio = forward_input
         _lib.require_cuda(spect, "WaveGlow.forward: spect")
         _lib.require_cuda(audio, "WaveGlow.forward: audio")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_autograd(spect.float(), audio.float())
         L = _lib.load()
         dev = spect.device
         spect = spect.float().contiguous()

@@ -122,6 +122,34 @@ int facppg_wg_forward(facppg_wg* h, const float* mel_dev, const float* audio_dev
                       int N, float* z_dev, float* log_s_dev, void* workspace_dev,
                       size_t workspace_bytes, void* stream);
 
+/* ---- WN training primitives (one flow's WN stack; WaveGlow training step, glow.py:154-175 +
+ * its autograd backward).  Plain (un-packed, weight-norm already applied) device weights: */
+typedef struct facppg_wn_weights {
+  const float* start_w; /* [256][n_in] */
+  const float* start_b; /* [256] */
+  const float* in_w[8];   /* [512][256][3] */
+  const float* in_b[8];   /* [512] */
+  const float* cond_w[8]; /* [512][640] */
+  const float* cond_b[8]; /* [512] */
+  const float* rs_w[8];   /* [512][256], last layer [256][256] */
+  const float* rs_b[8];
+  const float* end_w; /* [2*n_in][256] */
+  const float* end_b; /* [2*n_in] */
+} facppg_wn_weights;
+size_t facppg_wn_train_workspace_bytes(int n_layers, int B, int L);
+/* Lr = round_up(L, 64), Lp = 128 + Lr + 128.  Forward of WN keeping what the backward needs:
+ * h_all [n_layers+1][B][256][Lp], ts_all [n_layers][B][512][Lr], skip [B][256][Lr]. */
+int facppg_wn_forward_save(const facppg_wn_weights* w, int n_in, int n_layers, const float* a0_dev,
+                           const float* spect_pad_dev /*[B][640][Lr]*/, int B, int L, float* out_dev,
+                           float* h_all_dev, float* ts_all_dev, float* skip_dev, void* workspace_dev,
+                           size_t workspace_bytes, void* stream);
+/* Backward w.r.t. data; keeps dpre_all [n_layers][B][512][Lr], dh_all [n_layers+1][B][256][Lr] and
+ * dskip [B][256][Lr] for the caller's weight-gradient matrix products; dspect [B][640][Lr], da0 [B][n_in][L]. */
+int facppg_wn_backward_data(const facppg_wn_weights* w, int n_in, int n_layers, const float* dout_dev,
+                            const float* ts_all_dev, int B, int L, float* dpre_all_dev,
+                            float* dh_all_dev, float* dskip_dev, float* dspect_dev, float* da0_dev,
+                            void* workspace_dev, size_t workspace_bytes, void* stream);
+
 int facppg_wg_set_profiling(facppg_wg* h, int enable);
 int facppg_wg_last_layer_ms(facppg_wg* h, float* avg_ms, int* n_launches);
 

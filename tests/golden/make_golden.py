@@ -244,6 +244,47 @@ def gen_tacotron():
              memory=memory, mel=mel, mel_post=mel_post, gate=gate, align=align)
 
 
+def gen_waveglow_train():
+    """Reference forward + WaveGlowLoss + autograd backward on the weight-normed model (what
+    train_waveglow.py:121-133 does per step): loss value and per-parameter gradients."""
+    from waveglow import glow
+    cfg = dict(synth.WAVEGLOW_CONFIG)
+    B, T, hop = 2, 12, 160
+    m = glow.WaveGlow(**cfg)
+    sd = synth.waveglow_state_dict(cfg)
+    wn_sd = {}
+    for k, v in sd.items():
+        if k.startswith("WN.") and k.endswith(".weight") and ".end." not in k:
+            wn_sd[k[:-6] + "weight_v"] = v
+            wn_sd[k[:-6] + "weight_g"] = v.flatten(1).norm(dim=1).view(-1, 1, 1)
+        else:
+            wn_sd[k] = v
+    m.load_state_dict(wn_sd, strict=True)
+    m.train()
+    g = np.random.Generator(np.random.PCG64(123))
+    N = T * hop
+    wav = torch.from_numpy(np.clip(g.standard_normal((B, N), dtype=np.float32) * 0.1, -1, 1))
+    mel = synth.synthetic_mel(B, T + 1, seed=55)          # frames = N//hop + 1 as Mel2Samp yields
+    m.zero_grad()
+    out = m((mel, wav))
+    loss = glow.WaveGlowLoss(0.7071)(out)
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    keep = ["upsample.weight", "upsample.bias", "WN.0.start.weight_v", "WN.0.start.weight_g", "WN.0.start.bias",
+            "WN.0.in_layers.0.weight_v", "WN.0.in_layers.0.weight_g", "WN.0.in_layers.0.bias",
+            "WN.0.in_layers.7.weight_v", "WN.5.cond_layers.3.weight_v", "WN.5.cond_layers.3.bias",
+            "WN.11.res_skip_layers.7.weight_v", "WN.11.res_skip_layers.6.weight_v", "WN.11.res_skip_layers.6.bias",
+            "WN.3.end.weight", "WN.3.end.bias", "WN.11.end.weight", "convinv.0.conv.weight", "convinv.4.conv.weight",
+            "convinv.11.conv.weight"]
+    arrs = {"loss": loss.detach(), "B": B, "T": T, "hop": hop, "mel_seed": 55, "wav": wav,
+            "names": np.frombuffer(json.dumps(sorted(grads)).encode(), dtype=np.uint8),
+            "norms": np.array([float(grads[k].double().norm()) for k in sorted(grads)])}
+    for k in keep:                       # strided subsample (<= 4096 values) of each kept gradient
+        flat = grads[k].reshape(-1)
+        arrs["g:" + k] = flat[::max(1, -(-flat.numel() // 4096))].contiguous()
+    save("waveglow_train.npz", **arrs)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -252,6 +293,7 @@ def main():
     gen_masks()
     gen_stft()
     gen_waveglow()
+    gen_waveglow_train()
     gen_tacotron()
 
 

@@ -117,7 +117,8 @@ def test_forward_matches_reference_golden_and_inverts(tag, hop, model160):
     m, cfg = model160 if hop == 160 else make_model(hop)
     mel = synth.synthetic_mel(B, T, seed=int(d["mel_seed"])).cuda()
     wav = torch.from_numpy(d["fwd_audio_in"]).cuda()
-    z, log_s, log_det = m((mel, wav))
+    with torch.no_grad():
+        z, log_s, log_det = m((mel, wav))
     assert z.shape == (B, 8, T * hop // 8) and len(log_s) == 12 and [x.shape[1] for x in log_s] == [4] * 4 + [3] * 4 + [2] * 4
     ez = np.abs(z.cpu().numpy() - d["fwd_z"]).max()
     sums = np.array([float(x.double().sum()) for x in log_s])
@@ -134,3 +135,38 @@ def test_forward_matches_reference_golden_and_inverts(tag, hop, model160):
     e = (back - wav).cpu().numpy()
     print("round trip rms err", rms(e))
     assert rms(e) <= 1e-4
+
+
+def test_training_step_loss_and_gradients_match_reference():
+    """One WaveGlow training step (train_waveglow.py:121-133): forward, WaveGlowLoss, backward on the
+    weight-normed model; loss and every parameter gradient vs the reference's autograd results."""
+    import json
+    from test_gpu_e2e import weightnorm_state_dict
+    from waveglow.glow import WaveGlow, WaveGlowLoss
+    d = golden("waveglow_train.npz")
+    B, T, hop = int(d["B"]), int(d["T"]), int(d["hop"])
+    cfg = dict(synth.WAVEGLOW_CONFIG)
+    m = WaveGlow(**cfg)
+    m.load_state_dict(weightnorm_state_dict(synth.waveglow_state_dict(cfg)), strict=True)
+    m = m.cuda().train()
+    mel = synth.synthetic_mel(B, T + 1, seed=int(d["mel_seed"])).cuda()
+    wav = torch.from_numpy(d["wav"]).cuda()
+    m.zero_grad()
+    loss = WaveGlowLoss(0.7071)(m((mel, wav)))
+    loss.backward()
+    print("loss", float(loss), "ref", float(d["loss"]))
+    assert abs(float(loss) - float(d["loss"])) <= 1e-5 * max(1.0, abs(float(d["loss"])))
+    names = json.loads(bytes(d["names"]).decode())
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    assert sorted(grads) == names
+    norms = np.array([float(grads[k].double().norm()) for k in names])
+    rel = np.abs(norms - d["norms"]) / np.maximum(d["norms"], 1e-6)
+    print("grad-norm rel err: max %.2e (%s)" % (rel.max(), names[int(rel.argmax())]))
+    assert rel.max() <= 1e-3
+    for key in d.files:
+        if key.startswith("g:"):
+            g = grads[key[2:]].detach().cpu().reshape(-1)
+            sub = g[::max(1, -(-g.numel() // 4096))].numpy()
+            ref = d[key]
+            assert sub.shape == ref.shape, key
+            assert np.abs(sub - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()) + 1e-6, key
