@@ -1,0 +1,121 @@
+"""WaveGlow training loop -- drop-in for src/script/train_waveglow.py.
+
+Same config file (waveglow/config.json: train/data/dist/waveglow sections), checkpoint format
+(``{'model': <pickled WaveGlow>, 'iteration', 'optimizer', 'learning_rate'}``), Adam optimiser and
+data-parallel scheme (one process per GPU, gradients averaged by waveglow.distributed).  The step
+itself -- WaveGlow.forward, WaveGlowLoss, backward -- runs on libfacppg_hip through the model's
+autograd nodes; the mel features of each batch are computed on the GPU from the audio segments.
+
+  PYTHONPATH=fac-via-ppg_amd python -m script.train_waveglow -c fac-via-ppg_amd/waveglow/config.json
+"""
+import argparse
+import json
+import os
+
+import torch
+from torch.utils.data import DataLoader
+from torch.utils.data.distributed import DistributedSampler
+
+from waveglow.distributed import init_distributed, apply_gradient_allreduce, reduce_tensor
+from waveglow.glow import WaveGlow, WaveGlowLoss
+from waveglow.mel2samp import Mel2Samp
+
+
+def load_checkpoint(checkpoint_path, model, optimizer):
+    """train_waveglow.py:45-54"""
+    assert os.path.isfile(checkpoint_path)
+    checkpoint_dict = torch.load(checkpoint_path, map_location='cpu', weights_only=False)
+    iteration = checkpoint_dict['iteration']
+    optimizer.load_state_dict(checkpoint_dict['optimizer'])
+    model.load_state_dict(checkpoint_dict['model'].state_dict())
+    print("Loaded checkpoint '{}' (iteration {})".format(checkpoint_path, iteration))
+    return model, optimizer, iteration
+
+
+def save_checkpoint(model, optimizer, learning_rate, iteration, filepath, waveglow_config):
+    """train_waveglow.py:56-64: the whole module is pickled (load_waveglow_model relies on it)."""
+    print("Saving model and optimizer state at iteration {} to {}".format(iteration, filepath))
+    model_for_saving = WaveGlow(**waveglow_config)
+    model_for_saving.load_state_dict(model.state_dict())
+    torch.save({'model': model_for_saving, 'iteration': iteration, 'optimizer': optimizer.state_dict(),
+                'learning_rate': learning_rate}, filepath)
+
+
+def train_step(model, criterion, optimizer, mel, audio, num_gpus=1):
+    """One optimisation step (train_waveglow.py:121-134); returns the (rank-averaged) loss."""
+    model.zero_grad()
+    loss = criterion(model((mel, audio)))
+    reduced_loss = reduce_tensor(loss.data, num_gpus).item() if num_gpus > 1 else loss.item()
+    loss.backward()          # waveglow.distributed's hook averages the gradients over ranks
+    optimizer.step()
+    return reduced_loss
+
+
+def train(num_gpus, rank, group_name, output_directory, epochs, learning_rate, sigma, iters_per_checkpoint, batch_size, seed,
+          checkpoint_path, data_config, dist_config, waveglow_config, max_iterations=None):
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed(seed)
+    if num_gpus > 1:
+        init_distributed(rank, num_gpus, group_name, **dist_config)
+    criterion = WaveGlowLoss(sigma)
+    model = WaveGlow(**waveglow_config).cuda()
+    if num_gpus > 1:
+        model = apply_gradient_allreduce(model)
+    optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate)
+    iteration = 0
+    if checkpoint_path != "":
+        model, optimizer, iteration = load_checkpoint(checkpoint_path, model, optimizer)
+        iteration += 1
+    trainset = Mel2Samp(audio_only=True, **data_config)
+    train_sampler = DistributedSampler(trainset) if num_gpus > 1 else None
+    train_loader = DataLoader(trainset, num_workers=0, shuffle=train_sampler is None, sampler=train_sampler,
+                              batch_size=batch_size, pin_memory=True, drop_last=True)
+    if rank == 0:
+        os.makedirs(output_directory, exist_ok=True)
+        print("output directory", output_directory)
+    model.train()
+    epoch_offset = max(0, int(iteration / max(1, len(train_loader))))
+    for epoch in range(epoch_offset, epochs):
+        print("Epoch: {}".format(epoch))
+        for audio in train_loader:
+            audio = audio.cuda(non_blocking=True)
+            with torch.no_grad():
+                mel = trainset.mel_batch(audio)           # GPU STFT -> mel, no host round trip
+            reduced_loss = train_step(model, criterion, optimizer, mel, audio, num_gpus)
+            print("{}:\t{:.9f}".format(iteration, reduced_loss))
+            if iteration % iters_per_checkpoint == 0 and rank == 0:
+                save_checkpoint(model, optimizer, learning_rate, iteration, "{}/waveglow_{}".format(output_directory, iteration),
+                                waveglow_config)
+            iteration += 1
+            if max_iterations is not None and iteration >= max_iterations:
+                return model
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument('-c', '--config', type=str, default=os.path.join(os.path.dirname(__file__), '..', 'waveglow', 'config.json'))
+    parser.add_argument('-r', '--rank', type=int, default=None)
+    parser.add_argument('-g', '--group_name', type=str, default=None)
+    args = parser.parse_args(argv)
+    with open(args.config) as f:
+        config = json.load(f)
+    train_config, data_config = config["train_config"], config["data_config"]
+    dist_config, waveglow_config = dict(config["dist_config"]), config["waveglow_config"]
+    rank = dist_config.pop("rank") if args.rank is None else (dist_config.pop("rank"), args.rank)[1]
+    group_name = dist_config.pop("group_name") if args.group_name is None else (dist_config.pop("group_name"), args.group_name)[1]
+    num_gpus = torch.cuda.device_count()
+    if num_gpus > 1 and group_name == '':
+        print("WARNING: Multiple GPUs detected but no distributed group set")
+        print("Only running 1 GPU.  Use distributed launch (one process per GPU) for multiple GPUs")
+        num_gpus = 1
+    if num_gpus == 1 and rank != 0:
+        raise Exception("Doing single GPU training on rank > 0")
+    os.makedirs(train_config["output_directory"] or ".", exist_ok=True)
+    with open(os.path.join(train_config["output_directory"] or ".", 'config.json'), 'w') as writer:
+        json.dump(config, writer)
+    train(num_gpus, rank, group_name, data_config=data_config, dist_config=dist_config, waveglow_config=waveglow_config,
+          **train_config)
+
+
+if __name__ == "__main__":
+    main()
