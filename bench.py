@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the secondary batch-1 end-to-end measurement")
+    ap.add_argument("--dist-backend", default="nccl", help=argparse.SUPPRESS)   # "gloo" + --share-gpu: 1-GPU dry run of the N>1 path
+    ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-worker", nargs=2, type=int, metavar=("THREADS", "FRAMES"), help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -140,13 +142,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     from facppg import lib as flib, synth
     from waveglow.glow import WaveGlow
@@ -191,7 +198,7 @@ def main():
     layer_ms, layer_n = ms.value, n.value
     assert os.environ.get("FACPPG_BENCH_NO_CHECK") or torch.isfinite(audio).all()
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

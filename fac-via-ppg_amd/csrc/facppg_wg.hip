@@ -240,23 +240,38 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
     stage_load(c + 1 < NCH1 ? c + 1 : c);
     const float* lb = smem + (c & 1) * (KCH * TNt) + (4 * kh) * TNt + li;
     const int G = c * 8;
+    if constexpr (NCB == 1) {
+      // narrow tiles run ~1 wave/SIMD with registers to spare: read the B values one k-group ahead
+      // (double-buffered) so no ds_read -> s_waitcnt -> MFMA chain is exposed
+      float bq[2][4][NCB];
+      load_b<NCB>(bq[0], lb, 0);
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const int gi = j * 8 + g;   // position inside the unrolled iteration (ring phase is static)
-      // padded groups exist past the end of the packed image (RING-1 of them)
-      load_a<4>(ar[(gi + RING - 1) % RING], ap, NG1 * 64, G + g + RING - 1);
+      for (int g = 0; g < 8; ++g) {
+        const int gi = j * 8 + g;
+        load_a<4>(ar[(gi + RING - 1) % RING], ap, NG1 * 64, G + g + RING - 1);
+        if (g + 1 < 8) load_b<NCB>(bq[(g + 1) & 1], lb, g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group<4, NCB>(acc, ar[gi % RING], bq[g & 1]);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int gi = j * 8 + g;   // position inside the unrolled iteration (ring phase is static)
+        // padded groups exist past the end of the packed image (RING-1 of them)
+        load_a<4>(ar[(gi + RING - 1) % RING], ap, NG1 * 64, G + g + RING - 1);
 #ifndef FACPPG_WN_NOSCHEDBAR
-      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch PD groups ahead (hipcc sinks it otherwise)
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch PD groups ahead (hipcc sinks it otherwise)
 #endif
-      float bq[4][NCB];
-      load_b<NCB>(bq, lb, g);
+        float bq[4][NCB];
+        load_b<NCB>(bq, lb, g);
 #ifdef FACPPG_WN_SETPRIO
-      __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
 #endif
-      mfma_group<4, NCB>(acc, ar[gi % RING], bq);
+        mfma_group<4, NCB>(acc, ar[gi % RING], bq);
 #ifdef FACPPG_WN_SETPRIO
-      __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
 #endif
+      }
     }
 #if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 8)
     asm volatile("" ::"v"(stg[0]));   // ablation: no LDS staging write, no barrier

@@ -102,3 +102,35 @@ def test_stft_minimum_length_and_errors():
         st.transform(torch.zeros(1, 512, device="cuda"))
     with pytest.raises(flib.FacppgError, match="GPU tensor"):
         st.transform(torch.zeros(1, 2048))
+
+
+def test_large_sizes_properties():
+    """Maximum-size behaviour (properties only, the oracle would take minutes): a 48-second
+    utterance through WaveGlow (L = 96 000 positions, 1 500 tiles), batch independence at that size,
+    and a 1 500-frame PPG through the encoder/decoder (LDS-resident attention state scales with Tin)."""
+    from common.hparams import create_hparams_stage
+    from script.train_ppg2mel import load_model
+    m, cfg, _ = _wg(hop=256)
+    B, T = 2, 3000
+    mel = synth.synthetic_mel(B, T, seed=5).cuda()
+    a = m.infer(mel, sigma=0.6, seed=9)
+    assert a.shape == (B, T * 256) and torch.isfinite(a).all() and float(a.abs().max()) < 1e3
+    assert torch.equal(a, m.infer(mel, sigma=0.6, seed=9))
+    zs = synth.synthetic_z(B, T * 32, cfg, seed=3)
+    full = m.infer(mel, sigma=0.6, z=zs)
+    one = m.infer(mel[1:2].contiguous(), sigma=0.6, z=[z[1:2].contiguous() for z in zs])
+    assert torch.equal(one[0], full[1])
+    steps, Tin = 64, 1500
+    hp = create_hparams_stage(max_decoder_steps=steps)
+    t = load_model(hp)
+    t.load_state_dict(synth.tacotron_state_dict(hp, gate_bias=-10.0))
+    t.eval()
+    x = torch.from_numpy(synth.synthetic_ppg(Tin, 5816, seed=1)).t().unsqueeze(0).cuda()
+    mel_o, mel_post, gate, align = t.inference(x, seed=4)
+    assert mel_post.shape == (1, 80, steps) and align.shape == (1, steps, Tin)
+    assert torch.isfinite(mel_post).all()
+    al = align[0].cpu().numpy()
+    assert np.allclose(al.sum(1), 1.0, atol=1e-4)
+    for s_ in (0, 30, 63):                                   # support = the +-20 window of utils.py:64-77
+        nz = np.nonzero(al[s_])[0]
+        assert nz.min() >= max(0, s_ - 20) and nz.max() <= s_ + 20
