@@ -516,6 +516,7 @@ struct EdgeArgs {
   const int* t_valid;
   float sigma;
   int T, hop8, Lp, Lr, L, n_early, final_flow;
+  int swap, swap_next;     // legacy layout (glow_old.py:224-240): odd flows condition on the SECOND half
 };
 
 template <int HN>
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(256) void k_begin(EdgeArgs p) {
     a[j] = p.sigma * p.z0[((size_t)b * 2 * HN + j) * p.L + pos];
     p.aud_out[((size_t)b * 8 + j) * p.Lr + pos] = a[j];
   }
-  start_conv<HN>(p, b, pos, a);
+  start_conv<HN>(p, b, pos, a + (p.swap_next ? HN : 0));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -566,8 +567,11 @@ __global__ __launch_bounds__(256) void k_flow_end(EdgeArgs p) {
   float a[CC];
 #pragma unroll
   for (int j = 0; j < CC; ++j) a[j] = p.aud_in[((size_t)b * 8 + j) * p.Lr + pos];
+  {
+    const int tr = p.swap ? 0 : H;   // offset of the transformed half; the other half conditioned the WN
 #pragma unroll
-  for (int j = 0; j < H; ++j) a[H + j] = (a[H + j] - o[j]) / expf(o[H + j]);
+    for (int j = 0; j < H; ++j) a[tr + j] = (a[tr + j] - o[j]) / expf(o[H + j]);
+  }
   constexpr int CN = EARLY ? CC + 2 : CC;
   float y[CN];
   if (EARLY) {
@@ -589,7 +593,7 @@ __global__ __launch_bounds__(256) void k_flow_end(EdgeArgs p) {
   } else {
 #pragma unroll
     for (int j = 0; j < CN; ++j) p.aud_out[((size_t)b * 8 + j) * p.Lr + pos] = y[j];
-    start_conv<CN / 2>(p, b, pos, y);
+    start_conv<CN / 2>(p, b, pos, y + (p.swap_next ? CN / 2 : 0));
   }
 }
 
@@ -962,6 +966,7 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
   {
     const int k = nf - 1;
     e.z0 = z; e.aud_out = aud[ai]; e.h_out = hbuf[hi]; e.start_w = h->start_w[k]; e.start_b = h->start_b[k];
+    e.swap_next = c.alternate_halves && (k & 1);
     switch (h->n_half[k]) {
       case 1: k_begin<1><<<egrid, 256, 0, s>>>(e); break;
       case 2: k_begin<2><<<egrid, 256, 0, s>>>(e); break;
@@ -1007,6 +1012,8 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
     e.aud_in = aud[ai]; e.aud_out = aud[ai ^ 1]; e.h_out = hbuf[hi];
     e.end_w = h->end_w[k]; e.end_b = h->end_b[k]; e.winv = h->winv[k];
     e.final_flow = (k == 0);
+    e.swap = c.alternate_halves && (k & 1);
+    e.swap_next = c.alternate_halves && k > 0 && ((k - 1) & 1);
     e.z_early = nullptr;
     if (h->early[k]) { e.z_early = z + z_off; z_off += (size_t)B * c.n_early_size * w.L; }
     if (k > 0) { e.start_w = h->start_w[k - 1]; e.start_b = h->start_b[k - 1]; }
@@ -1048,6 +1055,7 @@ extern "C" int facppg_wg_forward(facppg_wg* h, const float* mel_dev, const float
   FACPPG_REQUIRE((F - 1) * c.hop_length + c.upsample_kernel >= N, FACPPG_EINVAL,
                  "upsampled mel (%d frames) is shorter than the audio (%d samples)  (glow.py:216)", F, N);
   FACPPG_REQUIRE(h->n_half[0] == 4, FACPPG_EUNSUPPORTED, "forward expects n_group = 8");
+  FACPPG_REQUIRE(!c.alternate_halves, FACPPG_EUNSUPPORTED, "the legacy alternating-halves layout has no training direction (glow_old.py:150-151 returns None)");
   // workspace: same layout as infer for T' frames covering N samples
   const int Tq = (N + c.hop_length - 1) / c.hop_length;
   WsLayout w = ws_layout(c, B, Tq);

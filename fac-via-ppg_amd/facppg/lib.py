@@ -25,7 +25,7 @@ class WgConfig(ctypes.Structure):
     """facppg_wg_config (include/facppg.h)."""
     _fields_ = [(n, ctypes.c_int32) for n in (
         "n_mel_channels", "hop_length", "n_flows", "n_group", "n_early_every", "n_early_size",
-        "wn_layers", "wn_channels", "wn_kernel_size", "upsample_kernel")]
+        "wn_layers", "wn_channels", "wn_kernel_size", "upsample_kernel", "alternate_halves")]
 
 
 class TacoConfig(ctypes.Structure):

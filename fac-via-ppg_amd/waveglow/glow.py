@@ -228,6 +228,7 @@ class WaveGlow(torch.nn.Module):
         cfg.wn_channels = self.WN[0].n_channels
         cfg.wn_kernel_size = self.WN[0].in_layers[0].kernel_size[0]
         cfg.upsample_kernel = self.upsample.kernel_size[0]
+        cfg.alternate_halves = 1 if getattr(self, "_alternate_halves", False) else 0
         return cfg
 
     def _flat_weights(self):

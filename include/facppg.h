@@ -55,6 +55,7 @@ typedef struct facppg_wg_config {
   int32_t wn_channels;    /* 256 (WN_config.n_channels) */
   int32_t wn_kernel_size; /* 3  (WN_config.kernel_size) */
   int32_t upsample_kernel; /* 1024: ConvTranspose1d kernel size, glow.py:184-186 */
+  int32_t alternate_halves; /* 0; 1 = legacy glow_old.py layout: odd flows condition on the second half */
 } facppg_wg_config;
 
 typedef struct facppg_wg facppg_wg;

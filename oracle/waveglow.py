@@ -58,7 +58,7 @@ def upsample_regroup(sd, cfg, spect, trim):
     return s.contiguous().view(s.size(0), s.size(1), -1).permute(0, 2, 1)
 
 
-def infer(sd, cfg, spect, sigma, z_list):
+def infer(sd, cfg, spect, sigma, z_list, alternate=False):
     """WaveGlow.infer, glow.py:252-293.  ``z_list`` = the N(0,1) draws in call order:
     [B, n_remaining, L] then one [B, n_early_size, L] per early-output flow (k = 8, then 4)."""
     T = spect.size(2)
@@ -69,11 +69,14 @@ def infer(sd, cfg, spect, sigma, z_list):
     audio = sigma * zs.pop(0)
     for k in reversed(range(cfg["n_flows"])):
         n_half = audio.size(1) // 2
-        a0, a1 = audio[:, :n_half], audio[:, n_half:]
+        if alternate and k % 2 == 1:           # legacy layout, glow_old.py:224-240: odd flows swap the halves
+            a1, a0 = audio[:, :n_half], audio[:, n_half:]
+        else:
+            a0, a1 = audio[:, :n_half], audio[:, n_half:]
         out = wn_forward(sd, k, cfg, a0, sp)
         s, b = out[:, n_half:], out[:, :n_half]
         a1 = (a1 - b) / torch.exp(s)
-        audio = torch.cat([a0, a1], 1)
+        audio = torch.cat([a1, a0], 1) if (alternate and k % 2 == 1) else torch.cat([a0, a1], 1)
         W = sd["convinv.%d.conv.weight" % k].squeeze(-1)
         audio = F.conv1d(audio, W.inverse()[..., None])                         # glow.py:88-97
         if k % cfg["n_early_every"] == 0 and k > 0:

@@ -244,6 +244,22 @@ def gen_tacotron():
              memory=memory, mel=mel, mel_post=mel_post, gate=gate, align=align)
 
 
+def gen_waveglow_old():
+    """Legacy layout (src/waveglow/glow_old.py): stride 256, odd flows condition on the second half."""
+    from waveglow import glow_old as rold
+    cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=256)
+    m = rold.WaveGlow(**{k: v for k, v in cfg.items() if k != "hop_length"})
+    m = rold.WaveGlow.remove_weightnorm(m)
+    m.load_state_dict(synth.waveglow_state_dict(cfg), strict=True)
+    m.eval()
+    B, T = 1, 10
+    mel = synth.synthetic_mel(B, T, seed=77)
+    zs = synth.synthetic_z(B, T * 32, cfg, seed=78)
+    with torch.no_grad(), InjectNormal(zs):
+        audio = m.infer(mel, sigma=0.6)
+    save("waveglow_old_hop256.npz", B=B, T=T, sigma=0.6, mel_seed=77, z_seed=78, audio=audio)
+
+
 def gen_waveglow_train():
     """Reference forward + WaveGlowLoss + autograd backward on the weight-normed model (what
     train_waveglow.py:121-133 does per step): loss value and per-parameter gradients."""
@@ -293,6 +309,7 @@ def main():
     gen_masks()
     gen_stft()
     gen_waveglow()
+    gen_waveglow_old()
     gen_waveglow_train()
     gen_tacotron()
 

@@ -170,3 +170,48 @@ def test_training_step_loss_and_gradients_match_reference():
             ref = d[key]
             assert sub.shape == ref.shape, key
             assert np.abs(sub - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()) + 1e-6, key
+
+
+def test_legacy_glow_old_layout_and_convert_model():
+    """waveglow.glow_old.WaveGlow (stride 256, alternating halves, glow_old.py:121-255) vs the
+    reference's golden; convert_model.update_model merges separate res/skip layers."""
+    from waveglow import convert_model, glow_old
+    d = golden("waveglow_old_hop256.npz")
+    cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=256)
+    m = glow_old.WaveGlow(**{k: v for k, v in cfg.items() if k != "hop_length"})
+    m = glow_old.WaveGlow.remove_weightnorm(m)
+    m.load_state_dict(synth.waveglow_state_dict(cfg), strict=True)
+    m = m.cuda().eval()
+    B, T = int(d["B"]), int(d["T"])
+    mel = synth.synthetic_mel(B, T, seed=int(d["mel_seed"])).cuda()
+    zs = synth.synthetic_z(B, T * 32, cfg, seed=int(d["z_seed"]))
+    audio = m.infer(mel, sigma=float(d["sigma"]), z=zs)
+    e = audio.cpu().numpy() - d["audio"]
+    print("glow_old rms err", rms(e))
+    assert rms(e) <= RMS_TOL and np.abs(e).max() <= 5e-3
+    assert m((mel, audio)) is None                       # forward is disabled in the legacy file
+    # pre-merge checkpoints: split res_skip into res + skip layers, convert back, same audio
+    from waveglow.glow import WaveGlow
+    new = WaveGlow(**cfg)
+    old = convert_model._clone(new)
+    wn = torch.nn.utils.weight_norm
+    for w_old in old.WN:
+        w_old.res_layers, w_old.skip_layers = torch.nn.ModuleList(), torch.nn.ModuleList()
+        for i, rs in enumerate(w_old.res_skip_layers):
+            rs = torch.nn.utils.remove_weight_norm(convert_model._clone(rs))
+            nc = w_old.n_channels
+            sk = torch.nn.Conv1d(nc, nc, 1)
+            if i < w_old.n_layers - 1:
+                r = torch.nn.Conv1d(nc, nc, 1)
+                r.weight.data, r.bias.data = rs.weight.data[:nc].clone(), rs.bias.data[:nc].clone()
+                sk.weight.data, sk.bias.data = rs.weight.data[nc:].clone(), rs.bias.data[nc:].clone()
+                w_old.res_layers.append(wn(r, name="weight"))
+            else:
+                sk.weight.data, sk.bias.data = rs.weight.data.clone(), rs.bias.data.clone()
+            w_old.skip_layers.append(wn(sk, name="weight"))
+        del w_old.res_skip_layers
+    conv = convert_model.update_model(old)
+    assert not hasattr(conv.WN[0], "res_layers") and convert_model.update_model(new) is new
+    a1 = WaveGlow.remove_weightnorm(conv).cuda().eval().infer(mel, sigma=0.6, z=zs)
+    a2 = WaveGlow.remove_weightnorm(new).cuda().eval().infer(mel, sigma=0.6, z=zs)
+    assert rms((a1 - a2).cpu().numpy()) <= 1e-5

@@ -37,6 +37,20 @@ def test_waveglow_infer_and_forward(tag, hop):
     assert np.abs(back.numpy() - d["fwd_audio_in"]).max() < 2e-5
 
 
+def test_waveglow_legacy_alternating_layout():
+    d = golden("waveglow_old_hop256.npz")
+    cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=256)
+    sd = synth.waveglow_state_dict(cfg)
+    B, T = int(d["B"]), int(d["T"])
+    mel = synth.synthetic_mel(B, T, seed=int(d["mel_seed"]))
+    zs = synth.synthetic_z(B, T * 32, cfg, seed=int(d["z_seed"]))
+    with torch.no_grad():
+        a = owg.infer(sd, cfg, mel, float(d["sigma"]), zs, alternate=True)
+        plain = owg.infer(sd, cfg, mel, float(d["sigma"]), zs)
+    assert np.abs(a.numpy() - d["audio"]).max() < 5e-5
+    assert np.abs(plain.numpy() - d["audio"]).max() > 1e-2       # the layouts really differ
+
+
 def test_stft_mel_denoiser():
     s = golden("stft.npz")
     y = torch.from_numpy(s["y"])
