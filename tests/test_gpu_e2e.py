@@ -111,3 +111,37 @@ def test_pipeline_matches_oracle_and_batches_equal_singles(checkpoints):
         e = wavs[b] - ref
         print("utt %d: Tout %d, wav rms err %.2e (rms ref %.3f)" % (b, tout[b], rms(e), rms(ref)))
         assert rms(e) <= 1e-3
+
+
+def test_waveglow_inference_cli_and_mel2samp(checkpoints, tmp_path):
+    """waveglow.inference (mel .pt list -> int16 wavs) fed by waveglow.mel2samp's GPU mel analysis."""
+    from waveglow import inference
+    from waveglow.mel2samp import Mel2Samp
+    g = np.random.Generator(np.random.PCG64(2))
+    wavs = []
+    for i, n in enumerate((4800, 3200)):
+        path = tmp_path / ("a%d.wav" % i)
+        wavfile.write(path, 16000, (3000 * np.sin(np.arange(n) * 0.05 * (i + 1)) + 50 * g.standard_normal(n)).astype(np.int16))
+        wavs.append(str(path))
+    (tmp_path / "wavs.txt").write_text("\n".join(wavs) + "\n")
+    ds = Mel2Samp(str(tmp_path / "wavs.txt"), segment_length=1600, filter_length=1024, hop_length=160, win_length=1024,
+                  sampling_rate=16000, mel_fmin=0.0, mel_fmax=8000.0)
+    mel, audio = ds[0]
+    assert mel.shape == (80, 1600 // 160 + 1) and audio.shape == (1600,) and float(audio.abs().max()) <= 1.0
+    mel_paths = []
+    for i, w in enumerate(wavs):
+        sr, data = wavfile.read(w)
+        m = ds.get_mel(torch.from_numpy(data).float()).cpu()
+        assert m.shape == (80, len(data) // 160 + 1)
+        torch.save(m, tmp_path / ("m%d.pt" % i))
+        mel_paths.append(str(tmp_path / ("m%d.pt" % i)))
+    (tmp_path / "mels.txt").write_text("\n".join(mel_paths) + "\n")
+    out = tmp_path / "syn"
+    torch.manual_seed(3)
+    inference.main(str(tmp_path / "mels.txt"), str(checkpoints / "waveglow.pt"), 0.6, str(out), 16000, False)
+    for i, w in enumerate(wavs):
+        sr, syn = wavfile.read(out / ("m%d_synthesis.wav" % i))
+        n_frames = wavfile.read(w)[1].shape[0] // 160 + 1
+        assert sr == 16000 and syn.dtype == np.int16 and syn.shape == (n_frames * 160,)
+    with pytest.raises(NotImplementedError):
+        inference.main(str(tmp_path / "mels.txt"), str(checkpoints / "waveglow.pt"), 0.6, str(out), 16000, True)
