@@ -1267,15 +1267,21 @@ extern "C" int facppg_wn_forward_save(const facppg_wn_weights* wts, int n_in, in
   }
   const dim3 egrid((L + 255) / 256, B);
   k_wn_start<<<egrid, 256, 0, s>>>(a0_dev, wts->start_w, wts->start_b, h_all_dev, n_in, L, Lp);
-  const dim3 lgrid(Lr / TN, B);
+  const bool narrow = (long)(Lr / TN) * B < 768;   // small batches: 32-wide tiles halve the per-layer latency
+  const dim3 lgrid(narrow ? Lr / 32 : Lr / TN, B);
   for (int i = 0; i < n_layers; ++i) {
     WnArgs a;
     a.h_in = h_all_dev + hsz * i; a.h_out = h_all_dev + hsz * (i + 1); a.spect = spect_pad_dev; a.skip = skip_dev;
     a.w1 = (const float4*)(ws + w.w1[i]); a.b1 = (const float*)(ws + w.b1[i]); a.w2 = (const float4*)(ws + w.w2[i]);
     a.b2 = wts->rs_b[i]; a.t_valid = nullptr; a.T = L; a.hop8 = 1; a.Lp = Lp; a.Lr = Lr; a.dil = 1 << i; a.first = (i == 0);
     a.save_ts = ts_all_dev + (size_t)B * 2 * C * Lr * i;
-    if (i == n_layers - 1) k_wn_layer<true, 2, true><<<lgrid, 256, 65536, s>>>(a);
-    else k_wn_layer<false, 2, true><<<lgrid, 256, 65536, s>>>(a);
+    if (narrow) {
+      if (i == n_layers - 1) k_wn_layer<true, 1, true><<<lgrid, 256, 32768, s>>>(a);
+      else k_wn_layer<false, 1, true><<<lgrid, 256, 32768, s>>>(a);
+    } else {
+      if (i == n_layers - 1) k_wn_layer<true, 2, true><<<lgrid, 256, 65536, s>>>(a);
+      else k_wn_layer<false, 2, true><<<lgrid, 256, 65536, s>>>(a);
+    }
   }
   k_wn_end<<<egrid, 256, 0, s>>>(skip_dev, wts->end_w, wts->end_b, out_dev, 2 * n_in, L, Lr);
   FACPPG_HIP_CHECK(hipGetLastError());

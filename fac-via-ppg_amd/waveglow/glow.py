@@ -306,7 +306,14 @@ class WaveGlow(torch.nn.Module):
         split) and the 0.4 %-of-FLOPs upsampling conv stay as torch ops so autograd links them."""
         F = torch.nn.functional
         g = self.n_group
-        spect = F.conv_transpose1d(spect, self.upsample.weight, self.upsample.bias, stride=self.upsample.stride[0])
+        # ConvTranspose1d as a matrix product + overlap-add (col2im): both are differentiable torch ops that
+        # run on rocBLAS / a native fold kernel; MIOpen's transposed-conv backward falls back to a naive
+        # kernel here that costs more than the rest of the step together
+        hop, ksz = self.upsample.stride[0], self.upsample.kernel_size[0]
+        Bm, nm, Tm = spect.shape
+        cols = torch.einsum('bit,ijk->bjkt', spect, self.upsample.weight).reshape(Bm, nm * ksz, Tm)
+        spect = F.fold(cols, output_size=(1, (Tm - 1) * hop + ksz), kernel_size=(1, ksz), stride=(1, hop)).squeeze(2)
+        spect = spect + self.upsample.bias.view(1, -1, 1)
         assert spect.size(2) >= audio.size(1)
         spect = spect[:, :, :audio.size(1)]
         spect = spect.unfold(2, g, g).permute(0, 2, 1, 3)
@@ -321,7 +328,7 @@ class WaveGlow(torch.nn.Module):
                 audio = audio[:, self.n_early_size:, :]
             W = self.convinv[k].conv.weight.squeeze(-1)
             log_det_W_list.append(audio.size(0) * audio.size(2) * torch.logdet(W))
-            audio = F.conv1d(audio, W.unsqueeze(-1))
+            audio = torch.einsum('ij,bjl->bil', W, audio)        # 1x1 mixing conv (c <= 8 channels)
             n_half = audio.size(1) // 2
             audio_0, audio_1 = audio[:, :n_half, :], audio[:, n_half:, :]
             output = _WNFunction.apply(audio_0.contiguous(), spect_pad, *self._wn_weights(k))
