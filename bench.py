@@ -32,9 +32,15 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 BATCH, FRAMES, HOP, SR = 8, 1000, 256, 22050
 
 
-def layer_flops_per_position(n_layers=8, C=256, ncond=640):
+def layer_flops_per_position(n_layers=8, C=256, ncond=None):
     """Algorithmic FLOPs of one k_wn_layer launch per group position, averaged over a flow's
-    layers: in_layer 2*C*2C*3 + cond 2*ncond*2C + res_skip 2*C*2C (C last)."""
+    layers: in_layer 2*C*2C*3 + cond 2*ncond*2C + res_skip 2*C*2C (C last).
+    The inference kernels fold the upsampling ConvTranspose1d into the conditioning conv, which
+    shrinks its reduction from 640 (= 80 mel x 8 group) to ceil(1024/hop)*80 = 320 rows: the FLOPs
+    counted here are those of the folded formulation that actually runs (FACPPG_WG_UNFOLDED=1
+    runs, and counts, the reference's 640)."""
+    if ncond is None:
+        ncond = 640 if os.environ.get("FACPPG_WG_UNFOLDED", "0") not in ("", "0") else -(-1024 // HOP) * 80
     g1 = 2 * (3 * C + ncond) * 2 * C
     return ((n_layers - 1) * (g1 + 2 * C * 2 * C) + (g1 + 2 * C * C)) / n_layers
 

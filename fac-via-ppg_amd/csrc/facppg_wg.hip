@@ -55,6 +55,11 @@ constexpr int NG1 = K1 / 8;   // 176 k-groups of 8
 constexpr int NG2 = C / 8;    // 32
 constexpr int NCH1 = K1 / KCH;  // 22 chunks
 constexpr int MAXF = 32;      // max flows
+// phase-major ("folded conditioning") inference layout, see k_wn_layer<.., PM = true>
+constexpr int NMEL = 80;      // mel channels (NCOND / n_group)
+constexpr int HQ = 16;        // zero margin in frames on both sides of a phase row (>= 128 / (hop/8) + 1)
+constexpr int NGH = 3 * C / 8;   // 96 k-groups of the dilated convolution
+constexpr int NCHH = 3 * C / KCH;  // its 12 chunks
 
 // ------------------------------------------------------------------------------------------
 // Weight packing (runs once in facppg_wg_create).
@@ -94,6 +99,60 @@ __global__ void k_pack_w2(const float* __restrict__ rs_w,  // [512 or 256][256]
   out[idx] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// Phase-major images: float4 index (g*16 + w*4 + rb)*64 + lane (k-group slowest), see k_wn_layer<PM>.
+__global__ void k_pack_w1_pm(const float* __restrict__ in_w, float4* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= NGH * 1024) return;
+  const int lane = idx & 63, wr = (idx >> 6) & 15, g = idx >> 10;
+  const int row = rowmap(wr >> 2, wr & 3, lane & 31);
+  float v[4];
+  for (int s = 0; s < 4; ++s) {
+    const int kk = 8 * g + 4 * (lane >> 5) + s;
+    v[s] = in_w[(row * C + (kk % C)) * 3 + kk / C];
+  }
+  out[idx] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// U[8m+g][ph*kcp + j*80 + m'] = Wu[m'][m][hop*j + 8*ph + g]: the upsampling kernel laid out so that
+// Wc[512 x 640] . U is every phase's folded conditioning matrix at once.
+__global__ void k_fold_u(const float* __restrict__ up_w, float* __restrict__ U, int P, int kcp, int kc, int hop, int ksize) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t ncol = (size_t)P * kcp;
+  if (idx >= NCOND * ncol) return;
+  const int n = idx % ncol, mg = idx / ncol;
+  const int ph = n / kcp, r = n % kcp, j = r / NMEL, mp = r % NMEL, m = mg >> 3, g = mg & 7;
+  const int k = hop * j + 8 * ph + g;
+  U[idx] = (r < kc && k < ksize) ? up_w[((size_t)mp * NMEL + m) * ksize + k] : 0.0f;
+}
+
+__global__ void k_pack_cond_pm(const float* __restrict__ F,   // [512][P*kcp] folded matrices
+                               float4* __restrict__ out, int P, int kcp) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int ngc = kcp / 8;
+  if (idx >= (size_t)P * ngc * 1024) return;
+  const int lane = idx & 63, wr = (idx >> 6) & 15, g = (idx >> 10) % ngc, ph = (idx >> 10) / ngc;
+  const int row = rowmap(wr >> 2, wr & 3, lane & 31);
+  const float* src = F + (size_t)row * P * kcp + (size_t)ph * kcp + 8 * g + 4 * (lane >> 5);
+  out[idx] = make_float4(src[0], src[1], src[2], src[3]);
+}
+
+// b'[o] = in_b[o] + cond_b[o] + sum_{m,g} Wc[o][8m+g] * up_b[m]   (the upsample bias seen through the 1x1 conv)
+__global__ void k_fold_bias(const float* in_b, const float* cond_b, const float* cond_w, const float* up_b, float* out) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= 2 * C) return;
+  float v = 0.0f;
+  for (int mg = 0; mg < NCOND; ++mg) v = fmaf(cond_w[o * NCOND + mg], up_b[mg >> 3], v);
+  out[o] = in_b[o] + cond_b[o] + v;
+}
+
+// mel [B][80][T] -> [B][80][HQ + Tr + HQ], zero outside each utterance's valid frames
+__global__ void k_mel_pad(const float* __restrict__ mel, float* __restrict__ melp, const int* __restrict__ t_valid, int T, int Tqp) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;   // row = b*80 + m
+  if (x >= Tqp) return;
+  const int q = x - HQ, Tb = t_valid ? t_valid[row / NMEL] : T;
+  melp[(size_t)row * Tqp + x] = (q >= 0 && q < Tb) ? mel[(size_t)row * T + q] : 0.0f;
+}
+
 __global__ void k_add_bias(const float* a, const float* b, float* out, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = a[i] + b[i];
@@ -114,7 +173,13 @@ struct WnArgs {
   const int* t_valid;  // may be null
   int T, hop8, Lp, Lr, dil, first;
   float* save_ts;      // training: [B][512][Lr] tanh / sigmoid halves of the gate (SAVE variant)
+  // phase-major variant only
+  const float* melp;   // [B][80][Tqp] zero-margined mel frames
+  const float4* wc;    // folded conditioning weights of this layer: P images [ngc][16][64] float4
+  int P, Tr, Tqp, ntq, nt, nch, ngc, kc, xcd_map;
 };
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
 
 template <int NRB>
 __device__ __forceinline__ void load_a(float4 (&a)[4], const float4* __restrict__ p, int rb_stride, int g) {
@@ -158,7 +223,18 @@ __device__ __forceinline__ float gate_tanh_sigmoid(float a, float b) {
   return __fdividef(1.0f - ea, (1.0f + ea) * (1.0f + eb));
 }
 
-template <bool LAST, int NCB, bool SAVE = false>
+// PM = true is the phase-major inference variant.  The upsampling ConvTranspose1d (glow.py:253) is
+// linear and the conditioning 1x1 conv (glow.py:160) is applied straight to its regrouped output, so
+// the two compose: with P = hop/8 group positions per mel frame, position l = P*q + ph sees
+//   cond[o][l] = b'[o] + sum_{j < NJ} sum_{m'} Wf[ph][o][j*80 + m'] * mel[m'][q - j],   NJ = ceil(K/hop)
+//   Wf[ph][o][j*80+m'] = sum_{m,g} Wc[o][8m+g] * Wu[m'][m][hop*j + 8*ph + g]   (folded once, at create)
+// i.e. K = NJ*80 = 320 rows instead of 640 (hop 256, K 1024), and the [B][640][L] spect tensor and
+// the upsample kernel disappear.  The price is one weight image per phase, so a tile must hold
+// positions of ONE phase: h and skip are stored phase-major, [B][C][P][frames], where a dilated tap
+// l -+ d is simply another phase row ((ph -+ d) mod P) at a frame offset floor((ph -+ d) / P) --
+// still one contiguous row per channel.  Workgroups of the same phase run together (and, with
+// xcd_map, on the same XCD) so a phase's 655 KB image is fetched into an L2 once.
+template <bool LAST, int NCB, bool SAVE = false, bool PM = false>
 __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   // LDS: 2 staging buffers [64 k][TNt] then the gated activations [256][TNt] (aliased)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -167,13 +243,38 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   constexpr int NSTG = 16 / RPL;         // staging loads per wave per chunk
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int li = lane & 31, kh = lane >> 5;
-  const int b = blockIdx.y, t0 = blockIdx.x * TNt;
-  const int Lb = (p.t_valid ? p.t_valid[b] : p.T) * p.hop8;
-  if (t0 >= Lb) return;
   const int srow = lane / TNt, scol = lane % TNt;   // this lane's slot inside a staging load
+  // tile coordinates: batch b, first column t0 (position, or frame of phase ph), nvalid live columns,
+  // in_off / sk_off = offset of column 0 inside a channel row of h / skip, tapo[] = same for the 3 taps
+  int b, t0, nvalid, ph = 0, in_off, sk_off, tapo[3];
+  if constexpr (PM) {
+    const int lin = blockIdx.x;
+    int tile;
+    if (p.xcd_map) { const int r = lin >> 3; ph = (r / p.nt) * 8 + (lin & 7); tile = r % p.nt; }
+    else { ph = lin / p.nt; tile = lin % p.nt; }
+    if (ph >= p.P) return;
+    b = tile / p.ntq; t0 = (tile % p.ntq) * TNt;
+    nvalid = (p.t_valid ? p.t_valid[b] : p.T) - t0;
+    in_off = ph * p.Tqp + HQ + t0;
+    sk_off = ph * p.Tr + t0;
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp) {
+      const int pp = ph + (tp - 1) * p.dil;
+      const int qsh = pp >= 0 ? pp / p.P : -((p.P - 1 - pp) / p.P);   // floor(pp / P)
+      tapo[tp] = (pp - qsh * p.P) * p.Tqp + HQ + t0 + qsh;
+    }
+  } else {
+    b = blockIdx.y; t0 = blockIdx.x * TNt;
+    nvalid = (p.t_valid ? p.t_valid[b] : p.T) * p.hop8 - t0;
+    in_off = HALO + t0;
+    sk_off = t0;
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp) tapo[tp] = in_off + (tp - 1) * p.dil;
+  }
+  if (nvalid <= 0) return;
 
-  const float* hb = p.h_in + (size_t)b * C * p.Lp + HALO + t0 + scol;
-  const float* sb = p.spect + (size_t)b * NCOND * p.Lr + t0 + scol;
+  const float* hb = p.h_in + (size_t)b * C * p.Lp + scol;
+  const float* sb = PM ? p.melp + (size_t)b * NMEL * p.Tqp + HQ + t0 + scol : p.spect + (size_t)b * NCOND * p.Lr + t0 + scol;
 
   // accumulators start at the bias (in_layer.bias + cond_layer.bias, summed at pack time)
   f32x16 acc[4][NCB];
@@ -192,26 +293,80 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
 #if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 4)
   const float4* wave_a_ptr = p.w1 + lane;   // ablation: every wave streams the same rows (L1 hits)
 #else
-  const float4* wave_a_ptr = p.w1 + (size_t)(w * 4) * NG1 * 64 + lane;
+  // PM images are [k-group][16 row blocks][64 lanes]: a k-group's four row blocks sit 1 KiB apart
+  const float4* wave_a_ptr = PM ? p.w1 + w * 256 + lane : p.w1 + (size_t)(w * 4) * NG1 * 64 + lane;
 #endif
+#if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 4)
+  const float4* wave_c_ptr = PM ? p.wc + lane : nullptr;
+#else
+  const float4* wave_c_ptr = PM ? p.wc + (size_t)ph * p.ngc * 1024 + w * 256 + lane : nullptr;
+#endif
+  const int nch = PM ? p.nch : NCH1;
+  constexpr int F4R = TNt / 4, RPL4 = 64 / F4R, NSTG4 = 16 / RPL4;   // PM staging: float4 per row, rows per wave load, loads
+  const int srow4 = lane / F4R, scol4 = (lane % F4R) * 4;
+  const float* hb4 = p.h_in + (size_t)b * C * p.Lp + scol4;
+  const float* sb4 = PM ? p.melp + (size_t)b * NMEL * p.Tqp + HQ + t0 + scol4 : nullptr;
   float stg[NSTG];
   auto stage_load = [&](int c) {
-    const float* src;
-    int pitch;
-    if (c < 12) {
-      src = hb + (size_t)((c & 3) * 64 + w * 16 + srow) * p.Lp + ((c >> 2) - 1) * p.dil;
-      pitch = p.Lp;
-    } else {
-      src = sb + (size_t)((c - 12) * 64 + w * 16 + srow) * p.Lr;
-      pitch = p.Lr;
-    }
+#if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 16)
+    for (int jj = 0; jj < NSTG; ++jj) stg[jj] = 0.001f * c;   // ablation: no activation loads
+    return;
+#endif
+    if constexpr (PM) {
+      // both kinds of chunk reduce to "base + per-row offset" so the loads themselves are branch-free.
+      // Phase rows are contiguous in frames, so a lane fetches 4 columns at once (16-byte loads at
+      // 4-byte alignment: tap offsets are arbitrary) -- 4 VMEM instructions per chunk instead of 16.
+      const bool conv = c < NCHH;
+      const float* base = conv ? hb4 : sb4;
+      int off[NSTG4];
 #pragma unroll
-    for (int j = 0; j < NSTG; ++j) stg[j] = src[(size_t)(j * RPL) * pitch];
+      for (int jj = 0; jj < NSTG4; ++jj) {
+        const int r0 = w * 16 + srow4 + jj * RPL4;
+        // folded conditioning rows r = j*80 + m' <- mel[m'][q - j]; rows past kc (K padding) meet zero weights
+        const int r = min((c - NCHH) * 64 + r0, p.kc - 1);
+        const int j = r / NMEL, m = r - j * NMEL;
+        off[jj] = conv ? ((c & 3) * 64 + r0) * p.Lp + (c < 4 ? tapo[0] : c < 8 ? tapo[1] : tapo[2]) : m * p.Tqp - j;
+      }
+#pragma unroll
+      for (int jj = 0; jj < NSTG4; ++jj) {
+        const f4u v = *reinterpret_cast<const f4u*>(base + off[jj]);
+        stg[4 * jj + 0] = v.x; stg[4 * jj + 1] = v.y; stg[4 * jj + 2] = v.z; stg[4 * jj + 3] = v.w;
+      }
+    } else {
+      const float* src;
+      int pitch;
+      if (c < 12) {
+        src = hb + (size_t)((c & 3) * 64 + w * 16 + srow) * p.Lp + in_off + ((c >> 2) - 1) * p.dil;
+        pitch = p.Lp;
+      } else {
+        src = sb + (size_t)((c - 12) * 64 + w * 16 + srow) * p.Lr;
+        pitch = p.Lr;
+      }
+#pragma unroll
+      for (int j = 0; j < NSTG; ++j) stg[j] = src[(size_t)(j * RPL) * pitch];
+    }
+  };
+  // A operand of k-group gg (PM: the convolution image, then this phase's conditioning image)
+  auto load_a1 = [&](float4 (&a)[4], const float4* ap_, int gg) {
+    if constexpr (PM) {
+      const float4* src = gg < NGH ? ap_ + (size_t)gg * 1024 : wave_c_ptr + (size_t)(gg - NGH) * 1024;
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) a[rb] = src[rb * 64];
+    } else {
+      load_a<4>(a, ap_, NG1 * 64, gg);
+    }
   };
   auto stage_write = [&](int buf) {
-    float* dst = smem + buf * (KCH * TNt) + (w * 16) * TNt + lane;   // (row srow, col scol) = + lane
+    if constexpr (PM) {
+      float* dst = smem + buf * (KCH * TNt) + (w * 16 + srow4) * TNt + scol4;
 #pragma unroll
-    for (int j = 0; j < NSTG; ++j) dst[j * 64] = stg[j];
+      for (int jj = 0; jj < NSTG4; ++jj)
+        *reinterpret_cast<float4*>(dst + jj * RPL4 * TNt) = make_float4(stg[4 * jj], stg[4 * jj + 1], stg[4 * jj + 2], stg[4 * jj + 3]);
+    } else {
+      float* dst = smem + buf * (KCH * TNt) + (w * 16) * TNt + lane;   // (row srow, col scol) = + lane
+#pragma unroll
+      for (int j = 0; j < NSTG; ++j) dst[j * 64] = stg[j];
+    }
   };
 
   // A operand: a ring of RING register sets, prefetched PD = RING-1 k-groups ahead.  vmcnt retires
@@ -226,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   float4 ar[RING][4];
   stage_load(0);
 #pragma unroll
-  for (int i = 0; i < RING - 1; ++i) load_a<4>(ar[i], ap, NG1 * 64, i);
+  for (int i = 0; i < RING - 1; ++i) load_a1(ar[i], ap, i);
   stage_write(0);
   __syncthreads();
 
@@ -237,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   // tail chunk is peeled instead of guarded.
   auto do_chunk = [&](int c, auto jc) {
     constexpr int j = decltype(jc)::value;
-    stage_load(c + 1 < NCH1 ? c + 1 : c);
+    stage_load(c + 1 < nch ? c + 1 : c);
     const float* lb = smem + (c & 1) * (KCH * TNt) + (4 * kh) * TNt + li;
     const int G = c * 8;
     if constexpr (NCB == 1) {
@@ -248,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         const int gi = j * 8 + g;
-        load_a<4>(ar[(gi + RING - 1) % RING], ap, NG1 * 64, G + g + RING - 1);
+        load_a1(ar[(gi + RING - 1) % RING], ap, G + g + RING - 1);
         if (g + 1 < 8) load_b<NCB>(bq[(g + 1) & 1], lb, g + 1);
         __builtin_amdgcn_sched_barrier(0);
         mfma_group<4, NCB>(acc, ar[gi % RING], bq[g & 1]);
@@ -258,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
       for (int g = 0; g < 8; ++g) {
         const int gi = j * 8 + g;   // position inside the unrolled iteration (ring phase is static)
         // padded groups exist past the end of the packed image (RING-1 of them)
-        load_a<4>(ar[(gi + RING - 1) % RING], ap, NG1 * 64, G + g + RING - 1);
+        load_a1(ar[(gi + RING - 1) % RING], ap, G + g + RING - 1);
 #ifndef FACPPG_WN_NOSCHEDBAR
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch PD groups ahead (hipcc sinks it otherwise)
 #endif
@@ -280,7 +435,16 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
     __syncthreads();
 #endif
   };
-  if constexpr (CPI == 3) {
+  if constexpr (CPI == 3 && PM) {
+    int c0 = 0;
+    for (; c0 + 3 <= nch; c0 += 3) {
+      do_chunk(c0, std::integral_constant<int, 0>{});
+      do_chunk(c0 + 1, std::integral_constant<int, 1>{});
+      do_chunk(c0 + 2, std::integral_constant<int, 2>{});
+    }
+    if (c0 < nch) do_chunk(c0, std::integral_constant<int, 0>{});
+    if (c0 + 1 < nch) do_chunk(c0 + 1, std::integral_constant<int, 1>{});
+  } else if constexpr (CPI == 3) {
     static_assert(NCH1 % 3 == 1, "peeling below assumes 22 chunks");
     for (int c0 = 0; c0 + 3 <= NCH1; c0 += 3) {
       do_chunk(c0, std::integral_constant<int, 0>{});
@@ -289,19 +453,19 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
     }
     do_chunk(NCH1 - 1, std::integral_constant<int, 0>{});
   } else {
-    for (int c = 0; c < NCH1; ++c) do_chunk(c, std::integral_constant<int, 0>{});
+    for (int c = 0; c < nch; ++c) do_chunk(c, std::integral_constant<int, 0>{});
   }
 
   // residual inputs h_in[ch][pos] for this lane's res rows are fetched BEFORE the gate so their
   // latency hides under its VALU work; they seed the second GEMM's accumulators (bias + h_in), which
   // makes the residual add free and takes the loads out of the epilogue
-  float hres[LAST ? 1 : 2][NCB][16];
-  if constexpr (!LAST) {
+  float hres[(LAST || PM) ? 1 : 2][NCB][16];
+  if constexpr (!LAST && !PM) {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
-        const float* src = p.h_in + ((size_t)b * C + w * 64 + rb * 32 + 4 * kh) * p.Lp + HALO + t0 + cb * 32 + li;
+        const float* src = p.h_in + ((size_t)b * C + w * 64 + rb * 32 + 4 * kh) * p.Lp + in_off + cb * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) hres[rb][cb][r] = src[(size_t)(8 * (r >> 2) + (r & 3)) * p.Lp];
       }
@@ -324,10 +488,10 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
           const float ea = __expf(-2.0f * fminf(fmaxf(acc[rb][cb][r], -15.0f), 15.0f));
           const float T = __fdividef(1.0f - ea, 1.0f + ea), S = __fdividef(1.0f, 1.0f + __expf(-acc[rb + 2][cb][r]));
           v = T * S;
-          const int pos = t0 + cb * 32 + li;
-          if (pos < Lb) {
-            p.save_ts[((size_t)b * 2 * C + ch) * p.Lr + pos] = T;
-            p.save_ts[((size_t)b * 2 * C + C + ch) * p.Lr + pos] = S;
+          const int col = cb * 32 + li;
+          if (col < nvalid) {
+            p.save_ts[((size_t)b * 2 * C + ch) * p.Lr + sk_off + col] = T;
+            p.save_ts[((size_t)b * 2 * C + C + ch) * p.Lr + sk_off + col] = S;
           }
         } else {
           v = gate_tanh_sigmoid(acc[rb][cb][r], acc[rb + 2][cb][r]);
@@ -349,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
     }
 #pragma unroll
     for (int cb = 1; cb < NCB; ++cb) acc[rb][cb] = acc[rb][0];
-    if constexpr (!LAST) {
+    if constexpr (!LAST && !PM) {
       if (rb < 2) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
@@ -387,6 +551,50 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
     }
   }
 
+  if constexpr (PM) {
+    // epilogue, phase-major: the MFMA result layout gives a lane one column of 16 rows, i.e. 4-byte
+    // accesses.  Each wave transposes its 64 res rows, then its 64 skip rows, through a private
+    // [64][TNt] LDS slab and touches HBM with 16-byte row segments instead (4x fewer VMEM instructions).
+    __syncthreads();   // every wave is done reading the gated activations
+    float* slab = smem + w * (64 * TNt);
+#pragma unroll
+    for (int half = 0; half < NRB2 / 2; ++half) {
+      const bool is_res = !LAST && half == 0;
+#pragma unroll
+      for (int rbh = 0; rbh < 2; ++rbh)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            slab[(rbh * 32 + 8 * (r >> 2) + (r & 3) + 4 * kh) * TNt + cb * 32 + li] = acc[half * 2 + rbh][cb][r];
+      const int nv = nvalid - scol4;   // live columns among this lane's four
+#if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 2)
+      if (acc[0][0][0] != 12345.678f) continue;   // ablation: no epilogue traffic
+#endif
+      if (nv <= 0) continue;
+      float* gbase = is_res ? p.h_out + (size_t)b * C * p.Lp + in_off + scol4 : p.skip + (size_t)b * C * p.Lr + sk_off + scol4;
+      const float* rbase = is_res ? p.h_in + (size_t)b * C * p.Lp + in_off + scol4 : gbase;
+      const int pitch = is_res ? p.Lp : p.Lr;
+      const bool add = is_res || !p.first;
+#pragma unroll 4
+      for (int i = 0; i < 64 / RPL4; ++i) {
+        const int row = i * RPL4 + srow4;
+        const size_t o = (size_t)(w * 64 + row) * pitch;
+        float4 v = *reinterpret_cast<const float4*>(slab + row * TNt + scol4);
+        if (nv >= 4) {
+          if (add) {
+            const float4 x = *reinterpret_cast<const float4*>(rbase + o);
+            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+          }
+          *reinterpret_cast<float4*>(gbase + o) = v;
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int k = 0; k < nv; ++k) gbase[o + k] = vv[k] + (add ? rbase[o + k] : 0.0f);
+        }
+      }
+    }
+    return;
+  }
   // epilogue: h_out = h_in + res (glow.py:165-166), skip (+)= skip part (glow.py:167-174)
 #pragma unroll
   for (int rb = 0; rb < NRB2; ++rb) {
@@ -394,16 +602,20 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
     const int chb = w * 64 + (rb & 1) * 32 + 4 * kh;
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
-      const int pos = t0 + cb * 32 + li;
-      if (pos < Lb) {
+      const int col = cb * 32 + li;
+#if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 2)
+      if (col < nvalid && acc[rb][cb][0] == 12345.678f) {   // ablation: no epilogue traffic
+#else
+      if (col < nvalid) {
+#endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ch = chb + 8 * (r >> 2) + (r & 3);
           if (is_res) {
-            const size_t o = ((size_t)b * C + ch) * p.Lp + HALO + pos;
+            const size_t o = ((size_t)b * C + ch) * p.Lp + in_off + col;
             p.h_out[o] = acc[rb][cb][r];   // bias + h_in + res (h_in was folded into the accumulator)
           } else {
-            const size_t o = ((size_t)b * C + ch) * p.Lr + pos;
+            const size_t o = ((size_t)b * C + ch) * p.Lr + sk_off + col;
             p.skip[o] = (p.first ? 0.0f : p.skip[o]) + acc[rb][cb][r];
           }
         }
@@ -517,11 +729,29 @@ struct EdgeArgs {
   float sigma;
   int T, hop8, Lp, Lr, L, n_early, final_flow;
   int swap, swap_next;     // legacy layout (glow_old.py:224-240): odd flows condition on the SECOND half
+  int La;                  // channel pitch of aud_in / aud_out (always position-major)
+  int P, Tr, Tqp;          // P > 0: h and skip are phase-major (k_wn_layer<PM>), grid = (frames/256, B, P)
 };
 
+// This thread's position: natural index `pos` (into aud / z / the output audio) and the offsets of
+// that position inside a channel row of h and of skip.
+__device__ __forceinline__ bool edge_pos(const EdgeArgs& p, int b, int& pos, int& h_off, int& sk_off) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Tb = p.t_valid ? p.t_valid[b] : p.T;
+  if (p.P > 0) {
+    const int ph = blockIdx.z;
+    if (x >= Tb) return false;
+    pos = x * p.P + ph; h_off = ph * p.Tqp + HQ + x; sk_off = ph * p.Tr + x;
+  } else {
+    if (x >= Tb * p.hop8) return false;
+    pos = x; h_off = HALO + x; sk_off = x;
+  }
+  return true;
+}
+
 template <int HN>
-__device__ __forceinline__ void start_conv(const EdgeArgs& p, int b, int pos, const float* a0) {
-  float* dst = p.h_out + (size_t)b * C * p.Lp + HALO + pos;
+__device__ __forceinline__ void start_conv(const EdgeArgs& p, int b, int h_off, const float* a0) {
+  float* dst = p.h_out + (size_t)b * C * p.Lp + h_off;
   for (int ch = 0; ch < C; ++ch) {
     float v = p.start_b[ch];
 #pragma unroll
@@ -532,16 +762,16 @@ __device__ __forceinline__ void start_conv(const EdgeArgs& p, int b, int pos, co
 
 template <int HN>
 __global__ __launch_bounds__(256) void k_begin(EdgeArgs p) {
-  const int pos = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-  const int Lb = (p.t_valid ? p.t_valid[b] : p.T) * p.hop8;
-  if (pos >= Lb) return;
+  const int b = blockIdx.y;
+  int pos, h_off, sk_off;
+  if (!edge_pos(p, b, pos, h_off, sk_off)) return;
   float a[2 * HN];
 #pragma unroll
   for (int j = 0; j < 2 * HN; ++j) {
     a[j] = p.sigma * p.z0[((size_t)b * 2 * HN + j) * p.L + pos];
-    p.aud_out[((size_t)b * 8 + j) * p.Lr + pos] = a[j];
+    p.aud_out[((size_t)b * 8 + j) * p.La + pos] = a[j];
   }
-  start_conv<HN>(p, b, pos, a + (p.swap_next ? HN : 0));
+  start_conv<HN>(p, b, h_off, a + (p.swap_next ? HN : 0));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -551,14 +781,14 @@ __global__ __launch_bounds__(256) void k_begin(EdgeArgs p) {
 // ------------------------------------------------------------------------------------------
 template <int H, bool EARLY>
 __global__ __launch_bounds__(256) void k_flow_end(EdgeArgs p) {
-  const int pos = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-  const int Lb = (p.t_valid ? p.t_valid[b] : p.T) * p.hop8;
-  if (pos >= Lb) return;
+  const int b = blockIdx.y;
+  int pos, h_off, sk_off;
+  if (!edge_pos(p, b, pos, h_off, sk_off)) return;
   constexpr int CC = 2 * H;
   float o[CC];
 #pragma unroll
   for (int j = 0; j < CC; ++j) o[j] = p.end_b[j];
-  const float* sk = p.skip + (size_t)b * C * p.Lr + pos;
+  const float* sk = p.skip + (size_t)b * C * p.Lr + sk_off;
   for (int ch = 0; ch < C; ++ch) {
     const float v = sk[(size_t)ch * p.Lr];
 #pragma unroll
@@ -566,7 +796,7 @@ __global__ __launch_bounds__(256) void k_flow_end(EdgeArgs p) {
   }
   float a[CC];
 #pragma unroll
-  for (int j = 0; j < CC; ++j) a[j] = p.aud_in[((size_t)b * 8 + j) * p.Lr + pos];
+  for (int j = 0; j < CC; ++j) a[j] = p.aud_in[((size_t)b * 8 + j) * p.La + pos];
   {
     const int tr = p.swap ? 0 : H;   // offset of the transformed half; the other half conditioned the WN
 #pragma unroll
@@ -592,8 +822,8 @@ __global__ __launch_bounds__(256) void k_flow_end(EdgeArgs p) {
     for (int j = 0; j < CN; ++j) dst[j] = y[j];
   } else {
 #pragma unroll
-    for (int j = 0; j < CN; ++j) p.aud_out[((size_t)b * 8 + j) * p.Lr + pos] = y[j];
-    start_conv<CN / 2>(p, b, pos, y + (p.swap_next ? CN / 2 : 0));
+    for (int j = 0; j < CN; ++j) p.aud_out[((size_t)b * 8 + j) * p.La + pos] = y[j];
+    start_conv<CN / 2>(p, b, h_off, y + (p.swap_next ? CN / 2 : 0));
   }
 }
 
@@ -711,6 +941,11 @@ struct facppg_wg {
   float4* w1[MAXF][8];
   float4* w2[MAXF][8];
   float *b1[MAXF][8], *b2[MAXF][8];
+  // phase-major inference images (k_wn_layer<PM>): convolution part, folded conditioning per phase, folded bias
+  int P, nj, kc, kcp;
+  float4* w1pm[MAXF][8];
+  float4* wcpm[MAXF][8];
+  float* b1pm[MAXF][8];
   int profiling;
   std::vector<hipEvent_t> ev;  // pairs around each k_wn_layer launch
   int ev_used;
@@ -785,7 +1020,13 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   const size_t nm = cfg->n_mel_channels;
   const size_t w1_bytes = (size_t)(16 * NG1 + 4) * 64 * sizeof(float4);
   auto w2_bytes = [&](int last) { return (size_t)(4 * (last ? 2 : 4) * NG2 + 4) * 64 * sizeof(float4); };
-  struct Off { size_t start_w, start_b, end_w, end_b, winv, wfwd, w1[8], w2[8], b1[8], b2[8]; } fo[MAXF];
+  struct Off { size_t start_w, start_b, end_w, end_b, winv, wfwd, w1[8], w2[8], b1[8], b2[8], w1pm[8], wcpm[8], b1pm[8]; } fo[MAXF];
+  h->P = cfg->hop_length / 8;
+  h->nj = (cfg->upsample_kernel + cfg->hop_length - 1) / cfg->hop_length;
+  h->kc = h->nj * NMEL;
+  h->kcp = round_up(h->kc, KCH);
+  const size_t w1pm_bytes = (size_t)NGH * 1024 * sizeof(float4);
+  const size_t wcpm_bytes = ((size_t)h->P * (h->kcp / 8) + 4) * 1024 * sizeof(float4);   // + RING look-ahead past the last phase
   const size_t o_up_w = take(nm * nm * cfg->upsample_kernel * 4), o_up_b = take(nm * 4);
   for (int k = 0; k < cfg->n_flows; ++k) {
     const size_t hh = h->n_half[k], cc = 2 * hh;
@@ -794,6 +1035,7 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
       const int last = i == cfg->wn_layers - 1;
       fo[k].w1[i] = take(w1_bytes); fo[k].b1[i] = take(2 * C * 4);
       fo[k].w2[i] = take(w2_bytes(last)); fo[k].b2[i] = take(2 * C * 4);
+      fo[k].w1pm[i] = take(w1pm_bytes); fo[k].wcpm[i] = take(wcpm_bytes); fo[k].b1pm[i] = take(2 * C * 4);
     }
     fo[k].end_w = take(cc * C * 4); fo[k].end_b = take(cc * 4); fo[k].winv = take(cc * cc * 4); fo[k].wfwd = take(cc * cc * 4);
   }
@@ -803,7 +1045,18 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
     delete h;
     return FACPPG_EHIP;
   }
-  auto fail = [&](int rc) { hipFree(h->arena); delete h; return rc; };
+  // scratch for folding the upsampler into the conditioning convs: U, one layer's folded matrices, packed Wc
+  const size_t ncol = (size_t)h->P * h->kcp;
+  const size_t t_u = 0, t_f = t_u + NCOND * ncol * 4, t_a = t_f + (size_t)2 * C * ncol * 4;
+  const size_t tmp_bytes = t_a + packed_a_float4s(2 * C, NCOND) * sizeof(float4);
+  char* tmp = nullptr;
+  if (hipMalloc((void**)&tmp, tmp_bytes) != hipSuccess) {
+    set_error("hipMalloc(%zu) for weight folding scratch failed", tmp_bytes);
+    hipFree(h->arena);
+    delete h;
+    return FACPPG_EHIP;
+  }
+  auto fail = [&](int rc) { hipFree(tmp); hipFree(h->arena); delete h; return rc; };
 #define WG_TRY(expr)                                                                     \
   do {                                                                                   \
     hipError_t e__ = (expr);                                                             \
@@ -816,6 +1069,11 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   h->up_w = F(o_up_w); h->up_b = F(o_up_b);
   WG_TRY(cpy(h->up_w, src, nm * nm * cfg->upsample_kernel)); src += nm * nm * cfg->upsample_kernel;
   WG_TRY(cpy(h->up_b, src, nm)); src += nm;
+  {
+    const size_t n = NCOND * ncol;
+    k_fold_u<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(h->up_w, (float*)(tmp + t_u), h->P, h->kcp, h->kc, cfg->hop_length,
+                                                             cfg->upsample_kernel);
+  }
   for (int k = 0; k < cfg->n_flows; ++k) {
     const size_t hh = h->n_half[k], cc = 2 * hh;
     h->start_w[k] = F(fo[k].start_w); h->start_b[k] = F(fo[k].start_b);
@@ -837,6 +1095,20 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
       k_pack_w2<<<(n2 + 255) / 256, 256, 0, stream>>>(rs_w, h->w2[k][i], last);
       k_add_bias<<<2, 256, 0, stream>>>(in_b, cond_b, h->b1[k][i], 2 * C);
       WG_TRY(cpy(h->b2[k][i], rs_b, rs));
+      // phase-major images: Wf = Wc . U (fp32 MFMA GEMM), then the MFMA A-operand layout per phase
+      h->w1pm[k][i] = (float4*)(h->arena + fo[k].w1pm[i]); h->wcpm[k][i] = (float4*)(h->arena + fo[k].wcpm[i]);
+      h->b1pm[k][i] = F(fo[k].b1pm[i]);
+      k_pack_w1_pm<<<(NGH * 1024 + 255) / 256, 256, 0, stream>>>(in_w, h->w1pm[k][i]);
+      if (int rc = pack_a(cond_w, 2 * C, NCOND, 1, (float4*)(tmp + t_a), stream)) return fail(rc);
+      GemmArgs ga;
+      ga.A = (const float4*)(tmp + t_a); ga.M = 2 * C; ga.Cin = NCOND; ga.X = (const float*)(tmp + t_u); ga.ldx = (int)ncol;
+      ga.N = (int)ncol; ga.C = (float*)(tmp + t_f); ga.ldc = (int)ncol;
+      if (int rc = gemm_launch(ga, stream)) return fail(rc);
+      {
+        const size_t n = (size_t)h->P * (h->kcp / 8) * 1024;
+        k_pack_cond_pm<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const float*)(tmp + t_f), h->wcpm[k][i], h->P, h->kcp);
+      }
+      k_fold_bias<<<2, 256, 0, stream>>>(in_b, cond_b, cond_w, h->up_b, h->b1pm[k][i]);
     }
     h->end_w[k] = F(fo[k].end_w); h->end_b[k] = F(fo[k].end_b); h->winv[k] = F(fo[k].winv);
     WG_TRY(cpy(h->end_w[k], src, cc * C)); src += cc * C;
@@ -849,6 +1121,9 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   WG_TRY(hipStreamSynchronize(stream));
   WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<false, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<true, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipFree(tmp);
 #undef WG_TRY
   *out = h;
   return FACPPG_OK;
@@ -883,11 +1158,37 @@ WsLayout ws_layout(const facppg_wg_config& c, int B, int T) {
   w.total = off;
   return w;
 }
+
+// phase-major layout (k_wn_layer<PM>): frames are the contiguous axis of every phase row
+struct PmLayout {
+  int L, La, Tr, Tqp, P;
+  size_t h0, h1, skip, melp, aud0, aud1, z, total;
+};
+PmLayout pm_layout(const facppg_wg_config& c, int B, int T) {
+  PmLayout w;
+  w.P = c.hop_length / 8;
+  w.L = T * w.P;
+  w.La = round_up(w.L, TN);
+  w.Tr = round_up(T, TN);
+  w.Tqp = HQ + w.Tr + HQ;
+  size_t off = 0;
+  auto take = [&](size_t floats) { size_t o = off; off += (floats * 4 + 255) / 256 * 256; return o; };
+  w.h0 = take((size_t)B * C * w.P * w.Tqp);
+  w.h1 = take((size_t)B * C * w.P * w.Tqp);
+  w.skip = take((size_t)B * C * w.P * w.Tr);
+  w.melp = take((size_t)B * NMEL * w.Tqp);
+  w.aud0 = take((size_t)B * 8 * w.La);
+  w.aud1 = take((size_t)B * 8 * w.La);
+  w.z = take((size_t)B * 8 * w.L + 4);
+  w.total = off;
+  return w;
+}
 }  // namespace
 
 extern "C" size_t facppg_wg_workspace_bytes(const facppg_wg* h, int B, int T) {
   if (!h || B <= 0 || T <= 0) return 0;
-  return ws_layout(h->cfg, B, T).total;
+  const size_t a = ws_layout(h->cfg, B, T).total, b = pm_layout(h->cfg, B, T).total;
+  return a > b ? a : b;
 }
 
 extern "C" int facppg_wg_set_profiling(facppg_wg* h, int enable) {
@@ -916,6 +1217,113 @@ static void launch_flow_end(bool early, dim3 grid, hipStream_t s, const EdgeArgs
   else k_flow_end<H, false><<<grid, 256, 0, s>>>(a);
 }
 
+template <int HN>
+static void launch_begin(dim3 grid, hipStream_t s, const EdgeArgs& a) { k_begin<HN><<<grid, 256, 0, s>>>(a); }
+
+// WaveGlow.infer on the phase-major layout (folded conditioning): no spect tensor, no upsample kernel.
+static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_valid_dev, const float* z_dev, uint64_t seed,
+                       float sigma, int B, int T, float* audio_dev, char* ws, hipStream_t s) {
+  const facppg_wg_config& c = h->cfg;
+  const PmLayout w = pm_layout(c, B, T);
+  FACPPG_REQUIRE((double)C * w.P * w.Tqp < 2.0e9, FACPPG_EUNSUPPORTED, "T = %d frames is too long for 32-bit row offsets", T);
+  float* hbuf[2] = {(float*)(ws + w.h0), (float*)(ws + w.h1)};
+  float* skip = (float*)(ws + w.skip);
+  float* melp = (float*)(ws + w.melp);
+  float* aud[2] = {(float*)(ws + w.aud0), (float*)(ws + w.aud1)};
+  float* zbuf = (float*)(ws + w.z);
+  const int nf = c.n_flows;
+  // zero margins of h (the convolution's zero padding) and the frames past each utterance's end
+  FACPPG_HIP_CHECK(hipMemsetAsync(ws + w.h0, 0, (size_t)B * C * w.P * w.Tqp * 4 * 2, s));
+  k_mel_pad<<<dim3((w.Tqp + 255) / 256, B * NMEL), 256, 0, s>>>(mel_dev, melp, T_valid_dev, T, w.Tqp);
+  const float* z = z_dev;
+  const size_t zn = (size_t)B * 8 * w.L;
+  if (!z) {
+    k_noise<<<(unsigned)((zn / 4 + 255) / 256 + 1), 256, 0, s>>>(zbuf, zn, seed);
+    z = zbuf;
+  }
+  EdgeArgs e;
+  memset(&e, 0, sizeof(e));
+  e.skip = skip; e.t_valid = T_valid_dev; e.sigma = sigma; e.T = T; e.hop8 = w.P; e.Lp = w.P * w.Tqp; e.Lr = w.P * w.Tr; e.L = w.L;
+  e.La = w.La; e.P = w.P; e.Tr = w.Tr; e.Tqp = w.Tqp;
+  e.final_audio = audio_dev;
+  const dim3 egrid((T + 255) / 256, B, w.P);
+  int ai = 0, hi = 0;
+  {
+    const int k = nf - 1;
+    e.z0 = z; e.aud_out = aud[ai]; e.h_out = hbuf[hi]; e.start_w = h->start_w[k]; e.start_b = h->start_b[k];
+    e.swap_next = c.alternate_halves && (k & 1);
+    switch (h->n_half[k]) {
+      case 1: launch_begin<1>(egrid, s, e); break;
+      case 2: launch_begin<2>(egrid, s, e); break;
+      case 3: launch_begin<3>(egrid, s, e); break;
+      case 4: launch_begin<4>(egrid, s, e); break;
+      default: FACPPG_REQUIRE(false, FACPPG_EUNSUPPORTED, "n_half %d", h->n_half[k]);
+    }
+  }
+  size_t z_off = (size_t)B * h->n_rem[nf - 1] * w.L;
+  if (h->profiling) {
+    const size_t need = (size_t)2 * nf * c.wn_layers;
+    while (h->ev.size() < need) {
+      hipEvent_t ev;
+      FACPPG_HIP_CHECK(hipEventCreate(&ev));
+      h->ev.push_back(ev);
+    }
+  }
+  h->ev_used = 0;
+  // 64-frame tiles for throughput; 32 when the launch would not fill the chip's 512 workgroup slots 1.5 times
+  static const char* force_narrow = getenv("FACPPG_WN_FORCE_NARROW");
+  const bool narrow = force_narrow ? atoi(force_narrow) != 0 : (long)(w.Tr / TN) * B * w.P < 768;
+  const int tn = narrow ? 32 : TN;
+  WnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.melp = melp; a.skip = skip; a.t_valid = T_valid_dev; a.T = T; a.hop8 = w.P; a.Lp = w.P * w.Tqp; a.Lr = w.P * w.Tr;
+  a.P = w.P; a.Tr = w.Tr; a.Tqp = w.Tqp; a.ntq = (T + tn - 1) / tn; a.nt = a.ntq * B;
+  a.nch = NCHH + h->kcp / KCH; a.ngc = h->kcp / 8; a.kc = h->kc;
+  // workgroup i lands on XCD i % 8: give every XCD its own phases so a phase's weight image lives in one L2
+  static const char* no_xcd = getenv("FACPPG_WN_NO_XCD_MAP");
+  a.xcd_map = (w.P % 8 == 0) && !no_xcd;
+  const unsigned lgrid = (unsigned)((a.xcd_map ? w.P : w.P) * a.nt);
+  for (int k = nf - 1; k >= 0; --k) {
+    for (int i = 0; i < c.wn_layers; ++i) {
+      a.h_in = hbuf[hi]; a.h_out = hbuf[hi ^ 1];
+      a.w1 = h->w1pm[k][i]; a.wc = h->wcpm[k][i]; a.b1 = h->b1pm[k][i]; a.w2 = h->w2[k][i]; a.b2 = h->b2[k][i];
+      a.dil = 1 << i; a.first = (i == 0);
+      const bool last = i == c.wn_layers - 1;
+      if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
+      if (narrow) {
+        if (last) k_wn_layer<true, 1, false, true><<<lgrid, 256, 32768, s>>>(a);
+        else k_wn_layer<false, 1, false, true><<<lgrid, 256, 32768, s>>>(a);
+      } else {
+        if (last) k_wn_layer<true, 2, false, true><<<lgrid, 256, 65536, s>>>(a);
+        else k_wn_layer<false, 2, false, true><<<lgrid, 256, 65536, s>>>(a);
+      }
+      if (!last) hi ^= 1;
+      if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
+    }
+    e.aud_in = aud[ai]; e.aud_out = aud[ai ^ 1]; e.h_out = hbuf[hi];
+    e.end_w = h->end_w[k]; e.end_b = h->end_b[k]; e.winv = h->winv[k];
+    e.final_flow = (k == 0);
+    e.swap = c.alternate_halves && (k & 1);
+    e.swap_next = c.alternate_halves && k > 0 && ((k - 1) & 1);
+    e.z_early = nullptr;
+    if (h->early[k]) { e.z_early = z + z_off; z_off += (size_t)B * c.n_early_size * w.L; }
+    if (k > 0) { e.start_w = h->start_w[k - 1]; e.start_b = h->start_b[k - 1]; }
+    const int cn = 2 * h->n_half[k] + (h->early[k] ? 2 : 0);
+    if (k > 0) FACPPG_REQUIRE(cn == 2 * h->n_half[k - 1], FACPPG_EUNSUPPORTED, "flow %d channel mismatch", k);
+    else FACPPG_REQUIRE(cn == 8, FACPPG_EUNSUPPORTED, "final flow must yield n_group channels");
+    switch (h->n_half[k]) {
+      case 1: launch_flow_end<1>(h->early[k], egrid, s, e); break;
+      case 2: launch_flow_end<2>(h->early[k], egrid, s, e); break;
+      case 3: launch_flow_end<3>(h->early[k], egrid, s, e); break;
+      case 4: launch_flow_end<4>(h->early[k], egrid, s, e); break;
+      default: FACPPG_REQUIRE(false, FACPPG_EUNSUPPORTED, "n_half %d", h->n_half[k]);
+    }
+    ai ^= 1;
+  }
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
 extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t* T_valid_dev, const float* z_dev,
                                uint64_t seed, float sigma, int B, int T, float* audio_dev, void* ws_, size_t ws_bytes,
                                void* stream_) {
@@ -923,8 +1331,20 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
   FACPPG_REQUIRE(B > 0 && T > 0, FACPPG_EINVAL, "B and T must be positive (got %d, %d)", B, T);
   const facppg_wg_config& c = h->cfg;
   const WsLayout w = ws_layout(c, B, T);
-  FACPPG_REQUIRE(ws_bytes >= w.total, FACPPG_EWORKSPACE, "workspace has %zu bytes, need %zu", ws_bytes, w.total);
+  {
+    const size_t need = facppg_wg_workspace_bytes(h, B, T);
+    FACPPG_REQUIRE(ws_bytes >= need, FACPPG_EWORKSPACE, "workspace has %zu bytes, need %zu", ws_bytes, need);
+  }
   FACPPG_REQUIRE(B <= 65535, FACPPG_EINVAL, "B too large");
+  {
+    // total noise channels = n_remaining(last flow) + n_early_size * (#early flows) = n_group
+    int tot = h->n_rem[c.n_flows - 1];
+    for (int k = 0; k < c.n_flows; ++k) tot += h->early[k] ? c.n_early_size : 0;
+    FACPPG_REQUIRE(tot == 8, FACPPG_EUNSUPPORTED, "noise channel count %d != n_group", tot);
+  }
+  static const char* unfolded = getenv("FACPPG_WG_UNFOLDED");
+  if (!unfolded || atoi(unfolded) == 0)
+    return wg_infer_pm(h, mel_dev, T_valid_dev, z_dev, seed, sigma, B, T, audio_dev, (char*)ws_, (hipStream_t)stream_);
   hipStream_t s = (hipStream_t)stream_;
   char* ws = (char*)ws_;
   float* hbuf[2] = {(float*)(ws + w.h0), (float*)(ws + w.h1)};
@@ -941,12 +1361,6 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
 
   const float* z = z_dev;
   const size_t zn = (size_t)B * 8 * w.L;
-  {
-    // total noise channels = n_remaining(last flow) + n_early_size * (#early flows) = n_group
-    int tot = h->n_rem[nf - 1];
-    for (int k = 0; k < nf; ++k) tot += h->early[k] ? c.n_early_size : 0;
-    FACPPG_REQUIRE(tot == 8, FACPPG_EUNSUPPORTED, "noise channel count %d != n_group", tot);
-  }
   if (!z) {
     k_noise<<<(unsigned)((zn / 4 + 255) / 256 + 1), 256, 0, s>>>(zbuf, zn, seed);
     z = zbuf;
@@ -960,6 +1374,7 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
   EdgeArgs e;
   memset(&e, 0, sizeof(e));
   e.skip = skip; e.t_valid = T_valid_dev; e.sigma = sigma; e.T = T; e.hop8 = hop8; e.Lp = w.Lp; e.Lr = w.Lr; e.L = w.L;
+  e.La = w.Lr;
   e.final_audio = audio_dev;
   const dim3 egrid((w.L + 255) / 256, B);
   int ai = 0, hi = 0;  // current audio / h buffer
