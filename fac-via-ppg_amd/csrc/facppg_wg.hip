@@ -55,6 +55,9 @@ constexpr int NG1 = K1 / 8;   // 176 k-groups of 8
 constexpr int NG2 = C / 8;    // 32
 constexpr int NCH1 = K1 / KCH;  // 22 chunks
 constexpr int MAXF = 32;      // max flows
+#ifndef FACPPG_NARROW_RING
+#define FACPPG_NARROW_RING 8  // weight prefetch depth (k-groups) of the 32-column tiles, see k_wn_layer
+#endif
 // phase-major ("folded conditioning") inference layout, see k_wn_layer<.., PM = true>
 constexpr int NMEL = 80;      // mel channels (NCOND / n_group)
 constexpr int HQ = 16;        // zero margin in frames on both sides of a phase row (>= 128 / (hop/8) + 1)
@@ -177,6 +180,7 @@ struct WnArgs {
   const float* melp;   // [B][80][Tqp] zero-margined mel frames
   const float4* wc;    // folded conditioning weights of this layer: P images [ngc][16][64] float4
   int P, Tr, Tqp, ntq, nt, nch, ngc, kc, xcd_map;
+  int flat_cols;       // > 0: uniform batch, tiles cut from the B*T frames of a phase laid end to end (no ragged last tile per utterance)
 };
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
@@ -253,15 +257,27 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
     if (p.xcd_map) { const int r = lin >> 3; ph = (r / p.nt) * 8 + (lin & 7); tile = r % p.nt; }
     else { ph = lin / p.nt; tile = lin % p.nt; }
     if (ph >= p.P) return;
-    b = tile / p.ntq; t0 = (tile % p.ntq) * TNt;
-    nvalid = (p.t_valid ? p.t_valid[b] : p.T) - t0;
-    in_off = ph * p.Tqp + HQ + t0;
-    sk_off = ph * p.Tr + t0;
+    // this lane's four columns (staging loads and epilogue stores use the same lane -> column map):
+    // batch b, first frame qcol, nvalid = live columns from qcol on (may be <= 0)
+    int qcol;
+    t0 = 0;
+    if (p.flat_cols > 0) {
+      const int c0 = tile * TNt + (lane % (TNt / 4)) * 4;
+      const int cl = min(c0, p.flat_cols - 4);
+      b = cl / p.T; qcol = cl - b * p.T; nvalid = p.flat_cols - c0;
+    } else {
+      b = tile / p.ntq;
+      const int q0 = (tile % p.ntq) * TNt, Tb = p.t_valid ? p.t_valid[b] : p.T;
+      if (q0 >= Tb) return;
+      qcol = q0 + (lane % (TNt / 4)) * 4; nvalid = Tb - qcol;
+    }
+    in_off = ph * p.Tqp + HQ + qcol;
+    sk_off = ph * p.Tr + qcol;
 #pragma unroll
     for (int tp = 0; tp < 3; ++tp) {
       const int pp = ph + (tp - 1) * p.dil;
       const int qsh = pp >= 0 ? pp / p.P : -((p.P - 1 - pp) / p.P);   // floor(pp / P)
-      tapo[tp] = (pp - qsh * p.P) * p.Tqp + HQ + t0 + qsh;
+      tapo[tp] = (pp - qsh * p.P) * p.Tqp + HQ + qcol + qsh;
     }
   } else {
     b = blockIdx.y; t0 = blockIdx.x * TNt;
@@ -271,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
 #pragma unroll
     for (int tp = 0; tp < 3; ++tp) tapo[tp] = in_off + (tp - 1) * p.dil;
   }
-  if (nvalid <= 0) return;
+  if (!PM && nvalid <= 0) return;
 
   const float* hb = p.h_in + (size_t)b * C * p.Lp + scol;
   const float* sb = PM ? p.melp + (size_t)b * NMEL * p.Tqp + HQ + t0 + scol : p.spect + (size_t)b * NCOND * p.Lr + t0 + scol;
@@ -304,8 +320,8 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   const int nch = PM ? p.nch : NCH1;
   constexpr int F4R = TNt / 4, RPL4 = 64 / F4R, NSTG4 = 16 / RPL4;   // PM staging: float4 per row, rows per wave load, loads
   const int srow4 = lane / F4R, scol4 = (lane % F4R) * 4;
-  const float* hb4 = p.h_in + (size_t)b * C * p.Lp + scol4;
-  const float* sb4 = PM ? p.melp + (size_t)b * NMEL * p.Tqp + HQ + t0 + scol4 : nullptr;
+  const float* hb4 = p.h_in + (size_t)b * C * p.Lp;                         // PM: tapo[] carry the lane's column
+  const float* sb4 = PM ? p.melp + (size_t)b * NMEL * p.Tqp + in_off - ph * p.Tqp : nullptr;   // = HQ + qcol
   float stg[NSTG];
   auto stage_load = [&](int c) {
 #if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 16)
@@ -375,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   // chunk stalled ~1 us on that; PD >= 2 gives the staging loads 3+ k-groups (>= 6144 cycles) to
   // land before the first younger A load is needed.  RING = 3 needs the group loop unrolled by
   // lcm(8, 3) = 24 groups = 3 chunks; 22 chunks = 7 x 3 + 1 and 168 % 3 == 0 keeps the phase static.
-  constexpr int RING = NCB == 1 ? 4 : 3;
+  constexpr int RING = NCB == 1 ? (PM ? FACPPG_NARROW_RING : 4) : 3;
   constexpr int CPI = RING == 3 ? 3 : 1;   // chunks per unrolled iteration
   const float4* ap = wave_a_ptr;
   float4 ar[RING][4];
@@ -567,13 +583,13 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             slab[(rbh * 32 + 8 * (r >> 2) + (r & 3) + 4 * kh) * TNt + cb * 32 + li] = acc[half * 2 + rbh][cb][r];
-      const int nv = nvalid - scol4;   // live columns among this lane's four
+      const int nv = nvalid;   // live columns among this lane's four
 #if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 2)
       if (acc[0][0][0] != 12345.678f) continue;   // ablation: no epilogue traffic
 #endif
       if (nv <= 0) continue;
-      float* gbase = is_res ? p.h_out + (size_t)b * C * p.Lp + in_off + scol4 : p.skip + (size_t)b * C * p.Lr + sk_off + scol4;
-      const float* rbase = is_res ? p.h_in + (size_t)b * C * p.Lp + in_off + scol4 : gbase;
+      float* gbase = is_res ? p.h_out + (size_t)b * C * p.Lp + in_off : p.skip + (size_t)b * C * p.Lr + sk_off;
+      const float* rbase = is_res ? p.h_in + (size_t)b * C * p.Lp + in_off : gbase;
       const int pitch = is_res ? p.Lp : p.Lr;
       const bool add = is_res || !p.first;
 #pragma unroll 4
@@ -1018,15 +1034,15 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t nm = cfg->n_mel_channels;
-  const size_t w1_bytes = (size_t)(16 * NG1 + 4) * 64 * sizeof(float4);
-  auto w2_bytes = [&](int last) { return (size_t)(4 * (last ? 2 : 4) * NG2 + 4) * 64 * sizeof(float4); };
+  const size_t w1_bytes = (size_t)(16 * NG1 + 8) * 64 * sizeof(float4);
+  auto w2_bytes = [&](int last) { return (size_t)(4 * (last ? 2 : 4) * NG2 + 8) * 64 * sizeof(float4); };
   struct Off { size_t start_w, start_b, end_w, end_b, winv, wfwd, w1[8], w2[8], b1[8], b2[8], w1pm[8], wcpm[8], b1pm[8]; } fo[MAXF];
   h->P = cfg->hop_length / 8;
   h->nj = (cfg->upsample_kernel + cfg->hop_length - 1) / cfg->hop_length;
   h->kc = h->nj * NMEL;
   h->kcp = round_up(h->kc, KCH);
   const size_t w1pm_bytes = (size_t)NGH * 1024 * sizeof(float4);
-  const size_t wcpm_bytes = ((size_t)h->P * (h->kcp / 8) + 4) * 1024 * sizeof(float4);   // + RING look-ahead past the last phase
+  const size_t wcpm_bytes = ((size_t)h->P * (h->kcp / 8) + 8) * 1024 * sizeof(float4);   // + RING look-ahead past the last phase
   const size_t o_up_w = take(nm * nm * cfg->upsample_kernel * 4), o_up_b = take(nm * 4);
   for (int k = 0; k < cfg->n_flows; ++k) {
     const size_t hh = h->n_half[k], cc = 2 * hh;
@@ -1278,6 +1294,9 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   memset(&a, 0, sizeof(a));
   a.melp = melp; a.skip = skip; a.t_valid = T_valid_dev; a.T = T; a.hop8 = w.P; a.Lp = w.P * w.Tqp; a.Lr = w.P * w.Tr;
   a.P = w.P; a.Tr = w.Tr; a.Tqp = w.Tqp; a.ntq = (T + tn - 1) / tn; a.nt = a.ntq * B;
+  // uniform batch: cut tiles from the B*T frames of a phase laid end to end, so only the very last tile is ragged
+  static const char* no_flat = getenv("FACPPG_WN_NO_FLAT");
+  if (!T_valid_dev && T % 4 == 0 && !no_flat) { a.flat_cols = B * T; a.nt = (B * T + tn - 1) / tn; }
   a.nch = NCHH + h->kcp / KCH; a.ngc = h->kcp / 8; a.kc = h->kc;
   // workgroup i lands on XCD i % 8: give every XCD its own phases so a phase's weight image lives in one L2
   static const char* no_xcd = getenv("FACPPG_WN_NO_XCD_MAP");
@@ -1621,9 +1640,9 @@ WnTrainWs wn_train_ws(int n_layers, int B, int Lr) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   for (int i = 0; i < n_layers; ++i) {
-    w.w1[i] = take((size_t)(16 * NG1 + 4) * 64 * sizeof(float4));
+    w.w1[i] = take((size_t)(16 * NG1 + 8) * 64 * sizeof(float4));
     w.b1[i] = take(2 * C * 4);
-    w.w2[i] = take((size_t)(16 * NG2 + 4) * 64 * sizeof(float4));
+    w.w2[i] = take((size_t)(16 * NG2 + 8) * 64 * sizeof(float4));
     w.rs_a[i] = take(packed_a_float4s(C, C) * 16);
     w.rs_b[i] = take(packed_a_float4s(C, C) * 16);
     w.in_t[i] = take(packed_a_float4s(C, 2 * C * 3) * 16);
