@@ -49,8 +49,8 @@ struct facppg_taco {
 
 namespace {
 
-constexpr int NT = 1024;  // threads of the persistent kernels (16 waves; the context/energy code assumes 16)
-constexpr int ACH = 4 * (NT / 64);  // attention positions per chunk: 4 per wave
+constexpr int NT = 1024;  // threads of the one-workgroup-per-utterance persistent kernels (16 waves, <= 128 VGPRs)
+constexpr int NTC = 512;  // threads of a cooperative decoder workgroup (8 waves, <= 256 VGPRs: no spills, deeper loads in flight)
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -97,6 +97,8 @@ __global__ void k_random_mask(uint8_t* __restrict__ out, size_t n, uint64_t seed
 }
 
 // partial matvec: part[ks][Rp] = sum_{k in split ks} WT[k][Rp] * v[k]; thread = (slot of 4 rows, k split)
+// UB = weight loads kept in flight per thread (the stream is L2-latency bound: bytes in flight decide)
+template <int UB = 4>
 __device__ __forceinline__ void matvec_part(const float* __restrict__ WT, int K, int Rp, int KS, const float* v, float* part,
                                             int tid) {
   const int ns = Rp >> 2;
@@ -105,15 +107,20 @@ __device__ __forceinline__ void matvec_part(const float* __restrict__ WT, int K,
   const int k0 = (int)((long)ks * K / KS), k1 = (int)((long)(ks + 1) * K / KS);
   const float4* w = reinterpret_cast<const float4*>(WT) + slot;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-  for (int k = k0; k < k1; ++k) {
-    const float4 wv = w[(size_t)k * ns];
-    const float vk = v[k];
-    acc.x = fmaf(wv.x, vk, acc.x); acc.y = fmaf(wv.y, vk, acc.y);
-    acc.z = fmaf(wv.z, vk, acc.z); acc.w = fmaf(wv.w, vk, acc.w);
+  for (int kb = k0; kb < k1; kb += UB) {
+    float4 wv[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) wv[u] = w[(size_t)min(kb + u, k1 - 1) * ns];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const float vk = kb + u < k1 ? v[kb + u] : 0.0f;
+      acc.x = fmaf(wv[u].x, vk, acc.x); acc.y = fmaf(wv[u].y, vk, acc.y);
+      acc.z = fmaf(wv[u].z, vk, acc.z); acc.w = fmaf(wv[u].w, vk, acc.w);
+    }
   }
   reinterpret_cast<float4*>(part)[ks * ns + slot] = acc;
 }
+template <int NT>
 __device__ __forceinline__ int pick_ks(int Rp, int K) {
   int ks = NT / (Rp >> 2);
   if (ks > K) ks = K;
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(NT) void k_bilstm(const float* __restrict__ xproj, 
   float* part = cv + H;       // [KS][R]
   const float* WT = dir ? whh_t1 : whh_t0;
   const int len = lengths ? lengths[b] : Tin;
-  const int KS = pick_ks(R, H);
+  const int KS = pick_ks<NT>(R, H);
   for (int i = tid; i < H; i += NT) { hv[i] = 0.0f; cv[i] = 0.0f; }
   __syncthreads();
   for (int s = 0; s < len; ++s) {
@@ -178,8 +185,8 @@ __global__ __launch_bounds__(NT) void k_bilstm(const float* __restrict__ xproj, 
 struct DecArgs {
   const float *dp0_t, *dp1_t, *att_t, *att_b, *dec_t, *dec_b, *q_t, *proj_t, *proj_b, *loc_conv, *loc_dense, *v;
   const float *att_coop, *dec_coop;  // [NWG][K][4U] slices (coop mode)
-  float* xchg;           // [B][2][A] hidden-state exchange (coop mode)
-  int* fin;              // [B] finished flags (coop mode)
+  unsigned long long* xchg;   // [B][2][A] {value, frame tag} hidden-state exchange words (coop mode)
+  int* fin;              // [B] per-utterance barrier counters (coop mode)
   long long* prof;       // optional [8] phase cycle counters (debug; FACPPG_DECODER_PROF=1)
   const float* memory;   // [B][Tin][E]
   const float* pm;       // [B][Tin][AD]
@@ -195,12 +202,15 @@ struct DecArgs {
 
 struct DecLds {
   float *in_att, *in_dec, *in_proj, *ac, *dc, *xin, *p1, *pq, *part, *feat, *lconv, *ldense, *vv, *wprev, *wcum, *en;
-  int KA, KD, KP, ADp, NFp, Pp, G;
+  int KA, KD, KP, ADp, NFp, Pp, G, AD32;
 };
 
 __host__ __device__ inline size_t dec_lds_floats(int P, int E, int A, int D, int NF, int AD, int NFIL, int KSZ, int Tin) {
-  return (size_t)(P + E + A) + (A + E + D) + (D + E) + A + D + round_up(NF, 4) + round_up(P, 4) + round_up(AD, 4) + 4096 +
-         64 * NFIL + round_up(NFIL * 2 * KSZ, 4) + (size_t)AD * NFIL + round_up(AD, 4) + 3 * (size_t)Tin;
+  // feat [32][64], lconv^T [2*KSZ (even)][32], ldense [32][ADp32], v / processed query [ADp32]
+  (void)NFIL;
+  const size_t ADp32 = round_up(AD, 32);
+  return (size_t)(P + E + A) + (A + E + D) + (D + E) + A + D + round_up(NF, 4) + round_up(P, 4) + ADp32 + 4096 +
+         64 * 32 + (size_t)round_up(2 * KSZ, 2) * 32 + 32 * ADp32 + ADp32 + 3 * (size_t)Tin;
 }
 
 __device__ __forceinline__ void dec_carve(const DecArgs& p, float* sm, DecLds& L) {
@@ -209,6 +219,7 @@ __device__ __forceinline__ void dec_carve(const DecArgs& p, float* sm, DecLds& L
   L.KD = p.A + p.E + p.D;   // decoder LSTM input:   [ah | ctx | dh]
   L.KP = p.D + p.E;         // projection input:     [dh | ctx]
   L.ADp = round_up(p.AD, 4); L.NFp = round_up(p.NF + 1, 4); L.Pp = round_up(p.P, 4);
+  L.AD32 = round_up(p.AD, 32);
   L.in_att = sm;
   L.in_dec = L.in_att + L.KA;
   L.in_proj = L.in_dec + L.KD;
@@ -217,37 +228,48 @@ __device__ __forceinline__ void dec_carve(const DecArgs& p, float* sm, DecLds& L
   L.xin = L.dc + p.D;
   L.p1 = L.xin + round_up(p.NF, 4);
   L.pq = L.p1 + L.Pp;
-  L.part = L.pq + L.ADp;
+  L.part = L.pq + L.AD32;
   L.feat = L.part + 4096;
-  L.lconv = L.feat + 64 * p.NFIL;
-  L.ldense = L.lconv + round_up(p.NFIL * 2 * p.KSZ, 4);
-  L.vv = L.ldense + p.AD * p.NFIL;
-  L.wprev = L.vv + L.ADp;
+  L.lconv = L.feat + 64 * 32;
+  L.ldense = L.lconv + round_up(2 * p.KSZ, 2) * 32;
+  L.vv = L.ldense + 32 * L.AD32;
+  L.wprev = L.vv + L.AD32;
   L.wcum = L.wprev + p.Tin;
   L.en = L.wcum + p.Tin;
 }
 
+template <int NT>
 __device__ __forceinline__ void dec_init(const DecArgs& p, const DecLds& L, float* sm, int tid) {
-  for (int i = tid; i < L.KA + L.KD + L.KP + p.A + p.D + round_up(p.NF, 4) + L.Pp + L.ADp; i += NT) sm[i] = 0.0f;
-  for (int i = tid; i < p.NFIL * 2 * p.KSZ; i += NT) L.lconv[i] = p.loc_conv[i];
-  for (int i = tid; i < p.AD * p.NFIL; i += NT) L.ldense[(i % p.NFIL) * p.AD + i / p.NFIL] = p.loc_dense[i];  // [f][a]
-  for (int i = tid; i < p.AD; i += NT) L.vv[i] = p.v[i];
+  for (int i = tid; i < L.KA + L.KD + L.KP + p.A + p.D + round_up(p.NF, 4) + L.Pp + L.AD32; i += NT) sm[i] = 0.0f;
+  // MFMA operand images, zero padded to 32 filters / a multiple of 32 attention dims:
+  //   lconv^T[kk = c*KSZ + k][f]  (location conv, model.py:49-53), ldense[f][a] (location dense, :54-56)
+  const int KK = 2 * p.KSZ;
+  for (int i = tid; i < round_up(KK, 2) * 32; i += NT) {
+    const int kk = i >> 5, f = i & 31;
+    L.lconv[i] = (kk < KK && f < p.NFIL) ? p.loc_conv[f * KK + kk] : 0.0f;
+  }
+  for (int i = tid; i < 32 * L.AD32; i += NT) {
+    const int f = i / L.AD32, a = i % L.AD32;
+    L.ldense[i] = (f < p.NFIL && a < p.AD) ? p.loc_dense[a * p.NFIL + f] : 0.0f;
+  }
+  for (int i = tid; i < L.AD32; i += NT) L.vv[i] = i < p.AD ? p.v[i] : 0.0f;
   for (int i = tid; i < 3 * p.Tin; i += NT) L.wprev[i] = 0.0f;
 }
 
 // prenet: 2 x (Linear no bias, ReLU, dropout p=0.5 always on)  xin -> in_att[0:P]   (model.py:132-135)
+template <int NT>
 __device__ __forceinline__ void dec_prenet(const DecArgs& p, const DecLds& L, int t, int b, int tid) {
   const uint8_t* mk = p.masks + ((size_t)t * 2 * p.B + b) * p.P;
   {
-    const int KS = pick_ks(L.Pp, p.NF);
-    matvec_part(p.dp0_t, p.NF, L.Pp, KS, L.xin, L.part, tid);
+    const int KS = pick_ks<NT>(L.Pp, p.NF);
+    matvec_part<(NT <= 512 ? 20 : 4)>(p.dp0_t, p.NF, L.Pp, KS, L.xin, L.part, tid);
     __syncthreads();
     if (tid < p.P) L.p1[tid] = fmaxf(part_sum(L.part, L.Pp, KS, tid), 0.0f) * (float)mk[tid] * 2.0f;
     __syncthreads();
   }
   {
-    const int KS = pick_ks(L.Pp, p.P);
-    matvec_part(p.dp1_t, p.P, L.Pp, KS, L.p1, L.part, tid);
+    const int KS = pick_ks<NT>(L.Pp, p.P);
+    matvec_part<(NT <= 512 ? 20 : 4)>(p.dp1_t, p.P, L.Pp, KS, L.p1, L.part, tid);
     __syncthreads();
     if (tid < p.P) L.in_att[tid] = fmaxf(part_sum(L.part, L.Pp, KS, tid), 0.0f) * (float)mk[(size_t)p.B * p.P + tid] * 2.0f;
     __syncthreads();
@@ -264,6 +286,7 @@ __device__ __forceinline__ float lstm_point(float gi, float gf, float gg, float 
 // Location-sensitive attention (model.py:63-121) evaluated on the index range the reference's
 // window mask keeps (utils.py:64-77).  Reads ah from in_att[P+E:], updates wprev/wcum and writes
 // the context into in_att[P:], in_dec[A:], in_proj[D:].
+template <int NT>
 __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L, const float* mem, const float* pm, int len,
                                               int t, int b, int tid, bool write_out) {
   const int lane = tid & 63, wave = tid >> 6;
@@ -281,70 +304,74 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
     hi = min(t + p.window, len - 1);
   }
   {
-    const int KS = pick_ks(L.ADp, p.A);
-    matvec_part(p.q_t, p.A, L.ADp, KS, ah, L.part, tid);
+    const int KS = pick_ks<NT>(L.ADp, p.A);
+    matvec_part<(NT <= 512 ? 20 : 4)>(p.q_t, p.A, L.ADp, KS, ah, L.part, tid);
     __syncthreads();
     if (tid < p.AD) L.pq[tid] = part_sum(L.part, L.ADp, KS, tid);
     __syncthreads();
   }
   APROF(8)
-  const int half = (p.KSZ - 1) / 2;
-  for (int c0 = lo; c0 <= hi; c0 += ACH) {
-    const int nc = min(ACH, hi - c0 + 1);
-    // location conv features feat[i][f] = sum_{c,k} Wc[f][c][k] * wcat[c][pos + k - half]
-    for (int i = tid; i < nc * p.NFIL; i += NT) {
-      const int pi = i / p.NFIL, f = i % p.NFIL, pos = c0 + pi;
-      float s = 0.0f;
-#pragma unroll 8
-      for (int k = 0; k < p.KSZ; ++k) {
-        const int q = pos + k - half;
-        if (q >= 0 && q < p.Tin) {
-          s = fmaf(L.lconv[(f * 2 + 0) * p.KSZ + k], L.wprev[q], s);
-          s = fmaf(L.lconv[(f * 2 + 1) * p.KSZ + k], L.wcum[q], s);
-        }
+  // Location features and energies of up to 64 window positions per pass, as two small fp32 MFMA
+  // products (positions are the N dimension; the <= 41-wide window of the reference is one pass):
+  //   featT[f][pos] = sum_kk lconvT[kk][f] * wcat[kk / KSZ][pos + kk % KSZ - half]      (waves 0,1)
+  //   pa[a][pos]    = sum_f  ldense[f][a] * featT[f][pos]                               (waves rb*2+cb)
+  //   e[pos]        = sum_a  v[a] * tanh(pq[a] + pa[a][pos] + pm[pos][a])               (model.py:101-104)
+  // The MFMA result layout leaves a lane with 16 rows (a) of one column (pos): the tanh and the
+  // v-weighted sum are lane-local, then one shuffle and a fixed-order sum over the row blocks.
+  const int half = (p.KSZ - 1) / 2, KK = 2 * p.KSZ, NRB = L.AD32 / 32;
+  const int li = lane & 31, kh = lane >> 5;
+  float* epart = L.part;   // [NRB][64]
+  for (int c0 = lo; c0 <= hi; c0 += 64) {
+    const int nc = min(64, hi - c0 + 1);
+    if (wave < 2 && 32 * wave < nc) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      const int q0 = c0 + 32 * wave + li - half;
+      for (int s2 = 0; s2 < (KK + 1) / 2; ++s2) {
+        const int kk = 2 * s2 + kh;
+        const int c = kk >= p.KSZ, q = q0 + kk - c * p.KSZ;
+        const float bv = (kk < KK && q >= 0 && q < p.Tin) ? (c ? L.wcum[q] : L.wprev[q]) : 0.0f;
+        acc = mfma32x32x2(L.lconv[kk * 32 + li], bv, acc);
       }
-      L.feat[pi * p.NFIL + f] = s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) L.feat[(8 * (r >> 2) + (r & 3) + 4 * kh) * 64 + 32 * wave + li] = acc[r];
     }
     __syncthreads();
     APROF(9)
-    // energies: one wave per position (<= 4 per wave per 64-chunk); the processed-memory rows are
-    // fetched up front so their L2 latency is paid once, not once per use
-    {
-      float pmv[4][3];
+    for (int pr = wave; pr < 2 * NRB; pr += NT / 64) {
+      const int rb = pr >> 1, cb = pr & 1;
+      if (32 * cb >= nc) continue;
+      const int pos = 32 * cb + li;
+      // processed-memory values of this lane's 16 rows, fetched up front (L2 latency under the MFMAs)
+      float pmv[16];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int pi = wave + j * (NT / 64);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const int a = lane + 64 * r;
-          pmv[j][r] = (pi < nc && a < p.AD) ? pm[(size_t)(c0 + pi) * p.AD + a] : 0.0f;
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int a = 32 * rb + 8 * (r >> 2) + (r & 3) + 4 * kh;
+        pmv[r] = (pos < nc && a < p.AD) ? pm[(size_t)(c0 + pos) * p.AD + a] : 0.0f;
       }
+      f32x16 acc;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int pi = wave + j * (NT / 64);
-        if (pi < nc) {
-          float e = 0.0f;
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            const int a = lane + 64 * r;
-            if (a < p.AD) {
-              float pa = 0.0f;
-#pragma unroll 8
-              for (int f = 0; f < p.NFIL; ++f) pa = fmaf(L.ldense[f * p.AD + a], L.feat[pi * p.NFIL + f], pa);
-              e = fmaf(L.vv[a], tanhf(L.pq[a] + pa + pmv[j][r]), e);
-            }
-          }
-          for (int a = lane + 192; a < p.AD; a += 64) {   // attention_dim > 192 (not the reference's 150)
-            float pa = 0.0f;
-            for (int f = 0; f < p.NFIL; ++f) pa = fmaf(L.ldense[f * p.AD + a], L.feat[pi * p.NFIL + f], pa);
-            e = fmaf(L.vv[a], tanhf(L.pq[a] + pa + pm[(size_t)(c0 + pi) * p.AD + a]), e);
-          }
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
-          if (lane == 0) L.en[c0 + pi] = e;
-        }
+      for (int s2 = 0; s2 < 16; ++s2) {
+        const int f = 2 * s2 + kh;
+        acc = mfma32x32x2(L.ldense[f * L.AD32 + 32 * rb + li], L.feat[f * 64 + pos], acc);
       }
+      float e = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int a = 32 * rb + 8 * (r >> 2) + (r & 3) + 4 * kh;
+        e = fmaf(L.vv[a], tanhf(L.pq[a] + acc[r] + pmv[r]), e);
+      }
+      e += __shfl_xor(e, 32);
+      if (kh == 0) epart[rb * 64 + pos] = e;
+    }
+    __syncthreads();
+    if (tid < nc) {
+      float e = 0.0f;
+      for (int j = 0; j < NRB; ++j) e += epart[j * 64 + tid];
+      L.en[c0 + tid] = e;
     }
     __syncthreads();
     APROF(10)
@@ -378,11 +405,11 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
   // free here) and are summed in a FIXED order: the result must be bitwise reproducible, because
   // in coop mode every workgroup recomputes it and must reach the same stop decision.
   {
-    constexpr int CW = 8;    // position groups (waves w and w+8 share a group, splitting the channels)
+    constexpr int CW = 8;    // position groups (with 16 waves, waves w and w+8 share a group and split the channels)
     constexpr int QU = 3;    // positions per wave issued together (2 rounds cover the 41-wide window)
-    constexpr int CR = 6;    // 64-channel rounds per half (E <= 768)
+    constexpr int CR = 12 / (NT / 64 / CW);   // 64-channel rounds per wave (E <= 768)
     float* cpart = L.part;   // [CW][E]  (part + feat = 6144 floats >= 8 * E for E <= 768)
-    static_assert(NT / 64 == 2 * CW, "context code deals positions to 8 wave pairs");
+    static_assert(NT / 64 == 2 * CW || NT / 64 == CW, "context code deals positions to 8 waves or wave pairs");
     const int grp = wave & (CW - 1), halfsel = wave / CW;
     float accv[CR];
 #pragma unroll
@@ -426,10 +453,11 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
 
 // linear projection + gate on [dh | ctx] (model.py:436-441) for frame index t; returns the stop
 // decision (model.py:524-528: the stopping frame is kept) through *s_stop.
+template <int NT>
 __device__ __forceinline__ void dec_project(const DecArgs& p, const DecLds& L, int t, int b, int tid, bool write_out,
                                             int* s_stop) {
-  const int KS = pick_ks(L.NFp, L.KP);
-  matvec_part(p.proj_t, L.KP, L.NFp, KS, L.in_proj, L.part, tid);
+  const int KS = pick_ks<NT>(L.NFp, L.KP);
+  matvec_part<(NT <= 512 ? 20 : 4)>(p.proj_t, L.KP, L.NFp, KS, L.in_proj, L.part, tid);
   __syncthreads();
   if (tid <= p.NF) {
     const float v = part_sum(L.part, L.NFp, KS, tid) + p.proj_b[tid];
@@ -451,7 +479,7 @@ __global__ __launch_bounds__(NT) void k_decoder(DecArgs p) {
   const int len = p.lengths ? p.lengths[b] : p.Tin;
   DecLds L;
   dec_carve(p, sm, L);
-  dec_init(p, L, sm, tid);
+  dec_init<NT>(p, L, sm, tid);
   if (tid == 0) s_stop = 0;
   __syncthreads();
   const float* mem = p.memory + (size_t)b * p.Tin * p.E;
@@ -460,10 +488,10 @@ __global__ __launch_bounds__(NT) void k_decoder(DecArgs p) {
   float* dh = L.in_dec + p.A + p.E;   // decoder hidden lives inside in_dec; copied into in_proj[0:D]
   int t = 0;
   for (;; ++t) {
-    dec_prenet(p, L, t, b, tid);
+    dec_prenet<NT>(p, L, t, b, tid);
     {  // attention LSTMCell on [prenet | ctx | ah]   (model.py:400-403)
-      const int KS = pick_ks(L.G, L.KA);
-      matvec_part(p.att_t, L.KA, L.G, KS, L.in_att, L.part, tid);
+      const int KS = pick_ks<NT>(L.G, L.KA);
+      matvec_part<(NT <= 512 ? 20 : 4)>(p.att_t, L.KA, L.G, KS, L.in_att, L.part, tid);
       __syncthreads();
       float hnew = 0.0f;
       if (tid < p.A)
@@ -474,10 +502,10 @@ __global__ __launch_bounds__(NT) void k_decoder(DecArgs p) {
       if (tid < p.A) { ah[tid] = hnew; L.in_dec[tid] = hnew; }
       __syncthreads();
     }
-    dec_attention(p, L, mem, pm, len, t, b, tid, true);
+    dec_attention<NT>(p, L, mem, pm, len, t, b, tid, true);
     {  // decoder LSTMCell on [ah | ctx | dh]   (model.py:425-428)
-      const int KS = pick_ks(L.G, L.KD);
-      matvec_part(p.dec_t, L.KD, L.G, KS, L.in_dec, L.part, tid);
+      const int KS = pick_ks<NT>(L.G, L.KD);
+      matvec_part<(NT <= 512 ? 20 : 4)>(p.dec_t, L.KD, L.G, KS, L.in_dec, L.part, tid);
       __syncthreads();
       float hnew = 0.0f;
       if (tid < p.D)
@@ -488,7 +516,7 @@ __global__ __launch_bounds__(NT) void k_decoder(DecArgs p) {
       if (tid < p.D) { dh[tid] = hnew; L.in_proj[tid] = hnew; }
       __syncthreads();
     }
-    dec_project(p, L, t, b, tid, true, &s_stop);
+    dec_project<NT>(p, L, t, b, tid, true, &s_stop);
     if (s_stop) break;
   }
   if (tid == 0) p.out_len[b] = t + 1;
@@ -496,47 +524,59 @@ __global__ __launch_bounds__(NT) void k_decoder(DecArgs p) {
 
 // One LSTMCell slice in coop mode: this workgroup's 4U gate rows (columns g*U + j of the packed
 // slice) over the full input vector; returns the new hidden value of unit j in thread j < U.
+template <int NT>
 __device__ __forceinline__ void coop_lstm_slice(const float* __restrict__ Wslice, const float* __restrict__ bias, int K, int U,
-                                                int A, int unit0, const float* in, float* part, float* cstate, float* xchg_out,
-                                                int tid) {
-  const int SC = 4 * U, KS = NT / SC;
-  const int col = tid % SC, ks = tid / SC;
-  if (ks < KS) {
-    const int k0 = (int)((long)ks * K / KS), k1 = (int)((long)(ks + 1) * K / KS);
-    const float* w = Wslice + col;
-    float acc = 0.0f;
-#pragma unroll 16
-    for (int k = k0; k < k1; ++k) acc = fmaf(w[(size_t)k * SC], in[k], acc);
-    part[ks * SC + col] = acc;
-  }
+                                                int A, int unit0, const float* in, float* part, float* cstate,
+                                                unsigned long long* xchg_out, unsigned tag, int tid) {
+  // the slice is a K-major [K][4U] matrix: the same float4-column stream as the other matvecs, with
+  // ~20 loads per thread in flight (one L2 round trip covers U = 8)
+  const int SC = 4 * U, KS = pick_ks<NT>(SC, K);
+  matvec_part<(NT <= 512 ? 20 : 4)>(Wslice, K, SC, KS, in, part, tid);
   __syncthreads();
   if (tid < SC) {
-    float s = 0.0f;
-#pragma unroll 8
-    for (int i = 0; i < KS; ++i) s += part[i * SC + tid];
     const int u = unit0 + tid % U;
-    part[NT + tid] = s + (u < A ? bias[(tid / U) * A + u] : 0.0f);
+    part[2 * NT + tid] = part_sum(part, SC, KS, tid) + (u < A ? bias[(tid / U) * A + u] : 0.0f);
   }
   __syncthreads();
   if (tid < U && unit0 + tid < A) {
-    const float* gs = part + NT;
+    const float* gs = part + 2 * NT;
     const float h = lstm_point(gs[tid], gs[U + tid], gs[2 * U + tid], gs[3 * U + tid], &cstate[tid]);
-    __hip_atomic_store(xchg_out + unit0 + tid, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // publish {value, frame tag} as ONE 8-byte sc1 store: readers poll the word itself (coop_gather)
+    __hip_atomic_store(xchg_out + unit0 + tid, ((unsigned long long)tag << 32) | __float_as_uint(h), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
-__global__ __launch_bounds__(NT) void k_decoder_coop(DecArgs p) {
-  namespace cg = cooperative_groups;
-  cg::grid_group grid = cg::this_grid();
+// Hidden-state exchange between the workgroups of one utterance without a barrier: every element
+// is an 8-byte {value, tag} word written once per frame by its owner (sc1 store) and polled by its
+// readers (sc1 loads) until the tag of this frame shows up -- one store-to-load latency instead of
+// store drain + ticket atomic + counter poll + load.  Reuse is safe because the two exchanges of a
+// frame alternate: nobody can publish frame t+1's attention state before having read every
+// decoder-state word of frame t, and each of those was written after its owner read frame t's
+// attention state (and vice versa).
+template <int NT>
+__device__ __forceinline__ void coop_gather(const unsigned long long* xchg, unsigned tag, int n, float* dst0, float* dst1, int tid) {
+  for (int i = tid; i < n; i += NT) {
+    unsigned long long v;
+    do {
+      v = __hip_atomic_load(xchg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } while ((unsigned)(v >> 32) != tag);
+    const float h = __uint_as_float((unsigned)v);
+    dst0[i] = h; dst1[i] = h;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(NTC) void k_decoder_coop(DecArgs p) {
   extern __shared__ float sm[];
-  __shared__ int s_stop, s_all;
+  __shared__ int s_stop;
   __shared__ float c_att[64], c_dec[64];   // U <= 64 units per workgroup
   const int wg = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const bool leader = wg == 0;
   const int len = p.lengths ? p.lengths[b] : p.Tin;
   DecLds L;
   dec_carve(p, sm, L);
-  dec_init(p, L, sm, tid);
+  dec_init<NTC>(p, L, sm, tid);
   if (tid == 0) s_stop = 0;
   if (tid < 64) { c_att[tid] = 0.0f; c_dec[tid] = 0.0f; }
   __syncthreads();
@@ -544,13 +584,11 @@ __global__ __launch_bounds__(NT) void k_decoder_coop(DecArgs p) {
   const float* pm = p.pm + (size_t)b * p.Tin * p.AD;
   float* ah = L.in_att + p.P + p.E;
   float* dh = L.in_dec + p.A + p.E;
-  float* xa = p.xchg + (size_t)b * 2 * p.A;
-  float* xd = xa + p.A;
+  unsigned long long* xa = p.xchg + (size_t)b * 2 * p.A;
+  unsigned long long* xd = xa + p.A;
   const int SC = 4 * p.U, unit0 = wg * p.U;
   const float* att_slice = p.att_coop + (size_t)wg * L.KA * SC;
   const float* dec_slice = p.dec_coop + (size_t)wg * L.KD * SC;
-  bool fin = false;
-  int n_out = 0;
   long long tk = clock64();
 #define PROF(slot)                                                        \
   if (p.prof && leader && b == 0 && tid == 0) {                           \
@@ -558,59 +596,31 @@ __global__ __launch_bounds__(NT) void k_decoder_coop(DecArgs p) {
     p.prof[slot] += now - tk;                                             \
     tk = now;                                                             \
   }
+  // Every workgroup of the utterance computes the same stop decision from bit-identical state, so
+  // they all leave the loop at the same frame and the barrier population stays NWG.
   for (int t = 0;; ++t) {
-    if (!fin) {
-      if (t > 0) {   // finish frame t-1: projection, gate, stop decision (identical in every workgroup)
-        dec_project(p, L, t - 1, b, tid, leader, &s_stop);
-        if (s_stop) {
-          fin = true;
-          n_out = t;
-          if (leader && tid == 0) {
-            p.out_len[b] = t;
-            __hip_atomic_store(p.fin + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-      }
-      PROF(0)
-      if (!fin) {
-        dec_prenet(p, L, t, b, tid);
-        PROF(1)
-        coop_lstm_slice(att_slice, p.att_b, L.KA, p.U, p.A, unit0, L.in_att, L.part, c_att, xa, tid);
-        PROF(2)
+    if (t > 0) {   // finish frame t-1: projection, gate, stop decision
+      dec_project<NTC>(p, L, t - 1, b, tid, leader, &s_stop);
+      if (s_stop) {
+        if (leader && tid == 0) p.out_len[b] = t;
+        break;
       }
     }
-    grid.sync();
+    PROF(0)
+    dec_prenet<NTC>(p, L, t, b, tid);
+    PROF(1)
+    coop_lstm_slice<NTC>(att_slice, p.att_b, L.KA, p.U, p.A, unit0, L.in_att, L.part, c_att, xa, t + 1, tid);
+    PROF(2)
+    coop_gather<NTC>(xa, t + 1, p.A, ah, L.in_dec, tid);
     PROF(3)
-    if (tid == 0) {
-      int all = 1;
-      for (int i = 0; i < p.B; ++i) all &= __hip_atomic_load(p.fin + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_all = all;
-    }
-    __syncthreads();
-    if (s_all) break;
-    if (!fin) {
-      for (int i = tid; i < p.A; i += NT) {
-        const float h = __hip_atomic_load(xa + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ah[i] = h; L.in_dec[i] = h;
-      }
-      __syncthreads();
-      PROF(4)
-      dec_attention(p, L, mem, pm, len, t, b, tid, leader);
-      PROF(5)
-      coop_lstm_slice(dec_slice, p.dec_b, L.KD, p.U, p.D, unit0, L.in_dec, L.part, c_dec, xd, tid);
-      PROF(6)
-    }
-    grid.sync();
+    PROF(4)
+    dec_attention<NTC>(p, L, mem, pm, len, t, b, tid, leader);
+    PROF(5)
+    coop_lstm_slice<NTC>(dec_slice, p.dec_b, L.KD, p.U, p.D, unit0, L.in_dec, L.part, c_dec, xd, t + 1, tid);
+    PROF(6)
+    coop_gather<NTC>(xd, t + 1, p.D, dh, L.in_proj, tid);
     PROF(7)
-    if (!fin) {
-      for (int i = tid; i < p.D; i += NT) {
-        const float h = __hip_atomic_load(xd + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        dh[i] = h; L.in_proj[i] = h;
-      }
-      __syncthreads();
-    }
   }
-  (void)n_out;
 #undef PROF
 }
 
@@ -645,9 +655,12 @@ static int taco_check(const facppg_taco_config* c) {
                  FACPPG_EUNSUPPORTED, "conv stack sizes out of range");
   FACPPG_REQUIRE(c->attention_rnn_dim == c->decoder_rnn_dim && c->attention_rnn_dim % 4 == 0 && 4 * c->attention_rnn_dim <= 4096,
                  FACPPG_EUNSUPPORTED, "attention_rnn_dim must equal decoder_rnn_dim, be a multiple of 4 and <= 1024");
-  FACPPG_REQUIRE(c->encoder_embedding_dim <= 768 && c->prenet_dim <= NT && c->attention_dim <= NT && c->n_acoustic_feat_dims < NT &&
+  FACPPG_REQUIRE(c->attention_location_n_filters >= 1 && c->attention_location_n_filters <= 32 && c->attention_dim >= 1 &&
+                     c->attention_dim <= 256,
+                 FACPPG_EUNSUPPORTED, "attention_location_n_filters must be <= 32 and attention_dim <= 256 (one MFMA pass each)");
+  FACPPG_REQUIRE(c->encoder_embedding_dim <= 768 && c->prenet_dim <= NTC && c->attention_dim <= NTC && c->n_acoustic_feat_dims < NTC &&
                      (2 * c->encoder_embedding_dim) % 4 == 0,
-                 FACPPG_EUNSUPPORTED, "decoder dims exceed the 1024-thread workgroup");
+                 FACPPG_EUNSUPPORTED, "decoder dims exceed the 512-thread cooperative workgroup");
   FACPPG_REQUIRE(c->attention_location_kernel_size % 2 == 1 && c->attention_location_n_filters > 0, FACPPG_EUNSUPPORTED,
                  "attention_location_kernel_size must be odd");
   return FACPPG_OK;
@@ -907,7 +920,7 @@ DecWs dec_ws(const facppg_taco_config& c, int B, int max_steps) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   w.mask = take((size_t)max_steps * 2 * B * c.prenet_dim);
-  w.xchg = take((size_t)B * 2 * c.attention_rnn_dim * 4);
+  w.xchg = take((size_t)B * 2 * c.attention_rnn_dim * 8);
   w.fin = take((size_t)B * 4);
   w.prof = take(16 * 8);
   w.total = off;
@@ -937,7 +950,7 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
   DecArgs a;
   a.dp0_t = h->dp0_t; a.dp1_t = h->dp1_t; a.att_t = h->att_t; a.att_b = h->att_b; a.dec_t = h->dec_t; a.dec_b = h->dec_b;
   a.q_t = h->q_t; a.proj_t = h->proj_t; a.proj_b = h->proj_b; a.loc_conv = h->loc_conv; a.loc_dense = h->loc_dense; a.v = h->v;
-  a.xchg = (float*)(ws + w.xchg); a.fin = (int*)(ws + w.fin);
+  a.xchg = (unsigned long long*)(ws + w.xchg); a.fin = (int*)(ws + w.fin);
   a.prof = getenv("FACPPG_DECODER_PROF") ? (long long*)(ws + w.prof) : nullptr;
   a.memory = memory_dev; a.pm = pm_dev; a.lengths = lengths_dev; a.masks = masks; a.mel = mel_dev; a.gate = gate_dev;
   a.align = align_dev; a.out_len = out_lengths_dev;
@@ -961,9 +974,10 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
   }
   if (coop) {
     FACPPG_HIP_CHECK(hipMemsetAsync(ws + w.xchg, 0, w.total - w.xchg, s));
-    FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_decoder_coop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const void* fn = (const void*)k_decoder_coop;
+    FACPPG_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     void* args[] = {(void*)&a};
-    FACPPG_HIP_CHECK(hipLaunchCooperativeKernel((const void*)k_decoder_coop, dim3(h->coop_nwg[variant], B), dim3(NT), args, smem, s));
+    FACPPG_HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(h->coop_nwg[variant], B), dim3(NTC), args, smem, s));
     if (a.prof) {
       long long pr[16];
       FACPPG_HIP_CHECK(hipMemcpyAsync(pr, a.prof, sizeof(pr), hipMemcpyDeviceToHost, s));
