@@ -53,6 +53,12 @@ constexpr int NT = 1024;  // threads of the one-workgroup-per-utterance persiste
 constexpr int NTC = 512;  // threads of a cooperative decoder workgroup (8 waves, <= 256 VGPRs: no spills, deeper loads in flight)
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+// tanh through one hardware exponential and one reciprocal (relative error ~1e-6; |x| > 9.02 is +-1 in
+// fp32, so clamping to +-15 changes nothing): libm's tanhf is ~40 instructions per value
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float e = __expf(-2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
+  return __fdividef(1.0f - e, 1.0f + e);
+}
 
 // dst[k_off + k][Rp] = src[r][k]  (k-major transpose with row padding)
 __global__ void k_transpose_pad(const float* __restrict__ src, float* __restrict__ dst, int R, int K, int Rp, int k_off) {
@@ -189,7 +195,7 @@ struct DecArgs {
   int* fin;              // [B] per-utterance barrier counters (coop mode)
   long long* prof;       // optional [8] phase cycle counters (debug; FACPPG_DECODER_PROF=1)
   const float* memory;   // [B][Tin][E]
-  const float* pm;       // [B][Tin][AD]
+  const float* pm;       // [B][AD][Tin]
   const int* lengths;    // [B] or null
   const uint8_t* masks;  // [steps][2][B][P]
   float* mel;            // [B][NF][max_steps]
@@ -262,14 +268,14 @@ __device__ __forceinline__ void dec_prenet(const DecArgs& p, const DecLds& L, in
   const uint8_t* mk = p.masks + ((size_t)t * 2 * p.B + b) * p.P;
   {
     const int KS = pick_ks<NT>(L.Pp, p.NF);
-    matvec_part<(NT <= 512 ? 20 : 4)>(p.dp0_t, p.NF, L.Pp, KS, L.xin, L.part, tid);
+    matvec_part<(NT <= 512 ? 16 : 4)>(p.dp0_t, p.NF, L.Pp, KS, L.xin, L.part, tid);
     __syncthreads();
     if (tid < p.P) L.p1[tid] = fmaxf(part_sum(L.part, L.Pp, KS, tid), 0.0f) * (float)mk[tid] * 2.0f;
     __syncthreads();
   }
   {
     const int KS = pick_ks<NT>(L.Pp, p.P);
-    matvec_part<(NT <= 512 ? 20 : 4)>(p.dp1_t, p.P, L.Pp, KS, L.p1, L.part, tid);
+    matvec_part<(NT <= 512 ? 16 : 4)>(p.dp1_t, p.P, L.Pp, KS, L.p1, L.part, tid);
     __syncthreads();
     if (tid < p.P) L.in_att[tid] = fmaxf(part_sum(L.part, L.Pp, KS, tid), 0.0f) * (float)mk[(size_t)p.B * p.P + tid] * 2.0f;
     __syncthreads();
@@ -305,7 +311,7 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
   }
   {
     const int KS = pick_ks<NT>(L.ADp, p.A);
-    matvec_part<(NT <= 512 ? 20 : 4)>(p.q_t, p.A, L.ADp, KS, ah, L.part, tid);
+    matvec_part<(NT <= 512 ? 16 : 4)>(p.q_t, p.A, L.ADp, KS, ah, L.part, tid);
     __syncthreads();
     if (tid < p.AD) L.pq[tid] = part_sum(L.part, L.ADp, KS, tid);
     __syncthreads();
@@ -323,32 +329,54 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
   float* epart = L.part;   // [NRB][64]
   for (int c0 = lo; c0 <= hi; c0 += 64) {
     const int nc = min(64, hi - c0 + 1);
-    if (wave < 2 && 32 * wave < nc) {
-      f32x16 acc;
+    // features: the K = 2*KSZ reduction is dealt to NWF waves per 32-position block (partial products
+    // meet in LDS in a fixed order) so the dependent MFMA chain is short
+    {
+      constexpr int NWF = 2;   // waves 0..3: (position block, K half)
+      const int cbf = wave / NWF, part_i = wave % NWF;
+      const int nsteps = (KK + 1) / 2, s_lo = part_i * nsteps / NWF, s_hi = (part_i + 1) * nsteps / NWF;
+      float* fpart = L.part;   // [2][NWF][32 f][32 pos] = 4096 floats
+      if (cbf < 2 && 32 * cbf < nc) {
+        f32x16 acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-      const int q0 = c0 + 32 * wave + li - half;
-      for (int s2 = 0; s2 < (KK + 1) / 2; ++s2) {
-        const int kk = 2 * s2 + kh;
-        const int c = kk >= p.KSZ, q = q0 + kk - c * p.KSZ;
-        const float bv = (kk < KK && q >= 0 && q < p.Tin) ? (c ? L.wcum[q] : L.wprev[q]) : 0.0f;
-        acc = mfma32x32x2(L.lconv[kk * 32 + li], bv, acc);
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const int q0 = c0 + 32 * cbf + li - half;
+        for (int s2 = s_lo; s2 < s_hi; ++s2) {
+          const int kk = 2 * s2 + kh;
+          const int c = kk >= p.KSZ, q = q0 + kk - c * p.KSZ;
+          const float bv = (kk < KK && q >= 0 && q < p.Tin) ? (c ? L.wcum[q] : L.wprev[q]) : 0.0f;
+          acc = mfma32x32x2(L.lconv[kk * 32 + li], bv, acc);
+        }
+        float* dst = fpart + (size_t)(cbf * NWF + part_i) * 1024;   // [f][32]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(8 * (r >> 2) + (r & 3) + 4 * kh) * 32 + li] = acc[r];
       }
+      __syncthreads();
+      for (int i = tid; i < 2048; i += NT) {
+        const int f = i >> 6, pos = i & 63, cb2 = pos >> 5;
+        float v = 0.0f;
+        if (32 * cb2 < nc) {
+          const float* src = fpart + (size_t)cb2 * NWF * 1024 + f * 32 + (pos & 31);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) L.feat[(8 * (r >> 2) + (r & 3) + 4 * kh) * 64 + 32 * wave + li] = acc[r];
+          for (int j = 0; j < NWF; ++j) v += src[j * 1024];
+        }
+        L.feat[f * 64 + pos] = v;
+      }
     }
     __syncthreads();
     APROF(9)
+    // energies: one (32 attention dims, 32 positions) block per wave and round
     for (int pr = wave; pr < 2 * NRB; pr += NT / 64) {
       const int rb = pr >> 1, cb = pr & 1;
       if (32 * cb >= nc) continue;
       const int pos = 32 * cb + li;
       // processed-memory values of this lane's 16 rows, fetched up front (L2 latency under the MFMAs)
       float pmv[16];
+      const float* pmp = pm + (size_t)(32 * rb + 4 * kh) * p.Tin + c0 + pos;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int a = 32 * rb + 8 * (r >> 2) + (r & 3) + 4 * kh;
-        pmv[r] = (pos < nc && a < p.AD) ? pm[(size_t)(c0 + pos) * p.AD + a] : 0.0f;
+        pmv[r] = (pos < nc && a < p.AD) ? pmp[(size_t)(8 * (r >> 2) + (r & 3)) * p.Tin] : 0.0f;
       }
       f32x16 acc;
 #pragma unroll
@@ -362,7 +390,7 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int a = 32 * rb + 8 * (r >> 2) + (r & 3) + 4 * kh;
-        e = fmaf(L.vv[a], tanhf(L.pq[a] + acc[r] + pmv[r]), e);
+        e = fmaf(L.vv[a], tanh_fast(L.pq[a] + acc[r] + pmv[r]), e);
       }
       e += __shfl_xor(e, 32);
       if (kh == 0) epart[rb * 64 + pos] = e;
@@ -457,7 +485,7 @@ template <int NT>
 __device__ __forceinline__ void dec_project(const DecArgs& p, const DecLds& L, int t, int b, int tid, bool write_out,
                                             int* s_stop) {
   const int KS = pick_ks<NT>(L.NFp, L.KP);
-  matvec_part<(NT <= 512 ? 20 : 4)>(p.proj_t, L.KP, L.NFp, KS, L.in_proj, L.part, tid);
+  matvec_part<(NT <= 512 ? 16 : 4)>(p.proj_t, L.KP, L.NFp, KS, L.in_proj, L.part, tid);
   __syncthreads();
   if (tid <= p.NF) {
     const float v = part_sum(L.part, L.NFp, KS, tid) + p.proj_b[tid];
@@ -491,7 +519,7 @@ __global__ __launch_bounds__(NT) void k_decoder(DecArgs p) {
     dec_prenet<NT>(p, L, t, b, tid);
     {  // attention LSTMCell on [prenet | ctx | ah]   (model.py:400-403)
       const int KS = pick_ks<NT>(L.G, L.KA);
-      matvec_part<(NT <= 512 ? 20 : 4)>(p.att_t, L.KA, L.G, KS, L.in_att, L.part, tid);
+      matvec_part<(NT <= 512 ? 16 : 4)>(p.att_t, L.KA, L.G, KS, L.in_att, L.part, tid);
       __syncthreads();
       float hnew = 0.0f;
       if (tid < p.A)
@@ -505,7 +533,7 @@ __global__ __launch_bounds__(NT) void k_decoder(DecArgs p) {
     dec_attention<NT>(p, L, mem, pm, len, t, b, tid, true);
     {  // decoder LSTMCell on [ah | ctx | dh]   (model.py:425-428)
       const int KS = pick_ks<NT>(L.G, L.KD);
-      matvec_part<(NT <= 512 ? 20 : 4)>(p.dec_t, L.KD, L.G, KS, L.in_dec, L.part, tid);
+      matvec_part<(NT <= 512 ? 16 : 4)>(p.dec_t, L.KD, L.G, KS, L.in_dec, L.part, tid);
       __syncthreads();
       float hnew = 0.0f;
       if (tid < p.D)
@@ -531,7 +559,7 @@ __device__ __forceinline__ void coop_lstm_slice(const float* __restrict__ Wslice
   // the slice is a K-major [K][4U] matrix: the same float4-column stream as the other matvecs, with
   // ~20 loads per thread in flight (one L2 round trip covers U = 8)
   const int SC = 4 * U, KS = pick_ks<NT>(SC, K);
-  matvec_part<(NT <= 512 ? 20 : 4)>(Wslice, K, SC, KS, in, part, tid);
+  matvec_part<(NT <= 512 ? 16 : 4)>(Wslice, K, SC, KS, in, part, tid);
   __syncthreads();
   if (tid < SC) {
     const int u = unit0 + tid % U;
@@ -907,7 +935,7 @@ extern "C" int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const in
   // processed_memory = memory_layer(memory), time-major [B][Tin][AD]
   GemmArgs m;
   m.B = B; m.N = Tin; m.n_valid = lengths_dev; m.A = h->mem_w; m.M = c.attention_dim; m.Cin = E; m.X = mem_cm; m.x_bs = (long)E * Tin;
-  m.ldx = Tin; m.C = pm_dev; m.c_bs = (long)Tin * c.attention_dim; m.ldc = c.attention_dim; m.c_transposed = 1;
+  m.ldx = Tin; m.C = pm_dev; m.c_bs = (long)Tin * c.attention_dim; m.ldc = Tin;   // [B][AD][Tin]: positions contiguous for the energy pass
   if (int rc = gemm_launch(m, s)) return rc;
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;

@@ -247,7 +247,8 @@ size_t facppg_taco_postnet_workspace_bytes(const facppg_taco* h, int B, int T);
  * (each utterance is encoded exactly as its own batch-1 run); masks_dev NULL (dropout keep-masks
  * are drawn on the device from `seed`) or uint8 {0,1} [2][B][symbols_embedding_dim][Tin]
  * (the prenet's two always-on p=0.5 dropouts, model.py:132-135).
- * Outputs: memory_dev [B][Tin][E] and processed-memory pm_dev [B][Tin][attention_dim]. */
+ * Outputs: memory_dev [B][Tin][E] and processed-memory pm_dev [B][attention_dim][Tin] (an opaque
+ * intermediate handed to facppg_taco_decode; positions contiguous). */
 int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const int32_t* lengths_dev,
                        const uint8_t* masks_dev, uint64_t seed, int B, int Tin, float* memory_dev,
                        float* pm_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
