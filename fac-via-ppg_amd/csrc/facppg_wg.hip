@@ -805,10 +805,16 @@ __global__ __launch_bounds__(256) void k_flow_end(EdgeArgs p) {
 #pragma unroll
   for (int j = 0; j < CC; ++j) o[j] = p.end_b[j];
   const float* sk = p.skip + (size_t)b * C * p.Lr + sk_off;
-  for (int ch = 0; ch < C; ++ch) {
-    const float v = sk[(size_t)ch * p.Lr];
+  // 16 skip rows in flight per thread: with few positions (one short utterance) this loop is a chain of
+  // L2 round trips, not a bandwidth stream
+  for (int c0 = 0; c0 < C; c0 += 16) {
+    float v[16];
 #pragma unroll
-    for (int j = 0; j < CC; ++j) o[j] = fmaf(p.end_w[j * C + ch], v, o[j]);
+    for (int u = 0; u < 16; ++u) v[u] = sk[(size_t)(c0 + u) * p.Lr];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+      for (int j = 0; j < CC; ++j) o[j] = fmaf(p.end_w[j * C + c0 + u], v[u], o[j]);
   }
   float a[CC];
 #pragma unroll

@@ -24,7 +24,7 @@ def main():
     crit = WaveGlowLoss(0.7071)
     from common.layers import TacotronSTFT
     stft = TacotronSTFT(1024, 160, 1024, 80, 16000, 0.0, 8000.0).cuda()
-    for B in (3, 12):
+    for B in ([int(a) for a in sys.argv[1:]] or (3, 12)):
         g = np.random.Generator(np.random.PCG64(1))
         audio = torch.from_numpy(np.clip(g.standard_normal((B, 10000), dtype=np.float32) * 0.1, -1, 1)).cuda()
         with torch.no_grad():
