@@ -177,6 +177,82 @@ __global__ __launch_bounds__(NT) void k_bilstm(const float* __restrict__ xproj, 
   }
 }
 
+// Latency shape of the same recurrence (few utterances): NWG workgroups per (utterance, direction),
+// each owning BU hidden units = 4*BU gate rows of W_hh, held IN REGISTERS for the whole sequence
+// (4*BU rows x H/4 columns per thread = 75 floats at H = 300) -- a step streams nothing but the
+// 4*BU input-projection values.  The new hidden values cross workgroups as 8-byte {value, step tag}
+// words (sc1 stores, polled sc1 loads; see coop_gather), double-buffered by step parity: a word of
+// step s+2 may overwrite step s only after its owner gathered all of step s+1, and every reader
+// published its step-s+1 word after consuming step s.  Fixed-order reductions: bit-identical to the
+// one-workgroup kernel's sums up to fp32 re-association of the K split.
+constexpr int BU = 32;        // hidden units per workgroup
+constexpr int BKP = NTC / (4 * BU);   // K parts per gate row (4)
+constexpr int BKR = 96;       // max columns per part held in registers (H <= 384)
+
+__global__ __launch_bounds__(NTC) void k_bilstm_coop(const float* __restrict__ xproj, const float* __restrict__ whh_t0,
+                                                     const float* __restrict__ whh_t1, const int* __restrict__ lengths, int Tin,
+                                                     int H, unsigned long long* __restrict__ xchg /*[B][2][2][H]*/,
+                                                     float* __restrict__ mem_tm, float* __restrict__ mem_cm) {
+  __shared__ float hv[4 * BKR];          // gathered hidden vector [H]
+  __shared__ float part[BKP][4 * BU];    // K-part partial sums per gate row
+  __shared__ float gates[4 * BU];
+  const int wg = blockIdx.x, dir = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int R = 4 * H, KR = (H + BKP - 1) / BKP;
+  const int r = tid % (4 * BU), kp = tid / (4 * BU);
+  const int u = wg * BU + r % BU, row = (r / BU) * H + u;    // this thread's gate row of W_hh
+  const float* WT = dir ? whh_t1 : whh_t0;                   // [H][4H] k-major
+  const int len = lengths ? lengths[b] : Tin;
+  float w[BKR];
+#pragma unroll
+  for (int i = 0; i < BKR; ++i) {
+    const int k = kp * KR + i;
+    w[i] = (i < KR && k < H && u < H) ? WT[(size_t)k * R + row] : 0.0f;
+  }
+  for (int i = tid; i < 4 * BKR; i += NTC) hv[i] = 0.0f;
+  float c = 0.0f;
+  unsigned long long* xb = xchg + (size_t)(b * 2 + dir) * 2 * H;
+  __syncthreads();
+  for (int s = 0; s < len; ++s) {
+    const int t = dir ? len - 1 - s : s;
+    // input projection of this row (independent of h): issued first, consumed after the matvec
+    const float xp = (kp == 0 && u < H) ? xproj[((size_t)b * Tin + t) * (2 * R) + dir * R + row] : 0.0f;
+    float acc = 0.0f;
+    const float* hk = hv + kp * KR;
+#pragma unroll
+    for (int i = 0; i < BKR; ++i) acc = fmaf(w[i], hk[i], acc);   // hk beyond KR multiplies zero weights
+    part[kp][r] = acc;
+    __syncthreads();
+    if (kp == 0) {
+      float g = xp;
+#pragma unroll
+      for (int j = 0; j < BKP; ++j) g += part[j][r];
+      gates[r] = g;
+    }
+    __syncthreads();
+    if (tid < BU && wg * BU + tid < H) {
+      const float cn = sigm(gates[BU + tid]) * c + sigm(gates[tid]) * tanhf(gates[2 * BU + tid]);
+      const float h = sigm(gates[3 * BU + tid]) * tanhf(cn);
+      c = cn;
+      const int uu = wg * BU + tid;
+      __hip_atomic_store(xb + (size_t)((s + 1) & 1) * H + uu, ((unsigned long long)(unsigned)(s + 1) << 32) | __float_as_uint(h),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      mem_tm[((size_t)b * Tin + t) * (2 * H) + dir * H + uu] = h;
+      mem_cm[((size_t)b * 2 * H + dir * H + uu) * Tin + t] = h;
+    }
+    if (s + 1 < len) {
+      const unsigned long long* src = xb + (size_t)((s + 1) & 1) * H;
+      for (int i = tid; i < H; i += NTC) {
+        unsigned long long v;
+        do {
+          v = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((unsigned)(v >> 32) != (unsigned)(s + 1));
+        hv[i] = __uint_as_float((unsigned)v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Decoder.  Two launch shapes share the per-step building blocks below:
 //   k_decoder       one workgroup per utterance (throughput mode: large batches; B workgroups)
@@ -654,7 +730,7 @@ __global__ __launch_bounds__(NTC) void k_decoder_coop(DecArgs p) {
 
 // ------------------------------------------------------------------------------------------
 struct TWs {
-  size_t a0, a1, xproj, mem_cm, mask, total;
+  size_t a0, a1, xproj, mem_cm, mask, xchg, total;
 };
 TWs tws_layout(const facppg_taco_config& c, int B, int Tin) {
   TWs w;
@@ -666,6 +742,7 @@ TWs tws_layout(const facppg_taco_config& c, int B, int Tin) {
   w.xproj = take((size_t)B * Tin * 4 * c.encoder_embedding_dim * 4);   // [B][Tin][2*4H], 4H = 2E
   w.mem_cm = take((size_t)B * c.encoder_embedding_dim * Tin * 4);
   w.mask = take((size_t)2 * B * c.symbols_embedding_dim * Tin);
+  w.xchg = take((size_t)B * 2 * 2 * (c.encoder_embedding_dim / 2) * 8);   // k_bilstm_coop {value, tag} words
   w.total = off;
   return w;
 }
@@ -927,7 +1004,19 @@ extern "C" int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const in
   p.B = B; p.N = Tin; p.n_valid = lengths_dev; p.A = h->wih; p.M = 8 * H; p.Cin = E; p.X = cur; p.x_bs = (long)E * Tin; p.ldx = Tin;
   p.bias = h->lstm_b; p.C = xproj; p.c_bs = (long)Tin * 8 * H; p.ldc = 8 * H; p.c_transposed = 1;
   if (int rc = gemm_launch(p, s)) return rc;
-  {
+  const int bnwg = (H + BU - 1) / BU;
+  static const char* bilstm_mode = getenv("FACPPG_BILSTM_MODE");   // "single" forces the one-workgroup kernel
+  if ((long)B * 2 * bnwg <= 240 && (H + BKP - 1) / BKP <= BKR && !(bilstm_mode && !strcmp(bilstm_mode, "single"))) {
+    // latency shape: W_hh register-resident, sliced over bnwg co-resident workgroups per (utterance, direction)
+    unsigned long long* xchg = (unsigned long long*)(ws + w.xchg);
+    FACPPG_HIP_CHECK(hipMemsetAsync(xchg, 0, (size_t)B * 2 * 2 * H * 8, s));
+    const float *w0 = h->whh_t[0], *w1 = h->whh_t[1];
+    const float* xp = xproj;
+    int Tin_ = Tin, H_ = H;
+    void* args[] = {(void*)&xp, (void*)&w0, (void*)&w1, (void*)&lengths_dev, (void*)&Tin_, (void*)&H_, (void*)&xchg,
+                    (void*)&memory_dev, (void*)&mem_cm};
+    FACPPG_HIP_CHECK(hipLaunchCooperativeKernel((const void*)k_bilstm_coop, dim3(bnwg, 2, B), dim3(NTC), args, 0, s));
+  } else {
     const int KS = NT / H < H ? NT / H : H;
     const size_t smem = (size_t)(2 * H + (KS > 0 ? KS : 1) * 4 * H) * 4;
     k_bilstm<<<dim3(2, B), NT, smem, s>>>(xproj, h->whh_t[0], h->whh_t[1], lengths_dev, Tin, H, memory_dev, mem_cm);
