@@ -641,6 +641,198 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_wn_layer8: the phase-major layer with EIGHT waves per tile.  Wave w8 owns one 32-channel block:
+// its tanh rows and the matching sigmoid rows in the first GEMM (2 row blocks instead of 4), its res
+// rows and skip rows in the second.  Same LDS footprint and weight traffic per tile as k_wn_layer,
+// but twice the waves per SIMD: when a launch has fewer tiles than the chip has workgroup slots
+// (one short utterance) a 4-wave tile leaves every SIMD with a single wave, and each barrier, LDS
+// round trip and weight load is fully exposed.
+// ------------------------------------------------------------------------------------------
+template <bool LAST, int NCB>
+__global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int TNt = 32 * NCB;
+  const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, wq = w8 >> 1, sub = w8 & 1;
+  const int li = lane & 31, kh = lane >> 5;
+  const int chb = wq * 64 + sub * 32;   // first channel of this wave's block
+  int b, nvalid, ph, in_off, sk_off, tapo[3];
+  {
+    const int lin = blockIdx.x;
+    int tile;
+    if (p.xcd_map) { const int r = lin >> 3; ph = (r / p.nt) * 8 + (lin & 7); tile = r % p.nt; }
+    else { ph = lin / p.nt; tile = lin % p.nt; }
+    if (ph >= p.P) return;
+    int qcol;
+    if (p.flat_cols > 0) {
+      const int c0 = tile * TNt + (lane % (TNt / 4)) * 4;
+      const int cl = min(c0, p.flat_cols - 4);
+      b = cl / p.T; qcol = cl - b * p.T; nvalid = p.flat_cols - c0;
+    } else {
+      b = tile / p.ntq;
+      const int q0 = (tile % p.ntq) * TNt, Tb = p.t_valid ? p.t_valid[b] : p.T;
+      if (q0 >= Tb) return;
+      qcol = q0 + (lane % (TNt / 4)) * 4; nvalid = Tb - qcol;
+    }
+    in_off = ph * p.Tqp + HQ + qcol;
+    sk_off = ph * p.Tr + qcol;
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp) {
+      const int pp = ph + (tp - 1) * p.dil;
+      const int qsh = pp >= 0 ? pp / p.P : -((p.P - 1 - pp) / p.P);
+      tapo[tp] = (pp - qsh * p.P) * p.Tqp + HQ + qcol + qsh;
+    }
+  }
+  f32x16 acc[2][NCB];   // [0] tanh rows / res rows, [1] sigmoid rows / skip rows of channels chb..chb+31
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 bv = *reinterpret_cast<const float4*>(p.b1 + rb * C + chb + 4 * kh + 8 * q);
+      acc[rb][0][4 * q + 0] = bv.x; acc[rb][0][4 * q + 1] = bv.y; acc[rb][0][4 * q + 2] = bv.z; acc[rb][0][4 * q + 3] = bv.w;
+    }
+#pragma unroll
+    for (int cb = 1; cb < NCB; ++cb) acc[rb][cb] = acc[rb][0];
+  }
+  // images are [k-group][16 row blocks][64 lanes]; row block index = wq*4 + sub (+2 for the second half)
+  const float4* wave_a = p.w1 + (wq * 4 + sub) * 64 + lane;
+  const float4* wave_c = p.wc + (size_t)ph * p.ngc * 1024 + (wq * 4 + sub) * 64 + lane;
+  const int nch = p.nch;
+  constexpr int F4R = TNt / 4, RPL4 = 64 / F4R, NSTG4 = 8 / RPL4;
+  const int srow4 = lane / F4R, scol4 = (lane % F4R) * 4;
+  const float* hb4 = p.h_in + (size_t)b * C * p.Lp;
+  const float* sb4 = p.melp + (size_t)b * NMEL * p.Tqp + in_off - ph * p.Tqp;
+  float4 stg[NSTG4];
+  auto stage_load = [&](int c) {
+    const bool conv = c < NCHH;
+    const float* base = conv ? hb4 : sb4;
+#pragma unroll
+    for (int jj = 0; jj < NSTG4; ++jj) {
+      const int r0 = w8 * 8 + srow4 + jj * RPL4;
+      const int r = min((c - NCHH) * 64 + r0, p.kc - 1);
+      const int j = r / NMEL, m = r - j * NMEL;
+      const int off = conv ? ((c & 3) * 64 + r0) * p.Lp + (c < 4 ? tapo[0] : c < 8 ? tapo[1] : tapo[2]) : m * p.Tqp - j;
+      const f4u v = *reinterpret_cast<const f4u*>(base + off);
+      stg[jj] = make_float4(v.x, v.y, v.z, v.w);
+    }
+  };
+  auto stage_write = [&](int buf) {
+    float* dst = smem + buf * (KCH * TNt) + (w8 * 8 + srow4) * TNt + scol4;
+#pragma unroll
+    for (int jj = 0; jj < NSTG4; ++jj) *reinterpret_cast<float4*>(dst + jj * RPL4 * TNt) = stg[jj];
+  };
+  auto load_a1 = [&](float4 (&a)[2], int gg) {
+    const float4* src = gg < NGH ? wave_a + (size_t)gg * 1024 : wave_c + (size_t)(gg - NGH) * 1024;
+    a[0] = src[0];
+    a[1] = src[128];
+  };
+  auto mfma2 = [&](const float4 (&a)[2], const float (&bv)[4][NCB], int nrb) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        if (rb >= nrb) continue;
+        const float av = s == 0 ? a[rb].x : s == 1 ? a[rb].y : s == 2 ? a[rb].z : a[rb].w;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mfma32x32x2(av, bv[s][cb], acc[rb][cb]);
+      }
+  };
+  constexpr int RING = 4;
+  float4 ar[RING][2];
+  stage_load(0);
+#pragma unroll
+  for (int i = 0; i < RING - 1; ++i) load_a1(ar[i], i);
+  stage_write(0);
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+    stage_load(c + 1 < nch ? c + 1 : c);
+    const float* lb = smem + (c & 1) * (KCH * TNt) + (4 * kh) * TNt + li;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      load_a1(ar[(g + RING - 1) % RING], c * 8 + g + RING - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      float bq[4][NCB];
+      load_b<NCB>(bq, lb, g);
+      mfma2(ar[g % RING], bq, 2);
+    }
+    stage_write((c + 1) & 1);
+    __syncthreads();
+  }
+  // gate -> LDS [256][TNt]
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      smem[(chb + 8 * (r >> 2) + (r & 3) + 4 * kh) * TNt + cb * 32 + li] = gate_tanh_sigmoid(acc[0][cb][r], acc[1][cb][r]);
+  __syncthreads();
+  // res_skip 1x1 conv
+  constexpr int NRB2 = LAST ? 1 : 2;
+#pragma unroll
+  for (int rb = 0; rb < NRB2; ++rb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 bv = *reinterpret_cast<const float4*>(p.b2 + (LAST ? 0 : rb * C) + chb + 4 * kh + 8 * q);
+      acc[rb][0][4 * q + 0] = bv.x; acc[rb][0][4 * q + 1] = bv.y; acc[rb][0][4 * q + 2] = bv.z; acc[rb][0][4 * q + 3] = bv.w;
+    }
+#pragma unroll
+    for (int cb = 1; cb < NCB; ++cb) acc[rb][cb] = acc[rb][0];
+  }
+  {
+    // w2 image: float4 index ((wq*nrb + rb4)*NG2 + g)*64 + lane, nrb = 2 (LAST) or 4
+    const float4* ap2 = p.w2 + (size_t)(LAST ? wq * 2 + sub : wq * 4 + sub) * NG2 * 64 + lane;
+    const float* lb = smem + (4 * kh) * TNt + li;
+    auto load_a2 = [&](float4 (&a)[2], int g) {
+      a[0] = ap2[g * 64];
+      if constexpr (!LAST) a[1] = ap2[(size_t)2 * NG2 * 64 + g * 64];
+    };
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i) load_a2(ar[i], i);
+    for (int c = 0; c < NG2 / 8; ++c) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        load_a2(ar[(g + RING - 1) % RING], c * 8 + g + RING - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        float bq[4][NCB];
+        load_b<NCB>(bq, lb, c * 8 + g);
+        mfma2(ar[g % RING], bq, NRB2);
+      }
+    }
+  }
+  // epilogue through a private [32][TNt] LDS slab per wave, 16-byte row segments to HBM
+  __syncthreads();
+  float* slab = smem + w8 * (32 * TNt);
+#pragma unroll
+  for (int half = 0; half < NRB2; ++half) {
+    const bool is_res = !LAST && half == 0;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) slab[(8 * (r >> 2) + (r & 3) + 4 * kh) * TNt + cb * 32 + li] = acc[half][cb][r];
+    const int nv = nvalid;
+    if (nv <= 0) continue;
+    float* gbase = is_res ? p.h_out + (size_t)b * C * p.Lp + in_off : p.skip + (size_t)b * C * p.Lr + sk_off;
+    const float* rbase = is_res ? p.h_in + (size_t)b * C * p.Lp + in_off : gbase;
+    const int pitch = is_res ? p.Lp : p.Lr;
+    const bool add = is_res || !p.first;
+#pragma unroll 4
+    for (int i = 0; i < 32 / RPL4; ++i) {
+      const int row = i * RPL4 + srow4;
+      const size_t o = (size_t)(chb + row) * pitch;
+      float4 v = *reinterpret_cast<const float4*>(slab + row * TNt + scol4);
+      if (nv >= 4) {
+        if (add) {
+          const float4 x = *reinterpret_cast<const float4*>(rbase + o);
+          v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+        }
+        *reinterpret_cast<float4*>(gbase + o) = v;
+      } else {
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        for (int k = 0; k < nv; ++k) gbase[o + k] = vv[k] + (add ? rbase[o + k] : 0.0f);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_upsample: ConvTranspose1d(n_mel, n_mel, K, stride=hop) + trim + regroup (glow.py:253-259)
 // out[m][n] = bias[m] + sum_{m'} sum_{t: 0 <= n - t*hop < K} mel[m'][t] * W[m'][m][n - t*hop]
 // One workgroup = (batch b, output channel m, block of QB frames).  Thread p owns the `hop`-phase
@@ -1145,6 +1337,8 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<false, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<true, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer8<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer8<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipFree(tmp);
 #undef WG_TRY
   *out = h;
@@ -1307,7 +1501,10 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   // workgroup i lands on XCD i % 8: give every XCD its own phases so a phase's weight image lives in one L2
   static const char* no_xcd = getenv("FACPPG_WN_NO_XCD_MAP");
   a.xcd_map = (w.P % 8 == 0) && !no_xcd;
-  const unsigned lgrid = (unsigned)((a.xcd_map ? w.P : w.P) * a.nt);
+  const unsigned lgrid = (unsigned)(w.P * a.nt);
+  // 8 waves per tile for launches that cannot give every SIMD two 4-wave tiles (FACPPG_WN_8W: 0 never, 2 always)
+  static const char* w8env = getenv("FACPPG_WN_8W");
+  const int w8mode = w8env ? atoi(w8env) : 1;
   for (int k = nf - 1; k >= 0; --k) {
     for (int i = 0; i < c.wn_layers; ++i) {
       a.h_in = hbuf[hi]; a.h_out = hbuf[hi ^ 1];
@@ -1316,8 +1513,16 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
       const bool last = i == c.wn_layers - 1;
       if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
       if (narrow) {
-        if (last) k_wn_layer<true, 1, false, true><<<lgrid, 256, 32768, s>>>(a);
-        else k_wn_layer<false, 1, false, true><<<lgrid, 256, 32768, s>>>(a);
+        if (w8mode == 0) {
+          if (last) k_wn_layer<true, 1, false, true><<<lgrid, 256, 32768, s>>>(a);
+          else k_wn_layer<false, 1, false, true><<<lgrid, 256, 32768, s>>>(a);
+        } else {
+          if (last) k_wn_layer8<true, 1><<<lgrid, 512, 32768, s>>>(a);
+          else k_wn_layer8<false, 1><<<lgrid, 512, 32768, s>>>(a);
+        }
+      } else if (w8mode == 2) {
+        if (last) k_wn_layer8<true, 2><<<lgrid, 512, 65536, s>>>(a);
+        else k_wn_layer8<false, 2><<<lgrid, 512, 65536, s>>>(a);
       } else {
         if (last) k_wn_layer<true, 2, false, true><<<lgrid, 256, 65536, s>>>(a);
         else k_wn_layer<false, 2, false, true><<<lgrid, 256, 65536, s>>>(a);
