@@ -19,7 +19,8 @@ namespace facppg {
 enum GemmAct { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_LOG_CLAMP = 3 /* log(max(v, 1e-5)) */ };
 
 inline int gemm_kpad(int K) { return round_up(K, 64); }
-inline size_t packed_a_float4s(int M, int K) { return (size_t)(round_up(M, 32) / 32) * (gemm_kpad(K) / 8 + 1) * 64; }
+// + 3 k-groups: k_gemm prefetches up to 3 groups past the last row block (never used)
+inline size_t packed_a_float4s(int M, int K) { return (size_t)(round_up(M, 32) / 32) * (gemm_kpad(K) / 8 + 1) * 64 + 3 * 64; }
 
 // src element (m, c, tap) at src[(m * Cin + c) * taps + tap]  (torch Conv1d / Linear weight layout)
 int pack_a(const float* src, int M, int Cin, int taps, float4* dst, hipStream_t s);

@@ -66,34 +66,38 @@ __global__ __launch_bounds__(256) void k_gemm(KArgs ka) {
     for (int j = 0; j < 16; ++j) dst[j * TN] = stg[j];
   };
 
+  // Weights: a ring of 4 register sets, fetched 3 k-groups (48 MFMAs) ahead.  Vector-memory loads
+  // retire in order, so the wait on a weight load also waits for the older activation staging loads:
+  // the staging load is therefore unconditional (no branch whose shorter path would drag the wait to
+  // the first MFMA group; the last chunk re-stages itself) and sits 3 groups ahead of the first
+  // younger weight load that is waited on.  The packed image carries one zero k-group of padding per
+  // row block and row blocks are contiguous, so reading up to 3 groups past a row block's end stays
+  // inside the image except for the last row block, which pack_a pads (packed_a_float4s).
   const float4* ap = p.A + (size_t)(active ? mb : 0) * (ka.KG + 1) * 64 + lane;
-  float4 a0, a1;
+  constexpr int RING = 4;
+  float4 ar[RING];
   stage_load(0);
-  a0 = ap[0];
+#pragma unroll
+  for (int i = 0; i < RING - 1; ++i) ar[i] = ap[i * 64];
   stage_write(0);
   __syncthreads();
   for (int c = 0; c < nch; ++c) {
-    if (c + 1 < nch) stage_load(c + 1);
+    stage_load(c + 1 < nch ? c + 1 : c);
     const float* lb = smem + (c & 1) * (KCH * TN) + (4 * kh) * TN + li;
     const int G = c * 8;
 #pragma unroll
-    for (int g = 0; g < 8; g += 2) {
-      a1 = ap[(G + g + 1) * 64];
+    for (int g = 0; g < 8; ++g) {
+      ar[(g + RING - 1) % RING] = ap[(size_t)(G + g + RING - 1) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      const float4 a0 = ar[g % RING];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const float av = s == 0 ? a0.x : s == 1 ? a0.y : s == 2 ? a0.z : a0.w;
         acc[0] = mfma32x32x2(av, lb[(8 * g + s) * TN], acc[0]);
         acc[1] = mfma32x32x2(av, lb[(8 * g + s) * TN + 32], acc[1]);
       }
-      a0 = ap[(G + g + 2) * 64];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float av = s == 0 ? a1.x : s == 1 ? a1.y : s == 2 ? a1.z : a1.w;
-        acc[0] = mfma32x32x2(av, lb[(8 * (g + 1) + s) * TN], acc[0]);
-        acc[1] = mfma32x32x2(av, lb[(8 * (g + 1) + s) * TN + 32], acc[1]);
-      }
     }
-    if (c + 1 < nch) stage_write((c + 1) & 1);
+    stage_write((c + 1) & 1);
     __syncthreads();
   }
   if (!active) return;
