@@ -42,6 +42,8 @@ struct facppg_taco {
   // U = 8 (38 workgroups/utterance, B <= 6), 20 (15, B <= 16), 40 (8, B <= 30)
   float *att_coop[3], *dec_coop[3];
   int coop_U[3], coop_nwg[3];
+  float *att_w4, *dec_w4;          // 4-unit slices for k_decoder_split's workers
+  int split_nwk;
   // postnet
   float4* post[8];
   float *post_b[8], *post_scale[8], *post_shift[8];
@@ -268,6 +270,8 @@ struct DecArgs {
   const float *dp0_t, *dp1_t, *att_t, *att_b, *dec_t, *dec_b, *q_t, *proj_t, *proj_b, *loc_conv, *loc_dense, *v;
   const float *att_coop, *dec_coop;  // [NWG][K][4U] slices (coop mode)
   unsigned long long* xchg;   // [B][2][A] {value, frame tag} hidden-state exchange words (coop mode)
+  const float *att_w4, *dec_w4;   // [NWK][K][16] slices of 4 units (split mode workers)
+  unsigned long long* xsplit;     // [B][P + A + E + D + 8] exchange words of the split decoder
   int* fin;              // [B] per-utterance barrier counters (coop mode)
   long long* prof;       // optional [8] phase cycle counters (debug; FACPPG_DECODER_PROF=1)
   const float* memory;   // [B][Tin][E]
@@ -365,48 +369,15 @@ __device__ __forceinline__ float lstm_point(float gi, float gf, float gg, float 
   return sigm(go) * tanhf(cn);
 }
 
-// Location-sensitive attention (model.py:63-121) evaluated on the index range the reference's
-// window mask keeps (utils.py:64-77).  Reads ah from in_att[P+E:], updates wprev/wcum and writes
-// the context into in_att[P:], in_dec[A:], in_proj[D:].
+// Location features of up to 64 window positions from c0 on: featT[f][pos] -> L.feat (uses L.part as
+// scratch).  They depend only on the previous frame's attention weights, so the split decoder computes
+// them while the attention LSTM's hidden state is still in flight.
 template <int NT>
-__device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L, const float* mem, const float* pm, int len,
-                                              int t, int b, int tid, bool write_out) {
-  const int lane = tid & 63, wave = tid >> 6;
-  long long atk = clock64();
-#define APROF(slot)                                                     \
-  if (p.prof && write_out && b == 0 && tid == 0) {                       \
-    const long long now = clock64();                                     \
-    p.prof[slot] += now - atk;                                           \
-    atk = now;                                                           \
-  }
-  const float* ah = L.in_att + p.P + p.E;
-  int lo = 0, hi = len - 1;
-  if (p.window >= 0) {
-    lo = min(max(0, t - p.window), len - 1);
-    hi = min(t + p.window, len - 1);
-  }
-  {
-    const int KS = pick_ks<NT>(L.ADp, p.A);
-    matvec_part<(NT <= 512 ? 16 : 4)>(p.q_t, p.A, L.ADp, KS, ah, L.part, tid);
-    __syncthreads();
-    if (tid < p.AD) L.pq[tid] = part_sum(L.part, L.ADp, KS, tid);
-    __syncthreads();
-  }
-  APROF(8)
-  // Location features and energies of up to 64 window positions per pass, as two small fp32 MFMA
-  // products (positions are the N dimension; the <= 41-wide window of the reference is one pass):
-  //   featT[f][pos] = sum_kk lconvT[kk][f] * wcat[kk / KSZ][pos + kk % KSZ - half]      (waves 0,1)
-  //   pa[a][pos]    = sum_f  ldense[f][a] * featT[f][pos]                               (waves rb*2+cb)
-  //   e[pos]        = sum_a  v[a] * tanh(pq[a] + pa[a][pos] + pm[pos][a])               (model.py:101-104)
-  // The MFMA result layout leaves a lane with 16 rows (a) of one column (pos): the tanh and the
-  // v-weighted sum are lane-local, then one shuffle and a fixed-order sum over the row blocks.
-  const int half = (p.KSZ - 1) / 2, KK = 2 * p.KSZ, NRB = L.AD32 / 32;
-  const int li = lane & 31, kh = lane >> 5;
-  float* epart = L.part;   // [NRB][64]
-  for (int c0 = lo; c0 <= hi; c0 += 64) {
-    const int nc = min(64, hi - c0 + 1);
-    // features: the K = 2*KSZ reduction is dealt to NWF waves per 32-position block (partial products
-    // meet in LDS in a fixed order) so the dependent MFMA chain is short
+__device__ __forceinline__ void attn_features(const DecArgs& p, const DecLds& L, int c0, int nc, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
+  const int half = (p.KSZ - 1) / 2, KK = 2 * p.KSZ;
+  // features: the K = 2*KSZ reduction is dealt to NWF waves per 32-position block (partial products
+  // meet in LDS in a fixed order) so the dependent MFMA chain is short
     {
       constexpr int NWF = 2;   // waves 0..3: (position block, K half)
       const int cbf = wave / NWF, part_i = wave % NWF;
@@ -439,6 +410,49 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
         L.feat[f * 64 + pos] = v;
       }
     }
+}
+
+// Location-sensitive attention (model.py:63-121) evaluated on the index range the reference's
+// window mask keeps (utils.py:64-77).  Reads ah from in_att[P+E:], updates wprev/wcum and writes
+// the context into in_att[P:], in_dec[A:], in_proj[D:].
+template <int NT>
+__device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L, const float* mem, const float* pm, int len,
+                                              int t, int b, int tid, bool write_out, bool feat_ready = false) {
+  const int lane = tid & 63, wave = tid >> 6;
+  long long atk = clock64();
+#define APROF(slot)                                                     \
+  if (p.prof && write_out && b == 0 && tid == 0) {                       \
+    const long long now = clock64();                                     \
+    p.prof[slot] += now - atk;                                           \
+    atk = now;                                                           \
+  }
+  const float* ah = L.in_att + p.P + p.E;
+  int lo = 0, hi = len - 1;
+  if (p.window >= 0) {
+    lo = min(max(0, t - p.window), len - 1);
+    hi = min(t + p.window, len - 1);
+  }
+  {
+    const int KS = pick_ks<NT>(L.ADp, p.A);
+    matvec_part<(NT <= 512 ? 16 : 4)>(p.q_t, p.A, L.ADp, KS, ah, L.part, tid);
+    __syncthreads();
+    if (tid < p.AD) L.pq[tid] = part_sum(L.part, L.ADp, KS, tid);
+    __syncthreads();
+  }
+  APROF(8)
+  // Location features and energies of up to 64 window positions per pass, as two small fp32 MFMA
+  // products (positions are the N dimension; the <= 41-wide window of the reference is one pass):
+  //   featT[f][pos] = sum_kk lconvT[kk][f] * wcat[kk / KSZ][pos + kk % KSZ - half]      (waves 0,1)
+  //   pa[a][pos]    = sum_f  ldense[f][a] * featT[f][pos]                               (waves rb*2+cb)
+  //   e[pos]        = sum_a  v[a] * tanh(pq[a] + pa[a][pos] + pm[pos][a])               (model.py:101-104)
+  // The MFMA result layout leaves a lane with 16 rows (a) of one column (pos): the tanh and the
+  // v-weighted sum are lane-local, then one shuffle and a fixed-order sum over the row blocks.
+  const int NRB = L.AD32 / 32;
+  const int li = lane & 31, kh = lane >> 5;
+  float* epart = L.part;   // [NRB][64]
+  for (int c0 = lo; c0 <= hi; c0 += 64) {
+    const int nc = min(64, hi - c0 + 1);
+    if (!(feat_ready && c0 == lo)) attn_features<NT>(p, L, c0, nc, tid);
     __syncthreads();
     APROF(9)
     // energies: one (32 attention dims, 32 positions) block per wave and round
@@ -729,6 +743,157 @@ __global__ __launch_bounds__(NTC) void k_decoder_coop(DecArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_decoder_split: the latency shape for up to 3 utterances.  One MAIN workgroup per utterance runs
+// the step's small dense parts (projection, prenet, attention) exactly as k_decoder does; the two
+// LSTMCells live in WORKER workgroups, SU = 4 units (16 gate rows) each, whose slices of both
+// recurrent matrices stay in REGISTERS for the whole utterance (thread (row, K part) holds <= 40
+// columns of each) -- the worker path is small, so unlike in k_decoder_coop nothing competes for
+// those registers.  All traffic between the roles is the tagged-word exchange:
+//   main:   [project frame t-1 -> stop?]  CTL(t), prenet -> X2(t) | features(t) | gather AH(t),
+//           attention -> CTX(t) | gather DH(t)
+//   worker: gather CTL/X2(t) | attention LSTM slice -> AH(t) | gather AH(t), CTX(t) |
+//           decoder LSTM slice -> DH(t) | gather DH(t)
+// Every word is written once per frame and a writer reaches frame t+1 only through gathers that
+// required all its readers to have consumed frame t, so single buffers suffice.  The location
+// features depend only on the previous frame's weights: the main computes them while the attention
+// LSTM's hidden state is in flight.
+// ------------------------------------------------------------------------------------------
+constexpr int SU = 4, SSC = 4 * SU, SKP = NTC / SSC, SKR = 40;   // 16 rows x 32 K parts x <= 40 columns (K <= 1280)
+
+__device__ __forceinline__ void xpub(unsigned long long* w, float v, unsigned tag) {
+  __hip_atomic_store(w, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float xwait(const unsigned long long* w, unsigned tag) {
+  unsigned long long v;
+  do {
+    v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } while ((unsigned)(v >> 32) != tag);
+  return __uint_as_float((unsigned)v);
+}
+
+__device__ __forceinline__ void stat_load(float (&w)[SKR], const float* __restrict__ Wslice, int K, int tid) {
+  const int r = tid % SSC, kp = tid / SSC, KR = (K + SKP - 1) / SKP;
+#pragma unroll
+  for (int i = 0; i < SKR; ++i) {
+    const int k = kp * KR + i;
+    w[i] = (i < KR && k < K) ? Wslice[(size_t)k * SSC + r] : 0.0f;
+  }
+}
+
+__device__ __forceinline__ void stat_lstm_slice(const float (&w)[SKR], const float* __restrict__ bias, int K, int A, int unit0,
+                                                const float* in, float* part, float* cstate, unsigned long long* xout,
+                                                unsigned tag, int tid) {
+  const int r = tid % SSC, kp = tid / SSC, KR = (K + SKP - 1) / SKP;
+  const int kb = kp * KR;
+  float acc = 0.0f;
+#pragma unroll
+  for (int i = 0; i < SKR; ++i) acc = fmaf(w[i], in[min(kb + i, K - 1)], acc);   // clamped reads meet zero weights
+  // the 4 K parts inside a wave by shuffles, the 8 waves through LDS, both in a fixed order
+  acc += __shfl_xor(acc, 16);
+  acc += __shfl_xor(acc, 32);
+  if ((tid & 63) < SSC) part[(tid >> 6) * SSC + r] = acc;
+  __syncthreads();
+  if (tid < SSC) {
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NTC / 64; ++j) s += part[j * SSC + tid];
+    const int u = unit0 + tid % SU;
+    part[256 + tid] = s + (u < A ? bias[(tid / SU) * A + u] : 0.0f);
+  }
+  __syncthreads();
+  if (tid < SU && unit0 + tid < A) {
+    const float* gs = part + 256;
+    xpub(xout + unit0 + tid, lstm_point(gs[tid], gs[SU + tid], gs[2 * SU + tid], gs[3 * SU + tid], &cstate[tid]), tag);
+  }
+}
+
+__global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
+  extern __shared__ float sm[];
+  __shared__ int s_stop;
+  __shared__ float c_att[SU], c_dec[SU];
+  const int blk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  unsigned long long* X2 = p.xsplit + (size_t)b * (p.P + p.A + p.E + p.D + 8);
+  unsigned long long *AH = X2 + p.P, *CTX = AH + p.A, *DH = CTX + p.E, *CTL = DH + p.D;
+  const int KA = p.P + p.E + p.A, KD = p.A + p.E + p.D;
+  if (blk > 0) {   // ------------------------------------------------ worker
+    const int wg = blk - 1, unit0 = wg * SU;
+    float* in_att = sm;            // [prenet | ctx | ah]
+    float* in_dec = in_att + KA;   // [ah | ctx | dh]
+    float* part = in_dec + KD;     // 512 floats
+    for (int i = tid; i < KA + KD; i += NTC) sm[i] = 0.0f;
+    if (tid < SU) { c_att[tid] = 0.0f; c_dec[tid] = 0.0f; }
+    float w_att[SKR], w_dec[SKR];
+    stat_load(w_att, p.att_w4 + (size_t)wg * KA * SSC, KA, tid);
+    stat_load(w_dec, p.dec_w4 + (size_t)wg * KD * SSC, KD, tid);
+    __syncthreads();
+    for (int t = 0;; ++t) {
+      const unsigned tag = t + 1;
+      if (tid == 0) s_stop = xwait(CTL, tag) != 0.0f;
+      for (int i = tid; i < p.P; i += NTC) in_att[i] = xwait(X2 + i, tag);
+      __syncthreads();
+      if (s_stop) break;
+      stat_lstm_slice(w_att, p.att_b, KA, p.A, unit0, in_att, part, c_att, AH, tag, tid);
+      for (int i = tid; i < p.A; i += NTC) { const float h = xwait(AH + i, tag); in_att[p.P + p.E + i] = h; in_dec[i] = h; }
+      for (int i = tid; i < p.E; i += NTC) { const float c = xwait(CTX + i, tag); in_att[p.P + i] = c; in_dec[p.A + i] = c; }
+      __syncthreads();
+      stat_lstm_slice(w_dec, p.dec_b, KD, p.D, unit0, in_dec, part, c_dec, DH, tag, tid);
+      for (int i = tid; i < p.D; i += NTC) in_dec[p.A + p.E + i] = xwait(DH + i, tag);
+      __syncthreads();
+    }
+    return;
+  }
+  // ------------------------------------------------------------------ main
+  const int len = p.lengths ? p.lengths[b] : p.Tin;
+  DecLds L;
+  dec_carve(p, sm, L);
+  dec_init<NTC>(p, L, sm, tid);
+  if (tid == 0) s_stop = 0;
+  __syncthreads();
+  const float* mem = p.memory + (size_t)b * p.Tin * p.E;
+  const float* pm = p.pm + (size_t)b * p.Tin * p.AD;
+  float* ah = L.in_att + p.P + p.E;
+  long long tk = clock64();
+#define PROF(slot)                                                        \
+  if (p.prof && b == 0 && tid == 0) {                                     \
+    const long long now = clock64();                                      \
+    p.prof[slot] += now - tk;                                             \
+    tk = now;                                                             \
+  }
+  for (int t = 0;; ++t) {
+    const unsigned tag = t + 1;
+    if (t > 0) dec_project<NTC>(p, L, t - 1, b, tid, true, &s_stop);   // ends with a barrier: s_stop is settled
+    if (tid == 0) xpub(CTL, s_stop ? 1.0f : 0.0f, tag);
+    if (s_stop) {
+      for (int i = tid; i < p.P; i += NTC) xpub(X2 + i, 0.0f, tag);   // release the workers' gather
+      if (tid == 0) p.out_len[b] = t;
+      break;
+    }
+    PROF(0)
+    dec_prenet<NTC>(p, L, t, b, tid);
+    for (int i = tid; i < p.P; i += NTC) xpub(X2 + i, L.in_att[i], tag);
+    PROF(1)
+    int lo = 0, hi = len - 1;
+    if (p.window >= 0) {
+      lo = min(max(0, t - p.window), len - 1);
+      hi = min(t + p.window, len - 1);
+    }
+    attn_features<NTC>(p, L, lo, min(64, hi - lo + 1), tid);
+    __syncthreads();
+    PROF(2)
+    for (int i = tid; i < p.A; i += NTC) ah[i] = xwait(AH + i, tag);
+    __syncthreads();
+    PROF(3)
+    dec_attention<NTC>(p, L, mem, pm, len, t, b, tid, true, true);
+    for (int i = tid; i < p.E; i += NTC) xpub(CTX + i, L.in_proj[p.D + i], tag);
+    PROF(5)
+    for (int i = tid; i < p.D; i += NTC) L.in_proj[i] = xwait(DH + i, tag);
+    __syncthreads();
+    PROF(7)
+  }
+#undef PROF
+}
+
+// ------------------------------------------------------------------------------------------
 struct TWs {
   size_t a0, a1, xproj, mem_cm, mask, xchg, total;
 };
@@ -817,7 +982,7 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   struct { size_t pre0, pre1, conv[8], conv_b[8], conv_sc[8], conv_sh[8], wih, whh[2], lstm_b, mem_w, dp0, dp1, att, att_b, dec, dec_b, q,
-           proj, proj_b, lc, ld, v, attc[3], decc[3], post[8], post_b[8], post_sc[8], post_sh[8]; } o;
+           proj, proj_b, lc, ld, v, attc[3], decc[3], att4, dec4, post[8], post_b[8], post_sc[8], post_sh[8]; } o;
   o.pre0 = take(packed_a_float4s(S, c.n_symbols) * 16);
   o.pre1 = take(packed_a_float4s(S, S) * 16);
   for (int j = 0; j < c.encoder_n_convolutions; ++j) {
@@ -838,6 +1003,8 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
     const int nwg = (A + CUs[v] - 1) / CUs[v];
     o.attc[v] = take((size_t)nwg * (P + E + A) * 4 * CUs[v] * 4); o.decc[v] = take((size_t)nwg * (A + E + D) * 4 * CUs[v] * 4);
   }
+  const int nwk = (A + 3) / 4;   // k_decoder_split workers: 4 units each
+  o.att4 = take((size_t)nwk * (P + E + A) * 16 * 4); o.dec4 = take((size_t)nwk * (A + E + D) * 16 * 4);
   o.lc = take((size_t)NFIL * 2 * KSZ * 4); o.ld = take((size_t)AD * NFIL * 4); o.v = take((size_t)AD * 4);
   for (int j = 0; j < c.postnet_n_convolutions; ++j) {
     const int ci = j == 0 ? NF : PE, co = j == c.postnet_n_convolutions - 1 ? NF : PE;
@@ -914,6 +1081,12 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
     const size_t na = (size_t)nwg * (P + E + A) * 4 * U, nd = (size_t)nwg * (A + E + D) * 4 * U;
     k_pack_coop<<<(unsigned)((na + 255) / 256), 256, 0, s>>>(h->att_t, h->att_coop[v], P + E + A, A, U, nwg);
     k_pack_coop<<<(unsigned)((nd + 255) / 256), 256, 0, s>>>(h->dec_t, h->dec_coop[v], A + E + D, D, U, nwg);
+  }
+  {
+    h->att_w4 = F(o.att4); h->dec_w4 = F(o.dec4); h->split_nwk = nwk;
+    const size_t na = (size_t)nwk * (P + E + A) * 16, nd = (size_t)nwk * (A + E + D) * 16;
+    k_pack_coop<<<(unsigned)((na + 255) / 256), 256, 0, s>>>(h->att_t, h->att_w4, P + E + A, A, 4, nwk);
+    k_pack_coop<<<(unsigned)((nd + 255) / 256), 256, 0, s>>>(h->dec_t, h->dec_w4, A + E + D, D, 4, nwk);
   }
   // projection rows 0..NF-1, gate row NF, K-major [D+E][NFp]
   {
@@ -1031,7 +1204,7 @@ extern "C" int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const in
 }
 
 namespace {
-struct DecWs { size_t mask, xchg, fin, prof, total; };
+struct DecWs { size_t mask, xchg, fin, prof, xsplit, total; };
 DecWs dec_ws(const facppg_taco_config& c, int B, int max_steps) {
   DecWs w;
   size_t off = 0;
@@ -1040,6 +1213,7 @@ DecWs dec_ws(const facppg_taco_config& c, int B, int max_steps) {
   w.xchg = take((size_t)B * 2 * c.attention_rnn_dim * 8);
   w.fin = take((size_t)B * 4);
   w.prof = take(16 * 8);
+  w.xsplit = take((size_t)B * (c.prenet_dim + c.attention_rnn_dim + c.encoder_embedding_dim + c.decoder_rnn_dim + 8) * 8);
   w.total = off;
   return w;
 }
@@ -1089,6 +1263,24 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
   if (coop) {
     a.att_coop = h->att_coop[variant]; a.dec_coop = h->dec_coop[variant]; a.U = h->coop_U[variant];
   }
+  // split shape: one main + split_nwk register-resident LSTM workers per utterance
+  static const char* no_split = getenv("FACPPG_DECODER_NO_SPLIT");
+  const bool split = coop && !no_split && (long)B * (h->split_nwk + 1) <= 240 && a.P + a.E + a.A <= SKP * SKR &&
+                     a.A + a.E + a.D <= SKP * SKR && !(mode && !strcmp(mode, "coop"));
+  if (split) {
+    a.att_w4 = h->att_w4; a.dec_w4 = h->dec_w4; a.xsplit = (unsigned long long*)(ws + w.xsplit);
+    FACPPG_HIP_CHECK(hipMemsetAsync(ws + w.xchg, 0, w.total - w.xchg, s));
+    FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_decoder_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    void* args[] = {(void*)&a};
+    FACPPG_HIP_CHECK(hipLaunchCooperativeKernel((const void*)k_decoder_split, dim3(h->split_nwk + 1, B), dim3(NTC), args, smem, s));
+    if (a.prof) {
+      long long pr[16];
+      FACPPG_HIP_CHECK(hipMemcpyAsync(pr, a.prof, sizeof(pr), hipMemcpyDeviceToHost, s));
+      FACPPG_HIP_CHECK(hipStreamSynchronize(s));
+      fprintf(stderr, "[facppg split decoder prof, shader cycles] project %lld prenet %lld features %lld wait_ah %lld attention %lld wait_dh %lld | att: query %lld feat %lld energy %lld softmax %lld update %lld context %lld\n",
+              pr[0], pr[1], pr[2], pr[3], pr[5], pr[7], pr[8], pr[9], pr[10], pr[11], pr[12], pr[13]);
+    }
+  } else
   if (coop) {
     FACPPG_HIP_CHECK(hipMemsetAsync(ws + w.xchg, 0, w.total - w.xchg, s));
     const void* fn = (const void*)k_decoder_coop;
