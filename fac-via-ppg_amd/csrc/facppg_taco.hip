@@ -271,7 +271,7 @@ struct DecArgs {
   const float *att_coop, *dec_coop;  // [NWG][K][4U] slices (coop mode)
   unsigned long long* xchg;   // [B][2][A] {value, frame tag} hidden-state exchange words (coop mode)
   const float *att_w4, *dec_w4;   // [NWK][K][16] slices of 4 units (split mode workers)
-  unsigned long long* xsplit;     // [B][P + A + E + D + 8] exchange words of the split decoder
+  unsigned long long* xsplit;     // [B][NF + 1 + 2P + A + E + D + 8] exchange words of the split decoder
   int* fin;              // [B] per-utterance barrier counters (coop mode)
   long long* prof;       // optional [8] phase cycle counters (debug; FACPPG_DECODER_PROF=1)
   const float* memory;   // [B][Tin][E]
@@ -743,22 +743,24 @@ __global__ __launch_bounds__(NTC) void k_decoder_coop(DecArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// k_decoder_split: the latency shape for up to 3 utterances.  One MAIN workgroup per utterance runs
-// the step's small dense parts (projection, prenet, attention) exactly as k_decoder does; the two
-// LSTMCells live in WORKER workgroups, SU = 4 units (16 gate rows) each, whose slices of both
-// recurrent matrices stay in REGISTERS for the whole utterance (thread (row, K part) holds <= 40
-// columns of each) -- the worker path is small, so unlike in k_decoder_coop nothing competes for
-// those registers.  All traffic between the roles is the tagged-word exchange:
-//   main:   [project frame t-1 -> stop?]  CTL(t), prenet -> X2(t) | features(t) | gather AH(t),
-//           attention -> CTX(t) | gather DH(t)
-//   worker: gather CTL/X2(t) | attention LSTM slice -> AH(t) | gather AH(t), CTX(t) |
-//           decoder LSTM slice -> DH(t) | gather DH(t)
+// k_decoder_split: the latency shape for up to 3 utterances.  Per utterance, ONE main workgroup
+// runs the attention (the only part that needs the encoder memory) and NWK worker workgroups run
+// every dense layer of the step, row-sliced, with their weights in REGISTERS for the whole
+// utterance: worker w owns LSTM units 4w..4w+3 of both LSTMCells (16 gate rows x K/32 columns per
+// thread) and, for w < ceil(rows/16), rows 16w..16w+15 of the projection+gate and of the two prenet
+// layers.  A step therefore streams no weights at all; what remains is a chain of tagged-word
+// exchanges (see coop_gather; ~1.5 us each):
+//   workers: [project rows -> MEL(t) | gather -> stop?]  prenet-1 rows -> X1 | gather | prenet-2 rows
+//            -> X2 | gather | attention-LSTM slice -> AH | gather AH, CTX | decoder-LSTM slice -> DH | gather
+//   main:    [gate word of MEL(t) -> stop?]  location features (they depend only on the previous
+//            weights: overlapped with the whole worker chain) | gather AH | query, energies, softmax,
+//            context -> CTX
 // Every word is written once per frame and a writer reaches frame t+1 only through gathers that
-// required all its readers to have consumed frame t, so single buffers suffice.  The location
-// features depend only on the previous frame's weights: the main computes them while the attention
-// LSTM's hidden state is in flight.
+// required all its readers to have consumed frame t, so single buffers suffice.  Sums are in a fixed
+// order and every value has exactly one producer, so all roles see identical bits and stop together.
 // ------------------------------------------------------------------------------------------
-constexpr int SU = 4, SSC = 4 * SU, SKP = NTC / SSC, SKR = 40;   // 16 rows x 32 K parts x <= 40 columns (K <= 1280)
+constexpr int SU = 4, SSC = 4 * SU, SKP = NTC / SSC;   // 16 rows x 32 K parts per workgroup
+constexpr int SKR_LSTM = 40, SKR_PROJ = 32, SKR_P1 = 4, SKR_P2 = 12;   // columns per thread: K <= 1280 / 1024 / 128 / 384
 
 __device__ __forceinline__ void xpub(unsigned long long* w, float v, unsigned tag) {
   __hip_atomic_store(w, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -771,23 +773,25 @@ __device__ __forceinline__ float xwait(const unsigned long long* w, unsigned tag
   return __uint_as_float((unsigned)v);
 }
 
-__device__ __forceinline__ void stat_load(float (&w)[SKR], const float* __restrict__ Wslice, int K, int tid) {
+// thread (row r = tid % 16, K part kp = tid / 16) keeps columns kp*KR .. kp*KR+KR-1 of row `row0 + r` of a
+// K-major matrix W[k][ld] (zero beyond nrows / K)
+template <int KRM>
+__device__ __forceinline__ void stat_load(float (&w)[KRM], const float* __restrict__ W, int ld, int row0, int nrows, int K, int tid) {
   const int r = tid % SSC, kp = tid / SSC, KR = (K + SKP - 1) / SKP;
 #pragma unroll
-  for (int i = 0; i < SKR; ++i) {
+  for (int i = 0; i < KRM; ++i) {
     const int k = kp * KR + i;
-    w[i] = (i < KR && k < K) ? Wslice[(size_t)k * SSC + r] : 0.0f;
+    w[i] = (i < KR && k < K && row0 + r < nrows) ? W[(size_t)k * ld + row0 + r] : 0.0f;
   }
 }
-
-__device__ __forceinline__ void stat_lstm_slice(const float (&w)[SKR], const float* __restrict__ bias, int K, int A, int unit0,
-                                                const float* in, float* part, float* cstate, unsigned long long* xout,
-                                                unsigned tag, int tid) {
+// 16-row matvec from the register-resident stretch; the row sums land in part[256 .. 271] (after a barrier)
+template <int KRM>
+__device__ __forceinline__ void stat_mv16(const float (&w)[KRM], int K, const float* in, float* part, int tid) {
   const int r = tid % SSC, kp = tid / SSC, KR = (K + SKP - 1) / SKP;
   const int kb = kp * KR;
   float acc = 0.0f;
 #pragma unroll
-  for (int i = 0; i < SKR; ++i) acc = fmaf(w[i], in[min(kb + i, K - 1)], acc);   // clamped reads meet zero weights
+  for (int i = 0; i < KRM; ++i) acc = fmaf(w[i], in[kb + i], acc);   // reads past K (into the next, finite LDS array) meet zero weights
   // the 4 K parts inside a wave by shuffles, the 8 waves through LDS, both in a fixed order
   acc += __shfl_xor(acc, 16);
   acc += __shfl_xor(acc, 32);
@@ -797,14 +801,9 @@ __device__ __forceinline__ void stat_lstm_slice(const float (&w)[SKR], const flo
     float s = 0.0f;
 #pragma unroll
     for (int j = 0; j < NTC / 64; ++j) s += part[j * SSC + tid];
-    const int u = unit0 + tid % SU;
-    part[256 + tid] = s + (u < A ? bias[(tid / SU) * A + u] : 0.0f);
+    part[256 + tid] = s;
   }
   __syncthreads();
-  if (tid < SU && unit0 + tid < A) {
-    const float* gs = part + 256;
-    xpub(xout + unit0 + tid, lstm_point(gs[tid], gs[SU + tid], gs[2 * SU + tid], gs[3 * SU + tid], &cstate[tid]), tag);
-  }
 }
 
 __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
@@ -812,32 +811,86 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
   __shared__ int s_stop;
   __shared__ float c_att[SU], c_dec[SU];
   const int blk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  unsigned long long* X2 = p.xsplit + (size_t)b * (p.P + p.A + p.E + p.D + 8);
-  unsigned long long *AH = X2 + p.P, *CTX = AH + p.A, *DH = CTX + p.E, *CTL = DH + p.D;
-  const int KA = p.P + p.E + p.A, KD = p.A + p.E + p.D;
+  // exchange words of this utterance
+  unsigned long long* MEL = p.xsplit + (size_t)b * (p.NF + 1 + 2 * p.P + p.A + p.E + p.D + 8);   // [NF] mel row + gate
+  unsigned long long *X1 = MEL + p.NF + 1, *X2 = X1 + p.P, *AH = X2 + p.P, *CTX = AH + p.A, *DH = CTX + p.E;
+  const int KA = p.P + p.E + p.A, KD = p.A + p.E + p.D, KP = p.D + p.E;
+  if (tid == 0) s_stop = 0;
   if (blk > 0) {   // ------------------------------------------------ worker
-    const int wg = blk - 1, unit0 = wg * SU;
-    float* in_att = sm;            // [prenet | ctx | ah]
-    float* in_dec = in_att + KA;   // [ah | ctx | dh]
-    float* part = in_dec + KD;     // 512 floats
-    for (int i = tid; i < KA + KD; i += NTC) sm[i] = 0.0f;
+    const int wg = blk - 1, unit0 = wg * SU, row0 = wg * SSC;
+    float* in_att = sm;              // [prenet | ctx | ah]
+    float* in_dec = in_att + KA;     // [ah | ctx | dh]
+    float* in_proj = in_dec + KD;    // [dh | ctx]
+    float* xin = in_proj + KP;       // previous mel frame [NF]
+    float* p1 = xin + round_up(p.NF, 4);   // prenet layer-1 output [P]
+    float* part = p1 + round_up(p.P, 4);   // 512 floats
+    for (int i = tid; i < KA + KD + KP + round_up(p.NF, 4) + round_up(p.P, 4) + 512; i += NTC) sm[i] = 0.0f;   // incl. part
     if (tid < SU) { c_att[tid] = 0.0f; c_dec[tid] = 0.0f; }
-    float w_att[SKR], w_dec[SKR];
-    stat_load(w_att, p.att_w4 + (size_t)wg * KA * SSC, KA, tid);
-    stat_load(w_dec, p.dec_w4 + (size_t)wg * KD * SSC, KD, tid);
+    float w_att[SKR_LSTM], w_dec[SKR_LSTM], w_proj[SKR_PROJ], w_p1[SKR_P1], w_p2[SKR_P2];
+    stat_load(w_att, p.att_w4 + (size_t)wg * KA * SSC, SSC, 0, SSC, KA, tid);
+    stat_load(w_dec, p.dec_w4 + (size_t)wg * KD * SSC, SSC, 0, SSC, KD, tid);
+    stat_load(w_proj, p.proj_t, round_up(p.NF + 1, 4), row0, p.NF + 1, KP, tid);
+    stat_load(w_p1, p.dp0_t, round_up(p.P, 4), row0, p.P, p.NF, tid);
+    stat_load(w_p2, p.dp1_t, round_up(p.P, 4), row0, p.P, p.P, tid);
+    const bool has_proj = row0 < p.NF + 1, has_pre = row0 < p.P;
     __syncthreads();
     for (int t = 0;; ++t) {
       const unsigned tag = t + 1;
-      if (tid == 0) s_stop = xwait(CTL, tag) != 0.0f;
+      if (t > 0) {
+        // projection + gate rows of frame t-1 (model.py:436-441); the stopping frame is kept (:524-528)
+        if (has_proj) {
+          stat_mv16(w_proj, KP, in_proj, part, tid);
+          if (tid < SSC && row0 + tid <= p.NF) {
+            const int row = row0 + tid;
+            const float v = part[256 + tid] + p.proj_b[row];
+            xpub(MEL + row, v, tag);
+            if (row < p.NF) p.mel[((size_t)b * p.NF + row) * p.max_steps + t - 1] = v;
+            else p.gate[(size_t)b * p.max_steps + t - 1] = v;
+          }
+        }
+        for (int i = tid; i < p.NF; i += NTC) xin[i] = xwait(MEL + i, tag);
+        if (tid == 0) s_stop = sigm(xwait(MEL + p.NF, tag)) > p.gate_thr || t == p.max_steps;
+        __syncthreads();
+        if (s_stop) break;
+      }
+      // prenet: 2 x (Linear no bias, ReLU, dropout p=0.5 always on)  (model.py:132-135)
+      const uint8_t* mk = p.masks + ((size_t)t * 2 * p.B + b) * p.P;
+      if (has_pre) {
+        stat_mv16(w_p1, p.NF, xin, part, tid);
+        if (tid < SSC && row0 + tid < p.P) xpub(X1 + row0 + tid, fmaxf(part[256 + tid], 0.0f) * (float)mk[row0 + tid] * 2.0f, tag);
+      }
+      for (int i = tid; i < p.P; i += NTC) p1[i] = xwait(X1 + i, tag);
+      __syncthreads();
+      if (has_pre) {
+        stat_mv16(w_p2, p.P, p1, part, tid);
+        if (tid < SSC && row0 + tid < p.P)
+          xpub(X2 + row0 + tid, fmaxf(part[256 + tid], 0.0f) * (float)mk[(size_t)p.B * p.P + row0 + tid] * 2.0f, tag);
+      }
       for (int i = tid; i < p.P; i += NTC) in_att[i] = xwait(X2 + i, tag);
       __syncthreads();
-      if (s_stop) break;
-      stat_lstm_slice(w_att, p.att_b, KA, p.A, unit0, in_att, part, c_att, AH, tag, tid);
+      // attention LSTMCell slice on [prenet | ctx | ah]  (model.py:400-403)
+      stat_mv16(w_att, KA, in_att, part, tid);
+      if (tid < SU && unit0 + tid < p.A) {
+        const float* gs = part + 256;
+        const int u = unit0 + tid;
+        xpub(AH + u, lstm_point(gs[tid] + p.att_b[u], gs[SU + tid] + p.att_b[p.A + u], gs[2 * SU + tid] + p.att_b[2 * p.A + u],
+                                gs[3 * SU + tid] + p.att_b[3 * p.A + u], &c_att[tid]), tag);
+      }
       for (int i = tid; i < p.A; i += NTC) { const float h = xwait(AH + i, tag); in_att[p.P + p.E + i] = h; in_dec[i] = h; }
-      for (int i = tid; i < p.E; i += NTC) { const float c = xwait(CTX + i, tag); in_att[p.P + i] = c; in_dec[p.A + i] = c; }
+      for (int i = tid; i < p.E; i += NTC) {
+        const float c = xwait(CTX + i, tag);
+        in_att[p.P + i] = c; in_dec[p.A + i] = c; in_proj[p.D + i] = c;
+      }
       __syncthreads();
-      stat_lstm_slice(w_dec, p.dec_b, KD, p.D, unit0, in_dec, part, c_dec, DH, tag, tid);
-      for (int i = tid; i < p.D; i += NTC) in_dec[p.A + p.E + i] = xwait(DH + i, tag);
+      // decoder LSTMCell slice on [ah | ctx | dh]  (model.py:425-428)
+      stat_mv16(w_dec, KD, in_dec, part, tid);
+      if (tid < SU && unit0 + tid < p.D) {
+        const float* gs = part + 256;
+        const int u = unit0 + tid;
+        xpub(DH + u, lstm_point(gs[tid] + p.dec_b[u], gs[SU + tid] + p.dec_b[p.D + u], gs[2 * SU + tid] + p.dec_b[2 * p.D + u],
+                                gs[3 * SU + tid] + p.dec_b[3 * p.D + u], &c_dec[tid]), tag);
+      }
+      for (int i = tid; i < p.D; i += NTC) { const float h = xwait(DH + i, tag); in_dec[p.A + p.E + i] = h; in_proj[i] = h; }
       __syncthreads();
     }
     return;
@@ -847,7 +900,6 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
   DecLds L;
   dec_carve(p, sm, L);
   dec_init<NTC>(p, L, sm, tid);
-  if (tid == 0) s_stop = 0;
   __syncthreads();
   const float* mem = p.memory + (size_t)b * p.Tin * p.E;
   const float* pm = p.pm + (size_t)b * p.Tin * p.AD;
@@ -861,34 +913,28 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
   }
   for (int t = 0;; ++t) {
     const unsigned tag = t + 1;
-    if (t > 0) dec_project<NTC>(p, L, t - 1, b, tid, true, &s_stop);   // ends with a barrier: s_stop is settled
-    if (tid == 0) xpub(CTL, s_stop ? 1.0f : 0.0f, tag);
-    if (s_stop) {
-      for (int i = tid; i < p.P; i += NTC) xpub(X2 + i, 0.0f, tag);   // release the workers' gather
-      if (tid == 0) p.out_len[b] = t;
-      break;
-    }
-    PROF(0)
-    dec_prenet<NTC>(p, L, t, b, tid);
-    for (int i = tid; i < p.P; i += NTC) xpub(X2 + i, L.in_att[i], tag);
-    PROF(1)
     int lo = 0, hi = len - 1;
     if (p.window >= 0) {
       lo = min(max(0, t - p.window), len - 1);
       hi = min(t + p.window, len - 1);
     }
-    attn_features<NTC>(p, L, lo, min(64, hi - lo + 1), tid);
-    __syncthreads();
+    attn_features<NTC>(p, L, lo, min(64, hi - lo + 1), tid);   // needs only frame t-1's weights
     PROF(2)
+    if (t > 0) {
+      if (tid == 0) s_stop = sigm(xwait(MEL + p.NF, tag)) > p.gate_thr || t == p.max_steps;
+      __syncthreads();
+      if (s_stop) {
+        if (tid == 0) p.out_len[b] = t;
+        break;
+      }
+    }
+    PROF(0)
     for (int i = tid; i < p.A; i += NTC) ah[i] = xwait(AH + i, tag);
     __syncthreads();
     PROF(3)
     dec_attention<NTC>(p, L, mem, pm, len, t, b, tid, true, true);
     for (int i = tid; i < p.E; i += NTC) xpub(CTX + i, L.in_proj[p.D + i], tag);
     PROF(5)
-    for (int i = tid; i < p.D; i += NTC) L.in_proj[i] = xwait(DH + i, tag);
-    __syncthreads();
-    PROF(7)
   }
 #undef PROF
 }
@@ -1213,7 +1259,7 @@ DecWs dec_ws(const facppg_taco_config& c, int B, int max_steps) {
   w.xchg = take((size_t)B * 2 * c.attention_rnn_dim * 8);
   w.fin = take((size_t)B * 4);
   w.prof = take(16 * 8);
-  w.xsplit = take((size_t)B * (c.prenet_dim + c.attention_rnn_dim + c.encoder_embedding_dim + c.decoder_rnn_dim + 8) * 8);
+  w.xsplit = take((size_t)B * (c.n_acoustic_feat_dims + 1 + 2 * c.prenet_dim + c.attention_rnn_dim + c.encoder_embedding_dim + c.decoder_rnn_dim + 8) * 8);
   w.total = off;
   return w;
 }
@@ -1265,8 +1311,10 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
   }
   // split shape: one main + split_nwk register-resident LSTM workers per utterance
   static const char* no_split = getenv("FACPPG_DECODER_NO_SPLIT");
-  const bool split = coop && !no_split && (long)B * (h->split_nwk + 1) <= 240 && a.P + a.E + a.A <= SKP * SKR &&
-                     a.A + a.E + a.D <= SKP * SKR && !(mode && !strcmp(mode, "coop"));
+  const bool split = coop && !no_split && (long)B * (h->split_nwk + 1) <= 240 && a.P + a.E + a.A <= SKP * SKR_LSTM &&
+                     a.A + a.E + a.D <= SKP * SKR_LSTM && a.D + a.E <= SKP * SKR_PROJ && a.NF <= SKP * SKR_P1 &&
+                     a.P <= SKP * SKR_P2 && a.NF + 1 <= h->split_nwk * SSC && a.P <= h->split_nwk * SSC &&
+                     !(mode && !strcmp(mode, "coop"));
   if (split) {
     a.att_w4 = h->att_w4; a.dec_w4 = h->dec_w4; a.xsplit = (unsigned long long*)(ws + w.xsplit);
     FACPPG_HIP_CHECK(hipMemsetAsync(ws + w.xchg, 0, w.total - w.xchg, s));
@@ -1277,8 +1325,8 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
       long long pr[16];
       FACPPG_HIP_CHECK(hipMemcpyAsync(pr, a.prof, sizeof(pr), hipMemcpyDeviceToHost, s));
       FACPPG_HIP_CHECK(hipStreamSynchronize(s));
-      fprintf(stderr, "[facppg split decoder prof, shader cycles] project %lld prenet %lld features %lld wait_ah %lld attention %lld wait_dh %lld | att: query %lld feat %lld energy %lld softmax %lld update %lld context %lld\n",
-              pr[0], pr[1], pr[2], pr[3], pr[5], pr[7], pr[8], pr[9], pr[10], pr[11], pr[12], pr[13]);
+      fprintf(stderr, "[facppg split decoder prof (main), shader cycles] features %lld wait_gate %lld wait_ah %lld attention %lld | att: query %lld energy %lld softmax %lld update %lld context %lld\n",
+              pr[2], pr[0], pr[3], pr[5], pr[8], pr[10], pr[11], pr[12], pr[13]);
     }
   } else
   if (coop) {
