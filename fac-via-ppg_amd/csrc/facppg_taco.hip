@@ -1315,6 +1315,7 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
                      a.A + a.E + a.D <= SKP * SKR_LSTM && a.D + a.E <= SKP * SKR_PROJ && a.NF <= SKP * SKR_P1 &&
                      a.P <= SKP * SKR_P2 && a.NF + 1 <= h->split_nwk * SSC && a.P <= h->split_nwk * SSC &&
                      !(mode && !strcmp(mode, "coop"));
+  if (mode && !strcmp(mode, "split")) FACPPG_REQUIRE(split, FACPPG_EUNSUPPORTED, "split decoder needs B <= 3 and the reference's layer widths");
   if (split) {
     a.att_w4 = h->att_w4; a.dec_w4 = h->dec_w4; a.xsplit = (unsigned long long*)(ws + w.xsplit);
     FACPPG_HIP_CHECK(hipMemsetAsync(ws + w.xchg, 0, w.total - w.xchg, s));

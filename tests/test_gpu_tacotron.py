@@ -17,11 +17,12 @@ def build(hp, sd):
     return m.eval()
 
 
-@pytest.mark.parametrize("mode", ["coop", "single"])
+@pytest.mark.parametrize("mode", ["split", "coop", "single"])
 @pytest.mark.parametrize("tag", ["nostop", "stop", "mono40"])
 def test_inference_matches_reference_golden(tag, mode, monkeypatch):
-    """Both decoder launch shapes: 'coop' (38 cooperating workgroups per utterance, latency mode)
-    and 'single' (one workgroup per utterance, throughput mode)."""
+    """All decoder launch shapes: 'split' (one attention workgroup + 75 register-resident dense-layer
+    workers per utterance, B <= 3), 'coop' (38 cooperating workgroups per utterance, B <= 30) and
+    'single' (one workgroup per utterance, throughput mode)."""
     monkeypatch.setenv("FACPPG_DECODER_MODE", mode)
     d, hp, sd, ppg, em, dm = tacotron_case(tag)
     m = build(hp, sd)
@@ -50,7 +51,7 @@ def test_get_inference_surface_and_clip():
     assert clipped.shape[2] == max(0, min(16, Tin - 10) - 10)
 
 
-@pytest.mark.parametrize("mode", ["coop", "single"])
+@pytest.mark.parametrize("mode", ["split", "coop", "single"])
 def test_padded_batch_equals_independent_runs(mode, monkeypatch):
     """Batched semantics the reference never defined (batch-1 only): identical to B independent
     batch-1 runs, including each utterance's own stop step."""
