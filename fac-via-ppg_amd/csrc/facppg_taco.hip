@@ -1224,7 +1224,7 @@ extern "C" int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const in
   p.bias = h->lstm_b; p.C = xproj; p.c_bs = (long)Tin * 8 * H; p.ldc = 8 * H; p.c_transposed = 1;
   if (int rc = gemm_launch(p, s)) return rc;
   const int bnwg = (H + BU - 1) / BU;
-  static const char* bilstm_mode = getenv("FACPPG_BILSTM_MODE");   // "single" forces the one-workgroup kernel
+  const char* bilstm_mode = getenv("FACPPG_BILSTM_MODE");   // "single" forces the one-workgroup kernel
   if ((long)B * 2 * bnwg <= 240 && (H + BKP - 1) / BKP <= BKR && !(bilstm_mode && !strcmp(bilstm_mode, "single"))) {
     // latency shape: W_hh register-resident, sliced over bnwg co-resident workgroups per (utterance, direction)
     unsigned long long* xchg = (unsigned long long*)(ws + w.xchg);

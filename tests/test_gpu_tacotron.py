@@ -39,6 +39,31 @@ def test_inference_matches_reference_golden(tag, mode, monkeypatch):
     assert e_mem <= 1e-4 and e_mel <= 1e-4 and e_post <= 1e-4 and e_al <= 1e-4 and e_gate <= 1e-4
 
 
+def test_bilstm_shapes_agree(monkeypatch):
+    """Encoder BiLSTM: the register-resident cooperative kernel (B <= 12) and the one-workgroup kernel give
+    the same memory up to the fp32 re-association of the K split, on a ragged batch."""
+    d, hp, sd, ppg, em, dm = tacotron_case("stop")
+    m = build(hp, sd)
+    from facppg import synth
+    lens = [24, 9, 17]
+    x = torch.zeros(len(lens), ppg.shape[1], max(lens))
+    for b, n in enumerate(lens):
+        x[b, :, :n] = torch.from_numpy(synth.synthetic_ppg(n, ppg.shape[1], seed=40 + b)).t()
+    g = np.random.Generator(np.random.PCG64(5))
+    emb = (g.random((2, len(lens), max(lens), 600)) < 0.5).astype(np.uint8)
+    dmb = (g.random((int(d["max_steps"]), 2, len(lens), 300)) < 0.5).astype(np.uint8)
+    mems = []
+    for mode in ("coop", "single"):
+        monkeypatch.setenv("FACPPG_BILSTM_MODE", mode)
+        m.inference(x.cuda(), lengths=lens, dropout_masks=(emb, dmb))
+        mems.append(m.last_memory.clone())
+    err = (mems[0] - mems[1]).abs().max().item()
+    print("bilstm coop vs single: max abs diff %.2e" % err)
+    assert err <= 1e-5
+    for b, n in enumerate(lens):
+        assert torch.count_nonzero(mems[0][b, n:]) == 0
+
+
 def test_get_inference_surface_and_clip():
     from common.utils import get_inference
     d, hp, sd, ppg, em, dm = tacotron_case("mono40")
