@@ -29,6 +29,7 @@ using namespace facppg;
 struct facppg_taco {
   facppg_taco_config c;
   int device;
+  int coop_limit;   // workgroups the cooperative (co-resident) kernels may use: CUs - 16 (one 512-thread workgroup per CU)
   char* arena;
   // encoder
   float4 *pre0, *pre1, *conv[8], *wih;
@@ -1014,9 +1015,11 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
   FACPPG_REQUIRE(n_floats == taco_count(cfg), FACPPG_EINVAL, "weight blob has %zu floats, expected %zu", n_floats, taco_count(cfg));
   hipStream_t s = (hipStream_t)stream_;
   FACPPG_HIP_CHECK(hipSetDevice(device));
+  int n_cu = 0;
+  FACPPG_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device));
   facppg_taco* h = new (std::nothrow) facppg_taco();
   FACPPG_REQUIRE(h, FACPPG_EINVAL, "out of host memory");
-  h->c = *cfg; h->device = device;
+  h->c = *cfg; h->device = device; h->coop_limit = n_cu > 32 ? n_cu - 16 : n_cu;
   const facppg_taco_config& c = *cfg;
   const int S = c.symbols_embedding_dim, E = c.encoder_embedding_dim, H = E / 2, K = c.encoder_kernel_size;
   const int P = c.prenet_dim, A = c.attention_rnn_dim, D = c.decoder_rnn_dim, AD = c.attention_dim, NF = c.n_acoustic_feat_dims;
@@ -1225,7 +1228,7 @@ extern "C" int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const in
   if (int rc = gemm_launch(p, s)) return rc;
   const int bnwg = (H + BU - 1) / BU;
   const char* bilstm_mode = getenv("FACPPG_BILSTM_MODE");   // "single" forces the one-workgroup kernel
-  if ((long)B * 2 * bnwg <= 240 && (H + BKP - 1) / BKP <= BKR && !(bilstm_mode && !strcmp(bilstm_mode, "single"))) {
+  if ((long)B * 2 * bnwg <= h->coop_limit && (H + BKP - 1) / BKP <= BKR && !(bilstm_mode && !strcmp(bilstm_mode, "single"))) {
     // latency shape: W_hh register-resident, sliced over bnwg co-resident workgroups per (utterance, direction)
     unsigned long long* xchg = (unsigned long long*)(ws + w.xchg);
     FACPPG_HIP_CHECK(hipMemsetAsync(xchg, 0, (size_t)B * 2 * 2 * H * 8, s));
@@ -1298,11 +1301,11 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
   const size_t smem = dec_lds_floats(a.P, a.E, a.A, a.D, a.NF, a.AD, a.NFIL, a.KSZ, Tin) * 4;
   FACPPG_REQUIRE(smem <= 160 * 1024 - 1024, FACPPG_EUNSUPPORTED, "decoder state (%zu bytes) exceeds LDS", smem);
   // latency mode (few utterances): NWG cooperating workgroups per utterance; throughput mode: one each
-  // slice width: the narrowest (most workgroups per utterance) that keeps B * NWG <= 240 resident
+  // slice width: the narrowest (most workgroups per utterance) that keeps B * NWG co-resident (coop_limit)
   const char* mode = getenv("FACPPG_DECODER_MODE");
   int variant = -1;
   for (int v = 0; v < 3 && variant < 0; ++v)
-    if ((long)B * h->coop_nwg[v] <= 240) variant = v;
+    if ((long)B * h->coop_nwg[v] <= h->coop_limit) variant = v;
   bool coop = variant >= 0;
   if (mode && !strcmp(mode, "single")) coop = false;
   if (mode && !strcmp(mode, "coop")) FACPPG_REQUIRE(coop, FACPPG_EUNSUPPORTED, "coop decoder needs B <= 30");
@@ -1311,7 +1314,7 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
   }
   // split shape: one main + split_nwk register-resident LSTM workers per utterance
   static const char* no_split = getenv("FACPPG_DECODER_NO_SPLIT");
-  const bool split = coop && !no_split && (long)B * (h->split_nwk + 1) <= 240 && a.P + a.E + a.A <= SKP * SKR_LSTM &&
+  const bool split = coop && !no_split && (long)B * (h->split_nwk + 1) <= h->coop_limit && a.P + a.E + a.A <= SKP * SKR_LSTM &&
                      a.A + a.E + a.D <= SKP * SKR_LSTM && a.D + a.E <= SKP * SKR_PROJ && a.NF <= SKP * SKR_P1 &&
                      a.P <= SKP * SKR_P2 && a.NF + 1 <= h->split_nwk * SSC && a.P <= h->split_nwk * SSC &&
                      !(mode && !strcmp(mode, "coop"));
