@@ -58,6 +58,10 @@ struct GemmArgs {
   long gate_bs = 0;
   int ldgate = 0;
   int B = 1;
+  // optional scratch for split-K (small-N products): [splits][B][M][N] partial sums; gemm_launch
+  // decides whether and how far to split
+  float* splitk_ws = nullptr;
+  size_t splitk_ws_bytes = 0;
 };
 
 int gemm_launch(const GemmArgs& a, hipStream_t s);

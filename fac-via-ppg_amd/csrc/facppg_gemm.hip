@@ -29,20 +29,40 @@ __global__ void k_pack_a(const float* __restrict__ src, float4* __restrict__ dst
 struct KArgs {
   GemmArgs g;
   int KG;  // k-groups of 8 (Kpad / 8)
+  int sk;  // K splits (1 = none): blockIdx.z = b * sk + ks, partial sums go to g.splitk_ws
 };
+
+// bias, eval-BN scale/shift, activation, dropout mask, residual, gate backward, store
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, int b, int m, int n, float v) {
+  if (p.bias) v += p.bias[m];
+  if (p.scale) v = v * p.scale[m] + p.shift[m];
+  if (p.act == ACT_RELU) v = fmaxf(v, 0.0f);
+  else if (p.act == ACT_TANH) v = tanhf(v);
+  else if (p.act == ACT_LOG_CLAMP) v = logf(fmaxf(v, 1e-5f));
+  if (p.mask) v = v * (float)p.mask[(size_t)b * p.mask_bs + (size_t)m * p.ldmask + n] * 2.0f;
+  if (p.res) v += p.res[(size_t)b * p.res_bs + (size_t)m * p.ldres + n];
+  if (p.gate_ts) {
+    const float T = p.gate_ts[(size_t)b * p.gate_bs + (size_t)m * p.ldgate + n];
+    const float S = p.gate_ts[(size_t)b * p.gate_bs + (size_t)(p.M + m) * p.ldgate + n];
+    p.C[(size_t)b * p.c_bs + (size_t)m * p.ldc + n] = v * S * (1.0f - T * T);
+    p.C[(size_t)b * p.c_bs + (size_t)(p.M + m) * p.ldc + n] = v * T * S * (1.0f - S);
+  } else if (p.c_transposed) p.C[(size_t)b * p.c_bs + (size_t)n * p.ldc + m] = v;
+  else p.C[(size_t)b * p.c_bs + (size_t)m * p.ldc + n] = v;
+}
 
 __global__ __launch_bounds__(256) void k_gemm(KArgs ka) {
   const GemmArgs& p = ka.g;
   __shared__ __attribute__((aligned(16))) float smem[2 * KCH * TN];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
-  const int b = blockIdx.z, n0 = blockIdx.x * TN;
+  const int b = blockIdx.z / ka.sk, ks = blockIdx.z % ka.sk, n0 = blockIdx.x * TN;
   const int Nb = p.n_valid ? min(p.N, p.n_valid[b] * p.n_valid_mul + p.n_valid_add) : p.N;
   if (n0 >= Nb) return;
   const int mb = blockIdx.y * 4 + w;
   const int MB = (p.M + 31) / 32;
   const bool active = mb < MB;
   const int K = p.Cin * p.taps;
-  const int nch = ka.KG / 8;
+  const int nch_all = ka.KG / 8;
+  const int c_lo = ks * nch_all / ka.sk, c_hi = (ks + 1) * nch_all / ka.sk;   // this split's chunks
 
   f32x16 acc[2];
 #pragma unroll
@@ -76,13 +96,13 @@ __global__ __launch_bounds__(256) void k_gemm(KArgs ka) {
   const float4* ap = p.A + (size_t)(active ? mb : 0) * (ka.KG + 1) * 64 + lane;
   constexpr int RING = 4;
   float4 ar[RING];
-  stage_load(0);
+  stage_load(c_lo);
 #pragma unroll
-  for (int i = 0; i < RING - 1; ++i) ar[i] = ap[i * 64];
-  stage_write(0);
+  for (int i = 0; i < RING - 1; ++i) ar[i] = ap[(size_t)(c_lo * 8 + i) * 64];
+  stage_write(c_lo & 1);
   __syncthreads();
-  for (int c = 0; c < nch; ++c) {
-    stage_load(c + 1 < nch ? c + 1 : c);
+  for (int c = c_lo; c < c_hi; ++c) {
+    stage_load(c + 1 < c_hi ? c + 1 : c);
     const float* lb = smem + (c & 1) * (KCH * TN) + (4 * kh) * TN + li;
     const int G = c * 8;
 #pragma unroll
@@ -109,23 +129,21 @@ __global__ __launch_bounds__(256) void k_gemm(KArgs ka) {
     for (int r = 0; r < 16; ++r) {
       const int m = mb * 32 + 8 * (r >> 2) + (r & 3) + 4 * kh;
       if (m >= p.M) continue;
-      float v = acc[cb][r];
-      if (p.bias) v += p.bias[m];
-      if (p.scale) v = v * p.scale[m] + p.shift[m];
-      if (p.act == ACT_RELU) v = fmaxf(v, 0.0f);
-      else if (p.act == ACT_TANH) v = tanhf(v);
-      else if (p.act == ACT_LOG_CLAMP) v = logf(fmaxf(v, 1e-5f));
-      if (p.mask) v = v * (float)p.mask[(size_t)b * p.mask_bs + (size_t)m * p.ldmask + n] * 2.0f;
-      if (p.res) v += p.res[(size_t)b * p.res_bs + (size_t)m * p.ldres + n];
-      if (p.gate_ts) {
-        const float T = p.gate_ts[(size_t)b * p.gate_bs + (size_t)m * p.ldgate + n];
-        const float S = p.gate_ts[(size_t)b * p.gate_bs + (size_t)(p.M + m) * p.ldgate + n];
-        p.C[(size_t)b * p.c_bs + (size_t)m * p.ldc + n] = v * S * (1.0f - T * T);
-        p.C[(size_t)b * p.c_bs + (size_t)(p.M + m) * p.ldc + n] = v * T * S * (1.0f - S);
-      } else if (p.c_transposed) p.C[(size_t)b * p.c_bs + (size_t)n * p.ldc + m] = v;
-      else p.C[(size_t)b * p.c_bs + (size_t)m * p.ldc + n] = v;
+      if (ka.sk > 1) p.splitk_ws[(((size_t)ks * p.B + b) * p.M + m) * p.N + n] = acc[cb][r];
+      else gemm_epilogue(p, b, m, n, acc[cb][r]);
     }
   }
+}
+
+// second pass of a split-K product: fixed-order sum of the partials, then the epilogue
+__global__ void k_gemm_reduce(KArgs ka) {
+  const GemmArgs& p = ka.g;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y, b = blockIdx.z;
+  const int Nb = p.n_valid ? min(p.N, p.n_valid[b] * p.n_valid_mul + p.n_valid_add) : p.N;
+  if (n >= Nb) return;
+  float v = 0.0f;
+  for (int ks = 0; ks < ka.sk; ++ks) v += p.splitk_ws[(((size_t)ks * p.B + b) * p.M + m) * p.N + n];
+  gemm_epilogue(p, b, m, n, v);
 }
 
 }  // namespace
@@ -148,8 +166,22 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
   KArgs ka;
   ka.g = a;
   ka.KG = gemm_kpad(a.Cin * a.taps) / 8;
+  ka.sk = 1;
   dim3 grid((a.N + TN - 1) / TN, (round_up(a.M, 32) / 32 + 3) / 4, a.B);
+  // Small-N products (one short utterance through the encoder / postnet) launch a few dozen workgroups with
+  // a long serial K loop each: split K over more workgroups when the caller lent a partial-sum buffer
+  const long wgs = (long)grid.x * grid.y * grid.z;
+  const int nch = ka.KG / 8;
+  if (a.splitk_ws && wgs < 128 && nch >= 8) {
+    long sk = (384 + wgs - 1) / wgs;
+    if (sk > nch / 4) sk = nch / 4;
+    const size_t per_split = (size_t)a.B * a.M * a.N * sizeof(float);
+    if ((size_t)sk * per_split > a.splitk_ws_bytes) sk = (long)(a.splitk_ws_bytes / per_split);
+    if (sk >= 2) ka.sk = (int)sk;
+  }
+  grid.z = a.B * ka.sk;
   k_gemm<<<grid, 256, 0, s>>>(ka);
+  if (ka.sk > 1) k_gemm_reduce<<<dim3((a.N + 255) / 256, a.M, a.B), 256, 0, s>>>(ka);
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
 }

@@ -942,7 +942,7 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
 
 // ------------------------------------------------------------------------------------------
 struct TWs {
-  size_t a0, a1, xproj, mem_cm, mask, xchg, total;
+  size_t a0, a1, xproj, mem_cm, mask, xchg, splitk, splitk_bytes, total;
 };
 TWs tws_layout(const facppg_taco_config& c, int B, int Tin) {
   TWs w;
@@ -955,6 +955,10 @@ TWs tws_layout(const facppg_taco_config& c, int B, int Tin) {
   w.mem_cm = take((size_t)B * c.encoder_embedding_dim * Tin * 4);
   w.mask = take((size_t)2 * B * c.symbols_embedding_dim * Tin);
   w.xchg = take((size_t)B * 2 * 2 * (c.encoder_embedding_dim / 2) * 8);   // k_bilstm_coop {value, tag} words
+  // split-K partial sums for the small-N encoder GEMMs (only short batches split; see gemm_launch)
+  w.splitk_bytes = (size_t)16 * B * 4 * c.encoder_embedding_dim * Tin * 4;
+  if (w.splitk_bytes > ((size_t)64 << 20)) w.splitk_bytes = (size_t)64 << 20;
+  w.splitk = take(w.splitk_bytes);
   w.total = off;
   return w;
 }
@@ -1204,6 +1208,7 @@ extern "C" int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const in
   }
   GemmArgs g;
   g.B = B; g.N = Tin; g.n_valid = lengths_dev;
+  g.splitk_ws = (float*)(ws + w.splitk); g.splitk_ws_bytes = w.splitk_bytes;
   // prenet: 2 x (Linear no bias, ReLU, dropout p=.5 always on)  model.py:124-135
   g.A = h->pre0; g.M = S; g.Cin = c.n_symbols; g.X = ppg_dev; g.x_bs = (long)c.n_symbols * Tin; g.ldx = Tin; g.act = ACT_RELU;
   g.mask = masks; g.mask_bs = (long)S * Tin; g.ldmask = Tin; g.C = a0; g.c_bs = (long)S * Tin; g.ldc = Tin;
@@ -1223,6 +1228,7 @@ extern "C" int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const in
   }
   // LSTM input projections for both directions, time-major out [B][Tin][8H]
   GemmArgs p;
+  p.splitk_ws = g.splitk_ws; p.splitk_ws_bytes = g.splitk_ws_bytes;
   p.B = B; p.N = Tin; p.n_valid = lengths_dev; p.A = h->wih; p.M = 8 * H; p.Cin = E; p.X = cur; p.x_bs = (long)E * Tin; p.ldx = Tin;
   p.bias = h->lstm_b; p.C = xproj; p.c_bs = (long)Tin * 8 * H; p.ldc = 8 * H; p.c_transposed = 1;
   if (int rc = gemm_launch(p, s)) return rc;
@@ -1245,6 +1251,7 @@ extern "C" int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const in
   }
   // processed_memory = memory_layer(memory), time-major [B][Tin][AD]
   GemmArgs m;
+  m.splitk_ws = g.splitk_ws; m.splitk_ws_bytes = g.splitk_ws_bytes;
   m.B = B; m.N = Tin; m.n_valid = lengths_dev; m.A = h->mem_w; m.M = c.attention_dim; m.Cin = E; m.X = mem_cm; m.x_bs = (long)E * Tin;
   m.ldx = Tin; m.C = pm_dev; m.c_bs = (long)Tin * c.attention_dim; m.ldc = Tin;   // [B][AD][Tin]: positions contiguous for the energy pass
   if (int rc = gemm_launch(m, s)) return rc;
@@ -1361,16 +1368,19 @@ extern "C" int facppg_taco_postnet(facppg_taco* h, const float* mel_dev, const i
   FACPPG_REQUIRE(B > 0 && T > 0 && ld >= T, FACPPG_EINVAL, "bad B/T/ld");
   const facppg_taco_config& c = h->c;
   const int PE = c.postnet_embedding_dim, NF = c.n_acoustic_feat_dims, n = c.postnet_n_convolutions;
-  const size_t need = (size_t)2 * B * PE * T * 4;
+  const size_t need = facppg_taco_postnet_workspace_bytes(h, B, T);
   FACPPG_REQUIRE(ws_bytes >= need, FACPPG_EWORKSPACE, "workspace has %zu bytes, need %zu", ws_bytes, need);
   hipStream_t s = (hipStream_t)stream_;
   float* buf[2] = {(float*)ws_, (float*)ws_ + (size_t)B * PE * T};
+  float* skws = (float*)ws_ + (size_t)2 * B * PE * T;
+  const size_t skws_bytes = need - (size_t)2 * B * PE * T * 4;
   const float* cur = mel_dev;
   long cur_bs = (long)NF * ld;
   int cur_ld = ld;
   for (int j = 0; j < n; ++j) {
     const int ci = j == 0 ? NF : PE, co = j == n - 1 ? NF : PE;
     GemmArgs g;
+    g.splitk_ws = skws; g.splitk_ws_bytes = skws_bytes;
     g.B = B; g.N = T; g.n_valid = out_lengths_dev; g.A = h->post[j]; g.M = co; g.Cin = ci; g.taps = c.postnet_kernel_size;
     g.pad = (c.postnet_kernel_size - 1) / 2; g.X = cur; g.x_bs = cur_bs; g.ldx = cur_ld; g.bias = h->post_b[j];
     g.scale = h->post_scale[j]; g.shift = h->post_shift[j];
@@ -1387,7 +1397,9 @@ extern "C" int facppg_taco_postnet(facppg_taco* h, const float* mel_dev, const i
 
 extern "C" size_t facppg_taco_postnet_workspace_bytes(const facppg_taco* h, int B, int T) {
   if (!h || B <= 0 || T <= 0) return 0;
-  return (size_t)2 * B * h->c.postnet_embedding_dim * T * 4;
+  size_t sk = (size_t)16 * B * h->c.postnet_embedding_dim * T * 4;   // split-K partial sums (short batches)
+  if (sk > ((size_t)64 << 20)) sk = (size_t)64 << 20;
+  return (size_t)2 * B * h->c.postnet_embedding_dim * T * 4 + sk;
 }
 
 extern "C" size_t facppg_taco_decode_workspace_bytes(const facppg_taco* h, int B, int max_steps) {
