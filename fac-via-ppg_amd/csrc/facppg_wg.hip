@@ -943,8 +943,7 @@ struct EdgeArgs {
 
 // This thread's position: natural index `pos` (into aud / z / the output audio) and the offsets of
 // that position inside a channel row of h and of skip.
-__device__ __forceinline__ bool edge_pos(const EdgeArgs& p, int b, int& pos, int& h_off, int& sk_off) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ bool edge_pos(const EdgeArgs& p, int b, int x, int& pos, int& h_off, int& sk_off) {
   const int Tb = p.t_valid ? p.t_valid[b] : p.T;
   if (p.P > 0) {
     const int ph = blockIdx.z;
@@ -958,9 +957,9 @@ __device__ __forceinline__ bool edge_pos(const EdgeArgs& p, int b, int& pos, int
 }
 
 template <int HN>
-__device__ __forceinline__ void start_conv(const EdgeArgs& p, int b, int h_off, const float* a0) {
+__device__ __forceinline__ void start_conv(const EdgeArgs& p, int b, int h_off, const float* a0, int ch0 = 0, int nch = C) {
   float* dst = p.h_out + (size_t)b * C * p.Lp + h_off;
-  for (int ch = 0; ch < C; ++ch) {
+  for (int ch = ch0; ch < ch0 + nch; ++ch) {
     float v = p.start_b[ch];
 #pragma unroll
     for (int j = 0; j < HN; ++j) v = fmaf(p.start_w[ch * HN + j], a0[j], v);
@@ -972,7 +971,7 @@ template <int HN>
 __global__ __launch_bounds__(256) void k_begin(EdgeArgs p) {
   const int b = blockIdx.y;
   int pos, h_off, sk_off;
-  if (!edge_pos(p, b, pos, h_off, sk_off)) return;
+  if (!edge_pos(p, b, blockIdx.x * blockDim.x + threadIdx.x, pos, h_off, sk_off)) return;
   float a[2 * HN];
 #pragma unroll
   for (int j = 0; j < 2 * HN; ++j) {
@@ -989,25 +988,35 @@ __global__ __launch_bounds__(256) void k_begin(EdgeArgs p) {
 // ------------------------------------------------------------------------------------------
 template <int H, bool EARLY>
 __global__ __launch_bounds__(256) void k_flow_end(EdgeArgs p) {
-  const int b = blockIdx.y;
-  int pos, h_off, sk_off;
-  if (!edge_pos(p, b, pos, h_off, sk_off)) return;
+  // 64 positions per workgroup; the four waves split the 256 skip channels of the end conv (and later the
+  // 256 output channels of the next start conv), so a launch with few positions still spreads over the chip
+  // and each thread's chain of L2 round trips is a quarter as long.  Partial sums meet in LDS, fixed order.
   constexpr int CC = 2 * H;
+  __shared__ float red[4][CC][64];
+  const int b = blockIdx.y, pl = threadIdx.x & 63, qtr = threadIdx.x >> 6;
+  int pos = 0, h_off = 0, sk_off = 0;
+  const bool valid = edge_pos(p, b, blockIdx.x * 64 + pl, pos, h_off, sk_off);
   float o[CC];
 #pragma unroll
-  for (int j = 0; j < CC; ++j) o[j] = p.end_b[j];
-  const float* sk = p.skip + (size_t)b * C * p.Lr + sk_off;
-  // 16 skip rows in flight per thread: with few positions (one short utterance) this loop is a chain of
-  // L2 round trips, not a bandwidth stream
-  for (int c0 = 0; c0 < C; c0 += 16) {
-    float v[16];
+  for (int j = 0; j < CC; ++j) o[j] = 0.0f;
+  if (valid) {
+    const float* sk = p.skip + (size_t)b * C * p.Lr + sk_off;
+    for (int c0 = qtr * 64; c0 < qtr * 64 + 64; c0 += 16) {
+      float v[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = sk[(size_t)(c0 + u) * p.Lr];
+      for (int u = 0; u < 16; ++u) v[u] = sk[(size_t)(c0 + u) * p.Lr];
 #pragma unroll
-    for (int u = 0; u < 16; ++u)
+      for (int u = 0; u < 16; ++u)
 #pragma unroll
-      for (int j = 0; j < CC; ++j) o[j] = fmaf(p.end_w[j * C + c0 + u], v[u], o[j]);
+        for (int j = 0; j < CC; ++j) o[j] = fmaf(p.end_w[j * C + c0 + u], v[u], o[j]);
+    }
   }
+#pragma unroll
+  for (int j = 0; j < CC; ++j) red[qtr][j][pl] = o[j];
+  __syncthreads();
+  if (!valid) return;
+#pragma unroll
+  for (int j = 0; j < CC; ++j) o[j] = p.end_b[j] + red[0][j][pl] + red[1][j][pl] + red[2][j][pl] + red[3][j][pl];
   float a[CC];
 #pragma unroll
   for (int j = 0; j < CC; ++j) a[j] = p.aud_in[((size_t)b * 8 + j) * p.La + pos];
@@ -1031,13 +1040,17 @@ __global__ __launch_bounds__(256) void k_flow_end(EdgeArgs p) {
   }
   if (p.final_flow) {
     // glow.py:292: [B, 8, L] -> permute -> [B, 8L]: sample n = 8*pos + channel
-    float* dst = p.final_audio + (size_t)b * p.T * p.hop8 * 8 + (size_t)pos * CN;
+    if (qtr == 0) {
+      float* dst = p.final_audio + (size_t)b * p.T * p.hop8 * 8 + (size_t)pos * CN;
 #pragma unroll
-    for (int j = 0; j < CN; ++j) dst[j] = y[j];
+      for (int j = 0; j < CN; ++j) dst[j] = y[j];
+    }
   } else {
+    if (qtr == 0) {
 #pragma unroll
-    for (int j = 0; j < CN; ++j) p.aud_out[((size_t)b * 8 + j) * p.La + pos] = y[j];
-    start_conv<CN / 2>(p, b, h_off, y + (p.swap_next ? CN / 2 : 0));
+      for (int j = 0; j < CN; ++j) p.aud_out[((size_t)b * 8 + j) * p.La + pos] = y[j];
+    }
+    start_conv<CN / 2>(p, b, h_off, y + (p.swap_next ? CN / 2 : 0), qtr * 64, 64);
   }
 }
 
@@ -1463,6 +1476,7 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   e.La = w.La; e.P = w.P; e.Tr = w.Tr; e.Tqp = w.Tqp;
   e.final_audio = audio_dev;
   const dim3 egrid((T + 255) / 256, B, w.P);
+  const dim3 fgrid((T + 63) / 64, B, w.P);   // k_flow_end: 64 positions per workgroup
   int ai = 0, hi = 0;
   {
     const int k = nf - 1;
@@ -1542,10 +1556,10 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
     if (k > 0) FACPPG_REQUIRE(cn == 2 * h->n_half[k - 1], FACPPG_EUNSUPPORTED, "flow %d channel mismatch", k);
     else FACPPG_REQUIRE(cn == 8, FACPPG_EUNSUPPORTED, "final flow must yield n_group channels");
     switch (h->n_half[k]) {
-      case 1: launch_flow_end<1>(h->early[k], egrid, s, e); break;
-      case 2: launch_flow_end<2>(h->early[k], egrid, s, e); break;
-      case 3: launch_flow_end<3>(h->early[k], egrid, s, e); break;
-      case 4: launch_flow_end<4>(h->early[k], egrid, s, e); break;
+      case 1: launch_flow_end<1>(h->early[k], fgrid, s, e); break;
+      case 2: launch_flow_end<2>(h->early[k], fgrid, s, e); break;
+      case 3: launch_flow_end<3>(h->early[k], fgrid, s, e); break;
+      case 4: launch_flow_end<4>(h->early[k], fgrid, s, e); break;
       default: FACPPG_REQUIRE(false, FACPPG_EUNSUPPORTED, "n_half %d", h->n_half[k]);
     }
     ai ^= 1;
@@ -1607,6 +1621,7 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
   e.La = w.Lr;
   e.final_audio = audio_dev;
   const dim3 egrid((w.L + 255) / 256, B);
+  const dim3 fgrid((w.L + 63) / 64, B);
   int ai = 0, hi = 0;  // current audio / h buffer
   {
     const int k = nf - 1;
@@ -1666,10 +1681,10 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
     if (k > 0) FACPPG_REQUIRE(cn == 2 * h->n_half[k - 1], FACPPG_EUNSUPPORTED, "flow %d channel mismatch", k);
     else FACPPG_REQUIRE(cn == 8, FACPPG_EUNSUPPORTED, "final flow must yield n_group channels");
     switch (h->n_half[k]) {
-      case 1: launch_flow_end<1>(h->early[k], egrid, s, e); break;
-      case 2: launch_flow_end<2>(h->early[k], egrid, s, e); break;
-      case 3: launch_flow_end<3>(h->early[k], egrid, s, e); break;
-      case 4: launch_flow_end<4>(h->early[k], egrid, s, e); break;
+      case 1: launch_flow_end<1>(h->early[k], fgrid, s, e); break;
+      case 2: launch_flow_end<2>(h->early[k], fgrid, s, e); break;
+      case 3: launch_flow_end<3>(h->early[k], fgrid, s, e); break;
+      case 4: launch_flow_end<4>(h->early[k], fgrid, s, e); break;
       default: FACPPG_REQUIRE(false, FACPPG_EUNSUPPORTED, "n_half %d", h->n_half[k]);
     }
     ai ^= 1;
