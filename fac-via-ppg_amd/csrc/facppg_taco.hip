@@ -8,15 +8,17 @@
 // Layout: activations are channel-major [B][C][T] (time contiguous), so every Linear/Conv1d of
 // the encoder and postnet is one exact-fp32 MFMA tapped GEMM (facppg_gemm) with the bias, eval
 // BatchNorm (as per-row scale/shift), ReLU/tanh, dropout mask and residual fused in its epilogue.
-// The two sequential parts run as persistent workgroups, one per (utterance[, direction]):
-//   k_bilstm   the encoder BiLSTM recurrence (input projections were one GEMM for all t)
-//   k_decoder  the whole autoregressive loop: no host round trip per frame (the reference syncs the
-//              host at least twice per frame: the stop test model.py:524 and the Python mask builder),
-//              the stop decision is taken on the device and the attention is evaluated only on
-//              the +-window positions the reference's mask keeps (<= 2W+1 of Tin).
+// The two sequential parts run as persistent kernels with a device-side loop (the reference syncs the
+// host at least twice per frame: the stop test model.py:524 and the Python mask builder); the stop
+// decision is taken on the device and the attention is evaluated only on the +-window positions the
+// reference's mask keeps (<= 2W+1 of Tin).  Each has a throughput shape and latency shapes:
+//   k_bilstm / k_bilstm_coop                       encoder BiLSTM recurrence (input projections were one GEMM)
+//   k_decoder / k_decoder_coop / k_decoder_split   the autoregressive decoder loop
+// The latency shapes spread one utterance over many co-resident workgroups (cooperative launch) that
+// exchange hidden state through 8-byte {value, tag} words; _split and _bilstm_coop keep their weight
+// slices in registers for the whole sequence.
 // Recurrent weights are stored K-major ([k][rows], rows padded to 4) so a thread streams float4
 // columns with fully coalesced 16-byte loads; a 1200x1200 step is 900 threads x 400 loads.
-#include <hip/hip_cooperative_groups.h>
 
 #include <cstdlib>
 #include <cstring>
@@ -273,7 +275,6 @@ struct DecArgs {
   unsigned long long* xchg;   // [B][2][A] {value, frame tag} hidden-state exchange words (coop mode)
   const float *att_w4, *dec_w4;   // [NWK][K][16] slices of 4 units (split mode workers)
   unsigned long long* xsplit;     // [B][NF + 1 + 2P + A + E + D + 8] exchange words of the split decoder
-  int* fin;              // [B] per-utterance barrier counters (coop mode)
   long long* prof;       // optional [8] phase cycle counters (debug; FACPPG_DECODER_PROF=1)
   const float* memory;   // [B][Tin][E]
   const float* pm;       // [B][AD][Tin]
@@ -1260,14 +1261,13 @@ extern "C" int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const in
 }
 
 namespace {
-struct DecWs { size_t mask, xchg, fin, prof, xsplit, total; };
+struct DecWs { size_t mask, xchg, prof, xsplit, total; };
 DecWs dec_ws(const facppg_taco_config& c, int B, int max_steps) {
   DecWs w;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   w.mask = take((size_t)max_steps * 2 * B * c.prenet_dim);
   w.xchg = take((size_t)B * 2 * c.attention_rnn_dim * 8);
-  w.fin = take((size_t)B * 4);
   w.prof = take(16 * 8);
   w.xsplit = take((size_t)B * (c.n_acoustic_feat_dims + 1 + 2 * c.prenet_dim + c.attention_rnn_dim + c.encoder_embedding_dim + c.decoder_rnn_dim + 8) * 8);
   w.total = off;
@@ -1297,7 +1297,7 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
   DecArgs a;
   a.dp0_t = h->dp0_t; a.dp1_t = h->dp1_t; a.att_t = h->att_t; a.att_b = h->att_b; a.dec_t = h->dec_t; a.dec_b = h->dec_b;
   a.q_t = h->q_t; a.proj_t = h->proj_t; a.proj_b = h->proj_b; a.loc_conv = h->loc_conv; a.loc_dense = h->loc_dense; a.v = h->v;
-  a.xchg = (unsigned long long*)(ws + w.xchg); a.fin = (int*)(ws + w.fin);
+  a.xchg = (unsigned long long*)(ws + w.xchg);
   a.prof = getenv("FACPPG_DECODER_PROF") ? (long long*)(ws + w.prof) : nullptr;
   a.memory = memory_dev; a.pm = pm_dev; a.lengths = lengths_dev; a.masks = masks; a.mel = mel_dev; a.gate = gate_dev;
   a.align = align_dev; a.out_len = out_lengths_dev;
