@@ -1860,6 +1860,7 @@ __global__ void k_wn_start_bwd(const float* __restrict__ dh0, const float* __res
 struct WnTrainWs {
   size_t w1[8], b1[8], w2[8], total;                     // forward operands
   size_t rs_a[8], rs_b[8], in_t[8], cond_t[8], tmp;      // backward operands ([K][M] transposes) + dacts temp
+  size_t splitk, splitk_bytes;                            // split-K partial sums of the small-N backward GEMMs
 };
 WnTrainWs wn_train_ws(int n_layers, int B, int Lr) {
   WnTrainWs w;
@@ -1875,6 +1876,9 @@ WnTrainWs wn_train_ws(int n_layers, int B, int Lr) {
     w.cond_t[i] = take(packed_a_float4s(NCOND, 2 * C) * 16);
   }
   w.tmp = take((size_t)B * C * Lr * 4);
+  w.splitk_bytes = (size_t)8 * B * C * Lr * 4;
+  if (w.splitk_bytes > ((size_t)48 << 20)) w.splitk_bytes = (size_t)48 << 20;
+  w.splitk = take(w.splitk_bytes);
   w.total = off;
   return w;
 }
@@ -1994,6 +1998,7 @@ extern "C" int facppg_wn_backward_data(const facppg_wn_weights* wts, int n_in, i
     float* dh = dh_all_dev + dh_sz * i;
     GemmArgs g;
     g.B = B; g.N = L; g.M = C; g.Cin = C; g.ldx = Lr; g.x_bs = (long)C * Lr;
+    g.splitk_ws = (float*)(ws + w.splitk); g.splitk_ws_bytes = w.splitk_bytes;
     const float* res = nullptr;
     if (!last) {   // tmp = Wrs_res^T dh_{i+1}
       g.A = (const float4*)(ws + w.rs_a[i]); g.X = dh_next; g.C = tmp; g.c_bs = (long)C * Lr; g.ldc = Lr;
@@ -2007,6 +2012,7 @@ extern "C" int facppg_wn_backward_data(const facppg_wn_weights* wts, int n_in, i
     if (int rc = gemm_launch(g, s)) return rc;
     // dh_i = dh_{i+1} + Win^T (*) dpre_i   (taps reversed, same dilation)
     GemmArgs t;
+    t.splitk_ws = g.splitk_ws; t.splitk_ws_bytes = g.splitk_ws_bytes;
     t.B = B; t.N = L; t.M = C; t.Cin = 2 * C; t.taps = 3; t.pad = 1; t.dil = 1 << i; t.A = (const float4*)(ws + w.in_t[i]);
     t.X = dpre; t.x_bs = (long)2 * C * Lr; t.ldx = Lr; t.res = last ? nullptr : dh_next; t.res_bs = (long)C * Lr; t.ldres = Lr;
     t.C = dh; t.c_bs = (long)C * Lr; t.ldc = Lr;
