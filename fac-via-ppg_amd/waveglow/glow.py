@@ -119,7 +119,9 @@ class _WNFunction(torch.autograd.Function):
                                                  _lib.ptr(work), work.numel(), _lib.current_stream(dev)))
 
         def outer(a, b):                      # sum over batch and positions of a[:, m, n] * b[:, k, n]
-            return torch.einsum('bmn,bkn->mk', a, b)
+            # batched NT product on the strided views, then a B-term sum: einsum would first copy both
+            # operands into [M, B*N] / [K, B*N] matrices (a tenth of the step in elementwise kernels)
+            return torch.bmm(a, b.transpose(1, 2)).sum(0)
 
         sp = spect_pad[:, :, :Lg]
         grads = [outer(dh_all[0][:, :, :Lg], a0).unsqueeze(-1), dh_all[0][:, :, :Lg].sum((0, 2))]
