@@ -1799,62 +1799,101 @@ extern "C" int facppg_wg_forward(facppg_wg* h, const float* mel_dev, const float
 namespace {
 using namespace facppg;
 
-__global__ void k_wn_start(const float* __restrict__ a0, const float* __restrict__ w, const float* __restrict__ bias,
-                           float* __restrict__ h0, int nh, int L, int Lp) {
-  const int pos = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+// The four 1x1 edge convs of a training WN stack.  256 threads = 64 positions x 4 channel quarters (wave q
+// owns channels 64q..64q+63), so a 10 000-sample segment still spreads over ~60 workgroups per batch item
+// and no thread walks all 256 channels; reductions over channels meet in LDS in a fixed order.
+__global__ __launch_bounds__(256) void k_wn_start(const float* __restrict__ a0, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, float* __restrict__ h0, int nh, int L, int Lp) {
+  const int pos = blockIdx.x * 64 + (threadIdx.x & 63), qtr = threadIdx.x >> 6, b = blockIdx.y;
   if (pos >= L) return;
   float a[8];
-  for (int j = 0; j < nh; ++j) a[j] = a0[((size_t)b * nh + j) * L + pos];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = j < nh ? a0[((size_t)b * nh + j) * L + pos] : 0.0f;
   float* dst = h0 + (size_t)b * C * Lp + HALO + pos;
-  for (int ch = 0; ch < C; ++ch) {
+  for (int ch = qtr * 64; ch < qtr * 64 + 64; ++ch) {
     float v = bias[ch];
-    for (int j = 0; j < nh; ++j) v = fmaf(w[ch * nh + j], a[j], v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < nh) v = fmaf(w[ch * nh + j], a[j], v);
     dst[(size_t)ch * Lp] = v;
   }
 }
 
-__global__ void k_wn_end(const float* __restrict__ skip, const float* __restrict__ w, const float* __restrict__ bias,
-                         float* __restrict__ out, int nout, int L, int Lr) {
-  const int pos = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-  if (pos >= L) return;
+__global__ __launch_bounds__(256) void k_wn_end(const float* __restrict__ skip, const float* __restrict__ w,
+                                                const float* __restrict__ bias, float* __restrict__ out, int nout, int L, int Lr) {
+  __shared__ float red[4][8][64];
+  const int pl = threadIdx.x & 63, pos = blockIdx.x * 64 + pl, qtr = threadIdx.x >> 6, b = blockIdx.y;
+  const bool valid = pos < L;
   float o[8];
-  for (int j = 0; j < nout; ++j) o[j] = bias[j];
-  const float* sk = skip + (size_t)b * C * Lr + pos;
-  for (int ch = 0; ch < C; ++ch) {
-    const float v = sk[(size_t)ch * Lr];
-    for (int j = 0; j < nout; ++j) o[j] = fmaf(w[j * C + ch], v, o[j]);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = 0.0f;
+  if (valid) {
+    const float* sk = skip + (size_t)b * C * Lr + pos;
+    for (int c0 = qtr * 64; c0 < qtr * 64 + 64; c0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = sk[(size_t)(c0 + u) * Lr];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < nout) o[j] = fmaf(w[j * C + c0 + u], v[u], o[j]);
+    }
   }
-  for (int j = 0; j < nout; ++j) out[((size_t)b * nout + j) * L + pos] = o[j];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[qtr][j][pl] = o[j];
+  __syncthreads();
+  if (!valid) return;
+  for (int j = qtr; j < nout; j += 4)   // outputs dealt to the four waves
+    out[((size_t)b * nout + j) * L + pos] = bias[j] + red[0][j][pl] + red[1][j][pl] + red[2][j][pl] + red[3][j][pl];
 }
 
 // dskip[b][ch][pos] = sum_j Wend[j][ch] * dout[b][j][pos]
-__global__ void k_wn_end_bwd(const float* __restrict__ dout, const float* __restrict__ w, float* __restrict__ dskip, int nout,
-                             int L, int Lr) {
-  const int pos = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+__global__ __launch_bounds__(256) void k_wn_end_bwd(const float* __restrict__ dout, const float* __restrict__ w,
+                                                    float* __restrict__ dskip, int nout, int L, int Lr) {
+  const int pos = blockIdx.x * 64 + (threadIdx.x & 63), qtr = threadIdx.x >> 6, b = blockIdx.y;
   if (pos >= L) return;
   float d[8];
-  for (int j = 0; j < nout; ++j) d[j] = dout[((size_t)b * nout + j) * L + pos];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) d[j] = j < nout ? dout[((size_t)b * nout + j) * L + pos] : 0.0f;
   float* dst = dskip + (size_t)b * C * Lr + pos;
-  for (int ch = 0; ch < C; ++ch) {
+  for (int ch = qtr * 64; ch < qtr * 64 + 64; ++ch) {
     float v = 0.0f;
-    for (int j = 0; j < nout; ++j) v = fmaf(w[j * C + ch], d[j], v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < nout) v = fmaf(w[j * C + ch], d[j], v);
     dst[(size_t)ch * Lr] = v;
   }
 }
 
 // da0[b][j][pos] = sum_ch Wstart[ch][j] * dh0[b][ch][pos]
-__global__ void k_wn_start_bwd(const float* __restrict__ dh0, const float* __restrict__ w, float* __restrict__ da0, int nh, int L,
-                               int Lr) {
-  const int pos = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-  if (pos >= L) return;
+__global__ __launch_bounds__(256) void k_wn_start_bwd(const float* __restrict__ dh0, const float* __restrict__ w,
+                                                      float* __restrict__ da0, int nh, int L, int Lr) {
+  __shared__ float red[4][8][64];
+  const int pl = threadIdx.x & 63, pos = blockIdx.x * 64 + pl, qtr = threadIdx.x >> 6, b = blockIdx.y;
+  const bool valid = pos < L;
   float d[8];
-  for (int j = 0; j < nh; ++j) d[j] = 0.0f;
-  const float* src = dh0 + (size_t)b * C * Lr + pos;
-  for (int ch = 0; ch < C; ++ch) {
-    const float v = src[(size_t)ch * Lr];
-    for (int j = 0; j < nh; ++j) d[j] = fmaf(w[ch * nh + j], v, d[j]);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) d[j] = 0.0f;
+  if (valid) {
+    const float* src = dh0 + (size_t)b * C * Lr + pos;
+    for (int c0 = qtr * 64; c0 < qtr * 64 + 64; c0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(c0 + u) * Lr];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < nh) d[j] = fmaf(w[(c0 + u) * nh + j], v[u], d[j]);
+    }
   }
-  for (int j = 0; j < nh; ++j) da0[((size_t)b * nh + j) * L + pos] = d[j];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[qtr][j][pl] = d[j];
+  __syncthreads();
+  if (!valid) return;
+  for (int j = qtr; j < nh; j += 4)
+    da0[((size_t)b * nh + j) * L + pos] = red[0][j][pl] + red[1][j][pl] + red[2][j][pl] + red[3][j][pl];
 }
 
 struct WnTrainWs {
@@ -1929,7 +1968,7 @@ extern "C" int facppg_wn_forward_save(const facppg_wn_weights* wts, int n_in, in
     k_pack_w2<<<(n2 + 255) / 256, 256, 0, s>>>(wts->rs_w[i], (float4*)(ws + w.w2[i]), last);
     k_add_bias<<<2, 256, 0, s>>>(wts->in_b[i], wts->cond_b[i], (float*)(ws + w.b1[i]), 2 * C);
   }
-  const dim3 egrid((L + 255) / 256, B);
+  const dim3 egrid((L + 63) / 64, B);   // 64 positions x 4 channel quarters per workgroup
   k_wn_start<<<egrid, 256, 0, s>>>(a0_dev, wts->start_w, wts->start_b, h_all_dev, n_in, L, Lp);
   const bool narrow = (long)(Lr / TN) * B < 768;   // small batches: 32-wide tiles halve the per-layer latency
   const dim3 lgrid(narrow ? Lr / 32 : Lr / TN, B);
@@ -1987,7 +2026,7 @@ extern "C" int facppg_wn_backward_data(const facppg_wn_weights* wts, int n_in, i
     // Wcond_i [512][640] -> A[m = cond channel][c = cout]
     if (int rc = pack_a_strided(wts->cond_w[i], NCOND, 2 * C, 1, 1, NCOND, 0, 0, (float4*)(ws + w.cond_t[i]), s)) return rc;
   }
-  const dim3 egrid((L + 255) / 256, B);
+  const dim3 egrid((L + 63) / 64, B);
   FACPPG_HIP_CHECK(hipMemsetAsync(dskip_dev, 0, dh_sz * 4, s));
   FACPPG_HIP_CHECK(hipMemsetAsync(dh_all_dev, 0, dh_sz * (n_layers + 1) * 4, s));
   k_wn_end_bwd<<<egrid, 256, 0, s>>>(dout_dev, wts->end_w, dskip_dev, 2 * n_in, L, Lr);
