@@ -190,6 +190,20 @@ __global__ __launch_bounds__(NT) void k_bilstm(const float* __restrict__ xproj, 
 // step s+2 may overwrite step s only after its owner gathered all of step s+1, and every reader
 // published its step-s+1 word after consuming step s.  Fixed-order reductions: bit-identical to the
 // one-workgroup kernel's sums up to fp32 re-association of the K split.
+// Poll an exchange word until its tag shows up.  The producers are co-resident by construction
+// (cooperative launch), so the wait is a few microseconds; the bound (~seconds) only turns a lost
+// producer -- a logic error or a device that did not honour co-residency -- into a trapped kernel
+// instead of a hung GPU.
+__device__ __forceinline__ unsigned long long poll_tag(const unsigned long long* w, unsigned tag) {
+  unsigned long long v;
+  unsigned spins = 0;
+  do {
+    v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (++spins == 0x400000u) __builtin_trap();   // ~4 M round trips = several seconds
+  } while ((unsigned)(v >> 32) != tag);
+  return v;
+}
+
 constexpr int BU = 32;        // hidden units per workgroup
 constexpr int BKP = NTC / (4 * BU);   // K parts per gate row (4)
 constexpr int BKR = 96;       // max columns per part held in registers (H <= 384)
@@ -247,11 +261,7 @@ __global__ __launch_bounds__(NTC) void k_bilstm_coop(const float* __restrict__ x
     if (s + 1 < len) {
       const unsigned long long* src = xb + (size_t)((s + 1) & 1) * H;
       for (int i = tid; i < H; i += NTC) {
-        unsigned long long v;
-        do {
-          v = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } while ((unsigned)(v >> 32) != (unsigned)(s + 1));
-        hv[i] = __uint_as_float((unsigned)v);
+        hv[i] = __uint_as_float((unsigned)poll_tag(src + i, (unsigned)(s + 1)));
       }
     }
     __syncthreads();
@@ -677,11 +687,7 @@ __device__ __forceinline__ void coop_lstm_slice(const float* __restrict__ Wslice
 template <int NT>
 __device__ __forceinline__ void coop_gather(const unsigned long long* xchg, unsigned tag, int n, float* dst0, float* dst1, int tid) {
   for (int i = tid; i < n; i += NT) {
-    unsigned long long v;
-    do {
-      v = __hip_atomic_load(xchg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } while ((unsigned)(v >> 32) != tag);
-    const float h = __uint_as_float((unsigned)v);
+    const float h = __uint_as_float((unsigned)poll_tag(xchg + i, tag));
     dst0[i] = h; dst1[i] = h;
   }
   __syncthreads();
@@ -768,11 +774,7 @@ __device__ __forceinline__ void xpub(unsigned long long* w, float v, unsigned ta
   __hip_atomic_store(w, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float xwait(const unsigned long long* w, unsigned tag) {
-  unsigned long long v;
-  do {
-    v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } while ((unsigned)(v >> 32) != tag);
-  return __uint_as_float((unsigned)v);
+  return __uint_as_float((unsigned)poll_tag(w, tag));
 }
 
 // thread (row r = tid % 16, K part kp = tid / 16) keeps columns kp*KR .. kp*KR+KR-1 of row `row0 + r` of a
