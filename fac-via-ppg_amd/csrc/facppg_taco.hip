@@ -42,9 +42,9 @@ struct facppg_taco {
   float *dp0_t, *dp1_t, *att_t, *att_b, *dec_t, *dec_b, *q_t, *proj_t, *proj_b;
   float *loc_conv, *loc_dense, *v;
   // per-workgroup LSTM slices [NWG][K][4U] for k_decoder_coop, packed for three slice widths:
-  // U = 8 (38 workgroups/utterance, B <= 6), 20 (15, B <= 16), 40 (8, B <= 30)
-  float *att_coop[3], *dec_coop[3];
-  int coop_U[3], coop_nwg[3];
+  // U = 8 (38 workgroups/utterance, B <= 6), 20 (15, B <= 16), 40 (8, B <= 30), 75 (4, B <= 60), 150 (2, B <= 120)
+  float *att_coop[5], *dec_coop[5];
+  int coop_U[5], coop_nwg[5];
   float *att_w4, *dec_w4;          // 4-unit slices for k_decoder_split's workers
   int split_nwk;
   // postnet
@@ -663,13 +663,13 @@ __device__ __forceinline__ void coop_lstm_slice(const float* __restrict__ Wslice
   const int SC = 4 * U, KS = pick_ks<NT>(SC, K);
   matvec_part<(NT <= 512 ? 16 : 4)>(Wslice, K, SC, KS, in, part, tid);
   __syncthreads();
-  if (tid < SC) {
-    const int u = unit0 + tid % U;
-    part[2 * NT + tid] = part_sum(part, SC, KS, tid) + (u < A ? bias[(tid / U) * A + u] : 0.0f);
+  for (int c = tid; c < SC; c += NT) {
+    const int u = unit0 + c % U;
+    part[4 * NT + c] = part_sum(part, SC, KS, c) + (u < A ? bias[(c / U) * A + u] : 0.0f);   // partials fill <= 4*NT floats
   }
   __syncthreads();
   if (tid < U && unit0 + tid < A) {
-    const float* gs = part + 2 * NT;
+    const float* gs = part + 4 * NT;
     const float h = lstm_point(gs[tid], gs[U + tid], gs[2 * U + tid], gs[3 * U + tid], &cstate[tid]);
     // publish {value, frame tag} as ONE 8-byte sc1 store: readers poll the word itself (coop_gather)
     __hip_atomic_store(xchg_out + unit0 + tid, ((unsigned long long)tag << 32) | __float_as_uint(h), __ATOMIC_RELAXED,
@@ -696,7 +696,7 @@ __device__ __forceinline__ void coop_gather(const unsigned long long* xchg, unsi
 __global__ __launch_bounds__(NTC) void k_decoder_coop(DecArgs p) {
   extern __shared__ float sm[];
   __shared__ int s_stop;
-  __shared__ float c_att[64], c_dec[64];   // U <= 64 units per workgroup
+  __shared__ float c_att[160], c_dec[160];   // U <= 160 units per workgroup
   const int wg = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const bool leader = wg == 0;
   const int len = p.lengths ? p.lengths[b] : p.Tin;
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(NTC) void k_decoder_coop(DecArgs p) {
   dec_carve(p, sm, L);
   dec_init<NTC>(p, L, sm, tid);
   if (tid == 0) s_stop = 0;
-  if (tid < 64) { c_att[tid] = 0.0f; c_dec[tid] = 0.0f; }
+  if (tid < 160) { c_att[tid] = 0.0f; c_dec[tid] = 0.0f; }
   __syncthreads();
   const float* mem = p.memory + (size_t)b * p.Tin * p.E;
   const float* pm = p.pm + (size_t)b * p.Tin * p.AD;
@@ -1038,7 +1038,7 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   struct { size_t pre0, pre1, conv[8], conv_b[8], conv_sc[8], conv_sh[8], wih, whh[2], lstm_b, mem_w, dp0, dp1, att, att_b, dec, dec_b, q,
-           proj, proj_b, lc, ld, v, attc[3], decc[3], att4, dec4, post[8], post_b[8], post_sc[8], post_sh[8]; } o;
+           proj, proj_b, lc, ld, v, attc[5], decc[5], att4, dec4, post[8], post_b[8], post_sc[8], post_sh[8]; } o;
   o.pre0 = take(packed_a_float4s(S, c.n_symbols) * 16);
   o.pre1 = take(packed_a_float4s(S, S) * 16);
   for (int j = 0; j < c.encoder_n_convolutions; ++j) {
@@ -1054,8 +1054,8 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
   o.dec = take((size_t)(A + E + D) * G * 4); o.dec_b = take((size_t)G * 4);
   o.q = take((size_t)A * ADp * 4);
   o.proj = take((size_t)(D + E) * NFp * 4); o.proj_b = take((size_t)NFp * 4);
-  const int CUs[3] = {8, 20, 40};
-  for (int v = 0; v < 3; ++v) {
+  const int CUs[5] = {8, 20, 40, 75, 150};
+  for (int v = 0; v < 5; ++v) {
     const int nwg = (A + CUs[v] - 1) / CUs[v];
     o.attc[v] = take((size_t)nwg * (P + E + A) * 4 * CUs[v] * 4); o.decc[v] = take((size_t)nwg * (A + E + D) * 4 * CUs[v] * 4);
   }
@@ -1131,7 +1131,7 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
   tr(src, h->dec_t, G, A + E, G, 0); src += (size_t)G * (A + E);
   tr(src, h->dec_t, G, D, G, A + E); src += (size_t)G * D;
   k_add2<<<(G + 255) / 256, 256, 0, s>>>(src, src + G, h->dec_b, G); src += 2 * (size_t)G;
-  for (int v = 0; v < 3; ++v) {
+  for (int v = 0; v < 5; ++v) {
     const int U = CUs[v], nwg = (A + U - 1) / U;
     h->att_coop[v] = F(o.attc[v]); h->dec_coop[v] = F(o.decc[v]); h->coop_U[v] = U; h->coop_nwg[v] = nwg;
     const size_t na = (size_t)nwg * (P + E + A) * 4 * U, nd = (size_t)nwg * (A + E + D) * 4 * U;
@@ -1313,11 +1313,12 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
   // slice width: the narrowest (most workgroups per utterance) that keeps B * NWG co-resident (coop_limit)
   const char* mode = getenv("FACPPG_DECODER_MODE");
   int variant = -1;
-  for (int v = 0; v < 3 && variant < 0; ++v)
-    if ((long)B * h->coop_nwg[v] <= h->coop_limit) variant = v;
+  const char* force_u = getenv("FACPPG_DECODER_COOP_U");   // tests / tuning: a specific slice width
+  for (int v = 0; v < 5 && variant < 0; ++v)
+    if ((long)B * h->coop_nwg[v] <= h->coop_limit && (!force_u || atoi(force_u) == h->coop_U[v])) variant = v;
   bool coop = variant >= 0;
   if (mode && !strcmp(mode, "single")) coop = false;
-  if (mode && !strcmp(mode, "coop")) FACPPG_REQUIRE(coop, FACPPG_EUNSUPPORTED, "coop decoder needs B <= 30");
+  if (mode && !strcmp(mode, "coop")) FACPPG_REQUIRE(coop, FACPPG_EUNSUPPORTED, "coop decoder needs B <= 120");
   if (coop) {
     a.att_coop = h->att_coop[variant]; a.dec_coop = h->dec_coop[variant]; a.U = h->coop_U[variant];
   }

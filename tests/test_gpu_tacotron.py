@@ -17,12 +17,15 @@ def build(hp, sd):
     return m.eval()
 
 
-@pytest.mark.parametrize("mode", ["split", "coop", "single"])
+@pytest.mark.parametrize("mode", ["split", "coop", "coop20", "coop40", "coop75", "coop150", "single"])
 @pytest.mark.parametrize("tag", ["nostop", "stop", "mono40"])
 def test_inference_matches_reference_golden(tag, mode, monkeypatch):
     """All decoder launch shapes: 'split' (one attention workgroup + 75 register-resident dense-layer
-    workers per utterance, B <= 3), 'coop' (38 cooperating workgroups per utterance, B <= 30) and
+    workers per utterance, B <= 3), 'coop' (38 / 15 / 8 / 4 / 2 cooperating workgroups per utterance for B <= 6 / 16 / 30 / 60 / 120) and
     'single' (one workgroup per utterance, throughput mode)."""
+    if mode.startswith("coop") and len(mode) > 4:     # the wider LSTM slices used for larger batches
+        monkeypatch.setenv("FACPPG_DECODER_COOP_U", mode[4:])
+        mode = "coop"
     monkeypatch.setenv("FACPPG_DECODER_MODE", mode)
     d, hp, sd, ppg, em, dm = tacotron_case(tag)
     m = build(hp, sd)
