@@ -204,15 +204,15 @@ __device__ __forceinline__ unsigned long long poll_tag(const unsigned long long*
   return v;
 }
 
-constexpr int BU = 32;        // hidden units per workgroup
-constexpr int BKP = NTC / (4 * BU);   // K parts per gate row (4)
-constexpr int BKR = 96;       // max columns per part held in registers (H <= 384)
-
+// BU = hidden units per workgroup, BKR = max columns of a gate row held per thread (NTC / (4*BU) K parts):
+// <32, 96>: 10 workgroups per direction at H = 300 (H <= 384), B <= 12;  <64, 152>: 5 per direction (H <= 304), B <= 24.
+template <int BU, int BKR>
 __global__ __launch_bounds__(NTC) void k_bilstm_coop(const float* __restrict__ xproj, const float* __restrict__ whh_t0,
                                                      const float* __restrict__ whh_t1, const int* __restrict__ lengths, int Tin,
                                                      int H, unsigned long long* __restrict__ xchg /*[B][2][2][H]*/,
                                                      float* __restrict__ mem_tm, float* __restrict__ mem_cm) {
-  __shared__ float hv[4 * BKR];          // gathered hidden vector [H]
+  constexpr int BKP = NTC / (4 * BU);    // K parts per gate row
+  __shared__ float hv[BKP * BKR];        // gathered hidden vector [H]
   __shared__ float part[BKP][4 * BU];    // K-part partial sums per gate row
   __shared__ float gates[4 * BU];
   const int wg = blockIdx.x, dir = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(NTC) void k_bilstm_coop(const float* __restrict__ x
     const int k = kp * KR + i;
     w[i] = (i < KR && k < H && u < H) ? WT[(size_t)k * R + row] : 0.0f;
   }
-  for (int i = tid; i < 4 * BKR; i += NTC) hv[i] = 0.0f;
+  for (int i = tid; i < BKP * BKR; i += NTC) hv[i] = 0.0f;
   float c = 0.0f;
   unsigned long long* xb = xchg + (size_t)(b * 2 + dir) * 2 * H;
   __syncthreads();
@@ -1235,10 +1235,13 @@ extern "C" int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const in
   p.B = B; p.N = Tin; p.n_valid = lengths_dev; p.A = h->wih; p.M = 8 * H; p.Cin = E; p.X = cur; p.x_bs = (long)E * Tin; p.ldx = Tin;
   p.bias = h->lstm_b; p.C = xproj; p.c_bs = (long)Tin * 8 * H; p.ldc = 8 * H; p.c_transposed = 1;
   if (int rc = gemm_launch(p, s)) return rc;
-  const int bnwg = (H + BU - 1) / BU;
-  const char* bilstm_mode = getenv("FACPPG_BILSTM_MODE");   // "single" forces the one-workgroup kernel
-  if ((long)B * 2 * bnwg <= h->coop_limit && (H + BKP - 1) / BKP <= BKR && !(bilstm_mode && !strcmp(bilstm_mode, "single"))) {
-    // latency shape: W_hh register-resident, sliced over bnwg co-resident workgroups per (utterance, direction)
+  // latency shapes: W_hh register-resident, sliced over co-resident workgroups per (utterance, direction):
+  // 32 units per workgroup (4 K parts of <= 96 columns) while they fit, else 64 units (2 K parts of <= 152)
+  const char* bilstm_mode = getenv("FACPPG_BILSTM_MODE");   // "single" forces the one-workgroup kernel, "wide" the 64-unit slices
+  const bool no_coop = bilstm_mode && !strcmp(bilstm_mode, "single");
+  const bool fit32 = (long)B * 2 * ((H + 31) / 32) <= h->coop_limit && (H + 3) / 4 <= 96 && !(bilstm_mode && !strcmp(bilstm_mode, "wide"));
+  const bool fit64 = (long)B * 2 * ((H + 63) / 64) <= h->coop_limit && (H + 1) / 2 <= 152;
+  if (!no_coop && (fit32 || fit64)) {
     unsigned long long* xchg = (unsigned long long*)(ws + w.xchg);
     FACPPG_HIP_CHECK(hipMemsetAsync(xchg, 0, (size_t)B * 2 * 2 * H * 8, s));
     const float *w0 = h->whh_t[0], *w1 = h->whh_t[1];
@@ -1246,7 +1249,8 @@ extern "C" int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const in
     int Tin_ = Tin, H_ = H;
     void* args[] = {(void*)&xp, (void*)&w0, (void*)&w1, (void*)&lengths_dev, (void*)&Tin_, (void*)&H_, (void*)&xchg,
                     (void*)&memory_dev, (void*)&mem_cm};
-    FACPPG_HIP_CHECK(hipLaunchCooperativeKernel((const void*)k_bilstm_coop, dim3(bnwg, 2, B), dim3(NTC), args, 0, s));
+    if (fit32) FACPPG_HIP_CHECK(hipLaunchCooperativeKernel((const void*)k_bilstm_coop<32, 96>, dim3((H + 31) / 32, 2, B), dim3(NTC), args, 0, s));
+    else FACPPG_HIP_CHECK(hipLaunchCooperativeKernel((const void*)k_bilstm_coop<64, 152>, dim3((H + 63) / 64, 2, B), dim3(NTC), args, 0, s));
   } else {
     const int KS = NT / H < H ? NT / H : H;
     const size_t smem = (size_t)(2 * H + (KS > 0 ? KS : 1) * 4 * H) * 4;
