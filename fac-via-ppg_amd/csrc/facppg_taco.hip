@@ -191,16 +191,23 @@ __global__ __launch_bounds__(NT) void k_bilstm(const float* __restrict__ xproj, 
 // published its step-s+1 word after consuming step s.  Fixed-order reductions: bit-identical to the
 // one-workgroup kernel's sums up to fp32 re-association of the K split.
 // Poll an exchange word until its tag shows up.  The producers are co-resident by construction
-// (cooperative launch), so the wait is a few microseconds; the bound (~seconds) only turns a lost
-// producer -- a logic error or a device that did not honour co-residency -- into a trapped kernel
-// instead of a hung GPU.
+// (hipLaunchCooperativeKernel refuses a grid that is not), so the wait is a few microseconds.  Building
+// with -DFACPPG_POLL_BOUNDED turns a lost producer (a logic error) into a trapped kernel after ~4 M polls
+// instead of a hung GPU; it is not the default because the bound's control flow costs 8 % on the decoder.
 __device__ __forceinline__ unsigned long long poll_tag(const unsigned long long* w, unsigned tag) {
   unsigned long long v;
+#ifdef FACPPG_POLL_BOUNDED
   unsigned spins = 0;
+#pragma unroll 1
   do {
     v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (++spins == 0x400000u) __builtin_trap();   // ~4 M round trips = several seconds
+    if (++spins == 0x400000u) __builtin_trap();
   } while ((unsigned)(v >> 32) != tag);
+#else
+  do {
+    v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } while ((unsigned)(v >> 32) != tag);
+#endif
   return v;
 }
 
