@@ -215,3 +215,17 @@ def test_legacy_glow_old_layout_and_convert_model():
     a1 = WaveGlow.remove_weightnorm(conv).cuda().eval().infer(mel, sigma=0.6, z=zs)
     a2 = WaveGlow.remove_weightnorm(new).cuda().eval().infer(mel, sigma=0.6, z=zs)
     assert rms((a1 - a2).cpu().numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize("env", ["FACPPG_WG_UNFOLDED=1", "FACPPG_WN_8W=0", "FACPPG_WN_NO_XCD_MAP=1", "FACPPG_WN_NO_FLAT=1"])
+def test_alternate_kernel_paths_match_golden(env):
+    """The A/B switches select other kernels for the same call (the unfolded K=1408 layer the training
+    direction uses; 4-wave tiles for small launches; no XCD-aware phase mapping; per-utterance tiles).  They
+    are read once per process, so each runs the golden comparison in its own interpreter."""
+    import os, subprocess, sys
+    k, v = env.split("=")
+    e = dict(os.environ, **{k: v})
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "test_infer_matches_reference_golden or test_ragged_batch"], env=e, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
