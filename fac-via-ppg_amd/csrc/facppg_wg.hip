@@ -4,24 +4,30 @@
 // calls: WN.forward (:154-175), fused_add_tanh_sigmoid_multiply (:33-40),
 // Invertible1x1Conv reverse (:88-97), the upsample ConvTranspose1d + regroup (:253-259).
 //
-// Data layout in HBM (all fp32), per facppg_wg_infer call, inside the caller's workspace:
-//   L  = T*hop/8 group positions per utterance, Lr = round_up(L, 64), Lp = 128 + Lr + 128
-//   spect [B][640][Lr]   conditioning, channel = mel*8 + phase (glow.py:258-259)
-//   h0,h1 [B][256][Lp]   WN hidden state, ping-pong per layer; the 128-wide zero margins on
-//                        both sides ARE the dilated convolution's zero padding (dilation <= 128)
-//   skip  [B][256][Lr]   running sum of the skip outputs of a flow
-//   aud0,aud1 [B][8][Lr] the flow variable ("audio" in glow.py:272-290), ping-pong per flow
-// Positions are the contiguous axis, so a tile of 64 positions of one channel is one 256-byte
-// row: global loads are coalesced and the LDS image [k][64] is read conflict-free.
+// Two data layouts, both fp32 and channel-major with the time axis contiguous (a tile row of one
+// channel is one 256-byte segment: coalesced global loads, conflict-free LDS image [k][64]):
+//
+// * inference (facppg_wg_infer): PHASE-MAJOR.  P = hop/8 group positions per mel frame; position
+//   l = P*q + ph is stored at [ph][q], because the upsampler is folded into the conditioning convs and
+//   the folded weights differ per phase (see k_wn_layer<PM>):
+//     h0,h1 [B][256][P][16 + Tr + 16]  WN hidden state, ping-pong per layer; the zero margins of every
+//                                      phase row ARE the dilated convolution's zero padding
+//     skip  [B][256][P][Tr]            running sum of the skip outputs of a flow
+//     melp  [B][80][16 + Tr + 16]      zero-margined mel frames (the conditioning operand)
+//     aud0,aud1 [B][8][Lr]             the flow variable ("audio" in glow.py:272-290), natural order
+// * training direction (facppg_wg_forward, facppg_wn_*) and FACPPG_WG_UNFOLDED=1: POSITION-MAJOR.
+//   L = T*hop/8, Lr = round_up(L, 64), Lp = 128 + Lr + 128:
+//     spect [B][640][Lr], h0,h1 [B][256][Lp] (128-wide zero margins), skip [B][256][Lr], aud [B][8][Lr]
 //
 // Kernels (one launch each):
-//   k_upsample   mel -> spect                      (HBM-streaming + VALU)
+//   k_mel_pad / k_upsample   mel -> melp (inference) / mel -> spect (training direction)
 //   k_noise      Philox4x32-10 + Box-Muller -> z   (only when z is not injected)
 //   k_begin      sigma*z -> aud, start conv of the last flow -> h
-//   k_wn_layer   ONE fused WaveNet layer: dilated conv (3 taps) + 1x1 conditioning conv as a
-//                single [512 x 1408] x [1408 x 64] fp32 MFMA GEMM per tile, tanh*sigmoid gate,
-//                res/skip 1x1 conv as a second [512 x 256] x [256 x 64] MFMA GEMM, residual and
-//                skip updates in the epilogue.  This is >99 % of the FLOPs.
+//   k_wn_layer   ONE fused WaveNet layer: dilated conv (3 taps) + conditioning as a single
+//                [512 x 1088] x [1088 x 64] fp32 MFMA GEMM per tile (1408 unfolded), tanh*sigmoid gate,
+//                res/skip 1x1 conv as a second [512 x 256] x [256 x 64] MFMA GEMM, residual and skip
+//                updates in the epilogue.  >99 % of the FLOPs.  k_wn_layer8 is the
+//                8-wave, 32-frame shape for launches smaller than the chip.
 //   k_flow_end   end 1x1 conv, affine-coupling inverse, inverse 1x1 conv, early-z concat, then
 //                either the next flow's start conv or the final group->time interleave.
 #include <cmath>
