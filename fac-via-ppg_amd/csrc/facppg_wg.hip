@@ -1506,9 +1506,19 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
     }
   }
   h->ev_used = 0;
-  // 64-frame tiles for throughput; 32 when the launch would not fill the chip's 512 workgroup slots 1.5 times
+  // Tile width: 64 frames (4 waves, k_wn_layer) or 32 frames (8 waves, k_wn_layer8).  A launch runs in rounds
+  // of 512 workgroup slots (2 per CU); measured per-round times in microseconds for a full round / a round
+  // that leaves every CU at most one workgroup: 64-frame 331 / 185, 32-frame 181 / 94.  Pick the cheaper.
   static const char* force_narrow = getenv("FACPPG_WN_FORCE_NARROW");
-  const bool narrow = force_narrow ? atoi(force_narrow) != 0 : (long)(w.Tr / TN) * B * w.P < 768;
+  auto launch_cost = [](long tiles, int full, int half) {
+    const long rem = tiles % 512;
+    return (tiles / 512) * full + (rem == 0 ? 0 : rem <= 256 ? half : full);
+  };
+  const bool uniform = !T_valid_dev && T % 4 == 0;
+  const long cols = (long)B * T;
+  const long tiles_w = uniform ? (long)w.P * ((cols + 63) / 64) : (long)w.P * B * ((T + 63) / 64);
+  const long tiles_n = uniform ? (long)w.P * ((cols + 31) / 32) : (long)w.P * B * ((T + 31) / 32);
+  const bool narrow = force_narrow ? atoi(force_narrow) != 0 : launch_cost(tiles_n, 181, 94) < launch_cost(tiles_w, 331, 185);
   const int tn = narrow ? 32 : TN;
   WnArgs a;
   memset(&a, 0, sizeof(a));
