@@ -1,0 +1,89 @@
+/* Plain-C client of libfacppg_hip.so: proves include/facppg.h is a self-contained C header and that the
+ * library can be driven without Python or torch (device memory through the HIP runtime C API only).
+ * Runs WaveGlow.infer twice on random weights with the same seed and checks: error codes, determinism,
+ * finite output, and the EINVAL / EWORKSPACE paths.  Built and run by tests/test_gpu_abi_c.py. */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include "facppg.h"
+
+#define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
+#define CHECK_RC(x) do { int rc_ = (x); if (rc_ != 0) { fprintf(stderr, "%s -> %d: %s\n", #x, rc_, facppg_last_error()); return 3; } } while (0)
+
+int main(void) {
+  facppg_wg_config cfg;
+  memset(&cfg, 0, sizeof(cfg));
+  cfg.n_mel_channels = 80; cfg.hop_length = 256; cfg.n_flows = 4; cfg.n_group = 8; cfg.n_early_every = 2; cfg.n_early_size = 2;
+  cfg.wn_layers = 8; cfg.wn_channels = 256; cfg.wn_kernel_size = 3; cfg.upsample_kernel = 1024; cfg.alternate_halves = 0;
+  const size_t nw = facppg_wg_weight_count(&cfg);
+  if (nw == 0) { fprintf(stderr, "weight_count: %s\n", facppg_last_error()); return 1; }
+  float* hw = (float*)malloc(nw * sizeof(float));
+  unsigned s = 12345u;
+  for (size_t i = 0; i < nw; ++i) {   /* small random weights: keeps the flow well conditioned */
+    s = s * 1664525u + 1013904223u;
+    hw[i] = ((float)(s >> 8) / 16777216.0f - 0.5f) * 0.02f;
+  }
+  /* the blob ends each flow with W_inverse then W (include/facppg.h): make those identities */
+  {
+    size_t off = (size_t)80 * 80 * 1024 + 80;
+    int n_half = 4, n_rem = 8;
+    for (int k = 0; k < cfg.n_flows; ++k) {
+      if (k % cfg.n_early_every == 0 && k > 0) { n_half -= 1; n_rem -= 2; }
+      const size_t cc = 2 * (size_t)n_half;
+      off += (size_t)256 * n_half + 256;
+      for (int i = 0; i < cfg.wn_layers; ++i) {
+        const size_t rs = i < cfg.wn_layers - 1 ? 512 : 256;
+        off += (size_t)512 * 256 * 3 + 512 + (size_t)512 * 640 + 512 + rs * 256 + rs;
+      }
+      off += cc * 256 + cc;
+      for (int m = 0; m < 2; ++m, off += cc * cc)
+        for (size_t i = 0; i < cc; ++i)
+          for (size_t j = 0; j < cc; ++j) hw[off + i * cc + j] = i == j ? 1.0f : 0.0f;
+    }
+    (void)n_rem;
+    if (off != nw) { fprintf(stderr, "blob walk %zu != %zu\n", off, nw); return 1; }
+  }
+  float* dw = NULL;
+  CHECK_HIP(hipMalloc((void**)&dw, nw * sizeof(float)));
+  CHECK_HIP(hipMemcpy(dw, hw, nw * sizeof(float), hipMemcpyHostToDevice));
+  facppg_wg* h = NULL;
+  CHECK_RC(facppg_wg_create(&cfg, dw, nw, 0, NULL, &h));
+
+  const int B = 2, T = 24;
+  const size_t n_mel = (size_t)B * 80 * T, n_audio = (size_t)B * T * cfg.hop_length;
+  float* hmel = (float*)malloc(n_mel * sizeof(float));
+  for (size_t i = 0; i < n_mel; ++i) { s = s * 1664525u + 1013904223u; hmel[i] = -5.0f + 2.0f * ((float)(s >> 8) / 16777216.0f - 0.5f); }
+  float *dmel = NULL, *daud = NULL;
+  void* ws = NULL;
+  const size_t wsb = facppg_wg_workspace_bytes(h, B, T);
+  CHECK_HIP(hipMalloc((void**)&dmel, n_mel * sizeof(float)));
+  CHECK_HIP(hipMalloc((void**)&daud, n_audio * sizeof(float)));
+  CHECK_HIP(hipMalloc(&ws, wsb));
+  CHECK_HIP(hipMemcpy(dmel, hmel, n_mel * sizeof(float), hipMemcpyHostToDevice));
+  float* a0 = (float*)malloc(n_audio * sizeof(float));
+  float* a1 = (float*)malloc(n_audio * sizeof(float));
+  for (int rep = 0; rep < 2; ++rep) {
+    CHECK_RC(facppg_wg_infer(h, dmel, NULL, NULL, 777u, 0.6f, B, T, daud, ws, wsb, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    CHECK_HIP(hipMemcpy(rep ? a1 : a0, daud, n_audio * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  double rms = 0.0;
+  for (size_t i = 0; i < n_audio; ++i) {
+    if (!isfinite(a0[i])) { fprintf(stderr, "non-finite sample %zu\n", i); return 4; }
+    if (a0[i] != a1[i]) { fprintf(stderr, "run-to-run mismatch at %zu\n", i); return 4; }
+    rms += (double)a0[i] * a0[i];
+  }
+  rms = sqrt(rms / (double)n_audio);
+  if (!(rms > 1e-3 && rms < 1e3)) { fprintf(stderr, "implausible rms %g\n", rms); return 4; }
+  /* error paths */
+  if (facppg_wg_infer(h, dmel, NULL, NULL, 1u, 0.6f, B, T, daud, ws, wsb / 2, NULL) != FACPPG_EWORKSPACE) { fprintf(stderr, "expected EWORKSPACE\n"); return 5; }
+  if (facppg_wg_infer(h, NULL, NULL, NULL, 1u, 0.6f, B, T, daud, ws, wsb, NULL) != FACPPG_EINVAL) { fprintf(stderr, "expected EINVAL\n"); return 5; }
+  facppg_wg_destroy(h);
+  printf("abi_smoke ok: version %d, %zu weights, %zu samples, rms %.4f, workspace %zu bytes\n", facppg_version(), nw, n_audio, rms, wsb);
+  return 0;
+}
