@@ -55,3 +55,18 @@ def test_no_cpu_fallback():
     m = WaveGlow(**cfg)
     with pytest.raises(flib.FacppgError, match="no CPU path"):
         m.infer(torch.zeros(1, 80, 4))
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under fac-via-ppg_amd/ may import it (only tests/,
+    __graft_entry__.smoke() and bench.py's cpu_baseline worker do)."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fac-via-ppg_amd")
+    pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b)", re.M)
+    offenders = []
+    for d, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py") and pat.search(open(os.path.join(d, f)).read()):
+                offenders.append(os.path.join(d, f))
+    assert not offenders, offenders
