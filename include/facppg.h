@@ -256,7 +256,12 @@ int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const int32_t* leng
  * (utils.py:46-78) and the stop rule (sigmoid(gate) > gate_threshold after appending the frame,
  * else stop at max_steps).  masks_dev NULL or uint8 [max_steps][2][B][prenet_dim].
  * Outputs: mel_dev [B][n_feat][max_steps], gate_dev [B][max_steps], align_dev NULL or
- * [B][max_steps][Tin], out_lengths_dev [B] (= Tout per utterance; columns beyond it untouched). */
+ * [B][max_steps][Tin], out_lengths_dev [B] (= Tout per utterance; columns beyond it untouched).
+ * One launch for the whole loop.  The launch shape follows B: up to 3 utterances run as one attention
+ * workgroup plus register-resident dense-layer workers each, up to 120 as 2-38 cooperating workgroups,
+ * beyond that one workgroup per utterance; the first two use hipLaunchCooperativeKernel (the workgroups
+ * of an utterance must be co-resident) and every shape returns the same values to fp32 round-off.
+ * FACPPG_DECODER_MODE=split|coop|single forces one (FACPPG_EUNSUPPORTED if B does not allow it). */
 int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const float* pm_dev,
                        const int32_t* lengths_dev, const uint8_t* masks_dev, uint64_t seed, int B,
                        int Tin, int max_steps, float* mel_dev, float* gate_dev, float* align_dev,
