@@ -452,6 +452,8 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
     }
 #if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 8)
     asm volatile("" ::"v"(stg[0]));   // ablation: no LDS staging write, no barrier
+#elif defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 32)
+    stage_write((c + 1) & 1);         // ablation: staging write but no barrier (racy: timing only)
 #else
     stage_write((c + 1) & 1);
     __syncthreads();
