@@ -88,14 +88,36 @@ def cpu_baseline(log):
                       "%.1f s on %d threads (best of 16/32 threads)" % (frames, HOP, frames * HOP, best["seconds"], best["threads"])}
 
 
-def end_to_end_batch1(dev, waveglow, log):
-    """Secondary figure (not `value`): the metric's "real-time factor at batch=1" for the whole
-    PPG -> mel -> wav path (Tacotron2.inference + WaveGlow.infer + Denoiser) on one 200-frame
-    utterance, best of 3, inputs resident on the device."""
+def end_to_end_batch1(log):
+    """Secondary figure (not `value`): measured in a child process (e2e_worker) so that nothing it does --
+    it uses cooperative launches, which rocprofv3 on this stack does not survive -- can take the primary
+    measurement down with it.  Returns None if the child fails."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--e2e-worker"], capture_output=True, text=True, timeout=300)
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        log("end-to-end batch=1: %d samples in %.2f ms" % (round(out["samples_per_s"] * out["ms"] * 1e-3), out["ms"]))
+        return out
+    except Exception as e:   # noqa: BLE001  (secondary figure: report its absence, never fail the bench)
+        log("end-to-end batch=1 measurement failed: %r" % (e,))
+        return None
+
+
+def e2e_worker():
+    """The metric's "real-time factor at batch=1" for the whole PPG -> mel -> wav path
+    (Tacotron2.inference + WaveGlow.infer + Denoiser) on one 200-frame utterance, best of 3; prints one
+    JSON line."""
     from common.hparams import create_hparams_stage
     from facppg import pipeline, synth
     from script.train_ppg2mel import load_model
     from waveglow.denoiser import Denoiser
+    from waveglow.glow import WaveGlow
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=HOP)
+    waveglow = WaveGlow.remove_weightnorm(WaveGlow(**cfg))
+    waveglow.load_state_dict(synth.waveglow_state_dict(cfg))
+    waveglow = waveglow.to(dev).eval()
     frames = 200
     hp = create_hparams_stage(max_decoder_steps=frames)
     taco = load_model(hp)
@@ -114,9 +136,8 @@ def end_to_end_batch1(dev, waveglow, log):
             times.append(time.perf_counter() - t0)
     t = min(times[1:])
     n = tout[0] * HOP
-    log("end-to-end batch=1: %d frames -> %d samples in %.2f ms" % (tout[0], n, t * 1e3))
-    return {"workload": "PPG [200 x 5816] -> mel -> wav, hop=%d, batch=1 (Tacotron2 + WaveGlow + Denoiser)" % HOP,
-            "ms": t * 1e3, "samples_per_s": n / t, "realtime_factor": n / t / SR}
+    print(json.dumps({"workload": "PPG [200 x 5816] -> mel -> wav, hop=%d, batch=1 (Tacotron2 + WaveGlow + Denoiser)" % HOP,
+                      "ms": t * 1e3, "samples_per_s": n / t, "realtime_factor": n / t / SR}))
 
 
 def pmc_traffic():
@@ -139,9 +160,12 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help=argparse.SUPPRESS)   # "gloo" + --share-gpu: 1-GPU dry run of the N>1 path
     ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-worker", nargs=2, type=int, metavar=("THREADS", "FRAMES"), help=argparse.SUPPRESS)
+    ap.add_argument("--e2e-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(*args.cpu_baseline_worker)
+    if args.e2e_worker:
+        return e2e_worker()
 
     t_start = time.perf_counter()
     rank = int(os.environ.get("RANK", "0"))
@@ -234,7 +258,7 @@ def main():
                                                "frac": achieved_ref / PEAK_F32_MFMA_TFLOPS}},
     }
     if rank == 0 and world == 1 and not args.no_e2e:
-        out["end_to_end_batch1"] = end_to_end_batch1(dev, model, log)
+        out["end_to_end_batch1"] = end_to_end_batch1(log)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(log)
     if rank == 0:
