@@ -168,16 +168,18 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
   ka.KG = gemm_kpad(a.Cin * a.taps) / 8;
   ka.sk = 1;
   dim3 grid((a.N + TN - 1) / TN, (round_up(a.M, 32) / 32 + 3) / 4, a.B);
-  // Small-N products (one short utterance through the encoder / postnet) launch a few dozen workgroups with
-  // a long serial K loop each: split K over more workgroups when the caller lent a partial-sum buffer
-  const long wgs = (long)grid.x * grid.y * grid.z;
+  // Long reductions are split over K when the caller lent a partial-sum buffer: a product with few columns
+  // (one short utterance through the encoder / postnet) otherwise launches a few dozen workgroups with a
+  // long serial K loop each.  The split factor depends on K ALONE -- not on the batch or the padded
+  // length -- so an utterance is summed in the same order whatever batch it rides in (padded batches equal
+  // independent runs bit for bit); large products pay a little extra partial-sum traffic for that.
   const int nch = ka.KG / 8;
-  if (a.splitk_ws && wgs < 128 && nch >= 8) {
-    long sk = (384 + wgs - 1) / wgs;
-    if (sk > nch / 4) sk = nch / 4;
-    const size_t per_split = (size_t)a.B * a.M * a.N * sizeof(float);
-    if ((size_t)sk * per_split > a.splitk_ws_bytes) sk = (long)(a.splitk_ws_bytes / per_split);
-    if (sk >= 2) ka.sk = (int)sk;
+  if (a.splitk_ws && nch >= 8) {
+    const int sk = nch / 4 < 16 ? nch / 4 : 16;
+    const size_t need = (size_t)sk * a.B * a.M * a.N * sizeof(float);
+    FACPPG_REQUIRE(need <= a.splitk_ws_bytes, FACPPG_EWORKSPACE, "gemm_launch: split-K buffer has %zu bytes, needs %zu",
+                   a.splitk_ws_bytes, need);
+    ka.sk = sk;
   }
   grid.z = a.B * ka.sk;
   k_gemm<<<grid, 256, 0, s>>>(ka);

@@ -817,26 +817,27 @@ __device__ __forceinline__ void stat_mv16(const float (&w)[KRM], int K, const fl
   __syncthreads();
 }
 
+constexpr int SNU = 4;   // max utterances sharing one set of workers
+
+template <int NU>
 __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
   extern __shared__ float sm[];
-  __shared__ int s_stop;
-  __shared__ float c_att[SU], c_dec[SU];
-  const int blk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  // exchange words of this utterance
-  unsigned long long* MEL = p.xsplit + (size_t)b * (p.NF + 1 + 2 * p.P + p.A + p.E + p.D + 8);   // [NF] mel row + gate
-  unsigned long long *X1 = MEL + p.NF + 1, *X2 = X1 + p.P, *AH = X2 + p.P, *CTX = AH + p.A, *DH = CTX + p.E;
+  __shared__ int s_stop[SNU];
+  __shared__ float c_att[SNU][SU], c_dec[SNU][SU];
+  // A group = NU utterances that share NWK workers (the register-resident weights serve all of them) and
+  // have one main workgroup each: blocks 0..NU-1 are the mains, the rest the workers.
+  const int blk = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x;
+  const size_t xstride = (size_t)(p.NF + 1 + 2 * p.P + p.A + p.E + p.D + 8);
   const int KA = p.P + p.E + p.A, KD = p.A + p.E + p.D, KP = p.D + p.E;
-  if (tid == 0) s_stop = 0;
-  if (blk > 0) {   // ------------------------------------------------ worker
-    const int wg = blk - 1, unit0 = wg * SU, row0 = wg * SSC;
-    float* in_att = sm;              // [prenet | ctx | ah]
-    float* in_dec = in_att + KA;     // [ah | ctx | dh]
-    float* in_proj = in_dec + KD;    // [dh | ctx]
-    float* xin = in_proj + KP;       // previous mel frame [NF]
-    float* p1 = xin + round_up(p.NF, 4);   // prenet layer-1 output [P]
-    float* part = p1 + round_up(p.P, 4);   // 512 floats
-    for (int i = tid; i < KA + KD + KP + round_up(p.NF, 4) + round_up(p.P, 4) + 512; i += NTC) sm[i] = 0.0f;   // incl. part
-    if (tid < SU) { c_att[tid] = 0.0f; c_dec[tid] = 0.0f; }
+  if (tid < SNU) s_stop[tid] = 0;
+  if (blk >= NU) {   // ------------------------------------------------ worker
+    const int wg = blk - NU, unit0 = wg * SU, row0 = wg * SSC;
+    // per utterance: in_att [prenet | ctx | ah], in_dec [ah | ctx | dh], in_proj [dh | ctx], xin (previous mel
+    // frame), p1 (prenet layer-1 output); then 512 floats of reduction scratch
+    const int ustride = KA + KD + KP + round_up(p.NF, 4) + round_up(p.P, 4);
+    float* part = sm + (size_t)NU * ustride;
+    for (int i = tid; i < NU * ustride + 512; i += NTC) sm[i] = 0.0f;
+    if (tid < SNU * SU) { (&c_att[0][0])[tid] = 0.0f; (&c_dec[0][0])[tid] = 0.0f; }
     float w_att[SKR_LSTM], w_dec[SKR_LSTM], w_proj[SKR_PROJ], w_p1[SKR_P1], w_p2[SKR_P2];
     stat_load(w_att, p.att_w4 + (size_t)wg * KA * SSC, SSC, 0, SSC, KA, tid);
     stat_load(w_dec, p.dec_w4 + (size_t)wg * KD * SSC, SSC, 0, SSC, KD, tid);
@@ -844,12 +845,24 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
     stat_load(w_p1, p.dp0_t, round_up(p.P, 4), row0, p.P, p.NF, tid);
     stat_load(w_p2, p.dp1_t, round_up(p.P, 4), row0, p.P, p.P, tid);
     const bool has_proj = row0 < p.NF + 1, has_pre = row0 < p.P;
+    unsigned alive = 0;   // bit u: utterance u of the group is still decoding (identical in every workgroup)
+    for (int u = 0; u < NU; ++u)
+      if (grp * NU + u < p.B) alive |= 1u << u;
     __syncthreads();
+#define FOR_ALIVE(u) _Pragma("unroll") for (int u = 0; u < NU; ++u) if (alive >> u & 1)
+#define UTT(u)                                                                                          \
+  const int b = grp * NU + u;                                                                           \
+  unsigned long long* MEL = p.xsplit + (size_t)b * xstride;                                             \
+  unsigned long long *X1 = MEL + p.NF + 1, *X2 = X1 + p.P, *AH = X2 + p.P, *CTX = AH + p.A, *DH = CTX + p.E; \
+  float* in_att = sm + (size_t)u * ustride; float* in_dec = in_att + KA; float* in_proj = in_dec + KD;  \
+  float* xin = in_proj + KP; float* p1 = xin + round_up(p.NF, 4);                                       \
+  (void)MEL; (void)X1; (void)X2; (void)AH; (void)CTX; (void)DH; (void)in_att; (void)in_dec; (void)in_proj; (void)xin; (void)p1
     for (int t = 0;; ++t) {
       const unsigned tag = t + 1;
       if (t > 0) {
         // projection + gate rows of frame t-1 (model.py:436-441); the stopping frame is kept (:524-528)
-        if (has_proj) {
+        if (has_proj) FOR_ALIVE(u) {
+          UTT(u);
           stat_mv16(w_proj, KP, in_proj, part, tid);
           if (tid < SSC && row0 + tid <= p.NF) {
             const int row = row0 + tid;
@@ -859,54 +872,89 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
             else p.gate[(size_t)b * p.max_steps + t - 1] = v;
           }
         }
-        for (int i = tid; i < p.NF; i += NTC) xin[i] = xwait(MEL + i, tag);
-        if (tid == 0) s_stop = sigm(xwait(MEL + p.NF, tag)) > p.gate_thr || t == p.max_steps;
+        FOR_ALIVE(u) {
+          UTT(u);
+          for (int i = tid; i < p.NF; i += NTC) xin[i] = xwait(MEL + i, tag);
+          if (tid == 0) s_stop[u] = sigm(xwait(MEL + p.NF, tag)) > p.gate_thr || t == p.max_steps;
+        }
         __syncthreads();
-        if (s_stop) break;
+        for (int u = 0; u < NU; ++u)
+          if (s_stop[u]) alive &= ~(1u << u);
+        if (!alive) break;
       }
       // prenet: 2 x (Linear no bias, ReLU, dropout p=0.5 always on)  (model.py:132-135)
-      const uint8_t* mk = p.masks + ((size_t)t * 2 * p.B + b) * p.P;
-      if (has_pre) {
+      if (has_pre) FOR_ALIVE(u) {
+        UTT(u);
+        const uint8_t* mk = p.masks + ((size_t)t * 2 * p.B + b) * p.P;
         stat_mv16(w_p1, p.NF, xin, part, tid);
         if (tid < SSC && row0 + tid < p.P) xpub(X1 + row0 + tid, fmaxf(part[256 + tid], 0.0f) * (float)mk[row0 + tid] * 2.0f, tag);
       }
-      for (int i = tid; i < p.P; i += NTC) p1[i] = xwait(X1 + i, tag);
+      FOR_ALIVE(u) {
+        UTT(u);
+        for (int i = tid; i < p.P; i += NTC) p1[i] = xwait(X1 + i, tag);
+      }
       __syncthreads();
-      if (has_pre) {
+      if (has_pre) FOR_ALIVE(u) {
+        UTT(u);
+        const uint8_t* mk = p.masks + ((size_t)t * 2 * p.B + b) * p.P;
         stat_mv16(w_p2, p.P, p1, part, tid);
         if (tid < SSC && row0 + tid < p.P)
           xpub(X2 + row0 + tid, fmaxf(part[256 + tid], 0.0f) * (float)mk[(size_t)p.B * p.P + row0 + tid] * 2.0f, tag);
       }
-      for (int i = tid; i < p.P; i += NTC) in_att[i] = xwait(X2 + i, tag);
+      FOR_ALIVE(u) {
+        UTT(u);
+        for (int i = tid; i < p.P; i += NTC) in_att[i] = xwait(X2 + i, tag);
+      }
       __syncthreads();
       // attention LSTMCell slice on [prenet | ctx | ah]  (model.py:400-403)
-      stat_mv16(w_att, KA, in_att, part, tid);
-      if (tid < SU && unit0 + tid < p.A) {
-        const float* gs = part + 256;
-        const int u = unit0 + tid;
-        xpub(AH + u, lstm_point(gs[tid] + p.att_b[u], gs[SU + tid] + p.att_b[p.A + u], gs[2 * SU + tid] + p.att_b[2 * p.A + u],
-                                gs[3 * SU + tid] + p.att_b[3 * p.A + u], &c_att[tid]), tag);
+      FOR_ALIVE(u) {
+        UTT(u);
+        stat_mv16(w_att, KA, in_att, part, tid);
+        if (tid < SU && unit0 + tid < p.A) {
+          const float* gs = part + 256;
+          const int un = unit0 + tid;
+          xpub(AH + un, lstm_point(gs[tid] + p.att_b[un], gs[SU + tid] + p.att_b[p.A + un], gs[2 * SU + tid] + p.att_b[2 * p.A + un],
+                                   gs[3 * SU + tid] + p.att_b[3 * p.A + un], &c_att[u][tid]), tag);
+        }
       }
-      for (int i = tid; i < p.A; i += NTC) { const float h = xwait(AH + i, tag); in_att[p.P + p.E + i] = h; in_dec[i] = h; }
-      for (int i = tid; i < p.E; i += NTC) {
-        const float c = xwait(CTX + i, tag);
-        in_att[p.P + i] = c; in_dec[p.A + i] = c; in_proj[p.D + i] = c;
+      FOR_ALIVE(u) {
+        UTT(u);
+        for (int i = tid; i < p.A; i += NTC) { const float h = xwait(AH + i, tag); in_att[p.P + p.E + i] = h; in_dec[i] = h; }
+      }
+      FOR_ALIVE(u) {
+        UTT(u);
+        for (int i = tid; i < p.E; i += NTC) {
+          const float c = xwait(CTX + i, tag);
+          in_att[p.P + i] = c; in_dec[p.A + i] = c; in_proj[p.D + i] = c;
+        }
       }
       __syncthreads();
       // decoder LSTMCell slice on [ah | ctx | dh]  (model.py:425-428)
-      stat_mv16(w_dec, KD, in_dec, part, tid);
-      if (tid < SU && unit0 + tid < p.D) {
-        const float* gs = part + 256;
-        const int u = unit0 + tid;
-        xpub(DH + u, lstm_point(gs[tid] + p.dec_b[u], gs[SU + tid] + p.dec_b[p.D + u], gs[2 * SU + tid] + p.dec_b[2 * p.D + u],
-                                gs[3 * SU + tid] + p.dec_b[3 * p.D + u], &c_dec[tid]), tag);
+      FOR_ALIVE(u) {
+        UTT(u);
+        stat_mv16(w_dec, KD, in_dec, part, tid);
+        if (tid < SU && unit0 + tid < p.D) {
+          const float* gs = part + 256;
+          const int un = unit0 + tid;
+          xpub(DH + un, lstm_point(gs[tid] + p.dec_b[un], gs[SU + tid] + p.dec_b[p.D + un], gs[2 * SU + tid] + p.dec_b[2 * p.D + un],
+                                   gs[3 * SU + tid] + p.dec_b[3 * p.D + un], &c_dec[u][tid]), tag);
+        }
       }
-      for (int i = tid; i < p.D; i += NTC) { const float h = xwait(DH + i, tag); in_dec[p.A + p.E + i] = h; in_proj[i] = h; }
+      FOR_ALIVE(u) {
+        UTT(u);
+        for (int i = tid; i < p.D; i += NTC) { const float h = xwait(DH + i, tag); in_dec[p.A + p.E + i] = h; in_proj[i] = h; }
+      }
       __syncthreads();
     }
+#undef FOR_ALIVE
+#undef UTT
     return;
   }
-  // ------------------------------------------------------------------ main
+  // ------------------------------------------------------------------ main of utterance b
+  const int b = grp * NU + blk;
+  if (b >= p.B) return;
+  unsigned long long* MEL = p.xsplit + (size_t)b * xstride;
+  unsigned long long *AH = MEL + p.NF + 1 + 2 * p.P, *CTX = AH + p.A;
   const int len = p.lengths ? p.lengths[b] : p.Tin;
   DecLds L;
   dec_carve(p, sm, L);
@@ -932,9 +980,9 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
     attn_features<NTC>(p, L, lo, min(64, hi - lo + 1), tid);   // needs only frame t-1's weights
     PROF(2)
     if (t > 0) {
-      if (tid == 0) s_stop = sigm(xwait(MEL + p.NF, tag)) > p.gate_thr || t == p.max_steps;
+      if (tid == 0) s_stop[0] = sigm(xwait(MEL + p.NF, tag)) > p.gate_thr || t == p.max_steps;
       __syncthreads();
-      if (s_stop) {
+      if (s_stop[0]) {
         if (tid == 0) p.out_len[b] = t;
         break;
       }
@@ -966,8 +1014,8 @@ TWs tws_layout(const facppg_taco_config& c, int B, int Tin) {
   w.mask = take((size_t)2 * B * c.symbols_embedding_dim * Tin);
   w.xchg = take((size_t)B * 2 * 2 * (c.encoder_embedding_dim / 2) * 8);   // k_bilstm_coop {value, tag} words
   // split-K partial sums for the small-N encoder GEMMs (only short batches split; see gemm_launch)
-  w.splitk_bytes = (size_t)16 * B * 4 * c.encoder_embedding_dim * Tin * 4;
-  if (w.splitk_bytes > ((size_t)64 << 20)) w.splitk_bytes = (size_t)64 << 20;
+  const size_t mx = c.encoder_embedding_dim > c.symbols_embedding_dim ? c.encoder_embedding_dim : c.symbols_embedding_dim;
+  w.splitk_bytes = (size_t)16 * B * mx * Tin * 4;   // <= 16 splits of the widest split product (rows x Tin per utterance)
   w.splitk = take(w.splitk_bytes);
   w.total = off;
   return w;
@@ -1333,19 +1381,31 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
   if (coop) {
     a.att_coop = h->att_coop[variant]; a.dec_coop = h->dec_coop[variant]; a.U = h->coop_U[variant];
   }
-  // split shape: one main + split_nwk register-resident LSTM workers per utterance
+  // split shape: split_nwk register-resident dense-layer workers serve NU utterances, each with its own main
+  // (attention) workgroup.  NU = the fewest utterances per worker set that keeps every workgroup co-resident;
+  // a worker's per-frame work grows with NU, so beyond SPLIT_MAX_NU the cooperative kernel wins.
   static const char* no_split = getenv("FACPPG_DECODER_NO_SPLIT");
-  const bool split = coop && !no_split && (long)B * (h->split_nwk + 1) <= h->coop_limit && a.P + a.E + a.A <= SKP * SKR_LSTM &&
+  const char* max_nu_env = getenv("FACPPG_DECODER_SPLIT_MAX_NU");
+  const int max_nu = max_nu_env ? atoi(max_nu_env) : 4;
+  const size_t ustride = (size_t)(a.P + a.E + a.A) + (a.A + a.E + a.D) + (a.D + a.E) + round_up(a.NF, 4) + round_up(a.P, 4);
+  int NU = 0;
+  for (int nu = 1; nu <= SNU && nu <= max_nu && !NU; ++nu)
+    if ((long)((B + nu - 1) / nu) * (h->split_nwk + nu) <= h->coop_limit && (nu * ustride + 512) * 4 <= 150 * 1024) NU = nu;
+  const bool split = coop && !no_split && NU > 0 && a.P + a.E + a.A <= SKP * SKR_LSTM &&
                      a.A + a.E + a.D <= SKP * SKR_LSTM && a.D + a.E <= SKP * SKR_PROJ && a.NF <= SKP * SKR_P1 &&
                      a.P <= SKP * SKR_P2 && a.NF + 1 <= h->split_nwk * SSC && a.P <= h->split_nwk * SSC &&
                      !(mode && !strcmp(mode, "coop"));
-  if (mode && !strcmp(mode, "split")) FACPPG_REQUIRE(split, FACPPG_EUNSUPPORTED, "split decoder needs B <= 3 and the reference's layer widths");
+  if (mode && !strcmp(mode, "split")) FACPPG_REQUIRE(split, FACPPG_EUNSUPPORTED, "split decoder needs a small batch and the reference's layer widths");
   if (split) {
     a.att_w4 = h->att_w4; a.dec_w4 = h->dec_w4; a.xsplit = (unsigned long long*)(ws + w.xsplit);
     FACPPG_HIP_CHECK(hipMemsetAsync(ws + w.xchg, 0, w.total - w.xchg, s));
-    FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_decoder_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    size_t ssm = (NU * ustride + 512) * 4;
+    if (ssm < smem) ssm = smem;
+    const void* fn = NU == 1 ? (const void*)k_decoder_split<1> : NU == 2 ? (const void*)k_decoder_split<2>
+                   : NU == 3 ? (const void*)k_decoder_split<3> : (const void*)k_decoder_split<4>;
+    FACPPG_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ssm));
     void* args[] = {(void*)&a};
-    FACPPG_HIP_CHECK(hipLaunchCooperativeKernel((const void*)k_decoder_split, dim3(h->split_nwk + 1, B), dim3(NTC), args, smem, s));
+    FACPPG_HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(h->split_nwk + NU, (B + NU - 1) / NU), dim3(NTC), args, ssm, s));
     if (a.prof) {
       long long pr[16];
       FACPPG_HIP_CHECK(hipMemcpyAsync(pr, a.prof, sizeof(pr), hipMemcpyDeviceToHost, s));
@@ -1411,8 +1471,7 @@ extern "C" int facppg_taco_postnet(facppg_taco* h, const float* mel_dev, const i
 
 extern "C" size_t facppg_taco_postnet_workspace_bytes(const facppg_taco* h, int B, int T) {
   if (!h || B <= 0 || T <= 0) return 0;
-  size_t sk = (size_t)16 * B * h->c.postnet_embedding_dim * T * 4;   // split-K partial sums (short batches)
-  if (sk > ((size_t)64 << 20)) sk = (size_t)64 << 20;
+  const size_t sk = (size_t)16 * B * h->c.postnet_embedding_dim * T * 4;   // split-K partial sums
   return (size_t)2 * B * h->c.postnet_embedding_dim * T * 4 + sk;
 }
 

@@ -1933,8 +1933,7 @@ WnTrainWs wn_train_ws(int n_layers, int B, int Lr) {
     w.cond_t[i] = take(packed_a_float4s(NCOND, 2 * C) * 16);
   }
   w.tmp = take((size_t)B * C * Lr * 4);
-  w.splitk_bytes = (size_t)8 * B * C * Lr * 4;
-  if (w.splitk_bytes > ((size_t)48 << 20)) w.splitk_bytes = (size_t)48 << 20;
+  w.splitk_bytes = (size_t)8 * B * C * Lr * 4;   // <= 6 splits (K = 1536) of a [256 x L] product per batch item
   w.splitk = take(w.splitk_bytes);
   w.total = off;
   return w;
