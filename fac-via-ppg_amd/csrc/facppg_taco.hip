@@ -819,6 +819,47 @@ __device__ __forceinline__ void stat_mv16(const float (&w)[KRM], int K, const fl
 
 constexpr int SNU = 4;   // max utterances sharing one set of workers
 
+// The same for up to NU input vectors at once (in0 + u * ustride, utterances with their `alive` bit set): one
+// pass over the register-resident weights, one pair of barriers; row sums land in part[512 + 16 u .. ].
+template <int KRM, int NU>
+__device__ __forceinline__ void stat_mv16n(const float (&w)[KRM], int K, const float* in0, int ustride, unsigned alive, float* part,
+                                           int tid) {
+  if constexpr (NU > 2) {   // three or more accumulator sets next to 128 weight registers spill: one vector at a time
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      if (alive >> u & 1) {
+        stat_mv16(w, K, in0 + (size_t)u * ustride, part, tid);
+        if (tid < SSC) part[512 + u * SSC + tid] = part[256 + tid];
+      }
+    return;
+  }
+  const int r = tid % SSC, kp = tid / SSC, KR = (K + SKP - 1) / SKP;
+  const int kb = kp * KR;
+  float acc[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) acc[u] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < KRM; ++i)
+#pragma unroll
+    for (int u = 0; u < NU; ++u) acc[u] = fmaf(w[i], in0[(size_t)u * ustride + kb + i], acc[u]);   // dead slots read zeros
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    acc[u] += __shfl_xor(acc[u], 16);
+    acc[u] += __shfl_xor(acc[u], 32);
+    if ((tid & 63) < SSC) part[((tid >> 6) * NU + u) * SSC + r] = acc[u];
+  }
+  __syncthreads();
+  if (tid < SSC * NU) {
+    const int u = tid / SSC, rr = tid % SSC;
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NTC / 64; ++j) s += part[(j * NU + u) * SSC + rr];
+    part[512 + tid] = s;
+  }
+  __syncthreads();
+  (void)alive;
+}
+
 template <int NU>
 __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
   extern __shared__ float sm[];
@@ -835,8 +876,8 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
     // per utterance: in_att [prenet | ctx | ah], in_dec [ah | ctx | dh], in_proj [dh | ctx], xin (previous mel
     // frame), p1 (prenet layer-1 output); then 512 floats of reduction scratch
     const int ustride = KA + KD + KP + round_up(p.NF, 4) + round_up(p.P, 4);
-    float* part = sm + (size_t)NU * ustride;
-    for (int i = tid; i < NU * ustride + 512; i += NTC) sm[i] = 0.0f;
+    float* part = sm + (size_t)NU * ustride;   // 1024 floats
+    for (int i = tid; i < NU * ustride + 1024; i += NTC) sm[i] = 0.0f;
     if (tid < SNU * SU) { (&c_att[0][0])[tid] = 0.0f; (&c_dec[0][0])[tid] = 0.0f; }
     float w_att[SKR_LSTM], w_dec[SKR_LSTM], w_proj[SKR_PROJ], w_p1[SKR_P1], w_p2[SKR_P2];
     stat_load(w_att, p.att_w4 + (size_t)wg * KA * SSC, SSC, 0, SSC, KA, tid);
@@ -861,12 +902,12 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
       const unsigned tag = t + 1;
       if (t > 0) {
         // projection + gate rows of frame t-1 (model.py:436-441); the stopping frame is kept (:524-528)
+        if (has_proj) stat_mv16n<SKR_PROJ, NU>(w_proj, KP, sm + KA + KD, ustride, alive, part, tid);
         if (has_proj) FOR_ALIVE(u) {
           UTT(u);
-          stat_mv16(w_proj, KP, in_proj, part, tid);
           if (tid < SSC && row0 + tid <= p.NF) {
             const int row = row0 + tid;
-            const float v = part[256 + tid] + p.proj_b[row];
+            const float v = part[512 + u * SSC + tid] + p.proj_b[row];
             xpub(MEL + row, v, tag);
             if (row < p.NF) p.mel[((size_t)b * p.NF + row) * p.max_steps + t - 1] = v;
             else p.gate[(size_t)b * p.max_steps + t - 1] = v;
@@ -883,23 +924,24 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
         if (!alive) break;
       }
       // prenet: 2 x (Linear no bias, ReLU, dropout p=0.5 always on)  (model.py:132-135)
+      if (has_pre) stat_mv16n<SKR_P1, NU>(w_p1, p.NF, sm + KA + KD + KP, ustride, alive, part, tid);
       if (has_pre) FOR_ALIVE(u) {
         UTT(u);
         const uint8_t* mk = p.masks + ((size_t)t * 2 * p.B + b) * p.P;
-        stat_mv16(w_p1, p.NF, xin, part, tid);
-        if (tid < SSC && row0 + tid < p.P) xpub(X1 + row0 + tid, fmaxf(part[256 + tid], 0.0f) * (float)mk[row0 + tid] * 2.0f, tag);
+        if (tid < SSC && row0 + tid < p.P)
+          xpub(X1 + row0 + tid, fmaxf(part[512 + u * SSC + tid], 0.0f) * (float)mk[row0 + tid] * 2.0f, tag);
       }
       FOR_ALIVE(u) {
         UTT(u);
         for (int i = tid; i < p.P; i += NTC) p1[i] = xwait(X1 + i, tag);
       }
       __syncthreads();
+      if (has_pre) stat_mv16n<SKR_P2, NU>(w_p2, p.P, sm + KA + KD + KP + round_up(p.NF, 4), ustride, alive, part, tid);
       if (has_pre) FOR_ALIVE(u) {
         UTT(u);
         const uint8_t* mk = p.masks + ((size_t)t * 2 * p.B + b) * p.P;
-        stat_mv16(w_p2, p.P, p1, part, tid);
         if (tid < SSC && row0 + tid < p.P)
-          xpub(X2 + row0 + tid, fmaxf(part[256 + tid], 0.0f) * (float)mk[(size_t)p.B * p.P + row0 + tid] * 2.0f, tag);
+          xpub(X2 + row0 + tid, fmaxf(part[512 + u * SSC + tid], 0.0f) * (float)mk[(size_t)p.B * p.P + row0 + tid] * 2.0f, tag);
       }
       FOR_ALIVE(u) {
         UTT(u);
@@ -907,11 +949,11 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
       }
       __syncthreads();
       // attention LSTMCell slice on [prenet | ctx | ah]  (model.py:400-403)
+      stat_mv16n<SKR_LSTM, NU>(w_att, KA, sm, ustride, alive, part, tid);
       FOR_ALIVE(u) {
         UTT(u);
-        stat_mv16(w_att, KA, in_att, part, tid);
         if (tid < SU && unit0 + tid < p.A) {
-          const float* gs = part + 256;
+          const float* gs = part + 512 + u * SSC;
           const int un = unit0 + tid;
           xpub(AH + un, lstm_point(gs[tid] + p.att_b[un], gs[SU + tid] + p.att_b[p.A + un], gs[2 * SU + tid] + p.att_b[2 * p.A + un],
                                    gs[3 * SU + tid] + p.att_b[3 * p.A + un], &c_att[u][tid]), tag);
@@ -930,11 +972,11 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
       }
       __syncthreads();
       // decoder LSTMCell slice on [ah | ctx | dh]  (model.py:425-428)
+      stat_mv16n<SKR_LSTM, NU>(w_dec, KD, sm + KA, ustride, alive, part, tid);
       FOR_ALIVE(u) {
         UTT(u);
-        stat_mv16(w_dec, KD, in_dec, part, tid);
         if (tid < SU && unit0 + tid < p.D) {
-          const float* gs = part + 256;
+          const float* gs = part + 512 + u * SSC;
           const int un = unit0 + tid;
           xpub(DH + un, lstm_point(gs[tid] + p.dec_b[un], gs[SU + tid] + p.dec_b[p.D + un], gs[2 * SU + tid] + p.dec_b[2 * p.D + un],
                                    gs[3 * SU + tid] + p.dec_b[3 * p.D + un], &c_dec[u][tid]), tag);
@@ -1386,11 +1428,11 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
   // a worker's per-frame work grows with NU, so beyond SPLIT_MAX_NU the cooperative kernel wins.
   static const char* no_split = getenv("FACPPG_DECODER_NO_SPLIT");
   const char* max_nu_env = getenv("FACPPG_DECODER_SPLIT_MAX_NU");
-  const int max_nu = max_nu_env ? atoi(max_nu_env) : 4;
+  const int max_nu = max_nu_env ? atoi(max_nu_env) : 3;   // 4 utterances per worker set only ties with the cooperative kernel (12.5 vs 12.4 ms at B = 12)
   const size_t ustride = (size_t)(a.P + a.E + a.A) + (a.A + a.E + a.D) + (a.D + a.E) + round_up(a.NF, 4) + round_up(a.P, 4);
   int NU = 0;
   for (int nu = 1; nu <= SNU && nu <= max_nu && !NU; ++nu)
-    if ((long)((B + nu - 1) / nu) * (h->split_nwk + nu) <= h->coop_limit && (nu * ustride + 512) * 4 <= 150 * 1024) NU = nu;
+    if ((long)((B + nu - 1) / nu) * (h->split_nwk + nu) <= h->coop_limit && (nu * ustride + 1024) * 4 <= 150 * 1024) NU = nu;
   const bool split = coop && !no_split && NU > 0 && a.P + a.E + a.A <= SKP * SKR_LSTM &&
                      a.A + a.E + a.D <= SKP * SKR_LSTM && a.D + a.E <= SKP * SKR_PROJ && a.NF <= SKP * SKR_P1 &&
                      a.P <= SKP * SKR_P2 && a.NF + 1 <= h->split_nwk * SSC && a.P <= h->split_nwk * SSC &&
@@ -1399,7 +1441,7 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
   if (split) {
     a.att_w4 = h->att_w4; a.dec_w4 = h->dec_w4; a.xsplit = (unsigned long long*)(ws + w.xsplit);
     FACPPG_HIP_CHECK(hipMemsetAsync(ws + w.xchg, 0, w.total - w.xchg, s));
-    size_t ssm = (NU * ustride + 512) * 4;
+    size_t ssm = (NU * ustride + 1024) * 4;
     if (ssm < smem) ssm = smem;
     const void* fn = NU == 1 ? (const void*)k_decoder_split<1> : NU == 2 ? (const void*)k_decoder_split<2>
                    : NU == 3 ? (const void*)k_decoder_split<3> : (const void*)k_decoder_split<4>;
