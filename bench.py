@@ -140,6 +140,30 @@ def e2e_worker():
                       "ms": t * 1e3, "samples_per_s": n / t, "realtime_factor": n / t / SR}))
 
 
+def reference_rate_config(dev, mel, log):
+    """Secondary figure (SURVEY.md 8d asks for both): the same WaveGlow.infer batch at the reference's own
+    rate, hop 160 / 16 kHz (config.json) -- only the upsampling stride, hence the number of group positions
+    per frame and the folded conditioning width, differs.  2 steps after 1 warm-up."""
+    from facppg import synth
+    from waveglow.glow import WaveGlow
+    hop, sr = 160, 16000
+    cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=hop)
+    m = WaveGlow.remove_weightnorm(WaveGlow(**cfg))
+    m.load_state_dict(synth.waveglow_state_dict(cfg))
+    m = m.to(dev).eval()
+    m.infer(mel, sigma=0.6, seed=1)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(2):
+        m.infer(mel, sigma=0.6, seed=2 + i)
+    torch.cuda.synchronize(dev)
+    t = (time.perf_counter() - t0) / 2
+    n = BATCH * FRAMES * hop
+    log("reference-rate config (hop 160): %.1f ms/step" % (t * 1e3))
+    return {"workload": "WaveGlow.infer batch=%d, mel 80x%d, hop=%d (%d Hz)" % (BATCH, FRAMES, hop, sr), "ms_per_step": t * 1e3,
+            "samples_per_s": n / t, "realtime_factor": n / t / sr}
+
+
 def pmc_traffic():
     """HBM bytes per k_wn_layer launch from the committed rocprofv3 PMC passes of this same command
     (profiles/r01_pmc.json; FETCH_SIZE doubled per the gfx950 correction, calibrated on k_flow_end)."""
@@ -259,6 +283,7 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_e2e:
         out["end_to_end_batch1"] = end_to_end_batch1(log)
+        out["reference_rate_config"] = reference_rate_config(dev, mel, log)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(log)
     if rank == 0:
