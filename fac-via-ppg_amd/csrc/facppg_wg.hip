@@ -186,6 +186,7 @@ struct WnArgs {
   const float* melp;   // [B][80][Tqp] zero-margined mel frames
   const float4* wc;    // folded conditioning weights of this layer: P images [ngc][16][64] float4
   int P, Tr, Tqp, ntq, nt, nch, ngc, kc, xcd_map;
+  int hop, ksize;      // upsampler stride / kernel size: late phases reach fewer mel frames (pm_chunks)
   int flat_cols;       // > 0: uniform batch, tiles cut from the B*T frames of a phase laid end to end (no ragged last tile per utterance)
 };
 
@@ -244,6 +245,15 @@ __device__ __forceinline__ float gate_tanh_sigmoid(float a, float b) {
 // l -+ d is simply another phase row ((ph -+ d) mod P) at a frame offset floor((ph -+ d) / P) --
 // still one contiguous row per channel.  Workgroups of the same phase run together (and, with
 // xcd_map, on the same XCD) so a phase's 655 KB image is fetched into an L2 once.
+// K chunks of a phase-major tile: the convolution's 12 plus the folded conditioning rows that are not all
+// zero for this phase -- sample hop*j + 8*ph + g exists in the upsampling kernel only for
+// j <= (ksize - 1 - 8*ph) / hop, so late phases reach one mel frame less (hop 160: 8 chunks instead of 9
+// for phases >= 8; hop 256: always 5).
+__device__ __forceinline__ int pm_chunks(const WnArgs& p, int ph) {
+  const int nj = (p.ksize - 1 - 8 * ph) / p.hop + 1;
+  return min(p.nch, NCHH + (nj * NMEL + KCH - 1) / KCH);
+}
+
 template <bool LAST, int NCB, bool SAVE = false, bool PM = false>
 __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   // LDS: 2 staging buffers [64 k][TNt] then the gated activations [256][TNt] (aliased)
@@ -323,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
 #else
   const float4* wave_c_ptr = PM ? p.wc + (size_t)ph * p.ngc * 1024 + w * 256 + lane : nullptr;
 #endif
-  const int nch = PM ? p.nch : NCH1;
+  const int nch = PM ? pm_chunks(p, ph) : NCH1;
   constexpr int F4R = TNt / 4, RPL4 = 64 / F4R, NSTG4 = 16 / RPL4;   // PM staging: float4 per row, rows per wave load, loads
   const int srow4 = lane / F4R, scol4 = (lane % F4R) * 4;
   const float* hb4 = p.h_in + (size_t)b * C * p.Lp;                         // PM: tapo[] carry the lane's column
@@ -704,7 +714,7 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
   // images are [k-group][16 row blocks][64 lanes]; row block index = wq*4 + sub (+2 for the second half)
   const float4* wave_a = p.w1 + (wq * 4 + sub) * 64 + lane;
   const float4* wave_c = p.wc + (size_t)ph * p.ngc * 1024 + (wq * 4 + sub) * 64 + lane;
-  const int nch = p.nch;
+  const int nch = pm_chunks(p, ph);
   constexpr int F4R = TNt / 4, RPL4 = 64 / F4R, NSTG4 = 8 / RPL4;
   const int srow4 = lane / F4R, scol4 = (lane % F4R) * 4;
   const float* hb4 = p.h_in + (size_t)b * C * p.Lp;
@@ -1529,7 +1539,7 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   // uniform batch: cut tiles from the B*T frames of a phase laid end to end, so only the very last tile is ragged
   static const char* no_flat = getenv("FACPPG_WN_NO_FLAT");
   if (!T_valid_dev && T % 4 == 0 && !no_flat) { a.flat_cols = B * T; a.nt = (B * T + tn - 1) / tn; }
-  a.nch = NCHH + h->kcp / KCH; a.ngc = h->kcp / 8; a.kc = h->kc;
+  a.nch = NCHH + h->kcp / KCH; a.ngc = h->kcp / 8; a.kc = h->kc; a.hop = c.hop_length; a.ksize = c.upsample_kernel;
   // workgroup i lands on XCD i % 8: give every XCD its own phases so a phase's weight image lives in one L2
   static const char* no_xcd = getenv("FACPPG_WN_NO_XCD_MAP");
   a.xcd_map = (w.P % 8 == 0) && !no_xcd;
