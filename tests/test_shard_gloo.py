@@ -71,3 +71,19 @@ def test_gather_ragged_world2_gloo(lengths):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=10) is True
+
+
+def test_pad_ppgs_layout_host_and_device_paths_agree():
+    """pad_ppgs: [Tin_i, D] frames -> channel-major [B, D, Tmax] with zero tails; the path that uploads
+    time-major and transposes on the device (here device='cpu') must give the same tensor as the host path."""
+    import numpy as np
+    import torch
+    from facppg import pipeline
+    g = np.random.Generator(np.random.PCG64(3))
+    ppgs = [g.random((n, 7), dtype=np.float32) for n in (5, 1, 9)]
+    x, lens = pipeline.pad_ppgs(ppgs)
+    y, lens2 = pipeline.pad_ppgs(ppgs, device="cpu")
+    assert lens == lens2 == [5, 1, 9] and x.shape == (3, 7, 9) and x.dtype == torch.float32
+    assert torch.equal(x, y)
+    for b, p in enumerate(ppgs):
+        assert np.array_equal(x[b, :, :lens[b]].numpy(), p.T) and torch.count_nonzero(x[b, :, lens[b]:]) == 0
