@@ -1004,37 +1004,56 @@ __global__ __launch_bounds__(256) void k_begin(EdgeArgs p) {
 //   out = end(skip) ; b = out[:H], s = out[H:] ; a1 = (a1 - b)/exp(s) ; audio = W^-1 [a0; a1]
 //   EARLY: audio = cat(sigma*z, audio) ; then next flow's start conv, or the final interleave
 // ------------------------------------------------------------------------------------------
-template <int H, bool EARLY>
+template <int H, bool EARLY, bool QS>
 __global__ __launch_bounds__(256) void k_flow_end(EdgeArgs p) {
-  // 64 positions per workgroup; the four waves split the 256 skip channels of the end conv (and later the
-  // 256 output channels of the next start conv), so a launch with few positions still spreads over the chip
-  // and each thread's chain of L2 round trips is a quarter as long.  Partial sums meet in LDS, fixed order.
+  // QS (launches with few positions -- one short utterance): 64 positions per workgroup; the four waves split
+  // the 256 skip channels of the end conv (and later the 256 output channels of the next start conv), so the
+  // launch still spreads over the chip and each thread's chain of L2 round trips is a quarter as long; the
+  // partial sums meet in LDS in a fixed order.  !QS (large launches, HBM-bound): one thread per position.
   constexpr int CC = 2 * H;
-  __shared__ float red[4][CC][64];
-  const int b = blockIdx.y, pl = threadIdx.x & 63, qtr = threadIdx.x >> 6;
+  __shared__ float red[QS ? 4 : 1][CC][QS ? 64 : 1];
+  const int b = blockIdx.y, pl = QS ? (threadIdx.x & 63) : threadIdx.x, qtr = QS ? (threadIdx.x >> 6) : 0;
+  constexpr int CQ = QS ? C / 4 : C;   // channels per thread
   int pos = 0, h_off = 0, sk_off = 0;
-  const bool valid = edge_pos(p, b, blockIdx.x * 64 + pl, pos, h_off, sk_off);
+  const bool valid = edge_pos(p, b, blockIdx.x * (QS ? 64 : 256) + pl, pos, h_off, sk_off);
+  // Both shapes sum the same way -- four 64-channel chains, then bias + q0 + q1 + q2 + q3 -- so an utterance
+  // gets the same bits whichever shape its batch selects.
   float o[CC];
+  const float* sk = p.skip + (size_t)b * C * p.Lr + sk_off;
+  auto quarter = [&](int q, float (&acc)[CC]) {
 #pragma unroll
-  for (int j = 0; j < CC; ++j) o[j] = 0.0f;
-  if (valid) {
-    const float* sk = p.skip + (size_t)b * C * p.Lr + sk_off;
-    for (int c0 = qtr * 64; c0 < qtr * 64 + 64; c0 += 16) {
+    for (int j = 0; j < CC; ++j) acc[j] = 0.0f;
+    for (int c0 = q * 64; c0 < q * 64 + 64; c0 += 16) {
       float v[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) v[u] = sk[(size_t)(c0 + u) * p.Lr];
 #pragma unroll
       for (int u = 0; u < 16; ++u)
 #pragma unroll
-        for (int j = 0; j < CC; ++j) o[j] = fmaf(p.end_w[j * C + c0 + u], v[u], o[j]);
+        for (int j = 0; j < CC; ++j) acc[j] = fmaf(p.end_w[j * C + c0 + u], v[u], acc[j]);
+    }
+  };
+  if constexpr (QS) {
+#pragma unroll
+    for (int j = 0; j < CC; ++j) o[j] = 0.0f;
+    if (valid) quarter(qtr, o);
+#pragma unroll
+    for (int j = 0; j < CC; ++j) red[qtr][j][pl] = o[j];
+    __syncthreads();
+    if (!valid) return;
+#pragma unroll
+    for (int j = 0; j < CC; ++j) o[j] = p.end_b[j] + red[0][j][pl] + red[1][j][pl] + red[2][j][pl] + red[3][j][pl];
+  } else {
+    if (!valid) return;
+#pragma unroll
+    for (int j = 0; j < CC; ++j) o[j] = p.end_b[j];
+    for (int q = 0; q < 4; ++q) {
+      float acc[CC];
+      quarter(q, acc);
+#pragma unroll
+      for (int j = 0; j < CC; ++j) o[j] += acc[j];
     }
   }
-#pragma unroll
-  for (int j = 0; j < CC; ++j) red[qtr][j][pl] = o[j];
-  __syncthreads();
-  if (!valid) return;
-#pragma unroll
-  for (int j = 0; j < CC; ++j) o[j] = p.end_b[j] + red[0][j][pl] + red[1][j][pl] + red[2][j][pl] + red[3][j][pl];
   float a[CC];
 #pragma unroll
   for (int j = 0; j < CC; ++j) a[j] = p.aud_in[((size_t)b * 8 + j) * p.La + pos];
@@ -1068,7 +1087,7 @@ __global__ __launch_bounds__(256) void k_flow_end(EdgeArgs p) {
 #pragma unroll
       for (int j = 0; j < CN; ++j) p.aud_out[((size_t)b * 8 + j) * p.La + pos] = y[j];
     }
-    start_conv<CN / 2>(p, b, h_off, y + (p.swap_next ? CN / 2 : 0), qtr * 64, 64);
+    start_conv<CN / 2>(p, b, h_off, y + (p.swap_next ? CN / 2 : 0), qtr * CQ, CQ);
   }
 }
 
@@ -1459,9 +1478,14 @@ extern "C" int facppg_wg_last_layer_ms(facppg_wg* h, float* avg_ms, int* n_launc
 }
 
 template <int H>
-static void launch_flow_end(bool early, dim3 grid, hipStream_t s, const EdgeArgs& a) {
-  if (early) k_flow_end<H, true><<<grid, 256, 0, s>>>(a);
-  else k_flow_end<H, false><<<grid, 256, 0, s>>>(a);
+static void launch_flow_end(bool early, bool qs, dim3 grid, hipStream_t s, const EdgeArgs& a) {
+  if (qs) {
+    if (early) k_flow_end<H, true, true><<<grid, 256, 0, s>>>(a);
+    else k_flow_end<H, false, true><<<grid, 256, 0, s>>>(a);
+  } else {
+    if (early) k_flow_end<H, true, false><<<grid, 256, 0, s>>>(a);
+    else k_flow_end<H, false, false><<<grid, 256, 0, s>>>(a);
+  }
 }
 
 template <int HN>
@@ -1494,7 +1518,8 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   e.La = w.La; e.P = w.P; e.Tr = w.Tr; e.Tqp = w.Tqp;
   e.final_audio = audio_dev;
   const dim3 egrid((T + 255) / 256, B, w.P);
-  const dim3 fgrid((T + 63) / 64, B, w.P);   // k_flow_end: 64 positions per workgroup
+  const bool fqs = (long)B * w.L < 65536;   // k_flow_end: split channels over the waves when positions are few
+  const dim3 fgrid(fqs ? (T + 63) / 64 : (T + 255) / 256, B, w.P);
   int ai = 0, hi = 0;
   {
     const int k = nf - 1;
@@ -1584,10 +1609,10 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
     if (k > 0) FACPPG_REQUIRE(cn == 2 * h->n_half[k - 1], FACPPG_EUNSUPPORTED, "flow %d channel mismatch", k);
     else FACPPG_REQUIRE(cn == 8, FACPPG_EUNSUPPORTED, "final flow must yield n_group channels");
     switch (h->n_half[k]) {
-      case 1: launch_flow_end<1>(h->early[k], fgrid, s, e); break;
-      case 2: launch_flow_end<2>(h->early[k], fgrid, s, e); break;
-      case 3: launch_flow_end<3>(h->early[k], fgrid, s, e); break;
-      case 4: launch_flow_end<4>(h->early[k], fgrid, s, e); break;
+      case 1: launch_flow_end<1>(h->early[k], fqs, fgrid, s, e); break;
+      case 2: launch_flow_end<2>(h->early[k], fqs, fgrid, s, e); break;
+      case 3: launch_flow_end<3>(h->early[k], fqs, fgrid, s, e); break;
+      case 4: launch_flow_end<4>(h->early[k], fqs, fgrid, s, e); break;
       default: FACPPG_REQUIRE(false, FACPPG_EUNSUPPORTED, "n_half %d", h->n_half[k]);
     }
     ai ^= 1;
@@ -1649,7 +1674,8 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
   e.La = w.Lr;
   e.final_audio = audio_dev;
   const dim3 egrid((w.L + 255) / 256, B);
-  const dim3 fgrid((w.L + 63) / 64, B);
+  const bool fqs = (long)B * w.L < 65536;
+  const dim3 fgrid(fqs ? (w.L + 63) / 64 : (w.L + 255) / 256, B);
   int ai = 0, hi = 0;  // current audio / h buffer
   {
     const int k = nf - 1;
@@ -1709,10 +1735,10 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
     if (k > 0) FACPPG_REQUIRE(cn == 2 * h->n_half[k - 1], FACPPG_EUNSUPPORTED, "flow %d channel mismatch", k);
     else FACPPG_REQUIRE(cn == 8, FACPPG_EUNSUPPORTED, "final flow must yield n_group channels");
     switch (h->n_half[k]) {
-      case 1: launch_flow_end<1>(h->early[k], fgrid, s, e); break;
-      case 2: launch_flow_end<2>(h->early[k], fgrid, s, e); break;
-      case 3: launch_flow_end<3>(h->early[k], fgrid, s, e); break;
-      case 4: launch_flow_end<4>(h->early[k], fgrid, s, e); break;
+      case 1: launch_flow_end<1>(h->early[k], fqs, fgrid, s, e); break;
+      case 2: launch_flow_end<2>(h->early[k], fqs, fgrid, s, e); break;
+      case 3: launch_flow_end<3>(h->early[k], fqs, fgrid, s, e); break;
+      case 4: launch_flow_end<4>(h->early[k], fqs, fgrid, s, e); break;
       default: FACPPG_REQUIRE(false, FACPPG_EUNSUPPORTED, "n_half %d", h->n_half[k]);
     }
     ai ^= 1;
