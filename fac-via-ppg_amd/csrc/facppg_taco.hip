@@ -302,6 +302,7 @@ struct DecArgs {
   float* align;          // [B][max_steps][Tin] or null
   int* out_len;          // [B]
   int B, Tin, E, P, A, D, AD, NF, NFIL, KSZ, window, max_steps, U;
+  int b0;                // k_decoder_coop: first utterance of this launch (large batches run in chunks)
   float gate_thr;
 };
 
@@ -704,7 +705,7 @@ __global__ __launch_bounds__(NTC) void k_decoder_coop(DecArgs p) {
   extern __shared__ float sm[];
   __shared__ int s_stop;
   __shared__ float c_att[160], c_dec[160];   // U <= 160 units per workgroup
-  const int wg = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int wg = blockIdx.x, b = p.b0 + blockIdx.y, tid = threadIdx.x;
   const bool leader = wg == 0;
   const int len = p.lengths ? p.lengths[b] : p.Tin;
   DecLds L;
@@ -1417,6 +1418,10 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
   const char* force_u = getenv("FACPPG_DECODER_COOP_U");   // tests / tuning: a specific slice width
   for (int v = 0; v < 5 && variant < 0; ++v)
     if ((long)B * h->coop_nwg[v] <= h->coop_limit && (!force_u || atoi(force_u) == h->coop_U[v])) variant = v;
+  // beyond that the widest slices run the batch in chunks of co-resident utterances, one cooperative launch
+  // after the other (0.31 ms per utterance at 200 frames; the one-workgroup kernel needs 0.45)
+  int chunk = B;
+  if (variant < 0 && !force_u && h->coop_limit / h->coop_nwg[4] >= 1) { variant = 4; chunk = h->coop_limit / h->coop_nwg[4]; }
   bool coop = variant >= 0;
   if (mode && !strcmp(mode, "single")) coop = false;
   if (mode && !strcmp(mode, "coop")) FACPPG_REQUIRE(coop, FACPPG_EUNSUPPORTED, "coop decoder needs B <= 120");
@@ -1460,8 +1465,16 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
     FACPPG_HIP_CHECK(hipMemsetAsync(ws + w.xchg, 0, w.total - w.xchg, s));
     const void* fn = (const void*)k_decoder_coop;
     FACPPG_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    void* args[] = {(void*)&a};
-    FACPPG_HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(h->coop_nwg[variant], B), dim3(NTC), args, smem, s));
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+      const int nb = B - b0 < chunk ? B - b0 : chunk;
+      int cv = variant;   // the last chunk may be small enough for narrower slices
+      if (!force_u)
+        for (int v = 0; v < variant; ++v)
+          if ((long)nb * h->coop_nwg[v] <= h->coop_limit) { cv = v; break; }
+      a.b0 = b0; a.att_coop = h->att_coop[cv]; a.dec_coop = h->dec_coop[cv]; a.U = h->coop_U[cv];
+      void* args[] = {(void*)&a};
+      FACPPG_HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(h->coop_nwg[cv], nb), dim3(NTC), args, smem, s));
+    }
     if (a.prof) {
       long long pr[16];
       FACPPG_HIP_CHECK(hipMemcpyAsync(pr, a.prof, sizeof(pr), hipMemcpyDeviceToHost, s));

@@ -258,8 +258,8 @@ int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const int32_t* leng
  * Outputs: mel_dev [B][n_feat][max_steps], gate_dev [B][max_steps], align_dev NULL or
  * [B][max_steps][Tin], out_lengths_dev [B] (= Tout per utterance; columns beyond it untouched).
  * One launch for the whole loop.  The launch shape follows B: up to 9 utterances run as one attention
- * workgroup each plus register-resident dense-layer workers shared by 1-3 of them, up to 120 as 2-38 cooperating workgroups,
- * beyond that one workgroup per utterance; the first two use hipLaunchCooperativeKernel (the workgroups
+ * workgroup each plus register-resident dense-layer workers shared by 1-3 of them, up to 120 as 2-38 cooperating workgroups
+ * (larger batches in chunks of 120), one workgroup per utterance as the fallback; the first two use hipLaunchCooperativeKernel (the workgroups
  * of an utterance must be co-resident) and every shape returns the same values to fp32 round-off.
  * FACPPG_DECODER_MODE=split|coop|single forces one (FACPPG_EUNSUPPORTED if B does not allow it). */
 int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const float* pm_dev,

@@ -108,3 +108,31 @@ def test_padded_batch_equals_independent_runs(mode, lens, monkeypatch):
         assert torch.equal(sm[0], mel[b, :, :To]) and torch.equal(sp[0], mel_post[b, :, :To])
         assert torch.equal(sa[0], align[b, :To, :n])
         assert torch.count_nonzero(mel_post[b, :, To:]) == 0
+
+
+def test_large_batch_runs_in_chunks_and_matches_single_runs():
+    """B = 130 exceeds what one cooperative launch can keep co-resident (120 utterances at 2 workgroups
+    each): the decoder runs it in chunks.  Spot-check utterances from both chunks against their own
+    batch-1 runs (other launch shape: equal to fp32 round-off, stop step exact)."""
+    d, hp, sd, ppg, em, dm = tacotron_case("stop")
+    m = build(hp, sd)
+    from facppg import synth
+    g = np.random.Generator(np.random.PCG64(9))
+    B, steps = 130, int(d["max_steps"])
+    lens = (8 + g.integers(0, 17, size=B)).tolist()
+    Tin = max(lens)
+    x = torch.zeros(B, ppg.shape[1], Tin)
+    for b, n in enumerate(lens):
+        x[b, :, :n] = torch.from_numpy(synth.synthetic_ppg(n, ppg.shape[1], seed=100 + b)).t()
+    emb = (g.random((2, B, Tin, 600)) < 0.5).astype(np.uint8)
+    dmb = (g.random((steps, 2, B, 300)) < 0.5).astype(np.uint8)
+    mel, mel_post, gate, align = m.inference(x.cuda(), lengths=lens, dropout_masks=(emb, dmb))
+    out_lens = m.last_output_lengths.tolist()
+    assert all(1 <= t <= steps for t in out_lens)
+    for b in (0, 57, 119, 120, 129):
+        n = lens[b]
+        sm, sp, sg, sa = m.inference(x[b:b + 1, :, :n].contiguous().cuda(), dropout_masks=(emb[:, b:b + 1, :n], dmb[:, :, b:b + 1]))
+        To = sm.shape[2]
+        assert To == out_lens[b]
+        assert (sp[0] - mel_post[b, :, :To]).abs().max().item() <= 1e-4
+        assert torch.count_nonzero(mel_post[b, :, To:]) == 0
