@@ -46,6 +46,7 @@ struct facppg_taco {
   float *att_coop[5], *dec_coop[5];
   int coop_U[5], coop_nwg[5];
   float *att_w4, *dec_w4;          // 4-unit slices for k_decoder_split's workers
+  float *w1p_t, *b1p;              // prenet layer 1 composed with the projection: [D+E][Pp] k-major, [Pp]
   int split_nwk;
   // postnet
   float4* post[8];
@@ -94,6 +95,22 @@ __global__ void k_pack_coop(const float* __restrict__ src_t, float* __restrict__
   const int col = (int)(i % SC), k = (int)((i / SC) % K), wg = (int)(i / ((size_t)SC * K));
   const int u = wg * U + col % U;
   dst[i] = u < A ? src_t[(size_t)k * 4 * A + (col / U) * A + u] : 0.0f;
+}
+
+// Prenet layer 1 applied to the projection's output is linear in [dh | ctx] until its ReLU:
+//   W1 (Wp v + bp) = (W1 Wp) v + W1 bp.   w1p_t[k][r] = sum_m proj_t[k][m] * dp0_t[m][r]  (row KP = the bias term)
+// The split decoder's workers use it to start the prenet straight from the decoder state, without waiting
+// for the mel frame to cross workgroups.
+__global__ void k_fold_prenet(const float* __restrict__ proj_t, const float* __restrict__ proj_b, const float* __restrict__ dp0_t,
+                              float* __restrict__ w1p_t, float* __restrict__ b1p, int KP, int NF, int NFp, int Pp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (KP + 1) * Pp) return;
+  const int k = i / Pp, r = i % Pp;
+  const float* a = k < KP ? proj_t + (size_t)k * NFp : proj_b;
+  float v = 0.0f;
+  for (int m = 0; m < NF; ++m) v = fmaf(a[m], dp0_t[(size_t)m * Pp + r], v);
+  if (k < KP) w1p_t[i] = v;
+  else b1p[r] = v;
 }
 
 // Philox-free cheap keep-mask: one 64-bit SplitMix hash per element (p = 0.5 Bernoulli).
@@ -291,6 +308,7 @@ struct DecArgs {
   const float *att_coop, *dec_coop;  // [NWG][K][4U] slices (coop mode)
   unsigned long long* xchg;   // [B][2][A] {value, frame tag} hidden-state exchange words (coop mode)
   const float *att_w4, *dec_w4;   // [NWK][K][16] slices of 4 units (split mode workers)
+  const float *w1p_t, *b1p;       // prenet-1 o projection (split mode workers)
   unsigned long long* xsplit;     // [B][NF + 1 + 2P + A + E + D + 8] exchange words of the split decoder
   long long* prof;       // optional [8] phase cycle counters (debug; FACPPG_DECODER_PROF=1)
   const float* memory;   // [B][Tin][E]
@@ -880,11 +898,13 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
     float* part = sm + (size_t)NU * ustride;   // 1024 floats
     for (int i = tid; i < NU * ustride + 1024; i += NTC) sm[i] = 0.0f;
     if (tid < SNU * SU) { (&c_att[0][0])[tid] = 0.0f; (&c_dec[0][0])[tid] = 0.0f; }
-    float w_att[SKR_LSTM], w_dec[SKR_LSTM], w_proj[SKR_PROJ], w_p1[SKR_P1], w_p2[SKR_P2];
+    // w_p1 holds rows of W1.Wp (prenet layer 1 composed with the projection, k_fold_prenet): the prenet
+    // starts from [dh | ctx] in the same stage as the projection, one exchange earlier
+    float w_att[SKR_LSTM], w_dec[SKR_LSTM], w_proj[SKR_PROJ], w_p1[SKR_PROJ], w_p2[SKR_P2];
     stat_load(w_att, p.att_w4 + (size_t)wg * KA * SSC, SSC, 0, SSC, KA, tid);
     stat_load(w_dec, p.dec_w4 + (size_t)wg * KD * SSC, SSC, 0, SSC, KD, tid);
     stat_load(w_proj, p.proj_t, round_up(p.NF + 1, 4), row0, p.NF + 1, KP, tid);
-    stat_load(w_p1, p.dp0_t, round_up(p.P, 4), row0, p.P, p.NF, tid);
+    stat_load(w_p1, p.w1p_t, round_up(p.P, 4), row0, p.P, KP, tid);
     stat_load(w_p2, p.dp1_t, round_up(p.P, 4), row0, p.P, p.P, tid);
     const bool has_proj = row0 < p.NF + 1, has_pre = row0 < p.P;
     unsigned alive = 0;   // bit u: utterance u of the group is still decoding (identical in every workgroup)
@@ -909,34 +929,33 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
           if (tid < SSC && row0 + tid <= p.NF) {
             const int row = row0 + tid;
             const float v = part[512 + u * SSC + tid] + p.proj_b[row];
-            xpub(MEL + row, v, tag);
             if (row < p.NF) p.mel[((size_t)b * p.NF + row) * p.max_steps + t - 1] = v;
-            else p.gate[(size_t)b * p.max_steps + t - 1] = v;
+            else { p.gate[(size_t)b * p.max_steps + t - 1] = v; xpub(MEL + row, v, tag); }   // only the gate crosses workgroups
           }
+        }
+        // prenet layer 1 of frame t from the same [dh | ctx]: relu((W1 Wp) v + W1 bp), dropout  (model.py:132-135)
+        if (has_pre) stat_mv16n<SKR_PROJ, NU>(w_p1, KP, sm + KA + KD, ustride, alive, part, tid);
+        if (has_pre) FOR_ALIVE(u) {
+          UTT(u);
+          const uint8_t* mk = p.masks + ((size_t)t * 2 * p.B + b) * p.P;
+          if (tid < SSC && row0 + tid < p.P)
+            xpub(X1 + row0 + tid, fmaxf(part[512 + u * SSC + tid] + p.b1p[row0 + tid], 0.0f) * (float)mk[row0 + tid] * 2.0f, tag);
         }
         FOR_ALIVE(u) {
           UTT(u);
-          for (int i = tid; i < p.NF; i += NTC) xin[i] = xwait(MEL + i, tag);
           if (tid == 0) s_stop[u] = sigm(xwait(MEL + p.NF, tag)) > p.gate_thr || t == p.max_steps;
         }
         __syncthreads();
         for (int u = 0; u < NU; ++u)
           if (s_stop[u]) alive &= ~(1u << u);
         if (!alive) break;
+        FOR_ALIVE(u) {
+          UTT(u);
+          for (int i = tid; i < p.P; i += NTC) p1[i] = xwait(X1 + i, tag);
+        }
+        __syncthreads();
       }
-      // prenet: 2 x (Linear no bias, ReLU, dropout p=0.5 always on)  (model.py:132-135)
-      if (has_pre) stat_mv16n<SKR_P1, NU>(w_p1, p.NF, sm + KA + KD + KP, ustride, alive, part, tid);
-      if (has_pre) FOR_ALIVE(u) {
-        UTT(u);
-        const uint8_t* mk = p.masks + ((size_t)t * 2 * p.B + b) * p.P;
-        if (tid < SSC && row0 + tid < p.P)
-          xpub(X1 + row0 + tid, fmaxf(part[512 + u * SSC + tid], 0.0f) * (float)mk[row0 + tid] * 2.0f, tag);
-      }
-      FOR_ALIVE(u) {
-        UTT(u);
-        for (int i = tid; i < p.P; i += NTC) p1[i] = xwait(X1 + i, tag);
-      }
-      __syncthreads();
+      // (frame 0: the go frame is zero and the prenet has no bias, so p1 = 0 as initialised)
       if (has_pre) stat_mv16n<SKR_P2, NU>(w_p2, p.P, sm + KA + KD + KP + round_up(p.NF, 4), ustride, alive, part, tid);
       if (has_pre) FOR_ALIVE(u) {
         UTT(u);
@@ -1136,7 +1155,7 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   struct { size_t pre0, pre1, conv[8], conv_b[8], conv_sc[8], conv_sh[8], wih, whh[2], lstm_b, mem_w, dp0, dp1, att, att_b, dec, dec_b, q,
-           proj, proj_b, lc, ld, v, attc[5], decc[5], att4, dec4, post[8], post_b[8], post_sc[8], post_sh[8]; } o;
+           proj, proj_b, lc, ld, v, attc[5], decc[5], att4, dec4, w1p, b1p, post[8], post_b[8], post_sc[8], post_sh[8]; } o;
   o.pre0 = take(packed_a_float4s(S, c.n_symbols) * 16);
   o.pre1 = take(packed_a_float4s(S, S) * 16);
   for (int j = 0; j < c.encoder_n_convolutions; ++j) {
@@ -1159,6 +1178,7 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
   }
   const int nwk = (A + 3) / 4;   // k_decoder_split workers: 4 units each
   o.att4 = take((size_t)nwk * (P + E + A) * 16 * 4); o.dec4 = take((size_t)nwk * (A + E + D) * 16 * 4);
+  o.w1p = take((size_t)(D + E) * Pp * 4); o.b1p = take((size_t)Pp * 4);
   o.lc = take((size_t)NFIL * 2 * KSZ * 4); o.ld = take((size_t)AD * NFIL * 4); o.v = take((size_t)AD * 4);
   for (int j = 0; j < c.postnet_n_convolutions; ++j) {
     const int ci = j == 0 ? NF : PE, co = j == c.postnet_n_convolutions - 1 ? NF : PE;
@@ -1253,6 +1273,9 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
     hipok(hipMemcpy2DAsync(h->proj_t + NF, (size_t)NFp * 4, gw, 4, 4, D + E, hipMemcpyDeviceToDevice, s));
     cpy(h->proj_b, pb, NF);
     cpy(h->proj_b + NF, gb, 1);
+    h->w1p_t = F(o.w1p); h->b1p = F(o.b1p);
+    const int n = (D + E + 1) * Pp;
+    k_fold_prenet<<<(n + 255) / 256, 256, 0, s>>>(h->proj_t, h->proj_b, h->dp0_t, h->w1p_t, h->b1p, D + E, NF, NFp, Pp);
   }
   for (int j = 0; j < c.postnet_n_convolutions; ++j) {
     const int ci = j == 0 ? NF : PE, co = j == c.postnet_n_convolutions - 1 ? NF : PE;
@@ -1445,6 +1468,7 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
   if (mode && !strcmp(mode, "split")) FACPPG_REQUIRE(split, FACPPG_EUNSUPPORTED, "split decoder needs a small batch and the reference's layer widths");
   if (split) {
     a.att_w4 = h->att_w4; a.dec_w4 = h->dec_w4; a.xsplit = (unsigned long long*)(ws + w.xsplit);
+    a.w1p_t = h->w1p_t; a.b1p = h->b1p;
     FACPPG_HIP_CHECK(hipMemsetAsync(ws + w.xchg, 0, w.total - w.xchg, s));
     size_t ssm = (NU * ustride + 1024) * 4;
     if (ssm < smem) ssm = smem;
