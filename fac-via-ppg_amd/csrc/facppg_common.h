@@ -40,4 +40,11 @@ __device__ __forceinline__ f32x16 mfma32x32x2(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f32_16x16x4_f32: D[16x16] += A[16x4] * B[4x16].  Lane l supplies A[l % 16][l / 16] and
+// B[l / 16][l % 16]; it holds D[4 * (l / 16) + r][l % 16] in c[r].
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16x16x4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
 }  // namespace facppg

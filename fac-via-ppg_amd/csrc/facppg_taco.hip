@@ -493,9 +493,15 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
     if (!(feat_ready && c0 == lo)) attn_features<NT>(p, L, c0, nc, tid);
     __syncthreads();
     APROF(9)
-    // energies: one (32 attention dims, 32 positions) block per wave and round
-    for (int pr = wave; pr < 2 * NRB; pr += NT / 64) {
-      const int rb = pr >> 1, cb = pr & 1;
+    // energies: one (32 attention dims, 32 positions) block per wave and round.  The reference's window is 41
+    // positions: a second position block would be 72 % padding and a second round for two of the waves, so
+    // when the tail beyond 32 positions is at most 16 the waves without a row block take it as 16x16x4 MFMA
+    // tiles and everything finishes in one round.
+    constexpr int NW = NT / 64;
+    const int ntail = nc - 32;
+    const bool tail_valu = ntail > 0 && ntail <= 16 && NW > NRB;
+    for (int pr = wave; pr < (tail_valu ? NRB : 2 * NRB); pr += NW) {
+      const int rb = tail_valu ? pr : pr >> 1, cb = tail_valu ? 0 : pr & 1;
       if (32 * cb >= nc) continue;
       const int pos = 32 * cb + li;
       // processed-memory values of this lane's 16 rows, fetched up front (L2 latency under the MFMAs)
@@ -523,10 +529,40 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
       e += __shfl_xor(e, 32);
       if (kh == 0) epart[rb * 64 + pos] = e;
     }
+    if (tail_valu && wave >= NRB) {
+      // tail positions 32 .. 32+ntail-1 as (16 attention dims x 16 positions) tiles of the 16x16x4 MFMA
+      const int pl = lane & 15, kq = lane >> 4, pos = 32 + pl;
+      float et = 0.0f;
+      for (int tile = wave - NRB; tile * 16 < p.AD; tile += NW - NRB) {
+        float pmv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int a = 16 * tile + 4 * kq + r;
+          pmv[r] = (pl < ntail && a < p.AD) ? pm[(size_t)a * p.Tin + c0 + pos] : 0.0f;
+        }
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+          const int f = 4 * s2 + kq;
+          acc = mfma16x16x4(L.ldense[f * L.AD32 + 16 * tile + pl], L.feat[f * 64 + pos], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int a = 16 * tile + 4 * kq + r;   // a < AD32: vv is zero past AD
+          et = fmaf(L.vv[a], tanh_fast(L.pq[a] + acc[r] + pmv[r]), et);
+        }
+      }
+      et += __shfl_xor(et, 16);
+      et += __shfl_xor(et, 32);
+      if (lane < 16) epart[NRB * 64 + (wave - NRB) * 16 + lane] = et;   // one partial per free wave
+    }
     __syncthreads();
     if (tid < nc) {
       float e = 0.0f;
-      for (int j = 0; j < NRB; ++j) e += epart[j * 64 + tid];
+      if (tail_valu && tid >= 32)
+        for (int j = 0; j < NW - NRB; ++j) e += epart[NRB * 64 + j * 16 + tid - 32];
+      else
+        for (int j = 0; j < NRB; ++j) e += epart[j * 64 + tid];
       L.en[c0 + tid] = e;
     }
     __syncthreads();
