@@ -61,6 +61,10 @@ constexpr int NG1 = K1 / 8;   // 176 k-groups of 8
 constexpr int NG2 = C / 8;    // 32
 constexpr int NCH1 = K1 / KCH;  // 22 chunks
 constexpr int MAXF = 32;      // max flows
+#ifndef FACPPG_COST16_FULL
+#define FACPPG_COST16_FULL 105   // microseconds per round of 16-frame tiles: full round / at most one workgroup per CU
+#define FACPPG_COST16_HALF 57
+#endif
 #ifndef FACPPG_NARROW_RING
 #define FACPPG_NARROW_RING 8  // weight prefetch depth (k-groups) of the 32-column tiles, see k_wn_layer
 #endif
@@ -143,6 +147,54 @@ __global__ void k_pack_cond_pm(const float* __restrict__ F,   // [512][P*kcp] fo
   const int row = rowmap(wr >> 2, wr & 3, lane & 31);
   const float* src = F + (size_t)row * P * kcp + (size_t)ph * kcp + 8 * g + 4 * (lane >> 5);
   out[idx] = make_float4(src[0], src[1], src[2], src[3]);
+}
+
+// Images for the 16-frame tile kernel (k_wn_layer16, v_mfma_f32_16x16x4_f32): float4 index
+// (g16*NB + blk)*64 + lane holds, for output row row16(blk, lane % 16) and kq = lane / 16, the K entries
+// 16*g16 + 4*s + kq for s = 0..3 -- the A operands of the four MFMAs of one 16-wide K group.  blk orders the
+// 16-row blocks wave by wave: blk = w8*4 + rbl -> rows (rbl>>1)*256 + 32*w8 + 16*(rbl&1) + i  (NB = 32), or
+// for the 256-row last res_skip layer blk = w8*2 + rbl -> rows 32*w8 + 16*rbl + i  (NB = 16).
+// K order inside a 16-wide group: MFMA s, lane quarter kq -> k16(s, kq).  It is chosen so that the running sum
+// meets the K entries in the same sequence as the 32x32x2 kernels do (0,4,1,5,2,6,3,7 within each group of 8):
+// a tile then gets the same bits from either kernel, and a batch equals its single runs whatever tile width
+// each launch picks.
+__device__ __forceinline__ int k16(int s, int kq) { return 8 * (s >> 1) + 2 * (s & 1) + (kq >> 1) + 4 * (kq & 1); }
+__device__ __forceinline__ int row16(int blk, int i) { return ((blk & 3) >> 1) * C + (blk >> 2) * 32 + (blk & 1) * 16 + i; }
+
+__global__ void k_pack_w1_16(const float* __restrict__ in_w, float4* __restrict__ out) {   // [512][256][3] -> K = 768
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (3 * C / 16) * 32 * 64) return;
+  const int lane = idx & 63, blk = (idx >> 6) & 31, g = idx >> 11;
+  const int row = row16(blk, lane & 15);
+  float v[4];
+  for (int s = 0; s < 4; ++s) {
+    const int kk = 16 * g + k16(s, lane >> 4);
+    v[s] = in_w[(row * C + (kk % C)) * 3 + kk / C];
+  }
+  out[idx] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__global__ void k_pack_cond_16(const float* __restrict__ F,   // [512][P*kcp] folded matrices
+                               float4* __restrict__ out, int P, int kcp) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int ng = kcp / 16;
+  if (idx >= (size_t)P * ng * 32 * 64) return;
+  const int lane = idx & 63, blk = (idx >> 6) & 31, g = (idx >> 11) % ng, ph = (idx >> 11) / ng;
+  const float* src = F + (size_t)row16(blk, lane & 15) * P * kcp + (size_t)ph * kcp + 16 * g;
+  const int kq = lane >> 4;
+  out[idx] = make_float4(src[k16(0, kq)], src[k16(1, kq)], src[k16(2, kq)], src[k16(3, kq)]);
+}
+
+__global__ void k_pack_w2_16(const float* __restrict__ rs_w,  // [512 or 256][256]
+                             float4* __restrict__ out, int last) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nb = last ? 16 : 32;
+  if (idx >= (C / 16) * nb * 64) return;
+  const int lane = idx & 63, blk = (idx >> 6) % nb, g = (idx >> 6) / nb;
+  const int row = last ? (blk >> 1) * 32 + (blk & 1) * 16 + (lane & 15) : row16(blk, lane & 15);
+  float v[4];
+  for (int s = 0; s < 4; ++s) v[s] = rs_w[row * C + 16 * g + k16(s, lane >> 4)];
+  out[idx] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // b'[o] = in_b[o] + cond_b[o] + sum_{m,g} Wc[o][8m+g] * up_b[m]   (the upsample bias seen through the 1x1 conv)
@@ -851,6 +903,173 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_wn_layer16: the phase-major layer on 16-frame tiles with v_mfma_f32_16x16x4_f32.  A launch smaller
+// than the chip (one short utterance; anything at hop 160, whose 20 phases give few tiles) is bound by
+// tile granularity: halving the tile doubles the workgroups that share the work.  Eight waves per tile,
+// wave w8 owning channels 32*w8 .. 32*w8+31 as four 16-row blocks (two tanh, two sigmoid; then two res,
+// two skip); ~115 VGPRs, 16 KiB of LDS: two workgroups per CU.  Tiles are per utterance (no flat cut).
+// ------------------------------------------------------------------------------------------
+constexpr int TN16 = 16;
+
+template <bool LAST>
+__global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6;
+  const int pl = lane & 15, kq = lane >> 4;
+  const int chb = w8 * 32;
+  int ph, tile;
+  {
+    const int lin = blockIdx.x;
+    if (p.xcd_map) { const int r = lin >> 3; ph = (r / p.nt) * 8 + (lin & 7); tile = r % p.nt; }
+    else { ph = lin / p.nt; tile = lin % p.nt; }
+    if (ph >= p.P) return;
+  }
+  const int b = tile / p.ntq, q0 = (tile % p.ntq) * TN16;
+  const int nvalid = (p.t_valid ? p.t_valid[b] : p.T) - q0;
+  if (nvalid <= 0) return;
+  const int in_off = ph * p.Tqp + HQ + q0, sk_off = ph * p.Tr + q0;
+  int tapo[3];
+#pragma unroll
+  for (int tp = 0; tp < 3; ++tp) {
+    const int pp = ph + (tp - 1) * p.dil;
+    const int qsh = pp >= 0 ? pp / p.P : -((p.P - 1 - pp) / p.P);
+    tapo[tp] = (pp - qsh * p.P) * p.Tqp + HQ + q0 + qsh;
+  }
+  f32x4 acc[4];
+#pragma unroll
+  for (int rbl = 0; rbl < 4; ++rbl) {
+    const float4 bv = *reinterpret_cast<const float4*>(p.b1 + (rbl >> 1) * C + chb + (rbl & 1) * 16 + 4 * kq);
+    acc[rbl][0] = bv.x; acc[rbl][1] = bv.y; acc[rbl][2] = bv.z; acc[rbl][3] = bv.w;
+  }
+  const float4* wave_a = p.w1 + (w8 * 4) * 64 + lane;                                    // + g16 * 2048 + rbl * 64
+  const float4* wave_c = p.wc + (size_t)ph * (p.ngc / 2) * 2048 + (w8 * 4) * 64 + lane;   // ngc counts 8-wide groups
+  const int nch = pm_chunks(p, ph), NGH16 = NCHH * 4;
+  // staging: a chunk is 64 k-rows x 16 frames = 1024 floats, two per thread
+  const int srow = tid >> 3, scol = (tid & 7) * 2;
+  const float* hb = p.h_in + (size_t)b * C * p.Lp + scol;
+  const float* sb = p.melp + (size_t)b * NMEL * p.Tqp + HQ + q0 + scol;
+  typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+  float2 stg;
+  auto stage_load = [&](int c) {
+    const bool conv = c < NCHH;
+    const int r = min((c - NCHH) * 64 + srow, p.kc - 1);
+    const int j = r / NMEL, m = r - j * NMEL;
+    const float* src = conv ? hb + (size_t)((c & 3) * 64 + srow) * p.Lp + (c < 4 ? tapo[0] : c < 8 ? tapo[1] : tapo[2])
+                            : sb + m * p.Tqp - j;
+    const f2u v = *reinterpret_cast<const f2u*>(src);
+    stg = make_float2(v.x, v.y);
+  };
+  auto stage_write = [&](int buf) { *reinterpret_cast<float2*>(smem + buf * (KCH * TN16) + srow * TN16 + scol) = stg; };
+  auto load_a = [&](float4 (&a)[4], int gg) {   // gg = 16-wide K group over [conv | cond]
+    const float4* src = gg < NGH16 ? wave_a + (size_t)gg * 2048 : wave_c + (size_t)(gg - NGH16) * 2048;
+#pragma unroll
+    for (int rbl = 0; rbl < 4; ++rbl) a[rbl] = src[rbl * 64];
+  };
+  constexpr int RING = 4;
+  float4 ar[RING][4];
+  stage_load(0);
+#pragma unroll
+  for (int i = 0; i < RING - 1; ++i) load_a(ar[i], i);
+  stage_write(0);
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+    stage_load(c + 1 < nch ? c + 1 : c);
+    const float* lb = smem + (c & 1) * (KCH * TN16) + k16(0, kq) * TN16 + pl;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      load_a(ar[(g + RING - 1) % RING], c * 4 + g + RING - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      float bq[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bq[s] = lb[(16 * g + k16(s, 0)) * TN16];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int rbl = 0; rbl < 4; ++rbl) {
+          const float4& a4 = ar[g % RING][rbl];
+          acc[rbl] = mfma16x16x4(s == 0 ? a4.x : s == 1 ? a4.y : s == 2 ? a4.z : a4.w, bq[s], acc[rbl]);
+        }
+    }
+    stage_write((c + 1) & 1);
+    __syncthreads();
+  }
+  // gate -> LDS [256][16]
+#pragma unroll
+  for (int rbl = 0; rbl < 2; ++rbl)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) smem[(chb + 16 * rbl + 4 * kq + r) * TN16 + pl] = gate_tanh_sigmoid(acc[rbl][r], acc[rbl + 2][r]);
+  __syncthreads();
+  // res_skip 1x1 conv: blocks rbl 0,1 = res rows chb.., rbl 2,3 = skip rows 256+chb.. (LAST: rbl 0,1 = skip rows chb..)
+  constexpr int NB2 = LAST ? 2 : 4;
+#pragma unroll
+  for (int rbl = 0; rbl < NB2; ++rbl) {
+    const float4 bv = *reinterpret_cast<const float4*>(p.b2 + (LAST ? 0 : (rbl >> 1) * C) + chb + (rbl & 1) * 16 + 4 * kq);
+    acc[rbl][0] = bv.x; acc[rbl][1] = bv.y; acc[rbl][2] = bv.z; acc[rbl][3] = bv.w;
+  }
+  {
+    const float4* ap2 = p.w2 + (w8 * NB2) * 64 + lane;   // [g16][NB2*8 blocks][64]
+    const float* lb = smem + k16(0, kq) * TN16 + pl;
+    auto load_a2 = [&](float4 (&a)[4], int g) {
+#pragma unroll
+      for (int rbl = 0; rbl < NB2; ++rbl) a[rbl] = ap2[(size_t)g * (NB2 * 8 * 64) + rbl * 64];
+    };
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i) load_a2(ar[i], i);
+    for (int c = 0; c < C / 64; ++c) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        load_a2(ar[(g + RING - 1) % RING], c * 4 + g + RING - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        float bq[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bq[s] = lb[(64 * c + 16 * g + k16(s, 0)) * TN16];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int rbl = 0; rbl < NB2; ++rbl) {
+            const float4& a4 = ar[g % RING][rbl];
+            acc[rbl] = mfma16x16x4(s == 0 ? a4.x : s == 1 ? a4.y : s == 2 ? a4.z : a4.w, bq[s], acc[rbl]);
+          }
+      }
+    }
+  }
+  // epilogue through a private [32][16] LDS slab per wave, 16-byte row segments to HBM
+  __syncthreads();
+  float* slab = smem + w8 * (32 * TN16);
+  const int erow = lane >> 2, ecol = (lane & 3) * 4;   // 16 rows x 4 float4 per pass, two passes
+#pragma unroll
+  for (int half = 0; half < NB2 / 2; ++half) {
+    const bool is_res = !LAST && half == 0;
+#pragma unroll
+    for (int rbl = 0; rbl < 2; ++rbl)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[(16 * rbl + 4 * kq + r) * TN16 + pl] = acc[half * 2 + rbl][r];
+    const int nv = nvalid - ecol;
+    if (nv <= 0) continue;
+    float* gbase = is_res ? p.h_out + (size_t)b * C * p.Lp + in_off + ecol : p.skip + (size_t)b * C * p.Lr + sk_off + ecol;
+    const float* rbase = is_res ? p.h_in + (size_t)b * C * p.Lp + in_off + ecol : gbase;
+    const int pitch = is_res ? p.Lp : p.Lr;
+    const bool add = is_res || !p.first;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = it * 16 + erow;
+      const size_t o = (size_t)(chb + row) * pitch;
+      float4 v = *reinterpret_cast<const float4*>(slab + row * TN16 + ecol);
+      if (nv >= 4) {
+        if (add) {
+          const float4 x = *reinterpret_cast<const float4*>(rbase + o);
+          v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+        }
+        *reinterpret_cast<float4*>(gbase + o) = v;
+      } else {
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        for (int k = 0; k < nv; ++k) gbase[o + k] = vv[k] + (add ? rbase[o + k] : 0.0f);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_upsample: ConvTranspose1d(n_mel, n_mel, K, stride=hop) + trim + regroup (glow.py:253-259)
 // out[m][n] = bias[m] + sum_{m'} sum_{t: 0 <= n - t*hop < K} mel[m'][t] * W[m'][m][n - t*hop]
 // One workgroup = (batch b, output channel m, block of QB frames).  Thread p owns the `hop`-phase
@@ -1210,6 +1429,7 @@ struct facppg_wg {
   float4* w1pm[MAXF][8];
   float4* wcpm[MAXF][8];
   float* b1pm[MAXF][8];
+  float4 *w1_16[MAXF][8], *wc_16[MAXF][8], *w2_16[MAXF][8];   // the same weights as k_wn_layer16's 16x16x4 images
   int profiling;
   std::vector<hipEvent_t> ev;  // pairs around each k_wn_layer launch
   int ev_used;
@@ -1284,7 +1504,7 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   const size_t nm = cfg->n_mel_channels;
   const size_t w1_bytes = (size_t)(16 * NG1 + 8) * 64 * sizeof(float4);
   auto w2_bytes = [&](int last) { return (size_t)(4 * (last ? 2 : 4) * NG2 + 8) * 64 * sizeof(float4); };
-  struct Off { size_t start_w, start_b, end_w, end_b, winv, wfwd, w1[8], w2[8], b1[8], b2[8], w1pm[8], wcpm[8], b1pm[8]; } fo[MAXF];
+  struct Off { size_t start_w, start_b, end_w, end_b, winv, wfwd, w1[8], w2[8], b1[8], b2[8], w1pm[8], wcpm[8], b1pm[8], w1_16[8], wc_16[8], w2_16[8]; } fo[MAXF];
   h->P = cfg->hop_length / 8;
   h->nj = (cfg->upsample_kernel + cfg->hop_length - 1) / cfg->hop_length;
   h->kc = h->nj * NMEL;
@@ -1300,6 +1520,9 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
       fo[k].w1[i] = take(w1_bytes); fo[k].b1[i] = take(2 * C * 4);
       fo[k].w2[i] = take(w2_bytes(last)); fo[k].b2[i] = take(2 * C * 4);
       fo[k].w1pm[i] = take(w1pm_bytes); fo[k].wcpm[i] = take(wcpm_bytes); fo[k].b1pm[i] = take(2 * C * 4);
+      fo[k].w1_16[i] = take(w1pm_bytes);                      // same floats, other lane order
+      fo[k].wc_16[i] = take(wcpm_bytes);                      // (the +8 groups of look-ahead padding cover 4 16-wide groups)
+      fo[k].w2_16[i] = take((size_t)(C / 16 + 4) * (last ? 16 : 32) * 64 * sizeof(float4));   // 16 K groups + 4 of look-ahead
     }
     fo[k].end_w = take(cc * C * 4); fo[k].end_b = take(cc * 4); fo[k].winv = take(cc * cc * 4); fo[k].wfwd = take(cc * cc * 4);
   }
@@ -1373,6 +1596,14 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
         k_pack_cond_pm<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const float*)(tmp + t_f), h->wcpm[k][i], h->P, h->kcp);
       }
       k_fold_bias<<<2, 256, 0, stream>>>(in_b, cond_b, cond_w, h->up_b, h->b1pm[k][i]);
+      h->w1_16[k][i] = (float4*)(h->arena + fo[k].w1_16[i]); h->wc_16[k][i] = (float4*)(h->arena + fo[k].wc_16[i]);
+      h->w2_16[k][i] = (float4*)(h->arena + fo[k].w2_16[i]);
+      k_pack_w1_16<<<(3 * C / 16 * 2048 + 255) / 256, 256, 0, stream>>>(in_w, h->w1_16[k][i]);
+      {
+        const size_t n = (size_t)h->P * (h->kcp / 16) * 2048;
+        k_pack_cond_16<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const float*)(tmp + t_f), h->wc_16[k][i], h->P, h->kcp);
+      }
+      k_pack_w2_16<<<((C / 16) * (last ? 16 : 32) * 64 + 255) / 256, 256, 0, stream>>>(rs_w, h->w2_16[k][i], last);
     }
     h->end_w[k] = F(fo[k].end_w); h->end_b[k] = F(fo[k].end_b); h->winv[k] = F(fo[k].winv);
     WG_TRY(cpy(h->end_w[k], src, cc * C)); src += cc * C;
@@ -1555,15 +1786,23 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   const long cols = (long)B * T;
   const long tiles_w = uniform ? (long)w.P * ((cols + 63) / 64) : (long)w.P * B * ((T + 63) / 64);
   const long tiles_n = uniform ? (long)w.P * ((cols + 31) / 32) : (long)w.P * B * ((T + 31) / 32);
-  const bool narrow = force_narrow ? atoi(force_narrow) != 0 : launch_cost(tiles_n, 181, 94) < launch_cost(tiles_w, 331, 185);
-  const int tn = narrow ? 32 : TN;
+  bool narrow = force_narrow ? atoi(force_narrow) != 0 : launch_cost(tiles_n, 181, 94) < launch_cost(tiles_w, 331, 185);
+  // 16-frame tiles (k_wn_layer16): per-round costs measured the same way
+  static const char* tile16_env = getenv("FACPPG_WN_TILE16");   // 0 never, 1 by cost, 2 always
+  const int tile16_mode = tile16_env ? atoi(tile16_env) : 1;
+  const long tiles_16 = (long)w.P * B * ((T + 15) / 16);
+  const long cost_16 = launch_cost(tiles_16, FACPPG_COST16_FULL, FACPPG_COST16_HALF);
+  const long cost_best = narrow ? launch_cost(tiles_n, 181, 94) : launch_cost(tiles_w, 331, 185);
+  const bool tile16 = tile16_mode == 2 || (tile16_mode == 1 && !force_narrow && cost_16 < cost_best);
+  if (tile16) narrow = false;
+  const int tn = tile16 ? TN16 : narrow ? 32 : TN;
   WnArgs a;
   memset(&a, 0, sizeof(a));
   a.melp = melp; a.skip = skip; a.t_valid = T_valid_dev; a.T = T; a.hop8 = w.P; a.Lp = w.P * w.Tqp; a.Lr = w.P * w.Tr;
   a.P = w.P; a.Tr = w.Tr; a.Tqp = w.Tqp; a.ntq = (T + tn - 1) / tn; a.nt = a.ntq * B;
   // uniform batch: cut tiles from the B*T frames of a phase laid end to end, so only the very last tile is ragged
   static const char* no_flat = getenv("FACPPG_WN_NO_FLAT");
-  if (!T_valid_dev && T % 4 == 0 && !no_flat) { a.flat_cols = B * T; a.nt = (B * T + tn - 1) / tn; }
+  if (!T_valid_dev && T % 4 == 0 && !no_flat && !tile16) { a.flat_cols = B * T; a.nt = (B * T + tn - 1) / tn; }
   a.nch = NCHH + h->kcp / KCH; a.ngc = h->kcp / 8; a.kc = h->kc; a.hop = c.hop_length; a.ksize = c.upsample_kernel;
   // workgroup i lands on XCD i % 8: give every XCD its own phases so a phase's weight image lives in one L2
   static const char* no_xcd = getenv("FACPPG_WN_NO_XCD_MAP");
@@ -1576,10 +1815,14 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
     for (int i = 0; i < c.wn_layers; ++i) {
       a.h_in = hbuf[hi]; a.h_out = hbuf[hi ^ 1];
       a.w1 = h->w1pm[k][i]; a.wc = h->wcpm[k][i]; a.b1 = h->b1pm[k][i]; a.w2 = h->w2[k][i]; a.b2 = h->b2[k][i];
+      if (tile16) { a.w1 = h->w1_16[k][i]; a.wc = h->wc_16[k][i]; a.w2 = h->w2_16[k][i]; }
       a.dil = 1 << i; a.first = (i == 0);
       const bool last = i == c.wn_layers - 1;
       if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
-      if (narrow) {
+      if (tile16) {
+        if (last) k_wn_layer16<true><<<lgrid, 512, 16384, s>>>(a);
+        else k_wn_layer16<false><<<lgrid, 512, 16384, s>>>(a);
+      } else if (narrow) {
         if (w8mode == 0) {
           if (last) k_wn_layer<true, 1, false, true><<<lgrid, 256, 32768, s>>>(a);
           else k_wn_layer<false, 1, false, true><<<lgrid, 256, 32768, s>>>(a);

@@ -217,10 +217,12 @@ def test_legacy_glow_old_layout_and_convert_model():
     assert rms((a1 - a2).cpu().numpy()) <= 1e-5
 
 
-@pytest.mark.parametrize("env", ["FACPPG_WG_UNFOLDED=1", "FACPPG_WN_8W=0", "FACPPG_WN_NO_XCD_MAP=1", "FACPPG_WN_NO_FLAT=1"])
+@pytest.mark.parametrize("env", ["FACPPG_WG_UNFOLDED=1", "FACPPG_WN_8W=0", "FACPPG_WN_NO_XCD_MAP=1", "FACPPG_WN_NO_FLAT=1", "FACPPG_WN_TILE16=2",
+                                 "FACPPG_WN_TILE16=0"])
 def test_alternate_kernel_paths_match_golden(env):
     """The A/B switches select other kernels for the same call (the unfolded K=1408 layer the training
-    direction uses; 4-wave tiles for small launches; no XCD-aware phase mapping; per-utterance tiles).  They
+    direction uses; 4-wave tiles for small launches; no XCD-aware phase mapping; per-utterance tiles; 16-frame
+    tiles always / never).  They
     are read once per process, so each runs the golden comparison in its own interpreter."""
     import os, subprocess, sys
     k, v = env.split("=")
