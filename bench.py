@@ -4,9 +4,12 @@
 A "step" is one WaveGlow.infer over one batch of synthetic mels = BASELINE.json configs[1]:
 batch 8, mel 80x1000, fp32, noise generated on the device, inputs resident in HBM.  The metric is
 BASELINE.json's: 22.05 kHz audio samples per second (hop 256), whole job over all ranks.
-With --gpus N > 1 it is launched under torch.distributed.run, one rank per GPU; utterance batches
-are independent, so each rank synthesises its own batch (weak scaling, no data-path collective;
-RCCL is used only for the barrier and the max-over-ranks of the elapsed time).
+With --gpus N > 1 it runs one rank per GPU: either launched under torch.distributed.run (RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* in the env), or -- when WORLD_SIZE is not set -- it spawns the N
+ranks itself (the one-process-per-GPU launcher pattern of the reference's distributed.py:145-170).
+Utterance batches are independent, so each rank synthesises its own batch (weak scaling, no
+data-path collective; RCCL is used only for the barrier and the max-over-ranks of the elapsed
+time).  The world size and the number of ranks RCCL actually sees are asserted to equal --gpus.
 
 Adds to the JSON line:
   roofline      fp32-MFMA roofline of the dominant kernel (k_wn_layer): algorithmic FLOPs per
@@ -88,25 +91,50 @@ def cpu_baseline(log):
                       "%.1f s on %d threads (best of 16/32 threads)" % (frames, HOP, frames * HOP, best["seconds"], best["threads"])}
 
 
-def end_to_end_batch1(log):
-    """Secondary figure (not `value`): measured in a child process (e2e_worker) so that nothing it does --
-    it uses cooperative launches, which rocprofv3 on this stack does not survive -- can take the primary
-    measurement down with it.  Returns None if the child fails."""
+def end_to_end(log):
+    """The metric's own configurations (PPG -> mel -> wav: Tacotron2 + WaveGlow + Denoiser), batch=1 (its
+    "real-time factor at batch=1") and BASELINE configs[2] (16 variable-length utterances), measured in a child
+    process (e2e_worker) so that nothing it does -- it uses cooperative launches, which rocprofv3 on this stack
+    does not survive -- can take the primary measurement down with it.  Returns None if the child fails."""
     import subprocess
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--e2e-worker"], capture_output=True, text=True, timeout=300)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--e2e-worker"], capture_output=True, text=True, timeout=600)
         out = json.loads(r.stdout.strip().splitlines()[-1])
-        log("end-to-end batch=1: %d samples in %.2f ms" % (round(out["samples_per_s"] * out["ms"] * 1e-3), out["ms"]))
+        for k, v in out.items():
+            log("end-to-end %s: %d samples in %.2f ms = %.0fx real time" % (k, v["samples"], v["ms"], v["realtime_factor"]))
         return out
     except Exception as e:   # noqa: BLE001  (secondary figure: report its absence, never fail the bench)
-        log("end-to-end batch=1 measurement failed: %r" % (e,))
+        log("end-to-end measurement failed: %r" % (e,))
         return None
 
 
+def stage_rooflines(stages, frames_in, frames_out, batch, hop):
+    """Per-stage achieved rates next to the roofline that bounds each (SURVEY.md 8d per-unit figures): the MFMA
+    stages in TFLOP/s of the fp32 MFMA peak, the streaming denoiser in GB/s of HBM peak, the autoregressive decoder as
+    microseconds per frame (latency-bound: neither roofline applies)."""
+    out = {}
+    pos = frames_out * hop // 8
+    flop = {"encoder": 22.8e6 * frames_in, "postnet": 8.68e6 * frames_out, "waveglow": 96 * layer_flops_per_position() * pos}
+    for k, f in flop.items():
+        if stages.get(k):
+            t = f / (stages[k] * 1e-3) / 1e12
+            out[k] = {"bound": "mfma", "achieved": t, "unit": "TFLOP/s", "frac": t / PEAK_F32_MFMA_TFLOPS}
+    if stages.get("denoiser"):
+        # compulsory 4 B in + 4 B out per sample plus the unfused STFT intermediates (frames, spectrum, frames back)
+        nbytes = frames_out * hop * 8 + frames_out * (2 * 1026 + 2 * 1024) * 4
+        g = nbytes / (stages["denoiser"] * 1e-3) / 1e9
+        out["denoiser"] = {"bound": "hbm", "achieved": g, "unit": "GB/s", "frac": g / 8000.0}
+    if stages.get("decoder"):
+        out["decoder"] = {"bound": "latency", "us_per_frame": stages["decoder"] * 1e3 / max(1, frames_out // batch)}
+    return out
+
+
 def e2e_worker():
-    """The metric's "real-time factor at batch=1" for the whole PPG -> mel -> wav path
-    (Tacotron2.inference + WaveGlow.infer + Denoiser) on one 200-frame utterance, best of 3; prints one
-    JSON line."""
+    """PPG -> mel -> wav (Tacotron2.inference + WaveGlow.infer + Denoiser) with inputs on the host (the PPG upload is
+    part of the path), timed with hipEvents on the launch stream (facppg.pipeline.StageTimer): total and per stage.
+    Median of 5 after 2 warm-ups.  Prints one JSON line {config: {...}}."""
+    import contextlib
+    import numpy as np
     from common.hparams import create_hparams_stage
     from facppg import pipeline, synth
     from script.train_ppg2mel import load_model
@@ -118,26 +146,36 @@ def e2e_worker():
     waveglow = WaveGlow.remove_weightnorm(WaveGlow(**cfg))
     waveglow.load_state_dict(synth.waveglow_state_dict(cfg))
     waveglow = waveglow.to(dev).eval()
-    frames = 200
-    hp = create_hparams_stage(max_decoder_steps=frames)
-    taco = load_model(hp)
-    taco.load_state_dict(synth.tacotron_state_dict(hp, gate_bias=-10.0))
-    taco.eval()
     den = Denoiser(waveglow, hop_length=HOP, mode="zeros")
-    ppgs = [synth.synthetic_ppg(frames, 5816, seed=0)]
-    import contextlib
-    times = []
+    g = np.random.Generator(np.random.PCG64(7))
+    configs = {"batch1": [200], "batch16_ragged": (100 + g.integers(0, 301, size=16)).tolist()}
+    out = {}
     with contextlib.redirect_stdout(sys.stderr):     # the model prints the reference's "Reached max decoder steps"
-        for i in range(4):
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            wavs, tout = pipeline.synthesize(ppgs, taco, waveglow, den, sigma=0.6, strength=0.005, seed=i, return_device=True)
-            torch.cuda.synchronize(dev)
-            times.append(time.perf_counter() - t0)
-    t = min(times[1:])
-    n = tout[0] * HOP
-    print(json.dumps({"workload": "PPG [200 x 5816] -> mel -> wav, hop=%d, batch=1 (Tacotron2 + WaveGlow + Denoiser)" % HOP,
-                      "ms": t * 1e3, "samples_per_s": n / t, "realtime_factor": n / t / SR}))
+        for name, lens in configs.items():
+            hp = create_hparams_stage(max_decoder_steps=max(lens))
+            taco = load_model(hp)
+            taco.load_state_dict(synth.tacotron_state_dict(hp, gate_bias=-10.0))
+            taco.eval()
+            ppgs = [synth.synthetic_ppg(n, 5816, seed=i) for i, n in enumerate(lens)]
+            runs = []
+            for i in range(7):
+                timer = pipeline.StageTimer()
+                wavs, tout = pipeline.synthesize(ppgs, taco, waveglow, den, sigma=0.6, strength=0.005, seed=i, return_device=True,
+                                                 step_limits=lens if len(lens) > 1 else None, timer=timer)
+                runs.append(timer.stages_ms())
+            runs = sorted(runs[2:], key=lambda r: r["total"])
+            st = runs[len(runs) // 2]
+            n = sum(tout) * HOP
+            out[name] = {"workload": "PPG [%s x 5816] -> mel -> wav, hop=%d, batch=%d%s (Tacotron2 + WaveGlow + Denoiser), host PPG in, "
+                                     "device wav out" % ("200" if len(lens) == 1 else "100..400", HOP, len(lens),
+                                                         "" if len(lens) == 1 else " ragged, max_decoder_steps = Tin_i"),
+                         "timing": "hipEvents on the launch stream, median of 5 after 2 warm-ups",
+                         "ms": st["total"], "samples": n, "samples_per_s": n / (st["total"] * 1e-3),
+                         "realtime_factor": n / (st["total"] * 1e-3) / SR, "frames": sum(tout),
+                         "stage_ms": {k: v for k, v in st.items() if k != "total"},
+                         "stage_roofline": stage_rooflines(st, sum(lens), sum(tout), len(lens), HOP)}
+            del taco
+    print(json.dumps(out))
 
 
 def reference_rate_config(dev, mel, log):
@@ -165,13 +203,73 @@ def reference_rate_config(dev, mel, log):
 
 
 def pmc_traffic():
-    """HBM bytes per k_wn_layer launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_pmc.json; FETCH_SIZE doubled per the gfx950 correction, calibrated on k_flow_end)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
-            return json.load(f)["k_wn_layer"]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    """HBM bytes per k_wn_layer launch, READ FROM the committed rocprofv3 PMC passes of this same command
+    (newest profiles/rNN_pmc.json; FETCH_SIZE doubled per the gfx950 correction, calibrated on k_flow_end) -- PMC
+    counters cannot be collected from inside the timed run.  Returns (bytes, provenance) or (None, None)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)["k_wn_layer"]
+            return d["hbm_bytes_per_launch"], "static: %s (%s)" % (os.path.basename(path), d.get("build", "separate rocprofv3 --pmc passes"))
+        except Exception:
+            continue
+    return None, None
+
+
+def spawn_ranks(n, argv):
+    """--gpus N without a launcher: start N copies of this script, one per GPU, with the env torch.distributed.run
+    would give them (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1, a free MASTER_PORT), wait for all, and pass
+    rank 0's JSON line through.  Any rank failing fails the run."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0 = procs[0].communicate()[0]
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        sys.stderr.write(out0)
+        raise SystemExit("bench.py: rank exit codes %s" % rcs)
+    sys.stdout.write(out0)
+    return 0
+
+
+def rank_census(dist, dev, backend):
+    """The number of ranks the collective backend really connects (an all_reduce of ones: RCCL over xGMI on the GPUs)
+    and each rank's device index (all_gather)."""
+    on = dev if backend == "nccl" else "cpu"
+    one = torch.ones(1, device=on, dtype=torch.int32)
+    dist.all_reduce(one)
+    mine = torch.tensor([dev.index if dev.type == "cuda" else -1], device=on, dtype=torch.int32)
+    all_dev = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(all_dev, mine)
+    return int(one.item()), [int(t.item()) for t in all_dev]
+
+
+def launch_check(args):
+    """CPU-runnable check of the N-rank launch path (tests/test_bench_launch.py): rendezvous, census, barrier, one JSON
+    line from rank 0 -- everything bench.py does around the timed region, without the GPU work."""
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    n, devs = rank_census(dist, torch.device("cpu"), args.dist_backend)
+    dist.barrier()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "world_size": dist.get_world_size(), "ranks_connected": n,
+                          "max_over_ranks": float(t.item())}))
+    dist.destroy_process_group()
 
 
 def main():
@@ -185,19 +283,27 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-worker", nargs=2, type=int, metavar=("THREADS", "FRAMES"), help=argparse.SUPPRESS)
     ap.add_argument("--e2e-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(*args.cpu_baseline_worker)
     if args.e2e_worker:
         return e2e_worker()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus, sys.argv[1:])
+    if args.launch_check:
+        return launch_check(args)
 
     t_start = time.perf_counter()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "WORLD_SIZE %d != --gpus %d: launch one rank per GPU (or drop WORLD_SIZE and let bench.py spawn them)" % (
+        world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     if args.share_gpu:
         local_rank = 0
+    assert local_rank < torch.cuda.device_count(), "rank %d has no GPU: %d visible, --gpus %d" % (rank, torch.cuda.device_count(), args.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -208,6 +314,10 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    ranks_connected, rank_devices = rank_census(dist, dev, args.dist_backend) if dist is not None else (1, [dev.index])
+    assert ranks_connected == args.gpus, "%d ranks connected, --gpus %d" % (ranks_connected, args.gpus)
+    if not args.share_gpu:
+        assert len(set(rank_devices)) == world, "ranks share a GPU: %s" % rank_devices
 
     from facppg import lib as flib, synth
     from waveglow.glow import WaveGlow
@@ -265,9 +375,11 @@ def main():
     # position); it can exceed the fp32 MFMA peak because the folded kernel executes 19 % fewer FLOPs
     flops_ref = layer_flops_per_position(ncond=640) * positions
     achieved_ref = flops_ref / (layer_ms * 1e-3) / 1e12 if layer_ms > 0 else 0.0
+    traffic, traffic_src = pmc_traffic()
     out = {
         "metric": "22.05 kHz audio samples/sec, WaveGlow.infer (mel->wav) of the PPG->wav path",
-        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "samples/s", "n_gpus": world, "world_size": world, "ranks_connected": ranks_connected,
+        "rank_devices": rank_devices, "collective_backend": ("RCCL (torch.distributed nccl)" if args.dist_backend == "nccl" else args.dist_backend) if world > 1 else None, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "WaveGlow.infer batch=%d, mel 80x%d, hop=%d (%d Hz), fp32, sigma=0.6, device Philox noise; "
@@ -275,14 +387,16 @@ def main():
                    "per_gpu_batch": BATCH, "global_batch": BATCH * world, "parallelism": "dp%d" % world},
         "realtime_factor": value / SR,
         "roofline": {"bound": "mfma", "kernel": "k_wn_layer", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(),
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "avg_launch_ms": layer_ms, "launches_timed": layer_n,
                      "flops_per_launch": flops,
                      "reference_formulation": {"flops_per_launch": flops_ref, "achieved": achieved_ref,
                                                "frac": achieved_ref / PEAK_F32_MFMA_TFLOPS}},
     }
     if rank == 0 and world == 1 and not args.no_e2e:
-        out["end_to_end_batch1"] = end_to_end_batch1(log)
+        e2e = end_to_end(log) or {}
+        out["end_to_end_batch1"] = e2e.get("batch1")
+        out["end_to_end_batch16_ragged"] = e2e.get("batch16_ragged")
         out["reference_rate_config"] = reference_rate_config(dev, mel, log)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(log)

@@ -10,8 +10,15 @@ import os
 import numpy as np
 
 
+def ppg_candidates(wav_path):
+    """Where the precomputed PPG of ``wav_path`` may live."""
+    if wav_path.endswith(".npy"):
+        return [wav_path]
+    return [wav_path + ".ppg.npy", os.path.splitext(wav_path)[0] + ".ppg.npy"]
+
+
 def get_ppg(wav_path, deps=None, is_fmllr=False):
-    candidates = [wav_path] if wav_path.endswith(".npy") else [wav_path + ".ppg.npy", os.path.splitext(wav_path)[0] + ".ppg.npy"]
+    candidates = ppg_candidates(wav_path)
     for c in candidates:
         if os.path.isfile(c):
             ppg = np.load(c)

@@ -14,6 +14,10 @@ Extensions over the reference signature (defaults reproduce it):
                    model.py:524-528)
     dropout_masks  (enc [2, B, Tin, E], dec [steps, 2, B, prenet_dim]) keep-masks in {0,1} for the
                    prenets' always-on dropout (model.py:132-135); None -> drawn on the device
+    utterance_seeds  B integers: the dropout draws of utterance b depend on utterance_seeds[b] alone, so the
+                   batch reproduces B independent batch-1 calls with the same seeds (facppg_taco_draw_dropout)
+    step_limits    B integers: utterance b stops after min(step_limits[b], max_decoder_steps) frames at the
+                   latest (per-utterance max_decoder_steps of a padded batch)
 """
 import torch
 from torch import nn
@@ -167,9 +171,14 @@ class Tacotron2(nn.Module):
         if h is not None:
             _lib.load().facppg_taco_destroy(h[0])
 
+    def _fingerprint(self):
+        """Identity + in-place version of every tensor the packed handle was built from: optimizer steps,
+        ``p.data.copy_()`` and buffer updates all bump ``_version``, re-assignment changes ``data_ptr``."""
+        return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values() if torch.is_tensor(t))
+
     def _handle(self, dev):
         h = self.__dict__.get("_facppg_handle")
-        if h is not None and h[1] == dev:
+        if h is not None and h[1] == dev and h[2] == self._fingerprint():
             return h[0]
         self._release()
         L = _lib.load()
@@ -182,7 +191,7 @@ class Tacotron2(nn.Module):
         with torch.cuda.device(dev):
             _lib.check(L.facppg_taco_create(cfg, _lib.ptr(blob), blob.numel(), dev.index, _lib.current_stream(dev),
                                             _lib.ctypes.byref(out)))
-        self.__dict__["_facppg_handle"] = (out, dev)
+        self.__dict__["_facppg_handle"] = (out, dev, self._fingerprint())
         return out
 
     def _apply(self, fn, *a, **k):
@@ -216,7 +225,24 @@ class Tacotron2(nn.Module):
     def forward(self, inputs):
         raise NotImplementedError("teacher-forced training of the PPG->mel model is out of scope (SURVEY.md section 2)")
 
-    def inference(self, inputs, lengths=None, dropout_masks=None, seed=None):
+    def draw_dropout_masks(self, utterance_seeds, Tin, device=None, steps=None):
+        """Per-utterance dropout keep-masks (facppg_taco_draw_dropout) in the DEVICE layouts the kernels read:
+        (enc uint8 [2, B, symbols_embedding_dim, Tin], dec uint8 [max_decoder_steps, 2, B, prenet_dim]).  Mask bits of
+        utterance b depend on utterance_seeds[b] only (not on B or Tin).  For ``inference(dropout_masks=...)``,
+        which takes the reference-shaped [2, B, Tin, E] encoder masks, pass ``enc.permute(0, 1, 3, 2)``."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        L = _lib.load()
+        h = self._handle(dev)
+        B, steps = len(utterance_seeds), int(self.decoder.max_decoder_steps if steps is None else steps)
+        sd = torch.tensor([int(v) & 0x7FFFFFFFFFFFFFFF for v in utterance_seeds], dtype=torch.int64, device=dev)
+        enc_m = torch.empty(2, B, self._hp["symbols_embedding_dim"], Tin, dtype=torch.uint8, device=dev)
+        dec_m = torch.empty(steps, 2, B, self._hp["prenet_dim"], dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.facppg_taco_draw_dropout(h, _lib.ptr(sd), B, Tin, steps, _lib.ptr(enc_m), _lib.ptr(dec_m),
+                                                  _lib.current_stream(dev)))
+        return enc_m, dec_m
+
+    def inference(self, inputs, lengths=None, dropout_masks=None, seed=None, utterance_seeds=None, step_limits=None, timer=None):
         """inputs [B, n_symbols, Tin] (GPU fp32) -> [mel, mel_post, gate, alignments]
         = [B,80,Tout], [B,80,Tout], [B,Tout,1], [B,Tout,Tin]  (model.py:597-610).  For B > 1 the
         outputs are zero beyond each utterance's own Tout, kept in ``self.last_output_lengths``."""
@@ -240,6 +266,13 @@ class Tacotron2(nn.Module):
         seed &= 0xFFFFFFFFFFFFFFFF
         enc_m = dec_m = None
         steps = int(self.decoder.max_decoder_steps)
+        sl = None
+        if step_limits is not None:
+            sl = torch.as_tensor(step_limits).to(dtype=torch.int32)
+            if sl.numel() != B or int(sl.min()) < 1:
+                raise _lib.FacppgError("step_limits must be B values >= 1")
+            steps = min(steps, int(sl.max()))          # no utterance can run longer: size the outputs for that
+            sl = sl.to(dev).contiguous()
         E, P, NF, AD = hp["encoder_embedding_dim"], hp["prenet_dim"], hp["n_acoustic_feat_dims"], hp["attention_dim"]
         if dropout_masks is not None:
             em, dm = dropout_masks
@@ -247,6 +280,11 @@ class Tacotron2(nn.Module):
             dec_m = torch.as_tensor(dm).to(dev).to(torch.uint8).contiguous()
             if dec_m.numel() != steps * 2 * B * P:
                 raise _lib.FacppgError("decoder masks must be [max_decoder_steps, 2, B, prenet_dim]")
+        st = _lib.current_stream(dev)
+        if utterance_seeds is not None:
+            if dropout_masks is not None or len(utterance_seeds) != B:
+                raise _lib.FacppgError("utterance_seeds: B integers, and not together with dropout_masks")
+            enc_m, dec_m = self.draw_dropout_masks(utterance_seeds, Tin, dev, steps)
         ws = torch.empty(max(L.facppg_taco_workspace_bytes(h, B, Tin), L.facppg_taco_decode_workspace_bytes(h, B, steps)),
                          dtype=torch.uint8, device=dev)
         memory = torch.zeros(B, Tin, E, device=dev)
@@ -255,21 +293,26 @@ class Tacotron2(nn.Module):
         gate = torch.zeros(B, steps, device=dev)
         align = torch.zeros(B, steps, Tin, device=dev)
         out_len = torch.zeros(B, dtype=torch.int32, device=dev)
-        st = _lib.current_stream(dev)
         with torch.cuda.device(dev):
             _lib.check(L.facppg_taco_encode(h, _lib.ptr(x), _lib.ptr(lt), _lib.ptr(enc_m), seed, B, Tin, _lib.ptr(memory),
                                             _lib.ptr(pm), _lib.ptr(ws), ws.numel(), st))
-            _lib.check(L.facppg_taco_decode(h, _lib.ptr(memory), _lib.ptr(pm), _lib.ptr(lt), _lib.ptr(dec_m), seed, B, Tin,
+            if timer is not None:
+                timer.mark("encoder")
+            _lib.check(L.facppg_taco_decode(h, _lib.ptr(memory), _lib.ptr(pm), _lib.ptr(lt), _lib.ptr(sl), _lib.ptr(dec_m), seed, B, Tin,
                                             steps, _lib.ptr(mel), _lib.ptr(gate), _lib.ptr(align), _lib.ptr(out_len),
                                             _lib.ptr(ws), ws.numel(), st))
             out_len_host = out_len.cpu()                       # the path's single device->host sync
+            if timer is not None:
+                timer.mark("decoder")
             Tout = int(out_len_host.max())
-            if Tout == steps and bool((out_len_host == steps).any()):
+            if Tout == int(self.decoder.max_decoder_steps):
                 print("Warning! Reached max decoder steps")     # model.py:527
             mel_post = torch.zeros_like(mel)
             ws2 = torch.empty(L.facppg_taco_postnet_workspace_bytes(h, B, Tout), dtype=torch.uint8, device=dev)
             _lib.check(L.facppg_taco_postnet(h, _lib.ptr(mel), _lib.ptr(out_len), B, Tout, steps, _lib.ptr(mel_post),
                                              _lib.ptr(ws2), ws2.numel(), st))
+            if timer is not None:
+                timer.mark("postnet")
         self.last_output_lengths = out_len_host.to(torch.long)
         self.last_memory = memory
         return self.parse_output([mel[:, :, :Tout], mel_post[:, :, :Tout], gate[:, :Tout].unsqueeze(-1), align[:, :Tout]])

@@ -19,10 +19,24 @@ def get_mask_from_lengths(lengths):
 def get_mask_from_lengths_window_and_time_step(lengths, attention_window_size, time_step):
     """Attention window mask, True = masked (utils.py:46-78).  Keeps, per utterance of length n,
     the index range [min(max(0, t-W), n-1), min(t+W, n-1)] -- including the reference's documented
-    quirk that the last frame stays unmasked once t-W has passed it.  The HIP decoder derives the
-    same range on the device; this host version exists for API compatibility and tests."""
+    quirk that the last frame stays unmasked once t-W has passed it.
+
+    ``lengths`` on the GPU (what the reference's decoder passes, model.py:424-427): the mask comes
+    from ``facppg_attention_window_mask``, i.e. from the same device range function the decoder
+    kernels evaluate the attention on.  Host lengths (lists / CPU tensors): pure integer host logic."""
+    if torch.is_tensor(lengths) and lengths.is_cuda:
+        from facppg import lib as _lib
+        L = _lib.load()
+        lt = lengths.to(torch.int32).contiguous()
+        B, t_max = lt.numel(), int(lt.max())
+        mask = torch.empty(B, t_max, dtype=torch.uint8, device=lt.device)
+        with torch.cuda.device(lt.device):
+            _lib.check(L.facppg_attention_window_mask(_lib.ptr(lt), B, t_max, -1 if attention_window_size is None
+                                                      else int(attention_window_size), int(time_step), _lib.ptr(mask),
+                                                      _lib.current_stream(lt.device)))
+        return mask.bool()
     lens = [int(v) for v in lengths]
-    mask = torch.ones(len(lens), max(lens), dtype=torch.bool, device=lengths.device if torch.is_tensor(lengths) else None)
+    mask = torch.ones(len(lens), max(lens), dtype=torch.bool)
     for row, n in enumerate(lens):
         first = min(max(0, time_step - attention_window_size), n - 1)
         last = min(time_step + attention_window_size, n - 1)

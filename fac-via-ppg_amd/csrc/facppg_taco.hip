@@ -20,6 +20,7 @@
 // Recurrent weights are stored K-major ([k][rows], rows padded to 4) so a thread streams float4
 // columns with fully coalesced 16-byte loads; a 1200x1200 step is 900 threads x 400 loads.
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -31,7 +32,7 @@ using namespace facppg;
 struct facppg_taco {
   facppg_taco_config c;
   int device;
-  int coop_limit;   // workgroups the cooperative (co-resident) kernels may use: CUs - 16 (one 512-thread workgroup per CU)
+  int coop_limit;   // workgroups the cooperative (co-resident) kernels may use: from the occupancy calculator, see facppg_taco_create
   char* arena;
   // encoder
   float4 *pre0, *pre1, *conv[8], *wih;
@@ -124,6 +125,30 @@ __global__ void k_random_mask(uint8_t* __restrict__ out, size_t n, uint64_t seed
   out[i] = (uint8_t)((z >> 40) & 1);
 }
 
+// Per-utterance keep-masks: bit (layer j, channel, frame) of utterance b is a function of seeds[b] alone, so a
+// padded batch drawn with per-utterance seeds reproduces each utterance's own batch-1 draw.
+__device__ __forceinline__ uint8_t mask_bit(uint64_t seed, uint64_t index) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (index + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint8_t)((z >> 40) & 1);
+}
+// enc [2][B][S][Tin]
+__global__ void k_random_mask_enc_utt(uint8_t* __restrict__ out, const uint64_t* __restrict__ seeds, int B, int S, int Tin) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)2 * B * S * Tin) return;
+  const int t = (int)(i % Tin), ch = (int)(i / Tin % S), b = (int)(i / Tin / S % B), j = (int)(i / Tin / S / B);
+  out[i] = mask_bit(seeds[b], ((uint64_t)(j * S + ch) << 32) | (uint32_t)t);
+}
+// dec [steps][2][B][P]
+__global__ void k_random_mask_dec_utt(uint8_t* __restrict__ out, const uint64_t* __restrict__ seeds, int B, int P, int steps) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)steps * 2 * B * P) return;
+  const int u = (int)(i % P), b = (int)(i / P % B), j = (int)(i / P / B % 2), t = (int)(i / P / B / 2);
+  out[i] = mask_bit(seeds[b] ^ 0xD1B54A32D192ED03ull, ((uint64_t)t << 32) | (uint32_t)(j * P + u));
+}
+
 // partial matvec: part[ks][Rp] = sum_{k in split ks} WT[k][Rp] * v[k]; thread = (slot of 4 rows, k split)
 // UB = weight loads kept in flight per thread (the stream is L2-latency bound: bytes in flight decide)
 template <int UB = 4>
@@ -208,23 +233,20 @@ __global__ __launch_bounds__(NT) void k_bilstm(const float* __restrict__ xproj, 
 // published its step-s+1 word after consuming step s.  Fixed-order reductions: bit-identical to the
 // one-workgroup kernel's sums up to fp32 re-association of the K split.
 // Poll an exchange word until its tag shows up.  The producers are co-resident by construction
-// (hipLaunchCooperativeKernel refuses a grid that is not), so the wait is a few microseconds.  Building
-// with -DFACPPG_POLL_BOUNDED turns a lost producer (a logic error) into a trapped kernel after ~4 M polls
-// instead of a hung GPU; it is not the default because the bound's control flow costs 8 % on the decoder.
+// (hipLaunchCooperativeKernel refuses a grid that is not), so the wait is a few microseconds.
+// Run-time bound (device constant, set per handle from FACPPG_POLL_LIMIT; default 4 M polls, 0 = unbounded): a
+// lost producer (a logic error, or a grid that was not co-resident after all) turns into a trapped kernel and a
+// HIP error instead of a hung GPU.
+__constant__ unsigned g_poll_limit = 0x400000u;
 __device__ __forceinline__ unsigned long long poll_tag(const unsigned long long* w, unsigned tag) {
   unsigned long long v;
-#ifdef FACPPG_POLL_BOUNDED
+  const unsigned limit = g_poll_limit;
   unsigned spins = 0;
 #pragma unroll 1
   do {
     v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (++spins == 0x400000u) __builtin_trap();
+    if (++spins == limit) __builtin_trap();
   } while ((unsigned)(v >> 32) != tag);
-#else
-  do {
-    v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } while ((unsigned)(v >> 32) != tag);
-#endif
   return v;
 }
 
@@ -314,6 +336,7 @@ struct DecArgs {
   const float* memory;   // [B][Tin][E]
   const float* pm;       // [B][AD][Tin]
   const int* lengths;    // [B] or null
+  const int* step_limits;   // [B] or null: utterance b stops after min(step_limits[b], max_steps) frames at the latest
   const uint8_t* masks;  // [steps][2][B][P]
   float* mel;            // [B][NF][max_steps]
   float* gate;           // [B][max_steps]
@@ -323,6 +346,12 @@ struct DecArgs {
   int b0;                // k_decoder_coop: first utterance of this launch (large batches run in chunks)
   float gate_thr;
 };
+
+// The frame count at which utterance b stops if its gate never fires (model.py:524-528's max_decoder_steps,
+// optionally tightened per utterance).
+__device__ __forceinline__ int dec_step_limit(const DecArgs& p, int b) {
+  return p.step_limits ? min(max(p.step_limits[b], 1), p.max_steps) : p.max_steps;
+}
 
 struct DecLds {
   float *in_att, *in_dec, *in_proj, *ac, *dc, *xin, *p1, *pq, *part, *feat, *lconv, *ldense, *vv, *wprev, *wcum, *en;
@@ -400,6 +429,21 @@ __device__ __forceinline__ void dec_prenet(const DecArgs& p, const DecLds& L, in
   }
 }
 
+// The index range [lo, hi] of encoder frames the attention window mask of decoder step t keeps for an
+// utterance of `len` frames (get_mask_from_lengths_window_and_time_step, src/common/utils.py:64-77):
+// lo = min(max(0, t - W), len - 1), hi = min(t + W, len - 1) -- so once t - W has passed the end only the
+// last frame stays unmasked (the reference's documented quirk, utils.py:65-69); window < 0 = no window
+// (attention_window_size None).  The ONE definition every decoder shape and k_window_mask use.
+__device__ __forceinline__ void attn_window_range(int window, int t, int len, int* lo, int* hi) {
+  if (window >= 0) {
+    *lo = min(max(0, t - window), len - 1);
+    *hi = min(t + window, len - 1);
+  } else {
+    *lo = 0;
+    *hi = len - 1;
+  }
+}
+
 // LSTMCell pointwise for unit `u` from the four gate pre-activations (gate order i,f,g,o)
 __device__ __forceinline__ float lstm_point(float gi, float gf, float gg, float go, float* c) {
   const float cn = sigm(gf) * (*c) + sigm(gi) * tanhf(gg);
@@ -465,11 +509,8 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
     atk = now;                                                           \
   }
   const float* ah = L.in_att + p.P + p.E;
-  int lo = 0, hi = len - 1;
-  if (p.window >= 0) {
-    lo = min(max(0, t - p.window), len - 1);
-    hi = min(t + p.window, len - 1);
-  }
+  int lo, hi;
+  attn_window_range(p.window, t, len, &lo, &hi);
   {
     const int KS = pick_ks<NT>(L.ADp, p.A);
     matvec_part<(NT <= 512 ? 16 : 4)>(p.q_t, p.A, L.ADp, KS, ah, L.part, tid);
@@ -658,7 +699,7 @@ __device__ __forceinline__ void dec_project(const DecArgs& p, const DecLds& L, i
       if (write_out) p.mel[((size_t)b * p.NF + tid) * p.max_steps + t] = v;
     } else {
       if (write_out) p.gate[(size_t)b * p.max_steps + t] = v;
-      if (sigm(v) > p.gate_thr || t + 1 == p.max_steps) *s_stop = 1;
+      if (sigm(v) > p.gate_thr || t + 1 == dec_step_limit(p, b)) *s_stop = 1;
     }
   }
   __syncthreads();
@@ -979,7 +1020,7 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
         }
         FOR_ALIVE(u) {
           UTT(u);
-          if (tid == 0) s_stop[u] = sigm(xwait(MEL + p.NF, tag)) > p.gate_thr || t == p.max_steps;
+          if (tid == 0) s_stop[u] = sigm(xwait(MEL + p.NF, tag)) > p.gate_thr || t == dec_step_limit(p, b);
         }
         __syncthreads();
         for (int u = 0; u < NU; ++u)
@@ -1070,15 +1111,12 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
   }
   for (int t = 0;; ++t) {
     const unsigned tag = t + 1;
-    int lo = 0, hi = len - 1;
-    if (p.window >= 0) {
-      lo = min(max(0, t - p.window), len - 1);
-      hi = min(t + p.window, len - 1);
-    }
+    int lo, hi;
+    attn_window_range(p.window, t, len, &lo, &hi);
     attn_features<NTC>(p, L, lo, min(64, hi - lo + 1), tid);   // needs only frame t-1's weights
     PROF(2)
     if (t > 0) {
-      if (tid == 0) s_stop[0] = sigm(xwait(MEL + p.NF, tag)) > p.gate_thr || t == p.max_steps;
+      if (tid == 0) s_stop[0] = sigm(xwait(MEL + p.NF, tag)) > p.gate_thr || t == dec_step_limit(p, b);
       __syncthreads();
       if (s_stop[0]) {
         if (tid == 0) p.out_len[b] = t;
@@ -1179,7 +1217,29 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
   FACPPG_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device));
   facppg_taco* h = new (std::nothrow) facppg_taco();
   FACPPG_REQUIRE(h, FACPPG_EINVAL, "out of host memory");
-  h->c = *cfg; h->device = device; h->coop_limit = n_cu > 32 ? n_cu - 16 : n_cu;
+  h->c = *cfg; h->device = device;
+  {
+    // How many workgroups the cooperative kernels may keep co-resident: what the occupancy calculator says fits
+    // per CU for each of them at its largest dynamic LDS, but never more than ONE per CU (each workgroup is sized
+    // for a whole CU's LDS / L1 bandwidth), less 1/16 of the chip kept free so that a second handle's launch or
+    // the neighbouring stages' kernels on other streams find a CU.  0 => the one-workgroup kernels run instead.
+    int per_cu = 1;
+    const struct { const void* fn; size_t lds; } coop_kernels[] = {
+        {(const void*)k_decoder_coop, 150 * 1024}, {(const void*)k_decoder_split<1>, 150 * 1024},
+        {(const void*)k_decoder_split<2>, 150 * 1024}, {(const void*)k_decoder_split<3>, 150 * 1024},
+        {(const void*)k_bilstm_coop<32, 96>, 0}, {(const void*)k_bilstm_coop<64, 152>, 0}};
+    for (const auto& k : coop_kernels) {
+      int nb = 0;
+      if (k.lds) FACPPG_HIP_CHECK(hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.lds));
+      FACPPG_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k.fn, NTC, k.lds));
+      per_cu = std::min(per_cu, nb);
+    }
+    const int resident = n_cu * per_cu;
+    h->coop_limit = resident - resident / 16;
+    const char* pl = getenv("FACPPG_POLL_LIMIT");
+    const unsigned limit = pl ? (unsigned)strtoul(pl, nullptr, 0) : 0x400000u;
+    FACPPG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_poll_limit), &limit, sizeof(limit)));
+  }
   const facppg_taco_config& c = *cfg;
   const int S = c.symbols_embedding_dim, E = c.encoder_embedding_dim, H = E / 2, K = c.encoder_kernel_size;
   const int P = c.prenet_dim, A = c.attention_rnn_dim, D = c.decoder_rnn_dim, AD = c.attention_dim, NF = c.n_acoustic_feat_dims;
@@ -1438,9 +1498,49 @@ DecWs dec_ws(const facppg_taco_config& c, int B, int max_steps) {
 }
 }  // namespace
 
+extern "C" int facppg_taco_draw_dropout(const facppg_taco* h, const uint64_t* seeds_dev, int B, int Tin, int max_steps,
+                                        uint8_t* enc_masks_dev, uint8_t* dec_masks_dev, void* stream_) {
+  FACPPG_REQUIRE(h && seeds_dev, FACPPG_EINVAL, "NULL argument");
+  FACPPG_REQUIRE(B > 0 && Tin > 0 && max_steps > 0, FACPPG_EINVAL, "bad B/Tin/max_steps");
+  hipStream_t s = (hipStream_t)stream_;
+  const int S = h->c.symbols_embedding_dim, P = h->c.prenet_dim;
+  if (enc_masks_dev) {
+    const size_t n = (size_t)2 * B * S * Tin;
+    k_random_mask_enc_utt<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(enc_masks_dev, seeds_dev, B, S, Tin);
+  }
+  if (dec_masks_dev) {
+    const size_t n = (size_t)max_steps * 2 * B * P;
+    k_random_mask_dec_utt<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(dec_masks_dev, seeds_dev, B, P, max_steps);
+  }
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+namespace {
+// get_mask_from_lengths_window_and_time_step (src/common/utils.py:46-78) as a byte mask, 1 = masked:
+// the decoder kernels never materialise it (they evaluate the attention on [lo, hi] only); this kernel
+// writes the same range out through the same attn_window_range() so it can be compared bit for bit.
+__global__ void k_window_mask(const int32_t* __restrict__ lengths, int B, int Tmax, int window, int t, uint8_t* __restrict__ mask) {
+  const int b = blockIdx.y;
+  int lo, hi;
+  attn_window_range(window, t, lengths[b], &lo, &hi);
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Tmax; q += gridDim.x * blockDim.x)
+    mask[(size_t)b * Tmax + q] = (q >= lo && q <= hi) ? 0 : 1;
+}
+}  // namespace
+
+extern "C" int facppg_attention_window_mask(const int32_t* lengths_dev, int B, int Tmax, int window, int time_step,
+                                            uint8_t* mask_dev, void* stream) {
+  FACPPG_REQUIRE(lengths_dev && mask_dev, FACPPG_EINVAL, "NULL argument");
+  FACPPG_REQUIRE(B > 0 && Tmax > 0 && B <= 65535 && time_step >= 0, FACPPG_EINVAL, "bad sizes B=%d Tmax=%d t=%d", B, Tmax, time_step);
+  k_window_mask<<<dim3((Tmax + 255) / 256, B), 256, 0, (hipStream_t)stream>>>(lengths_dev, B, Tmax, window, time_step, mask_dev);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
 // Decoder.inference (model.py:489-535).
 extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const float* pm_dev, const int32_t* lengths_dev,
-                                  const uint8_t* masks_dev, uint64_t seed, int B, int Tin, int max_steps, float* mel_dev,
+                                  const int32_t* step_limits_dev, const uint8_t* masks_dev, uint64_t seed, int B, int Tin, int max_steps, float* mel_dev,
                                   float* gate_dev, float* align_dev, int32_t* out_lengths_dev, void* ws_, size_t ws_bytes,
                                   void* stream_) {
   FACPPG_REQUIRE(h && memory_dev && pm_dev && mel_dev && gate_dev && out_lengths_dev && ws_, FACPPG_EINVAL, "NULL argument");
@@ -1462,7 +1562,7 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
   a.q_t = h->q_t; a.proj_t = h->proj_t; a.proj_b = h->proj_b; a.loc_conv = h->loc_conv; a.loc_dense = h->loc_dense; a.v = h->v;
   a.xchg = (unsigned long long*)(ws + w.xchg);
   a.prof = getenv("FACPPG_DECODER_PROF") ? (long long*)(ws + w.prof) : nullptr;
-  a.memory = memory_dev; a.pm = pm_dev; a.lengths = lengths_dev; a.masks = masks; a.mel = mel_dev; a.gate = gate_dev;
+  a.memory = memory_dev; a.pm = pm_dev; a.lengths = lengths_dev; a.step_limits = step_limits_dev; a.masks = masks; a.mel = mel_dev; a.gate = gate_dev;
   a.align = align_dev; a.out_len = out_lengths_dev;
   a.B = B; a.Tin = Tin; a.E = c.encoder_embedding_dim; a.P = c.prenet_dim; a.A = c.attention_rnn_dim; a.D = c.decoder_rnn_dim;
   a.AD = c.attention_dim; a.NF = c.n_acoustic_feat_dims; a.NFIL = c.attention_location_n_filters;

@@ -1,0 +1,154 @@
+// Training-direction kernels of the WaveGlow flow edges (src/waveglow/glow.py:82-102, 208-250): the c x c
+// channel-mixing conv of Invertible1x1Conv (c <= 8) forward / data gradient (the same kernel with the
+// transposed matrix) and its weight gradient.  These are HBM-streaming kernels: one position's c channels are
+// c strided 4-byte-per-lane rows, a lane owns 4 consecutive positions (16-byte accesses), the c x c matrix
+// sits in SGPRs/registers.
+#include <algorithm>
+
+#include "facppg_common.h"
+
+namespace facppg {
+namespace {
+
+// out[b][i][l] = sum_j W[i][j] * z[b][j][l]   (TRANS: W[j][i])
+template <int C, bool TRANS>
+__global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ W, const float* __restrict__ z, float* __restrict__ out,
+                                                 int L) {
+  const int b = blockIdx.y;
+  const size_t base = (size_t)b * C * L;
+  float w[C][C];
+#pragma unroll
+  for (int i = 0; i < C; ++i)
+#pragma unroll
+    for (int j = 0; j < C; ++j) w[i][j] = TRANS ? W[j * C + i] : W[i * C + j];
+  const int l0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+  if (l0 >= L) return;
+  if (l0 + 4 <= L && (L & 3) == 0) {
+    float4 x[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) x[j] = *(const float4*)(z + base + (size_t)j * L + l0);
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+      float4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < C; ++j) {
+        a.x = fmaf(w[i][j], x[j].x, a.x); a.y = fmaf(w[i][j], x[j].y, a.y);
+        a.z = fmaf(w[i][j], x[j].z, a.z); a.w = fmaf(w[i][j], x[j].w, a.w);
+      }
+      *(float4*)(out + base + (size_t)i * L + l0) = a;
+    }
+  } else {
+    for (int l = l0; l < min(l0 + 4, L); ++l) {
+      float x[C];
+#pragma unroll
+      for (int j = 0; j < C; ++j) x[j] = z[base + (size_t)j * L + l];
+#pragma unroll
+      for (int i = 0; i < C; ++i) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) a = fmaf(w[i][j], x[j], a);
+        out[base + (size_t)i * L + l] = a;
+      }
+    }
+  }
+}
+
+// dW[i][j] = sum_{b,l} dout[b][i][l] * z[b][j][l]: per-workgroup partial sums in a fixed order (wave shuffle tree,
+// then the waves' partials in LDS order), then a second pass sums the workgroups in index order -- deterministic.
+template <int C>
+__global__ __launch_bounds__(256) void k_conv1x1_wgrad_part(const float* __restrict__ dout, const float* __restrict__ z,
+                                                            float* __restrict__ part, int B, int L) {
+  float acc[C][C];
+#pragma unroll
+  for (int i = 0; i < C; ++i)
+#pragma unroll
+    for (int j = 0; j < C; ++j) acc[i][j] = 0.f;
+  const size_t n = (size_t)B * L;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = p / L, l = p - b * L;
+    float d[C], x[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) { d[i] = dout[(b * C + i) * L + l]; x[i] = z[(b * C + i) * L + l]; }
+#pragma unroll
+    for (int i = 0; i < C; ++i)
+#pragma unroll
+      for (int j = 0; j < C; ++j) acc[i][j] = fmaf(d[i], x[j], acc[i][j]);
+  }
+  __shared__ float red[4][C * C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < C; ++i)
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      float v = acc[i][j];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) red[wave][i * C + j] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < C * C)
+    part[(size_t)blockIdx.x * C * C + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void k_sum_parts(const float* __restrict__ part, float* __restrict__ out, int n_parts, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = 0.f;
+  for (int p = 0; p < n_parts; ++p) v += part[(size_t)p * n + i];
+  out[i] = v;
+}
+
+template <int C>
+int conv1x1_c(const float* W, const float* z, float* out, int B, int L, bool trans, hipStream_t s) {
+  const dim3 grid((L + 1023) / 1024, B);
+  if (trans) k_conv1x1<C, true><<<grid, 256, 0, s>>>(W, z, out, L);
+  else k_conv1x1<C, false><<<grid, 256, 0, s>>>(W, z, out, L);
+  return FACPPG_OK;
+}
+
+constexpr int kWgradParts = 512;
+
+}  // namespace
+}  // namespace facppg
+
+using namespace facppg;
+
+extern "C" int facppg_conv1x1(const float* w_dev, const float* z_dev, float* out_dev, int B, int c, int L, int transpose_w,
+                              void* stream) {
+  FACPPG_REQUIRE(w_dev && z_dev && out_dev, FACPPG_EINVAL, "NULL argument");
+  FACPPG_REQUIRE(B > 0 && L > 0 && B <= 65535, FACPPG_EINVAL, "bad B/L");
+  FACPPG_REQUIRE(z_dev != out_dev, FACPPG_EINVAL, "facppg_conv1x1 is not in-place");
+  hipStream_t s = (hipStream_t)stream;
+  switch (c) {
+    case 2: conv1x1_c<2>(w_dev, z_dev, out_dev, B, L, transpose_w != 0, s); break;
+    case 4: conv1x1_c<4>(w_dev, z_dev, out_dev, B, L, transpose_w != 0, s); break;
+    case 6: conv1x1_c<6>(w_dev, z_dev, out_dev, B, L, transpose_w != 0, s); break;
+    case 8: conv1x1_c<8>(w_dev, z_dev, out_dev, B, L, transpose_w != 0, s); break;
+    default: FACPPG_REQUIRE(false, FACPPG_EUNSUPPORTED, "channel count %d (built: 2, 4, 6, 8)", c);
+  }
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+extern "C" size_t facppg_conv1x1_wgrad_workspace_bytes(int c) { return (size_t)kWgradParts * c * c * 4; }
+
+extern "C" int facppg_conv1x1_wgrad(const float* dout_dev, const float* z_dev, float* dw_dev, int B, int c, int L,
+                                    void* workspace_dev, size_t workspace_bytes, void* stream) {
+  FACPPG_REQUIRE(dout_dev && z_dev && dw_dev && workspace_dev, FACPPG_EINVAL, "NULL argument");
+  FACPPG_REQUIRE(B > 0 && L > 0, FACPPG_EINVAL, "bad B/L");
+  FACPPG_REQUIRE(workspace_bytes >= facppg_conv1x1_wgrad_workspace_bytes(c), FACPPG_EWORKSPACE, "workspace has %zu bytes, need %zu",
+                 workspace_bytes, facppg_conv1x1_wgrad_workspace_bytes(c));
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)workspace_dev;
+  const int parts = (int)std::min<size_t>(kWgradParts, ((size_t)B * L + 255) / 256);
+  switch (c) {
+    case 2: k_conv1x1_wgrad_part<2><<<parts, 256, 0, s>>>(dout_dev, z_dev, part, B, L); break;
+    case 4: k_conv1x1_wgrad_part<4><<<parts, 256, 0, s>>>(dout_dev, z_dev, part, B, L); break;
+    case 6: k_conv1x1_wgrad_part<6><<<parts, 256, 0, s>>>(dout_dev, z_dev, part, B, L); break;
+    case 8: k_conv1x1_wgrad_part<8><<<parts, 256, 0, s>>>(dout_dev, z_dev, part, B, L); break;
+    default: FACPPG_REQUIRE(false, FACPPG_EUNSUPPORTED, "channel count %d (built: 2, 4, 6, 8)", c);
+  }
+  k_sum_parts<<<1, 64, 0, s>>>(part, dw_dev, parts, c * c);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}

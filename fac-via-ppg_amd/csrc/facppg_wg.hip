@@ -1135,12 +1135,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-__global__ void k_noise(float* __restrict__ z, size_t n, uint64_t seed) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // produces z[4i .. 4i+3]
-  if (4 * i >= n) return;
-  uint32_t r[4];
-  philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-  float o[4];
+// four N(0,1) values from one Philox block (two Box-Muller pairs)
+__device__ __forceinline__ void normal4(const uint32_t (&r)[4], float (&o)[4]) {
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const float u1 = ((float)(r[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
@@ -1150,8 +1146,42 @@ __global__ void k_noise(float* __restrict__ z, size_t n, uint64_t seed) {
     sincosf(6.28318530717958647692f * u2, &sn, &cs);
     o[2 * h] = rad * cs; o[2 * h + 1] = rad * sn;
   }
+}
+
+__global__ void k_noise(float* __restrict__ z, size_t n, uint64_t seed) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // produces z[4i .. 4i+3]
+  if (4 * i >= n) return;
+  uint32_t r[4];
+  philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  float o[4];
+  normal4(r, o);
   for (int j = 0; j < 4; ++j)
     if (4 * i + j < n) z[4 * i + j] = o[j];
+}
+
+// Per-utterance noise streams: value (segment, channel, position) of utterance b depends only on seeds[b] --
+// not on the batch size, the utterance's slot in the batch or the padded length -- so a padded batch drawn with
+// per-utterance seeds reproduces every utterance's own batch-1 draw (Philox key = seeds[b], counter =
+// (position / 4, channel, segment)).  z: the flat injected-z layout of facppg_wg_infer.
+__global__ void k_noise_utt(float* __restrict__ z, const uint64_t* __restrict__ seeds, int B, int L, int n_first, int n_early,
+                            int n_seg) {
+  const int l4 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (4 * l4 >= L) return;
+  const uint64_t seed = seeds[b];
+  size_t seg_off = 0;
+  for (int sg = 0; sg < n_seg; ++sg) {
+    const int nch = sg == 0 ? n_first : n_early;
+    for (int ch = 0; ch < nch; ++ch) {
+      uint32_t r[4];
+      philox4x32_10((uint32_t)l4, (uint32_t)ch, (uint32_t)sg, 0x7A5Eu, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+      float o[4];
+      normal4(r, o);
+      float* dst = z + seg_off + ((size_t)b * nch + ch) * L + 4 * l4;
+      for (int j = 0; j < 4; ++j)
+        if (4 * l4 + j < L) dst[j] = o[j];
+    }
+    seg_off += (size_t)B * nch * L;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1986,6 +2016,18 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
     }
     ai ^= 1;
   }
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+extern "C" int facppg_wg_draw_noise(const facppg_wg* h, const uint64_t* seeds_dev, int B, int T, float* z_dev, void* stream_) {
+  FACPPG_REQUIRE(h && seeds_dev && z_dev, FACPPG_EINVAL, "NULL argument");
+  FACPPG_REQUIRE(B > 0 && T > 0 && B <= 65535, FACPPG_EINVAL, "bad B/T");
+  const facppg_wg_config& c = h->cfg;
+  const int nf = c.n_flows, L = T * (c.hop_length / c.n_group);
+  int n_seg = 1;
+  for (int k = 0; k < nf; ++k) n_seg += h->early[k] ? 1 : 0;
+  k_noise_utt<<<dim3((L / 4 + 256) / 256, B), 256, 0, (hipStream_t)stream_>>>(z_dev, seeds_dev, B, L, h->n_rem[nf - 1], c.n_early_size, n_seg);
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
 }

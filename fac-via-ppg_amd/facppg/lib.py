@@ -65,6 +65,9 @@ def _declare(lib):
                                              vp, sz, vp]),
         "facppg_wn_backward_data": (c.c_int, [c.POINTER(WnWeights), c.c_int, c.c_int, vp, vp, c.c_int, c.c_int, vp, vp, vp, vp,
                                               vp, vp, sz, vp]),
+        "facppg_conv1x1": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, c.c_int, c.c_int, vp]),
+        "facppg_conv1x1_wgrad_workspace_bytes": (sz, [c.c_int]),
+        "facppg_conv1x1_wgrad": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, c.c_int, vp, sz, vp]),
         "facppg_wg_set_profiling": (c.c_int, [vp, c.c_int]),
         "facppg_wg_last_layer_ms": (c.c_int, [vp, c.POINTER(f32), c.POINTER(c.c_int)]),
         "facppg_stft_create": (c.c_int, [c.c_int, c.c_int, vp, vp, vp, vp, c.c_int, c.c_int, vp, c.POINTER(vp)]),
@@ -81,8 +84,11 @@ def _declare(lib):
         "facppg_taco_decode_workspace_bytes": (sz, [vp, c.c_int, c.c_int]),
         "facppg_taco_postnet_workspace_bytes": (sz, [vp, c.c_int, c.c_int]),
         "facppg_taco_encode": (c.c_int, [vp, vp, vp, vp, u64, c.c_int, c.c_int, vp, vp, vp, sz, vp]),
-        "facppg_taco_decode": (c.c_int, [vp, vp, vp, vp, vp, u64, c.c_int, c.c_int, c.c_int, vp, vp, vp, vp, vp, sz, vp]),
+        "facppg_taco_decode": (c.c_int, [vp, vp, vp, vp, vp, vp, u64, c.c_int, c.c_int, c.c_int, vp, vp, vp, vp, vp, sz, vp]),
+        "facppg_taco_draw_dropout": (c.c_int, [vp, vp, c.c_int, c.c_int, c.c_int, vp, vp, vp]),
+        "facppg_wg_draw_noise": (c.c_int, [vp, vp, c.c_int, c.c_int, vp, vp]),
         "facppg_taco_postnet": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, c.c_int, vp, vp, sz, vp]),
+        "facppg_attention_window_mask": (c.c_int, [vp, c.c_int, c.c_int, c.c_int, c.c_int, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch

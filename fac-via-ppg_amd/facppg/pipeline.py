@@ -5,8 +5,70 @@ runs the same three stages -- Tacotron2.inference, WaveGlow.infer, Denoiser -- o
 with per-utterance lengths threaded through every HIP call, so each utterance's result equals
 its own batch-1 run; everything stays on the device until the final copy of the audio.
 """
+import os
+
 import numpy as np
 import torch
+
+
+class Synthesizer(object):
+    """The three models of the synthesis path loaded from the reference's checkpoint formats and kept on the GPU:
+    the PPG->mel state dict (``{'state_dict': ...}``, train_ppg2mel.py:113-119), the pickled WaveGlow module
+    (``{'model': ...}``, train_waveglow.py:56-64) once with weight norm removed for synthesis
+    (utils.py:177-181) and once as pickled for the denoiser's bias estimate (generate_synthesis.py:58-61)."""
+
+    def __init__(self, ppg2mel_path, waveglow_path, hparams=None, denoiser_mode='zeros'):
+        from common.hparams import create_hparams_stage
+        from common.utils import load_waveglow_model
+        from script.train_ppg2mel import load_model
+        from waveglow.denoiser import Denoiser
+        self.hparams = hparams if hparams is not None else create_hparams_stage()
+        self.tacotron = load_model(self.hparams)
+        self.tacotron.load_state_dict(torch.load(ppg2mel_path, weights_only=False)['state_dict'])
+        self.tacotron.eval()
+        self.denoiser = Denoiser(torch.load(waveglow_path, weights_only=False)['model'].cuda(), mode=denoiser_mode)
+        self.waveglow = load_waveglow_model(waveglow_path)
+
+    def __call__(self, ppgs, sigma=0.6, strength=0.005, **kw):
+        return synthesize(ppgs, self.tacotron, self.waveglow, self.denoiser, sigma=sigma, strength=strength, **kw)
+
+    @staticmethod
+    def has_utterance(utterance_path):
+        """The reference checks the teacher wav itself (generate_synthesis.py:89); here a precomputed PPG next to
+        it (or given directly) counts as well, since that is what this build reads."""
+        from common.data_utils import ppg_candidates
+        return any(os.path.isfile(c) for c in [utterance_path] + ppg_candidates(utterance_path))
+
+    def synthesize_file(self, utterance_path, wav_path, fs, sigma=0.6, strength=0.005, ppg_deps=None):
+        """One teacher utterance -> ``wav_path`` (float32 [N, 1] at ``fs``, generate_synthesis.py:90-98)."""
+        from common.data_utils import get_ppg
+        from scipy.io import wavfile
+        wavs, tout = self([get_ppg(utterance_path, ppg_deps)], sigma=sigma, strength=strength)
+        wavfile.write(wav_path, fs, wavs[0].astype(np.float32)[:, None])
+        return tout[0]
+
+
+class StageTimer(object):
+    """hipEvent timestamps on the launch stream between the stages of one synthesize() call (the kernels run on
+    torch's current stream, so torch.cuda.Event brackets them).  ``mark(name)`` closes stage ``name``."""
+
+    def __init__(self):
+        self.marks = []
+        self.mark("start")
+
+    def mark(self, name):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.marks.append((name, ev))
+
+    def stages_ms(self):
+        """{stage: ms} in order, plus 'total'; synchronises the last event."""
+        self.marks[-1][1].synchronize()
+        out = {}
+        for (_, a), (name, b) in zip(self.marks[:-1], self.marks[1:]):
+            out[name] = out.get(name, 0.0) + a.elapsed_time(b)
+        out["total"] = self.marks[0][1].elapsed_time(self.marks[-1][1])
+        return out
 
 
 def pad_ppgs(ppgs, device=None):
@@ -27,19 +89,34 @@ def pad_ppgs(ppgs, device=None):
 
 
 def synthesize(ppgs, tacotron, waveglow, denoiser=None, sigma=0.6, strength=0.005, seed=None, dropout_masks=None, z=None,
-               return_device=False):
-    """Returns (list of float32 waveforms [N_i], list of mel lengths).  Models must be on the GPU."""
+               return_device=False, utterance_seeds=None, step_limits=None, timer=None):
+    """Returns (list of float32 waveforms [N_i], list of mel lengths).  Models must be on the GPU.
+
+    utterance_seeds: one integer per utterance -- its dropout and noise streams then depend on that seed alone,
+    so the result for an utterance is the same whatever batch, batch size or GPU it is synthesised in.
+    step_limits: per-utterance max_decoder_steps (e.g. its PPG length)."""
     dev = next(tacotron.parameters()).device
+    if timer is not None:
+        timer.__init__()
     x, lens = pad_ppgs(ppgs, device=dev)
     hop = waveglow.upsample.stride[0]
+    if timer is not None:
+        timer.mark("ppg_upload")
     with torch.no_grad():
-        _, mel_post, _, _ = tacotron.inference(x, lengths=lens if len(lens) > 1 else None,
-                                               dropout_masks=dropout_masks, seed=seed)
+        _, mel_post, _, _ = tacotron.inference(x, lengths=lens if len(lens) > 1 else None, dropout_masks=dropout_masks,
+                                               seed=seed, utterance_seeds=utterance_seeds, step_limits=step_limits,
+                                               **({"timer": timer} if timer is not None else {}))
         tout = [int(v) for v in tacotron.last_output_lengths]
         multi = len(tout) > 1
-        audio = waveglow.infer(mel_post.contiguous(), sigma=sigma, z=z, lengths=tout if multi else None, seed=seed)
+        wg_seeds = None if utterance_seeds is None else [int(v) + 1 for v in utterance_seeds]
+        audio = waveglow.infer(mel_post.contiguous(), sigma=sigma, z=z, lengths=tout if multi else None, seed=seed,
+                               utterance_seeds=wg_seeds)
+        if timer is not None:
+            timer.mark("waveglow")
         if denoiser is not None:
             audio = denoiser(audio, strength=strength, lengths=[t * hop for t in tout] if multi else None)[:, 0]
+            if timer is not None:
+                timer.mark("denoiser")
     if return_device:
         return [audio[b, :tout[b] * hop] for b in range(len(tout))], tout
     host = audio.cpu().numpy()

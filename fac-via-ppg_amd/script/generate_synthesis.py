@@ -1,88 +1,61 @@
-"""Accent-conversion synthesis CLI -- drop-in for src/script/generate_synthesis.py.
+"""Accent-conversion synthesis CLI -- the drop-in for src/script/generate_synthesis.py.
 
-Same four required flags, constants (fs 16 kHz, sigma 0.6, denoiser 'zeros' / 0.005, is_clip
-False), ``debug.log`` lines and ``ac.wav`` output (float32 [N, 1]) as the reference
-(generate_synthesis.py:29-102); the models it loads run on libfacppg_hip.so.  The teacher
-utterance's PPG is read from a precomputed .npy (see common.data_utils.get_ppg).
+The contract kept from the reference (generate_synthesis.py:29-102) is its interface: the four required flags,
+the fixed settings (16 kHz, sigma 0.6, denoiser 'zeros' at 0.005, no clipping), what ``debug.log`` says, and
+``ac.wav`` (float32 [N, 1]) in the output directory -- or a logged warning and exit 0 when the teacher utterance
+is missing.  The work itself is ``facppg.pipeline.Synthesizer``: models on libfacppg_hip.so, PPG read from a
+precomputed .npy (common.data_utils.get_ppg).
 
-  PYTHONPATH=fac-via-ppg_amd python -m script.generate_synthesis --ppg2mel_model tacotron.pt \
+  PYTHONPATH=fac-via-ppg_amd python -m script.generate_synthesis --ppg2mel_model tacotron.pt \\
       --waveglow_model waveglow.pt --teacher_utterance_path utt.wav --output_dir out/
 """
-from common.data_utils import get_ppg
-from common.hparams import create_hparams_stage
-from common.layers import TacotronSTFT
-from common.utils import waveglow_audio, get_inference, load_waveglow_model
-from scipy.io import wavfile
-from script.train_ppg2mel import load_model
-from waveglow.denoiser import Denoiser
 import argparse
 import logging
 import os
+
 import ppg
-import torch
+from facppg.pipeline import Synthesizer
+
+SETTINGS = {"is_clip": False, "fs": 16000, "sigma": 0.6, "denoiser_strength": 0.005, "denoiser_mode": "zeros"}
+
+FLAGS = (("--ppg2mel_model", "Path to the PPG-to-Mel model."),
+         ("--waveglow_model", "Path to the WaveGlow model."),
+         ("--teacher_utterance_path", "Path to a native speaker recording (its PPG: <path>.ppg.npy, or a .npy path)."),
+         ("--output_dir", "Output dir, will save the audio and log info."))
+
+
+def parse(argv=None):
+    parser = argparse.ArgumentParser(description="Generate accent conversion speech using pre-trained models.")
+    for flag, text in FLAGS:
+        parser.add_argument(flag, type=str, required=True, help=text)
+    return parser.parse_args(argv)
+
+
+def log_settings(args):
+    """The reference's debug.log header (generate_synthesis.py:49,64-71), same wording and formats."""
+    logging.info("Output dir: %s", args.output_dir)
+    for fmt, value in (("Tacotron: %s", args.ppg2mel_model), ("Waveglow: %s", args.waveglow_model), ("AM: %s", "SI model"),
+                       ("is_clip: %d", SETTINGS["is_clip"]), ("Fs: %d", SETTINGS["fs"]), ("Sigma: %f", SETTINGS["sigma"]),
+                       ("Denoiser strength: %f", SETTINGS["denoiser_strength"]),
+                       ("Denoiser mode: %s", SETTINGS["denoiser_mode"])):
+        logging.debug(fmt, value)
 
 
 def main(argv=None):
-    parser = argparse.ArgumentParser(description='Generate accent conversion speech using pre-trained models.')
-    parser.add_argument('--ppg2mel_model', type=str, required=True, help='Path to the PPG-to-Mel model.')
-    parser.add_argument('--waveglow_model', type=str, required=True, help='Path to the WaveGlow model.')
-    parser.add_argument('--teacher_utterance_path', type=str, required=True,
-                        help='Path to a native speaker recording (its PPG: <path>.ppg.npy, or a .npy path).')
-    parser.add_argument('--output_dir', type=str, required=True, help='Output dir, will save the audio and log info.')
-    args = parser.parse_args(argv)
-
-    output_dir = args.output_dir
-    if not os.path.isdir(output_dir):
-        os.mkdir(output_dir)
-    logging.basicConfig(filename=os.path.join(output_dir, 'debug.log'), level=logging.DEBUG, force=True)
-    logging.info('Output dir: %s', output_dir)
-
-    # Parameters (generate_synthesis.py:51-62)
-    teacher_utt_path = args.teacher_utterance_path
-    checkpoint_path = args.ppg2mel_model
-    waveglow_path = args.waveglow_model
-    is_clip = False
-    fs = 16000
-    waveglow_sigma = 0.6
-    waveglow_for_denoiser = torch.load(waveglow_path, weights_only=False)['model']
-    waveglow_for_denoiser.cuda()
-    denoiser_mode = 'zeros'
-    denoiser = Denoiser(waveglow_for_denoiser, mode=denoiser_mode)
-    denoiser_strength = 0.005
-
-    logging.debug('Tacotron: %s', checkpoint_path)
-    logging.debug('Waveglow: %s', waveglow_path)
-    logging.debug('AM: SI model')
-    logging.debug('is_clip: %d', is_clip)
-    logging.debug('Fs: %d', fs)
-    logging.debug('Sigma: %f', waveglow_sigma)
-    logging.debug('Denoiser strength: %f', denoiser_strength)
-    logging.debug('Denoiser mode: %s', denoiser_mode)
-
-    hparams = create_hparams_stage()
-    taco_stft = TacotronSTFT(hparams.filter_length, hparams.hop_length, hparams.win_length, hparams.n_acoustic_feat_dims,
-                             hparams.sampling_rate, hparams.mel_fmin, hparams.mel_fmax)  # constructed, unused (as the reference)
-
-    tacotron_model = load_model(hparams)
-    tacotron_model.load_state_dict(torch.load(checkpoint_path, weights_only=False)['state_dict'])
-    _ = tacotron_model.eval()
-    waveglow_model = load_waveglow_model(waveglow_path)
-
-    deps = ppg.DependenciesPPG()
-
-    ppg_exists = os.path.isfile(teacher_utt_path) or os.path.isfile(teacher_utt_path + ".ppg.npy") or \
-        os.path.isfile(os.path.splitext(teacher_utt_path)[0] + ".ppg.npy")
-    if ppg_exists:
-        logging.info('Perform AC on %s', teacher_utt_path)
-        teacher_ppg = get_ppg(teacher_utt_path, deps)
-        ac_mel = get_inference(teacher_ppg, tacotron_model, is_clip)
-        ac_wav = waveglow_audio(ac_mel, waveglow_model, waveglow_sigma, True)
-        ac_wav = denoiser(ac_wav, strength=denoiser_strength)[:, 0].cpu().numpy().T
-        wavfile.write(os.path.join(output_dir, 'ac.wav'), fs, ac_wav)
+    args = parse(argv)
+    os.makedirs(args.output_dir, exist_ok=True)
+    logging.basicConfig(filename=os.path.join(args.output_dir, "debug.log"), level=logging.DEBUG, force=True)
+    log_settings(args)
+    synthesizer = Synthesizer(args.ppg2mel_model, args.waveglow_model, denoiser_mode=SETTINGS["denoiser_mode"])
+    utt = args.teacher_utterance_path
+    if synthesizer.has_utterance(utt):
+        logging.info("Perform AC on %s", utt)
+        synthesizer.synthesize_file(utt, os.path.join(args.output_dir, "ac.wav"), SETTINGS["fs"], SETTINGS["sigma"],
+                                    SETTINGS["denoiser_strength"], ppg_deps=ppg.DependenciesPPG())
     else:
-        logging.warning('Missing %s', teacher_utt_path)
-    logging.info('Done!')
+        logging.warning("Missing %s", utt)
+    logging.info("Done!")
 
 
-if __name__ == '__main__':
+if __name__ == "__main__":
     main()

@@ -10,8 +10,8 @@ IS RCCL on ROCm; "gloo" in the CPU tests):
   * gradients: one flat fp32 bucket per dtype, averaged with a single all_reduce per step
     (distributed.py:105-129).  RCCL turns a large all_reduce into reduce-scatter + all-gather over
     all 7 xGMI links of the full mesh; a 351.5 MB fp32 bucket moves 2*(7/8)*S per GPU.  The
-    reduction is launched from a post-accumulate hook on the LAST parameter to receive its gradient,
-    i.e. as soon as backward has produced everything, not from an engine callback.
+    reduction runs from an autograd-engine callback queued by the first gradient hook of each backward pass,
+    i.e. once per backward, after everything has been produced.
 """
 import torch
 import torch.distributed as dist
@@ -78,22 +78,25 @@ def allreduce_gradients(module):
 
 def apply_gradient_allreduce(module):
     """Make ``loss.backward()`` on ``module`` leave rank-averaged gradients behind, without changing
-    the module's class (distributed.py:90-142)."""
+    the module's class (distributed.py:90-142).  The first gradient to arrive in a backward pass queues ONE
+    autograd-engine callback, which runs after the whole pass -- so the exchange happens exactly once per
+    ``backward()`` whatever the set of parameters that received gradients: frozen or unused parameters, a second
+    backward on a retained graph and gradient accumulation all stay in step across ranks (ranks must agree on the
+    set of parameters with gradients, as in the reference)."""
     broadcast_parameters(module, 0)
     params = [p for p in module.parameters() if p.requires_grad]
-    state = {"pending": 0}
+    state = {"queued": False}
 
-    def arm(_module, _inputs, _output):                 # forward hook: a backward pass is coming
-        state["pending"] = len(params)
+    def exchange():
+        state["queued"] = False
+        allreduce_gradients(module)
 
     def on_grad(_param):
-        if state["pending"] > 0:
-            state["pending"] -= 1
-            if state["pending"] == 0:
-                allreduce_gradients(module)
+        if not state["queued"]:
+            state["queued"] = True
+            torch.autograd.Variable._execution_engine.queue_callback(exchange)
 
     for p in params:
         p.register_post_accumulate_grad_hook(on_grad)
-    module.register_forward_hook(arm)
     module.allreduce_params = lambda: allreduce_gradients(module)
     return module

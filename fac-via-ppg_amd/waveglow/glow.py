@@ -13,6 +13,8 @@ Extensions over the reference signature (all optional, defaults = reference beha
              one flat tensor); None -> generated on the device (Philox) from ``seed``
     lengths  per-utterance valid frame counts for padded batches: utterance b is synthesised
              exactly as a batch-1 call on spect[b, :, :lengths[b]] would be
+    utterance_seeds  B integers: the noise of utterance b depends on utterance_seeds[b] alone
+             (facppg_wg_draw_noise), so the batch reproduces B batch-1 calls with the same seeds
 """
 import torch
 
@@ -140,6 +142,46 @@ class _WNFunction(torch.autograd.Function):
         return (da0, dspect, *grads)
 
 
+def _conv1x1(W, z, transpose=False):
+    """[c, c] x [B, c, L] channel mixing on the HIP flow-edge kernel (facppg_conv1x1)."""
+    L = _lib.load()
+    z = z.float().contiguous()
+    W = W.detach().float().contiguous().to(z.device)
+    out = torch.empty_like(z)
+    B, c, Lg = z.shape
+    with torch.cuda.device(z.device):
+        _lib.check(L.facppg_conv1x1(_lib.ptr(W), _lib.ptr(z), _lib.ptr(out), B, c, Lg, 1 if transpose else 0,
+                                    _lib.current_stream(z.device)))
+    return out
+
+
+class _Conv1x1Function(torch.autograd.Function):
+    """The mixing conv of Invertible1x1Conv.forward (glow.py:98-102) as an autograd node on HIP kernels:
+    forward W z, backward dz = W^T dout (same kernel, transposed matrix) and dW = sum_{b,l} dout z^T."""
+
+    @staticmethod
+    def forward(ctx, W, z):
+        ctx.save_for_backward(W, z)
+        return _conv1x1(W, z)
+
+    @staticmethod
+    def backward(ctx, dout):
+        W, z = ctx.saved_tensors
+        L = _lib.load()
+        dout = dout.float().contiguous()
+        B, c, Lg = z.shape
+        dz = _conv1x1(W, dout, transpose=True) if ctx.needs_input_grad[1] else None
+        dW = None
+        if ctx.needs_input_grad[0]:
+            zc = z.float().contiguous()
+            dW = torch.empty(c, c, device=z.device)
+            ws = torch.empty(L.facppg_conv1x1_wgrad_workspace_bytes(c), dtype=torch.uint8, device=z.device)
+            with torch.cuda.device(z.device):
+                _lib.check(L.facppg_conv1x1_wgrad(_lib.ptr(dout), _lib.ptr(zc), _lib.ptr(dW), B, c, Lg, _lib.ptr(ws), ws.numel(),
+                                                  _lib.current_stream(z.device)))
+        return dW, dz
+
+
 class Invertible1x1Conv(torch.nn.Module):
     """glow.py:62-102: parameter container for the c x c mixing matrix.  In inference the
     inverse matrix is applied inside k_flow_end (fused with the affine coupling)."""
@@ -153,15 +195,31 @@ class Invertible1x1Conv(torch.nn.Module):
         self.conv.weight.data = W.view(c, c, 1).contiguous()
 
     def inverse_matrix(self):
-        """W^-1 as the reference computes and caches it (glow.py:88-95)."""
-        if not hasattr(self, "W_inverse"):
-            W = self.conv.weight.squeeze(-1)
-            self.W_inverse = W.float().inverse()[..., None]
-        return self.W_inverse.squeeze(-1)
+        """W^-1 as the reference computes and caches it (glow.py:88-95); the cache is keyed by the weight's
+        storage, in-place version and device so an optimizer step / .to() never leaves a stale inverse."""
+        W = self.conv.weight
+        key = (W.data_ptr(), W._version, W.device)
+        cached = self.__dict__.get("_W_inverse")
+        if cached is None or cached[0] != key:
+            cached = (key, W.detach().squeeze(-1).float().inverse())
+            self.__dict__["_W_inverse"] = cached
+        return cached[1]
+
+    @property
+    def W_inverse(self):                                 # the reference's attribute (glow.py:93), [c, c, 1]
+        return self.inverse_matrix()[..., None]
 
     def forward(self, z, reverse=False):
-        raise NotImplementedError(
-            "Invertible1x1Conv is fused into libfacppg_hip's flow kernels; call WaveGlow.infer")
+        """glow.py:82-102 as a stand-alone module: z [B, c, L] (GPU) -> W^-1 z when ``reverse``, else
+        (W z, B * L * log|det W|); runs the flow-edge channel-mixing kernel (facppg_conv1x1)."""
+        _lib.require_cuda(z, "Invertible1x1Conv.forward: z")
+        W = self.conv.weight.squeeze(-1)
+        if reverse:
+            return _conv1x1(self.inverse_matrix(), z)
+        log_det_W = z.size(0) * z.size(2) * torch.logdet(W.float())
+        if torch.is_grad_enabled() and (W.requires_grad or z.requires_grad):
+            return _Conv1x1Function.apply(W.float(), z.float()), log_det_W
+        return _conv1x1(W, z), log_det_W
 
 
 class WN(torch.nn.Module):
@@ -191,8 +249,37 @@ class WN(torch.nn.Module):
             rs = 2 * n_channels if i < n_layers - 1 else n_channels
             self.res_skip_layers.append(wn(torch.nn.Conv1d(n_channels, rs, 1), name='weight'))
 
+    def _plain_weights(self):
+        ws = [_effective_weight(self.start), self.start.bias]
+        for i in range(self.n_layers):
+            ws += [_effective_weight(self.in_layers[i]), self.in_layers[i].bias, _effective_weight(self.cond_layers[i]),
+                   self.cond_layers[i].bias, _effective_weight(self.res_skip_layers[i]), self.res_skip_layers[i].bias]
+        return ws + [self.end.weight, self.end.bias]
+
+    def _check_kernel_config(self):
+        """The fused layer kernels are built for one WN shape (config.json:36-40 with n_group 8, 80 mel bins);
+        anything else would read weights and saved activations with the wrong strides."""
+        n_in, n_cond = self.start.in_channels, self.cond_layers[0].in_channels
+        ks = self.in_layers[0].kernel_size[0]
+        if not (self.n_channels == 256 and ks == 3 and 1 <= self.n_layers <= 8 and n_cond == 640 and 1 <= n_in <= 4):
+            raise _lib.FacppgError(
+                "WN on the HIP kernels needs n_channels=256, kernel_size=3, n_layers<=8, 640 conditioning channels "
+                "(n_mel_channels*n_group) and n_in<=4; got n_channels=%d kernel_size=%d n_layers=%d cond=%d n_in=%d"
+                % (self.n_channels, ks, self.n_layers, n_cond, n_in))
+
     def forward(self, forward_input):
-        raise NotImplementedError("WN is fused into libfacppg_hip's k_wn_layer; call WaveGlow.infer")
+        """glow.py:154-175 as a stand-alone module: (audio [B, n_in, L], spect [B, 640, L]) on the GPU ->
+        [B, 2*n_in, L]; the fused k_wn_layer launches of facppg_wn_forward_save, differentiable through
+        facppg_wn_backward_data (the same autograd node the training step uses per flow)."""
+        audio, spect = forward_input
+        _lib.require_cuda(audio, "WN.forward: audio")
+        _lib.require_cuda(spect, "WN.forward: spect")
+        self._check_kernel_config()
+        Lg = audio.size(2)
+        if spect.size(2) != Lg or spect.size(0) != audio.size(0):
+            raise _lib.FacppgError("WN.forward: audio %s and spect %s disagree" % (tuple(audio.shape), tuple(spect.shape)))
+        spect_pad = torch.nn.functional.pad(spect.float(), (0, -(-Lg // _TN) * _TN - Lg)).contiguous()
+        return _WNFunction.apply(audio.float().contiguous(), spect_pad, *self._plain_weights())
 
 
 class WaveGlow(torch.nn.Module):
@@ -252,9 +339,14 @@ class WaveGlow(torch.nn.Module):
             _lib.load().facppg_wg_destroy(h[0])
         self.__dict__.pop("_facppg_ws", None)
 
+    def _fingerprint(self):
+        """Identity + in-place version of every tensor the packed handle was built from (optimizer steps,
+        ``p.data.copy_()`` bump ``_version``; re-assignment changes ``data_ptr``)."""
+        return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values() if torch.is_tensor(t))
+
     def _handle(self, device):
         h = self.__dict__.get("_facppg_handle")
-        if h is not None and h[1] == device:
+        if h is not None and h[1] == device and h[2] == self._fingerprint():
             return h[0]
         self._release()
         L = _lib.load()
@@ -267,7 +359,7 @@ class WaveGlow(torch.nn.Module):
         with torch.cuda.device(device):
             _lib.check(L.facppg_wg_create(cfg, _lib.ptr(blob), blob.numel(), device.index,
                                           _lib.current_stream(device), _lib.ctypes.byref(out)))
-        self.__dict__["_facppg_handle"] = (out, device)
+        self.__dict__["_facppg_handle"] = (out, device, self._fingerprint())
         return out
 
     def _apply(self, fn, *a, **k):                       # .cuda()/.to()/.float(): weights moved
@@ -276,8 +368,6 @@ class WaveGlow(torch.nn.Module):
 
     def load_state_dict(self, *a, **k):
         self._release()
-        for c in self.convinv:
-            c.__dict__.pop("W_inverse", None)
         return super(WaveGlow, self).load_state_dict(*a, **k)
 
     def __getstate__(self):                              # never pickle device handles
@@ -293,14 +383,6 @@ class WaveGlow(torch.nn.Module):
             pass
 
     # ---------------------------------------------------------------- the hot path
-    def _wn_weights(self, k):
-        wn = self.WN[k]
-        ws = [_effective_weight(wn.start), wn.start.bias]
-        for i in range(wn.n_layers):
-            ws += [_effective_weight(wn.in_layers[i]), wn.in_layers[i].bias, _effective_weight(wn.cond_layers[i]),
-                   wn.cond_layers[i].bias, _effective_weight(wn.res_skip_layers[i]), wn.res_skip_layers[i].bias]
-        return ws + [wn.end.weight, wn.end.bias]
-
     def _forward_autograd(self, spect, audio):
         """Training forward with a differentiable graph (train_waveglow.py:126-133).  Per flow the WN
         stack -- >99 % of the work -- is one HIP autograd node (_WNFunction); the flow edges
@@ -308,6 +390,11 @@ class WaveGlow(torch.nn.Module):
         split) and the 0.4 %-of-FLOPs upsampling conv stay as torch ops so autograd links them."""
         F = torch.nn.functional
         g = self.n_group
+        if _lib.load().facppg_wg_weight_count(self._config()) == 0:      # same check the inference handle makes
+            raise _lib.FacppgError("unsupported WaveGlow config for the HIP training kernels: %s"
+                                   % _lib.load().facppg_last_error().decode())
+        for wn in self.WN:
+            wn._check_kernel_config()
         # ConvTranspose1d as a matrix product + overlap-add (col2im): both are differentiable torch ops that
         # run on rocBLAS / a native fold kernel; MIOpen's transposed-conv backward falls back to a naive
         # kernel here that costs more than the rest of the step together
@@ -333,7 +420,7 @@ class WaveGlow(torch.nn.Module):
             audio = torch.einsum('ij,bjl->bil', W, audio)        # 1x1 mixing conv (c <= 8 channels)
             n_half = audio.size(1) // 2
             audio_0, audio_1 = audio[:, :n_half, :], audio[:, n_half:, :]
-            output = _WNFunction.apply(audio_0.contiguous(), spect_pad, *self._wn_weights(k))
+            output = _WNFunction.apply(audio_0.contiguous(), spect_pad, *self.WN[k]._plain_weights())
             log_s, b = output[:, n_half:, :], output[:, :n_half, :]
             audio_1 = torch.exp(log_s) * audio_1 + b
             log_s_list.append(log_s)
@@ -354,7 +441,8 @@ class WaveGlow(torch.nn.Module):
         L = _lib.load()
         dev = spect.device
         spect = spect.float().contiguous()
-        audio = audio.float().contiguous()
+        audio = audio.float()
+        audio = audio[:, :audio.shape[1] - audio.shape[1] % self.n_group].contiguous()   # unfold drops the tail (glow.py:224)
         B, _, F = spect.shape
         N = audio.shape[1]
         hop = self.upsample.stride[0]
@@ -380,7 +468,21 @@ class WaveGlow(torch.nn.Module):
             log_det_W_list.append(B * Lg * torch.logdet(W))          # glow.py:100
         return z, log_s_list, log_det_W_list
 
-    def infer(self, spect, sigma=1.0, z=None, lengths=None, seed=None):
+    def draw_noise(self, utterance_seeds, T, device=None):
+        """Per-utterance N(0,1) streams (facppg_wg_draw_noise) for a batch of len(utterance_seeds) mels of T frames,
+        flat in the injected-z layout ([B, n_remaining, L] ++ [B, n_early, L] per early output): the values of
+        utterance b depend on utterance_seeds[b] only."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        L = _lib.load()
+        h = self._handle(dev)
+        B, hop = len(utterance_seeds), self.upsample.stride[0]
+        sd = torch.tensor([int(v) & 0x7FFFFFFFFFFFFFFF for v in utterance_seeds], dtype=torch.int64, device=dev)
+        zt = torch.empty(B * self.n_group * (T * hop // self.n_group), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.facppg_wg_draw_noise(h, _lib.ptr(sd), B, T, _lib.ptr(zt), _lib.current_stream(dev)))
+        return zt
+
+    def infer(self, spect, sigma=1.0, z=None, lengths=None, seed=None, utterance_seeds=None):
         """mel [B, n_mel, T] (GPU, fp32) -> audio [B, T*hop]   (glow.py:252-293)."""
         _lib.require_cuda(spect, "WaveGlow.infer: spect")
         if spect.dtype != torch.float32:
@@ -397,7 +499,11 @@ class WaveGlow(torch.nn.Module):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             self.__dict__["_facppg_ws"] = ws
         zt = None
-        if z is not None:
+        if utterance_seeds is not None:
+            if z is not None or len(utterance_seeds) != B:
+                raise _lib.FacppgError("utterance_seeds: B integers, and not together with z")
+            zt = self.draw_noise(utterance_seeds, T, dev)
+        elif z is not None:
             if isinstance(z, (list, tuple)):
                 z = torch.cat([t.to(dev).float().reshape(-1) for t in z])
             zt = z.to(dev).float().contiguous()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FACPPG_VERSION 100 /* 0.1.0 */
+#define FACPPG_VERSION 101 /* 0.1.1 */
 
 #define FACPPG_OK 0
 #define FACPPG_EINVAL (-1)       /* bad argument (NULL pointer, non-positive size, ...) */
@@ -104,10 +104,14 @@ int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t* T_valid_d
                     const float* z_dev, uint64_t seed, float sigma, int B, int T,
                     float* audio_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
-/* Average device time (ms) of the dominant kernel (the fused WN layer) over the launches of
- * the most recent facppg_wg_infer on this handle, measured with hipEvents on the stream the
- * kernels ran on when profiling was enabled with facppg_wg_set_profiling(h, 1).  Synchronises
- * the recorded events.  *n_launches receives the number of launches averaged. */
+/* The three normal_() draws of WaveGlow.infer (glow.py:261-270, 285-290) as PER-UTTERANCE streams:
+ * writes z_dev in the flat injected-z layout of facppg_wg_infer for a batch of B mels of T frames, where
+ * every value of utterance b is a function of seeds_dev[b] (uint64 [B]) and its own (draw, channel,
+ * position) only.  A padded batch synthesised with this z therefore equals B independent batch-1 runs
+ * with the same seeds, whatever the batch composition, padding or sharding over GPUs. */
+int facppg_wg_draw_noise(const facppg_wg* h, const uint64_t* seeds_dev, int B, int T, float* z_dev,
+                         void* stream);
+
 /* Replaces: WaveGlow.forward((spect, audio)) (glow.py:208-250), the training direction
  * audio -> z: upsample + crop to the audio length, 8-sample regroup, per flow the forward 1x1
  * mixing conv, WN, and a1 = exp(log_s)*a1 + b, with early outputs split off every n_early_every
@@ -122,6 +126,17 @@ size_t facppg_wg_log_s_count(const facppg_wg* h, int B, int N);
 int facppg_wg_forward(facppg_wg* h, const float* mel_dev, const float* audio_dev, int B, int F,
                       int N, float* z_dev, float* log_s_dev, void* workspace_dev,
                       size_t workspace_bytes, void* stream);
+
+/* Replaces Invertible1x1Conv.forward (glow.py:82-102) as a stand-alone op: out[b][i][l] = sum_j W[i][j] z[b][j][l]
+ * for the c x c mixing matrix (c in {2,4,6,8}; z, out [B][c][L], not in place).  transpose_w != 0 applies W^T, which
+ * is the op's data gradient; the reverse direction is the same call with W^-1.  log|det W| is a property of the
+ * weights alone and is left to the caller (glow.py:100). */
+int facppg_conv1x1(const float* w_dev, const float* z_dev, float* out_dev, int B, int c, int L,
+                   int transpose_w, void* stream);
+/* Its weight gradient dW[i][j] = sum_{b,l} dout[b][i][l] z[b][j][l], summed in a fixed order (bit-reproducible). */
+size_t facppg_conv1x1_wgrad_workspace_bytes(int c);
+int facppg_conv1x1_wgrad(const float* dout_dev, const float* z_dev, float* dw_dev, int B, int c, int L,
+                         void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ---- WN training primitives (one flow's WN stack; WaveGlow training step, glow.py:154-175 +
  * its autograd backward).  Plain (un-packed, weight-norm already applied) device weights: */
@@ -151,6 +166,10 @@ int facppg_wn_backward_data(const facppg_wn_weights* w, int n_in, int n_layers, 
                             float* dh_all_dev, float* dskip_dev, float* dspect_dev, float* da0_dev,
                             void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* Average device time (ms) of the dominant kernel (the fused WN layer) over the launches of
+ * the most recent facppg_wg_infer on this handle, measured with hipEvents on the stream the
+ * kernels ran on when profiling was enabled with facppg_wg_set_profiling(h, 1).  Synchronises
+ * the recorded events.  *n_launches receives the number of launches averaged. */
 int facppg_wg_set_profiling(facppg_wg* h, int enable);
 int facppg_wg_last_layer_ms(facppg_wg* h, float* avg_ms, int* n_launches);
 
@@ -254,7 +273,9 @@ int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const int32_t* leng
                        float* pm_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 /* Replaces Decoder.inference (model.py:489-535) including the attention window mask
  * (utils.py:46-78) and the stop rule (sigmoid(gate) > gate_threshold after appending the frame,
- * else stop at max_steps).  masks_dev NULL or uint8 [max_steps][2][B][prenet_dim].
+ * else stop at max_steps).  step_limits_dev NULL, or [B] int32: utterance b stops after
+ * min(step_limits[b], max_steps) frames at the latest (a padded batch whose utterances each have their
+ * own max_decoder_steps, e.g. = their PPG length).  masks_dev NULL or uint8 [max_steps][2][B][prenet_dim].
  * Outputs: mel_dev [B][n_feat][max_steps], gate_dev [B][max_steps], align_dev NULL or
  * [B][max_steps][Tin], out_lengths_dev [B] (= Tout per utterance; columns beyond it untouched).
  * One launch for the whole loop.  The launch shape follows B: up to 9 utterances run as one attention
@@ -263,10 +284,25 @@ int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const int32_t* leng
  * of an utterance must be co-resident) and every shape returns the same values to fp32 round-off.
  * FACPPG_DECODER_MODE=split|coop|single forces one (FACPPG_EUNSUPPORTED if B does not allow it). */
 int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const float* pm_dev,
-                       const int32_t* lengths_dev, const uint8_t* masks_dev, uint64_t seed, int B,
+                       const int32_t* lengths_dev, const int32_t* step_limits_dev,
+                       const uint8_t* masks_dev, uint64_t seed, int B,
                        int Tin, int max_steps, float* mel_dev, float* gate_dev, float* align_dev,
                        int32_t* out_lengths_dev, void* workspace_dev, size_t workspace_bytes,
                        void* stream);
+/* The always-on p=0.5 dropout draws of both prenets (Prenet.forward, model.py:132-135) as PER-UTTERANCE
+ * streams keyed by seeds_dev[b] (uint64 [B]): enc_masks_dev uint8 [2][B][symbols_embedding_dim][Tin] and
+ * dec_masks_dev uint8 [max_steps][2][B][prenet_dim] in the layouts facppg_taco_encode / _decode accept
+ * (either may be NULL).  Bit (layer, channel, frame) of utterance b does not depend on B, Tin or max_steps. */
+int facppg_taco_draw_dropout(const facppg_taco* h, const uint64_t* seeds_dev, int B, int Tin,
+                             int max_steps, uint8_t* enc_masks_dev, uint8_t* dec_masks_dev,
+                             void* stream);
+/* Replaces get_mask_from_lengths_window_and_time_step(memory_lengths, attention_window_size,
+ * time_step) (src/common/utils.py:46-78), the integer part of the attention: mask_dev [B][Tmax]
+ * uint8, 0 = keep for index in [min(max(0, t-W), len-1), min(t+W, len-1)], 1 = masked (so the last
+ * frame stays unmasked once t-W has passed it, utils.py:65-69); window < 0 = no window.  lengths_dev [B]
+ * int32, each in [1, Tmax].  Uses the very range function the decoder kernels evaluate the attention on. */
+int facppg_attention_window_mask(const int32_t* lengths_dev, int B, int Tmax, int window,
+                                 int time_step, uint8_t* mask_dev, void* stream);
 /* Replaces Postnet.forward + the residual add (model.py:178-184, 604-605):
  * mel_dev [B][n_feat][ld] (first T columns used) -> mel_post_dev, same layout. */
 int facppg_taco_postnet(facppg_taco* h, const float* mel_dev, const int32_t* out_lengths_dev,

@@ -301,6 +301,61 @@ def gen_waveglow_train():
     save("waveglow_train.npz", **arrs)
 
 
+def gen_e2e():
+    """The body of the reference CLI (generate_synthesis.py:55-62,75-95) on synthetic checkpoints: PPG ->
+    get_inference -> waveglow_audio(sigma 0.6, is_cuda_output=True) -> Denoiser('zeros')(strength 0.005), with the
+    weight-normed model for the denoiser and the weight-norm-removed one for synthesis, exactly as the script
+    builds them.  Dropout masks and z are injected; the decoder runs under the CLI's own hparams
+    (create_hparams_stage(): max_decoder_steps 1000) and stops on its gate."""
+    from common import hparams as rh
+    from common import model as rmodel
+    from common.utils import get_inference, waveglow_audio
+    from waveglow import glow
+    from waveglow.denoiser import Denoiser
+    Tin, gate_bias, n_sym = 40, -0.1, 5816
+    hp = rh.create_hparams_stage()
+    taco = rmodel.Tacotron2(hp)
+    taco.load_state_dict(synth.tacotron_state_dict(hp, seed=16807, gate_bias=gate_bias), strict=True)
+    taco.eval()
+    cfg = dict(synth.WAVEGLOW_CONFIG)
+    sd = synth.waveglow_state_dict(cfg)
+    wn_sd = {}
+    for k, v in sd.items():
+        if k.startswith("WN.") and k.endswith(".weight") and ".end." not in k:
+            wn_sd[k[:-6] + "weight_v"] = v
+            wn_sd[k[:-6] + "weight_g"] = v.flatten(1).norm(dim=1).view(-1, 1, 1)
+        else:
+            wn_sd[k] = v
+    wg_for_denoiser = glow.WaveGlow(**cfg)
+    wg_for_denoiser.load_state_dict(wn_sd, strict=True)
+    denoiser = Denoiser(wg_for_denoiser, mode="zeros")          # generate_synthesis.py:58-61 (bias: sigma 0, any z)
+    wg = ref_waveglow(cfg)                                      # load_waveglow_model: weight norm removed, eval
+    ppg = synth.synthetic_ppg(Tin, n_sym, seed=3, alpha=0.002)
+    steps = hp.max_decoder_steps
+    enc_masks = masks_from_seed(881, (2, 1, Tin, hp.symbols_embedding_dim))
+    dec_masks = masks_from_seed(882, (steps, 2, 1, hp.prenet_dim))
+    queue = [enc_masks[0], enc_masks[1]] + [dec_masks[t, j] for t in range(steps) for j in range(2)]
+    with torch.no_grad(), InjectDropout(rmodel, queue):
+        ac_mel = get_inference(ppg, taco, False)
+    Tout = ac_mel.shape[2]
+    assert Tout < steps, "the gate never fired"
+    with torch.no_grad(), InjectDropout(rmodel, queue):       # stop decisions must not sit on the fp32 edge
+        gate = taco.inference(torch.from_numpy(ppg).float().t().unsqueeze(0))[2]
+    margin = float(gate.abs().min())
+    print("e2e: smallest |gate logit| over the %d steps: %.4f" % (Tout, margin))
+    assert margin > 1e-3
+    zs = synth.synthetic_z(1, Tout * 20, cfg, seed=883)
+    with InjectNormal(zs) as inj:
+        ac_wav = waveglow_audio(ac_mel, wg, 0.6, True)
+        assert inj.i == 3
+    with torch.no_grad():
+        out = denoiser(ac_wav, strength=0.005)[:, 0].cpu().numpy().T       # what wavfile.write receives: [N, 1]
+    print("e2e: Tin", Tin, "Tout", Tout, "samples", out.shape)
+    save("e2e_cli.npz", Tin=Tin, gate_bias=gate_bias, n_symbols=n_sym, ppg_seed=3, ppg_alpha=0.002, enc_mask_seed=881,
+         dec_mask_seed=882, z_seed=883, sigma=0.6, strength=0.005, Tout=Tout, ppg_sha=sha(ppg), mel_post=ac_mel,
+         audio=ac_wav, ac_wav=out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -312,6 +367,7 @@ def main():
     gen_waveglow_old()
     gen_waveglow_train()
     gen_tacotron()
+    gen_e2e()
 
 
 if __name__ == "__main__":

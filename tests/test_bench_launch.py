@@ -1,0 +1,36 @@
+"""CPU: bench.py's own N-rank launcher (--gpus N without torch.distributed.run): it must spawn N ranks, rendezvous on
+127.0.0.1, count N connected ranks and print one JSON line from rank 0 with n_gpus == N.  --launch-check runs that
+path without the GPU work (gloo)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=e, timeout=300)
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_spawns_n_ranks(n):
+    r = _run(["--gpus", str(n), "--launch-check", "--dist-backend", "gloo"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]          # (gloo itself prints a connection notice)
+    assert len(lines) == 1                                   # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["world_size"] == n and d["ranks_connected"] == n and d["max_over_ranks"] == float(n)
+
+
+def test_bench_refuses_world_size_mismatch():
+    """Launched as ONE process with WORLD_SIZE=1 but --gpus 2 (what silently produced an n_gpus:1 line before):
+    must fail loudly, not report a 1-rank number as a 2-GPU one."""
+    r = _run(["--gpus", "2", "--launch-check", "--dist-backend", "gloo"], env={"WORLD_SIZE": "1", "RANK": "0", "MASTER_PORT": "29999"})
+    assert r.returncode != 0 and "WORLD_SIZE 1 != --gpus 2" in r.stderr

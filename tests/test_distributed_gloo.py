@@ -57,6 +57,29 @@ def _worker(rank, world, port, q):
                 exp = g if exp is None else [a + b for a, b in zip(exp, g)]
             ok = all(torch.allclose(a, b / world, atol=1e-6) for a, b in zip(got, exp))
             same_params = same_params and ok
+        # a parameter that receives no gradient (frozen) and a second backward on a retained graph (accumulation):
+        # the exchange must still run once per backward and leave rank-averaged sums
+        m.b.bias.requires_grad_(False)
+        m.zero_grad()
+        out = m(xs[rank]).pow(2).sum()
+        out.backward(retain_graph=True)
+        g1 = [p.grad.clone() for p in m.parameters() if p.grad is not None]
+        out.backward()
+        g2 = [p.grad.clone() for p in m.parameters() if p.grad is not None]
+        ga = [torch.zeros_like(g) for g in g1]
+        for r in range(world):
+            ref.zero_grad()
+            ref.load_state_dict(m.state_dict())
+            ref(xs[r]).pow(2).sum().backward()
+            gr = [p.grad for n, p in ref.named_parameters() if n != "b.bias"]
+            ga = [a + b / world for a, b in zip(ga, gr)]
+        same_params = same_params and all(torch.allclose(a, b, atol=1e-6) for a, b in zip(g1, ga))
+        # second pass: grad = averaged(first) + local(second), then averaged again = avg + avg(local)/... every rank equal
+        flat2 = torch.cat([g.reshape(-1) for g in g2])
+        both = [torch.zeros_like(flat2) for _ in range(world)]
+        dist.all_gather(both, flat2)
+        same_params = same_params and all(torch.allclose(both[0], b, atol=1e-6) for b in both)
+        same_params = same_params and all(torch.allclose(b, 2 * a, atol=1e-5) for a, b in zip(ga, g2))
         loss = reduce_tensor(torch.tensor(float(rank + 1)), world)
         q.put((rank, bool(same_params), float(loss)))
     finally:

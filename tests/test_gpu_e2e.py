@@ -65,6 +65,163 @@ def test_generate_synthesis_cli(checkpoints, tmp_path, capsys):
     assert not os.path.exists(out2 / "ac.wav") and "Missing" in open(out2 / "debug.log").read()
 
 
+def test_generate_synthesis_cli_output_matches_reference_golden(tmp_path, monkeypatch):
+    """a20: the CLI's ac.wav against tests/golden/e2e_cli.npz -- the body of the reference's generate_synthesis.py
+    (get_inference -> waveglow_audio -> Denoiser) run on the imported reference with the same synthetic checkpoints.
+    The only intervention is INJECTION of the random draws the fixture captured (prenet dropout masks, z), done by
+    wrapping the two model entry points the CLI reaches; everything else (checkpoint loading incl. weight-norm
+    removal, hparams, the denoiser's bias estimate, the WAV writer) is the CLI's own code."""
+    from common.hparams import create_hparams_stage
+    from common.model import Tacotron2
+    from helpers import golden
+    from script import generate_synthesis
+    from waveglow.glow import WaveGlow
+    d = golden("e2e_cli.npz")
+    Tin, Tout = int(d["Tin"]), int(d["Tout"])
+    cfg = dict(synth.WAVEGLOW_CONFIG)
+    wg = WaveGlow(**cfg)
+    wg.load_state_dict(weightnorm_state_dict(synth.waveglow_state_dict(cfg)), strict=True)
+    torch.save({"model": wg, "iteration": 0, "optimizer": None, "learning_rate": 1e-4}, tmp_path / "waveglow.pt")
+    hp = create_hparams_stage()
+    torch.save({"state_dict": synth.tacotron_state_dict(hp, gate_bias=float(d["gate_bias"])), "iteration": 0}, tmp_path / "tacotron.pt")
+    ppg = synth.synthetic_ppg(Tin, int(d["n_symbols"]), seed=int(d["ppg_seed"]), alpha=float(d["ppg_alpha"]))
+    np.save(str(tmp_path / "teacher.wav") + ".ppg.npy", ppg)
+    em = masks_from_seed(int(d["enc_mask_seed"]), (2, 1, Tin, hp.symbols_embedding_dim))
+    dm = masks_from_seed(int(d["dec_mask_seed"]), (hp.max_decoder_steps, 2, 1, hp.prenet_dim))
+    taco_inference, wg_infer = Tacotron2.inference, WaveGlow.infer
+    seen = {}
+
+    def inference_injected(self, x, **kw):
+        out = taco_inference(self, x, dropout_masks=(em, dm))
+        seen["mel_post"] = out[1].cpu().numpy()
+        return out
+
+    def infer_injected(self, spect, sigma=1.0, **kw):
+        if sigma == 0.0:                       # the denoiser's bias estimate: z is multiplied by 0
+            return wg_infer(self, spect, sigma=sigma)
+        seen["audio"] = wg_infer(self, spect, sigma=sigma, z=synth.synthetic_z(1, spect.shape[2] * 20, cfg, seed=int(d["z_seed"])))
+        return seen["audio"]
+
+    monkeypatch.setattr(Tacotron2, "inference", inference_injected)
+    monkeypatch.setattr(WaveGlow, "infer", infer_injected)
+    out = tmp_path / "out"
+    generate_synthesis.main(["--ppg2mel_model", str(tmp_path / "tacotron.pt"), "--waveglow_model", str(tmp_path / "waveglow.pt"),
+                             "--teacher_utterance_path", str(tmp_path / "teacher.wav"), "--output_dir", str(out)])
+    sr, wav = wavfile.read(out / "ac.wav")
+    assert sr == 16000 and wav.dtype == np.float32
+    assert seen["mel_post"].shape == d["mel_post"].shape == (1, 80, Tout)                 # same stop frame
+    assert np.abs(seen["mel_post"] - d["mel_post"]).max() <= 1e-4
+    assert wav.shape == (Tout * 160,) == d["ac_wav"][:, 0].shape                          # integer: N = Tout * hop
+    e_pre = rms(seen["audio"].cpu().numpy() - d["audio"])
+    e = rms(wav - d["ac_wav"][:, 0])
+    print("CLI vs reference golden: mel_post %.2e, audio rms err %.2e, ac.wav rms err %.2e (rms %.3f)" % (
+        np.abs(seen["mel_post"] - d["mel_post"]).max(), e_pre, e, rms(d["ac_wav"])))
+    assert e_pre <= 1e-3 and e <= 1e-3
+
+
+def _config3_lengths(n, seed, scale=1.0):
+    """Tin_i = 100 + PCG64(seed).integers(0, 301) frames (1-4 s)."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    return [max(8, int(round(v * scale))) for v in (100 + g.integers(0, 301, size=n)).tolist()]
+
+
+def test_config3_batch16_ragged_end_to_end(checkpoints, monkeypatch):
+    """BASELINE config 3: 16 variable-length utterances (Tin_i = 100 + PCG64(7).integers(0,301), i.e. 1-4 s),
+    max_decoder_steps = Tin_i per utterance, PPG -> mel -> wav -> denoised in ONE padded batch with
+    per-utterance random streams.  Every utterance must equal its own batch-1 run bit for bit (same decoder launch
+    shape forced for both; across shapes the LSTM sums are cut differently), and the three shortest are checked
+    against the CPU oracle of the whole path fed with the very masks / noise the device drew."""
+    from common.hparams import create_hparams_stage
+    from common.utils import load_waveglow_model
+    from facppg import pipeline
+    from oracle import dsp, tacotron as otac, waveglow as owg
+    from script.train_ppg2mel import load_model
+    from waveglow.denoiser import Denoiser
+    monkeypatch.setenv("FACPPG_DECODER_MODE", "coop")
+    monkeypatch.setenv("FACPPG_DECODER_COOP_U", "20")         # what B = 16 picks by itself (15 workgroups per utterance)
+    monkeypatch.setenv("FACPPG_BILSTM_MODE", "single")        # B = 16 is beyond the register-resident BiLSTM (B <= 12)
+    lens = _config3_lengths(16, 7)
+    assert len(set(lens)) > 8 and min(lens) >= 100 and max(lens) <= 400
+    hp = create_hparams_stage(max_decoder_steps=max(lens))
+    tsd = synth.tacotron_state_dict(hp, gate_bias=-10.0)
+    taco = load_model(hp)
+    taco.load_state_dict(tsd)
+    taco.eval()
+    den = Denoiser(torch.load(checkpoints / "waveglow.pt", weights_only=False)["model"].cuda(), mode="zeros")
+    wg = load_waveglow_model(str(checkpoints / "waveglow.pt"))
+    cfg = dict(synth.WAVEGLOW_CONFIG)
+    wsd = synth.waveglow_state_dict(cfg)
+    ppgs = [synth.synthetic_ppg(n, 5816, seed=300 + i, alpha=0.002) for i, n in enumerate(lens)]
+    seeds = [9000 + 17 * i for i in range(16)]
+    wavs, tout = pipeline.synthesize(ppgs, taco, wg, den, sigma=0.6, strength=0.005, utterance_seeds=seeds, step_limits=lens)
+    assert tout == lens and [len(w) for w in wavs] == [n * 160 for n in lens]        # integer facts: Tout_i, N_i = Tout_i*hop
+    assert all(np.isfinite(w).all() for w in wavs)
+    for b in range(16):
+        single, t1 = pipeline.synthesize([ppgs[b]], taco, wg, den, sigma=0.6, strength=0.005, utterance_seeds=[seeds[b]],
+                                         step_limits=[lens[b]])
+        assert t1 == [lens[b]] and np.array_equal(single[0], wavs[b]), b
+    with torch.no_grad():
+        bias = owg.infer(wsd, cfg, torch.zeros(1, 80, 88), 0.0, [torch.zeros(1, 4, 1760), torch.zeros(1, 2, 1760), torch.zeros(1, 2, 1760)])
+    oden = dsp.DenoiserOracle(bias)
+    for b in sorted(range(16), key=lambda i: lens[i])[:3]:
+        n = lens[b]
+        enc, dec = taco.draw_dropout_masks([seeds[b]], n, steps=n)             # device layouts
+        em = enc.permute(0, 1, 3, 2).cpu().float()                             # -> reference shape [2, 1, Tin, E]
+        dm = dec.cpu().float()
+        zflat = wg.draw_noise([seeds[b] + 1], n).cpu()
+        L = n * 20
+        zs = [zflat[:4 * L].view(1, 4, L), zflat[4 * L:6 * L].view(1, 2, L), zflat[6 * L:].view(1, 2, L)]
+        x = torch.from_numpy(ppgs[b]).t().unsqueeze(0)
+        hp_b = create_hparams_stage(max_decoder_steps=n)
+        mel, mel_post, gate, align = otac.inference(tsd, hp_b, x, em, dm)
+        assert mel_post.shape[2] == n
+        with torch.no_grad():
+            ref = oden(owg.infer(wsd, cfg, mel_post, 0.6, zs), 0.005)[0, 0].numpy()
+        e = rms(wavs[b] - ref)
+        print("config 3 utt %d: %d frames, wav rms err vs oracle %.2e (rms %.3f)" % (b, n, e, rms(ref)))
+        assert e <= 1e-3
+
+
+def test_config4_corpus_script_world1(tmp_path, monkeypatch):
+    """BASELINE config 4 on one GPU: script.synthesize_corpus.main() over 64 ragged synthetic PPGs (length law of
+    SURVEY 8d config 4: 100 + PCG64(11).integers(0,301), scaled by 1/4 to keep the fixture files small), batches of 16,
+    per-utterance decoder limits.  Every wav it writes must equal that utterance's own batch-1 synthesis with the same
+    utterance seed, bit for bit, and re-running with another batch size must write identical files."""
+    from common.hparams import create_hparams_stage
+    from facppg.pipeline import Synthesizer
+    from script import synthesize_corpus
+    from waveglow.glow import WaveGlow
+    monkeypatch.setenv("FACPPG_DECODER_MODE", "coop")
+    monkeypatch.setenv("FACPPG_DECODER_COOP_U", "20")
+    monkeypatch.setenv("FACPPG_BILSTM_MODE", "single")
+    cfg = dict(synth.WAVEGLOW_CONFIG)
+    wg = WaveGlow(**cfg)
+    wg.load_state_dict(weightnorm_state_dict(synth.waveglow_state_dict(cfg)), strict=True)
+    torch.save({"model": wg, "iteration": 0, "optimizer": None, "learning_rate": 1e-4}, tmp_path / "waveglow.pt")
+    hp = create_hparams_stage()
+    torch.save({"state_dict": synth.tacotron_state_dict(hp, gate_bias=-10.0), "iteration": 0}, tmp_path / "tacotron.pt")
+    lens = _config3_lengths(64, 11, scale=0.25)
+    assert len(set(lens)) > 20
+    paths = []
+    for i, n in enumerate(lens):
+        paths.append(str(tmp_path / ("utt%03d.npy" % i)))
+        np.save(paths[-1], synth.synthetic_ppg(n, 5816, seed=500 + i, alpha=0.002))
+    (tmp_path / "ppgs.txt").write_text("\n".join(paths) + "\n")
+    common = ["--ppg2mel_model", str(tmp_path / "tacotron.pt"), "--waveglow_model", str(tmp_path / "waveglow.pt"),
+              "--ppg_list", str(tmp_path / "ppgs.txt"), "--seed", "77", "--limit_steps_to_input"]
+    written = synthesize_corpus.main(common + ["--output_dir", str(tmp_path / "out16"), "--batch_size", "16"])
+    assert written == ["utt%03d.wav" % i for i in range(64)]
+    synthesize_corpus.main(common + ["--output_dir", str(tmp_path / "out5"), "--batch_size", "5"])
+    one = Synthesizer(str(tmp_path / "tacotron.pt"), str(tmp_path / "waveglow.pt"))
+    for i, n in enumerate(lens):
+        sr, a = wavfile.read(tmp_path / "out16" / ("utt%03d.wav" % i))
+        assert sr == 16000 and a.dtype == np.float32 and a.shape == (n * 160,)             # Tout_i = Tin_i, N = Tout*hop
+        assert np.array_equal(a, wavfile.read(tmp_path / "out5" / ("utt%03d.wav" % i))[1]), i
+        if i % 4 == 0:                                                                    # 16 of the 64 against their own runs
+            single, tout = one([np.load(paths[i])], utterance_seeds=[77 + 2 * i], step_limits=[n])
+            assert tout == [n] and np.array_equal(single[0], a), i
+
+
 def test_pipeline_matches_oracle_and_batches_equal_singles(checkpoints):
     from common.hparams import create_hparams_stage
     from common.utils import load_waveglow_model

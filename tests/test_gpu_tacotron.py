@@ -40,6 +40,60 @@ def test_inference_matches_reference_golden(tag, mode, monkeypatch):
     e_gate = np.abs(gate.cpu().numpy() - d["gate"]).max()
     print(tag, mode, "memory %.2e mel %.2e mel_post %.2e align %.2e gate %.2e" % (e_mem, e_mel, e_post, e_al, e_gate))
     assert e_mem <= 1e-4 and e_mel <= 1e-4 and e_post <= 1e-4 and e_al <= 1e-4 and e_gate <= 1e-4
+    # a17, integer: the masked-out pattern (the reference's masked_fill(-inf) -> softmax == exactly 0) must be the
+    # golden's entry for entry -- a window off by one would pass the float check whenever the edge weight is < 1e-4
+    assert np.array_equal(align.cpu().numpy() == 0, d["align"] == 0)
+
+
+def test_attention_window_mask_hip_bit_exact():
+    """a17 on the device: facppg_attention_window_mask (the decoder kernels' own attn_window_range) over all 144
+    reference masks of tests/golden/attn_masks.npz -- get_mask_from_lengths_window_and_time_step run on the imported
+    reference (utils.py:46-78), incl. len 1, ragged batches and steps far past the end (the 'last frame stays
+    unmasked' quirk, utils.py:65-69)."""
+    import json
+    from common.utils import get_mask_from_lengths_window_and_time_step
+    from helpers import golden
+    d = golden("attn_masks.npz")
+    cases = json.loads(bytes(d["cases"]).decode())
+    assert len(cases) == 144
+    quirk = 0
+    for c in cases:
+        lengths = torch.tensor(c["lengths"], dtype=torch.int64, device="cuda")
+        m = get_mask_from_lengths_window_and_time_step(lengths, c["W"], c["t"])
+        assert m.is_cuda and m.dtype == torch.bool
+        got = m.cpu().numpy().astype(np.uint8)
+        assert got.shape == d[c["key"]].shape and np.array_equal(got, d[c["key"]]), c
+        quirk += any(c["t"] - c["W"] > n - 1 for n in c["lengths"])
+    assert quirk > 0                      # the fixture does exercise the quirk
+
+
+@pytest.mark.parametrize("mode", ["split", "coop", "single"])
+def test_alignment_support_is_the_reference_window_past_the_end(mode, monkeypatch):
+    """a17 through the decoder itself where the quirk bites: Tin = 6 and 40 steps, so from step 26 on t-W has
+    passed the last frame and ONLY frame Tin-1 may carry weight (utils.py:65-69).  The non-zero pattern of the
+    device alignments must equal the reference mask for every step, and equal the oracle's pattern."""
+    from common.hparams import create_hparams_stage
+    from common.utils import get_mask_from_lengths_window_and_time_step
+    from facppg import synth
+    from helpers import masks_from_seed
+    from oracle import tacotron as otac
+    monkeypatch.setenv("FACPPG_DECODER_MODE", mode)
+    Tin, steps, W = 6, 40, 20
+    hp = create_hparams_stage(max_decoder_steps=steps)
+    sd = synth.tacotron_state_dict(hp, gate_bias=-10.0)
+    m = build(hp, sd)
+    ppg = synth.synthetic_ppg(Tin, 5816, seed=2)
+    em, dm = masks_from_seed(1, (2, 1, Tin, 600)), masks_from_seed(2, (steps, 2, 1, 300))
+    x = torch.from_numpy(ppg).t().unsqueeze(0)
+    _, _, _, align = m.inference(x.cuda(), dropout_masks=(em, dm))
+    al = align[0].cpu().numpy()
+    ref = otac.inference(sd, hp, x, torch.from_numpy(em.astype(np.float32)), torch.from_numpy(dm.astype(np.float32)))[3][0].numpy()
+    assert al.shape == ref.shape == (steps, Tin)
+    for t in range(steps):
+        keep = ~get_mask_from_lengths_window_and_time_step([Tin], W, t)[0].numpy()
+        assert np.array_equal(al[t] != 0, keep), (t, al[t])
+        assert np.array_equal(ref[t] != 0, keep)
+    assert np.array_equal(al[30] != 0, np.arange(Tin) == Tin - 1) and abs(al[30, Tin - 1] - 1.0) < 1e-6
 
 
 def test_bilstm_shapes_agree(monkeypatch):

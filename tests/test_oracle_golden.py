@@ -89,6 +89,10 @@ def test_attention_window_mask_bit_exact():
     for c in cases:
         m = otac.window_mask(c["lengths"], c["W"], c["t"]).numpy().astype(np.uint8)
         assert np.array_equal(m, d[c["key"]]), c
+        # the product's host-side function (lists / CPU tensors; GPU lengths go through the HIP kernel, -m gpu)
+        from common.utils import get_mask_from_lengths_window_and_time_step as product_mask
+        pm = product_mask(torch.tensor(c["lengths"]), c["W"], c["t"])
+        assert pm.dtype == torch.bool and np.array_equal(pm.numpy().astype(np.uint8), d[c["key"]]), c
 
 
 @pytest.mark.parametrize("tag", ["nostop", "stop", "mono40"])

@@ -87,3 +87,54 @@ def test_pad_ppgs_layout_host_and_device_paths_agree():
     assert torch.equal(x, y)
     for b, p in enumerate(ppgs):
         assert np.array_equal(x[b, :, :lens[b]].numpy(), p.T) and torch.count_nonzero(x[b, :, lens[b]:]) == 0
+
+
+class _RampSynthesizer(object):
+    """Stand-in for facppg.pipeline.Synthesizer (the HIP path needs a GPU): utterance -> a ramp determined by its
+    seed and its PPG (length and first value), on the CPU.  Same call signature as the real one."""
+
+    def __call__(self, ppgs, sigma=0.6, strength=0.005, utterance_seeds=None, step_limits=None, return_device=False):
+        assert return_device and utterance_seeds is not None and len(utterance_seeds) == len(ppgs)
+        lens = [int(p.shape[0]) for p in ppgs]
+        assert lens == sorted(lens, reverse=True)                  # a rank's batches arrive longest first
+        tout = list(step_limits) if step_limits is not None else lens
+        wavs = [torch.arange(t * 160, dtype=torch.float32) * 1e-3 + float(s) + float(p[0, 0]) for t, s, p in zip(tout, utterance_seeds, ppgs)]
+        return wavs, tout
+
+
+def _corpus_worker(rank, world, port, argv):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from script import synthesize_corpus
+    written = synthesize_corpus.main(argv, synthesizer=_RampSynthesizer())
+    assert (written is not None) == (rank == 0)
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_synthesize_corpus_script_gloo(tmp_path, world):
+    """BASELINE config 4's N>1 data path, driven through script.synthesize_corpus.main itself on CPU (gloo): its own
+    argument parsing, partition, batching, per-utterance seeds / step limits, ragged gather to rank 0 and WAV writer;
+    only the synthesiser is a stand-in.  The files must not depend on the world size."""
+    from scipy.io import wavfile
+    g = np.random.Generator(np.random.PCG64(11))
+    lens = [max(2, int(v) // 40) for v in (100 + g.integers(0, 301, size=37))]       # config-4 length law, scaled down
+    paths = []
+    for i, n in enumerate(lens):
+        paths.append(str(tmp_path / ("u%02d.npy" % i)))
+        np.save(paths[-1], np.full((n, 3), i / 64.0, dtype=np.float32))
+    (tmp_path / "list.txt").write_text("\n".join(paths) + "\n")
+    out = tmp_path / ("out%d" % world)
+    argv = ["--ppg2mel_model", "unused", "--waveglow_model", "unused", "--ppg_list", str(tmp_path / "list.txt"),
+            "--output_dir", str(out), "--batch_size", "4", "--seed", "5", "--limit_steps_to_input", "--dist_backend", "gloo"]
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_corpus_worker, args=(r, world, port, argv)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert sorted(os.listdir(out)) == ["u%02d.wav" % i for i in range(len(lens))]
+    for i, n in enumerate(lens):
+        sr, a = wavfile.read(out / ("u%02d.wav" % i))
+        assert sr == 16000 and a.dtype == np.float32 and a.shape == (n * 160,)
+        assert np.array_equal(a, (np.arange(n * 160, dtype=np.float32) * np.float32(1e-3) + np.float32(5 + 2 * i) + np.float32(i / 64.0)))
