@@ -172,9 +172,18 @@ class Tacotron2(nn.Module):
             _lib.load().facppg_taco_destroy(h[0])
 
     def _fingerprint(self):
-        """Identity + in-place version of every tensor the packed handle was built from: optimizer steps,
-        ``p.data.copy_()`` and buffer updates all bump ``_version``, re-assignment changes ``data_ptr``."""
+        """Identity + in-place version of every tensor the packed handle was built from: optimizer steps and in-place
+        ops bump ``_version``, re-assignment changes ``data_ptr``.  Writes through the ``.data`` alias bypass the
+        version counter by design; the handle is also dropped on every ``train()`` / ``eval()`` switch, and
+        ``invalidate_packed_weights()`` covers code that pokes ``.data`` within one mode."""
         return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values() if torch.is_tensor(t))
+
+    def invalidate_packed_weights(self):
+        self._release()
+
+    def train(self, mode=True):
+        self._release()
+        return super(Tacotron2, self).train(mode)
 
     def _handle(self, dev):
         h = self.__dict__.get("_facppg_handle")

@@ -340,9 +340,20 @@ class WaveGlow(torch.nn.Module):
         self.__dict__.pop("_facppg_ws", None)
 
     def _fingerprint(self):
-        """Identity + in-place version of every tensor the packed handle was built from (optimizer steps,
-        ``p.data.copy_()`` bump ``_version``; re-assignment changes ``data_ptr``)."""
+        """Identity + in-place version of every tensor the packed handle was built from: optimizer steps and any
+        in-place op on a parameter bump ``_version``, re-assignment changes ``data_ptr``.  Writes through the
+        ``.data`` alias bypass autograd's version counter by design and cannot be seen here; the handle is therefore
+        also dropped on every ``train()`` / ``eval()`` switch and gradient-enabled forward, and
+        ``invalidate_packed_weights()`` is there for code that pokes ``.data`` within one mode."""
         return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values() if torch.is_tensor(t))
+
+    def invalidate_packed_weights(self):
+        """Forget the packed MFMA weight images; the next infer()/forward() repacks from the live parameters."""
+        self._release()
+
+    def train(self, mode=True):
+        self._release()
+        return super(WaveGlow, self).train(mode)
 
     def _handle(self, device):
         h = self.__dict__.get("_facppg_handle")
@@ -390,6 +401,7 @@ class WaveGlow(torch.nn.Module):
         split) and the 0.4 %-of-FLOPs upsampling conv stay as torch ops so autograd links them."""
         F = torch.nn.functional
         g = self.n_group
+        self._release()                      # the weights are about to be trained: never serve a stale packed copy
         if _lib.load().facppg_wg_weight_count(self._config()) == 0:      # same check the inference handle makes
             raise _lib.FacppgError("unsupported WaveGlow config for the HIP training kernels: %s"
                                    % _lib.load().facppg_last_error().decode())

@@ -41,7 +41,7 @@ def test_invertible1x1conv_forward_reverse_and_gradients(c, L):
         assert (back.cpu() - z).abs().max() <= 1e-4
         assert m.W_inverse.shape == (c, c, 1)
         # in-place weight change: the cached inverse must follow (stale W_inverse)
-        m.conv.weight.data.mul_(2.0)
+        m.conv.weight.mul_(2.0)
         assert (m(out.detach(), reverse=True).cpu() - 0.5 * z).abs().max() <= 1e-4
     with pytest.raises(flib.FacppgError, match="GPU tensor"):
         m(z)
@@ -128,12 +128,22 @@ def test_handles_follow_inplace_weight_updates():
     x = torch.from_numpy(synth.synthetic_ppg(9, 5816, seed=1)).t().unsqueeze(0).cuda()
     m0 = t.inference(x, seed=5)[1].clone()
     with torch.no_grad():
-        t.decoder.linear_projection.linear_layer.bias.data.add_(0.25)
+        t.decoder.linear_projection.linear_layer.bias.add_(0.25)         # in-place op: version counter moves
     m1 = t.inference(x, seed=5)[1]
     assert not torch.equal(m0, m1)
     t2 = load_model(hp)
     t2.load_state_dict(t.state_dict())
     assert torch.equal(t2.eval().inference(x, seed=5)[1], m1)
+    # a write through .data is invisible to the version counter: covered by the train()/eval() switch and the explicit call
+    saved = t.decoder.linear_projection.linear_layer.bias.detach().clone()
+    t.decoder.linear_projection.linear_layer.bias.data.add_(0.25)
+    t.train()
+    t.eval()
+    m2 = t.inference(x, seed=5)[1].clone()
+    assert not torch.equal(m2, m1)
+    t.decoder.linear_projection.linear_layer.bias.data.copy_(saved)
+    t.invalidate_packed_weights()
+    assert torch.equal(t.inference(x, seed=5)[1], m1)
 
 
 def test_training_path_rejects_unsupported_configs():
