@@ -240,6 +240,7 @@ struct WnArgs {
   int P, Tr, Tqp, ntq, nt, nch, ngc, kc, xcd_map;
   int hop, ksize;      // upsampler stride / kernel size: late phases reach fewer mel frames (pm_chunks)
   int flat_cols;       // > 0: uniform batch, tiles cut from the B*T frames of a phase laid end to end (no ragged last tile per utterance)
+  int stagger_first, stagger_sleeps;   // FACPPG_STAGGER experiment
 };
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
@@ -319,6 +320,28 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   // tile coordinates: batch b, first column t0 (position, or frame of phase ph), nvalid live columns,
   // in_off / sk_off = offset of column 0 inside a channel row of h / skip, tapo[] = same for the 3 taps
   int b, t0, nvalid, ph = 0, in_off, sk_off, tapo[3];
+#ifdef FACPPG_STAGGER
+  // experiment: the two workgroups of a CU start in lock step, so their gate / epilogue / prologue phases (no MFMA)
+  // coincide; delaying the one in the odd wave slot of the first round by a fraction of a tile lets each phase hide
+  // under the other workgroup's MFMA stream (later workgroups inherit the offset: they start when a slot frees).
+  if constexpr (PM && NCB == 2) {
+    // stagger_first selects which first-round workgroups wait: 1 = the second half of the first 512 (if the dispatcher
+    // fills every CU once before doubling up), 2 = odd (lin / 8), 3 = odd hardware wave slot
+    bool delay = false;
+    if (blockIdx.x < 512u) {
+      if (p.stagger_first == 1) delay = blockIdx.x >= 256u;
+      else if (p.stagger_first == 2) delay = (blockIdx.x >> 3) & 1;
+      else {
+        int* sd = reinterpret_cast<int*>(smem);
+        if (tid == 0) sd[0] = __builtin_amdgcn_s_getreg(6148) & 1;   // HW_ID.WAVE_ID[3:0]
+        __syncthreads();
+        delay = sd[0];
+        __syncthreads();
+      }
+    }
+    if (delay) for (int i = 0; i < p.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   if constexpr (PM) {
     const int lin = blockIdx.x;
     int tile;
@@ -1838,6 +1861,12 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   static const char* no_xcd = getenv("FACPPG_WN_NO_XCD_MAP");
   a.xcd_map = (w.P % 8 == 0) && !no_xcd;
   const unsigned lgrid = (unsigned)(w.P * a.nt);
+  {
+    static const char* st_env = getenv("FACPPG_WN_STAGGER");   // experiment: sleeps (of ~3.4 us) for odd-slot first-round tiles
+    a.stagger_sleeps = st_env ? atoi(st_env) : 0;
+    static const char* sm_env = getenv("FACPPG_WN_STAGGER_MODE");
+    a.stagger_first = sm_env ? atoi(sm_env) : 1;
+  }
   // 8 waves per tile for launches that cannot give every SIMD two 4-wave tiles (FACPPG_WN_8W: 0 never, 2 always)
   static const char* w8env = getenv("FACPPG_WN_8W");
   const int w8mode = w8env ? atoi(w8env) : 1;

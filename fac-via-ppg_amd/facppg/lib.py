@@ -47,6 +47,11 @@ class WnWeights(ctypes.Structure):
                 ("end_w", ctypes.c_void_p), ("end_b", ctypes.c_void_p)]
 
 
+class WnGrads(ctypes.Structure):
+    """facppg_wn_grads (include/facppg.h): fp32 gradient outputs, same shapes as WnWeights."""
+    _fields_ = WnWeights._fields_
+
+
 def _declare(lib):
     c = ctypes
     vp, i32, u64, f32, sz = c.c_void_p, c.c_int32, c.c_uint64, c.c_float, c.c_size_t
@@ -68,6 +73,14 @@ def _declare(lib):
         "facppg_conv1x1": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, c.c_int, c.c_int, vp]),
         "facppg_conv1x1_wgrad_workspace_bytes": (sz, [c.c_int]),
         "facppg_conv1x1_wgrad": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, c.c_int, vp, sz, vp]),
+        "facppg_wn_bf16_padded_len": (c.c_int, [c.c_int]),
+        "facppg_wn_bf16_state_bytes": (sz, [c.c_int, c.c_int, c.c_int]),
+        "facppg_wn_bf16_scratch_bytes": (sz, [c.c_int, c.c_int, c.c_int]),
+        "facppg_spect_to_bf16": (c.c_int, [vp, c.c_int, c.c_int, c.c_int, c.c_int, vp, vp]),
+        "facppg_posmajor_to_f32": (c.c_int, [vp, c.c_int, c.c_int, c.c_int, vp, c.c_int, vp]),
+        "facppg_wn_forward_bf16": (c.c_int, [c.POINTER(WnWeights), c.c_int, c.c_int, vp, vp, c.c_int, c.c_int, vp, vp, sz, vp, sz, vp]),
+        "facppg_wn_backward_bf16": (c.c_int, [c.POINTER(WnWeights), c.POINTER(WnGrads), c.c_int, c.c_int, vp, vp, vp, c.c_int, c.c_int,
+                                              vp, sz, vp, vp, vp, sz, vp]),
         "facppg_wg_set_profiling": (c.c_int, [vp, c.c_int]),
         "facppg_wg_last_layer_ms": (c.c_int, [vp, c.POINTER(f32), c.POINTER(c.c_int)]),
         "facppg_stft_create": (c.c_int, [c.c_int, c.c_int, vp, vp, vp, vp, c.c_int, c.c_int, vp, c.POINTER(vp)]),

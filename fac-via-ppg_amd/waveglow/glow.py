@@ -68,9 +68,9 @@ class _WNFunction(torch.autograd.Function):
     (in.w, in.b, cond.w, cond.b, res_skip.w, res_skip.b), end.w, end.b -- plain effective weights."""
 
     @staticmethod
-    def _weights_struct(ws):
+    def _weights_struct(ws, struct=None):
         n_layers = (len(ws) - 4) // 6
-        st = _lib.WnWeights()
+        st = (struct or _lib.WnWeights)()
         st.start_w, st.start_b = ws[0].data_ptr(), ws[1].data_ptr()
         for i in range(n_layers):
             q = ws[2 + 6 * i: 8 + 6 * i]
@@ -140,6 +140,69 @@ class _WNFunction(torch.autograd.Function):
         grads += [outer(dout, skip[:, :, :Lg]).unsqueeze(-1), dout.sum((0, 2))]
         grads = [g.reshape(w.shape) for g, w in zip(grads, ws_t)]
         return (da0, dspect, *grads)
+
+
+def spect_to_posmajor_bf16(spect, Lg):
+    """[B, 640, >= Lg] fp32 channel-major -> the bf16 position-major operand [B, Lr, 640] of the bf16 training kernels
+    (rows >= Lg zero)."""
+    L = _lib.load()
+    spect = spect.detach().float().contiguous()
+    B, Cn, ld = spect.shape
+    Lr = L.facppg_wn_bf16_padded_len(Lg)
+    out = torch.empty(B, Lr, Cn, dtype=torch.bfloat16, device=spect.device)
+    with torch.cuda.device(spect.device):
+        _lib.check(L.facppg_spect_to_bf16(_lib.ptr(spect), B, Cn, Lg, ld, _lib.ptr(out), _lib.current_stream(spect.device)))
+    return out
+
+
+class _WNFunctionBf16(torch.autograd.Function):
+    """One flow's WN stack with bf16 MFMA operands, fp32 accumulation and fp32 gradients (BASELINE config 5).
+    forward  = facppg_wn_forward_bf16 (fused dilated-conv + conditioning GEMM with the gate in its epilogue, res/skip
+               GEMM with the residual / skip update in its epilogue, per layer);
+    backward = facppg_wn_backward_bf16: data gradients AND every weight / bias gradient (NT products over the positions,
+               batched over layers and taps) -- nothing of the stack's backward runs in torch or rocBLAS.
+    Inputs: a0 [B, n_in, L]; spect [B, 640, >= L] fp32 (only to route its gradient); spect_pm, its bf16 position-major
+    copy (spect_to_posmajor_bf16); then the plain effective weights as in _WNFunction."""
+
+    @staticmethod
+    def forward(ctx, a0, spect, spect_pm, *weights):
+        L = _lib.load()
+        dev = a0.device
+        a0 = a0.detach().float().contiguous()
+        ws_t = [w.detach().float().contiguous() for w in weights]
+        st, n_layers = _WNFunction._weights_struct(ws_t)
+        B, n_in, Lg = a0.shape
+        out = torch.empty(B, 2 * n_in, Lg, device=dev)
+        state = torch.empty(L.facppg_wn_bf16_state_bytes(n_layers, B, Lg), dtype=torch.uint8, device=dev)
+        work = torch.empty(L.facppg_wn_bf16_scratch_bytes(n_layers, B, Lg), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.facppg_wn_forward_bf16(st, n_in, n_layers, _lib.ptr(a0), _lib.ptr(spect_pm), B, Lg, _lib.ptr(out),
+                                                _lib.ptr(state), state.numel(), _lib.ptr(work), work.numel(), _lib.current_stream(dev)))
+        ctx.save_for_backward(a0, spect_pm, state, *ws_t)
+        ctx.spect_shape = tuple(spect.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.load()
+        a0, spect_pm, state, *ws_t = ctx.saved_tensors
+        dev = a0.device
+        st, n_layers = _WNFunction._weights_struct(ws_t)
+        B, n_in, Lg = a0.shape
+        dout = dout.contiguous().float()
+        grads = [torch.empty_like(w) for w in ws_t]
+        gs, _ = _WNFunction._weights_struct(grads, _lib.WnGrads)
+        da0 = torch.empty_like(a0)
+        dspect_pm = torch.empty(spect_pm.shape, dtype=torch.float32, device=dev)
+        work = torch.empty(L.facppg_wn_bf16_scratch_bytes(n_layers, B, Lg), dtype=torch.uint8, device=dev)
+        dspect = torch.zeros(ctx.spect_shape, device=dev)
+        with torch.cuda.device(dev):
+            s = _lib.current_stream(dev)
+            _lib.check(L.facppg_wn_backward_bf16(st, gs, n_in, n_layers, _lib.ptr(a0), _lib.ptr(spect_pm), _lib.ptr(dout), B, Lg,
+                                                 _lib.ptr(state), state.numel(), _lib.ptr(da0), _lib.ptr(dspect_pm), _lib.ptr(work),
+                                                 work.numel(), s))
+            _lib.check(L.facppg_posmajor_to_f32(_lib.ptr(dspect_pm), B, dspect.shape[1], Lg, _lib.ptr(dspect), dspect.shape[2], s))
+        return (da0, dspect, None, *grads)
 
 
 def _conv1x1(W, z, transpose=False):
@@ -278,6 +341,9 @@ class WN(torch.nn.Module):
         Lg = audio.size(2)
         if spect.size(2) != Lg or spect.size(0) != audio.size(0):
             raise _lib.FacppgError("WN.forward: audio %s and spect %s disagree" % (tuple(audio.shape), tuple(spect.shape)))
+        if getattr(self, "train_precision", "fp32") == "bf16":
+            spect = spect.float().contiguous()
+            return _WNFunctionBf16.apply(audio.float().contiguous(), spect, spect_to_posmajor_bf16(spect, Lg), *self._plain_weights())
         spect_pad = torch.nn.functional.pad(spect.float(), (0, -(-Lg // _TN) * _TN - Lg)).contiguous()
         return _WNFunction.apply(audio.float().contiguous(), spect_pad, *self._plain_weights())
 
@@ -305,6 +371,20 @@ class WaveGlow(torch.nn.Module):
             self.convinv.append(Invertible1x1Conv(n_remaining_channels))
             self.WN.append(WN(n_half, n_mel_channels * n_group, **WN_config))
         self.n_remaining_channels = n_remaining_channels
+
+    @property
+    def train_precision(self):
+        """Operand precision of the training step's MFMA products: 'fp32' (exact, the default: bit-compatible with
+        the reference's fp32 training) or 'bf16' (BASELINE config 5: bf16 operands, fp32 accumulation, fp32 master
+        weights and gradients).  Set the attribute, or FACPPG_TRAIN_PRECISION in the environment."""
+        import os
+        return self.__dict__.get("_train_precision") or os.environ.get("FACPPG_TRAIN_PRECISION", "fp32")
+
+    @train_precision.setter
+    def train_precision(self, value):
+        if value not in ("fp32", "bf16"):
+            raise ValueError("train_precision must be 'fp32' or 'bf16'")
+        self.__dict__["_train_precision"] = value
 
     # ---------------------------------------------------------------- HIP handle management
     def _config(self):
@@ -420,7 +500,12 @@ class WaveGlow(torch.nn.Module):
         spect = spect.unfold(2, g, g).permute(0, 2, 1, 3)
         spect = spect.contiguous().view(spect.size(0), spect.size(1), -1).permute(0, 2, 1)
         Lg = spect.size(2)
-        spect_pad = F.pad(spect, (0, -(-Lg // _TN) * _TN - Lg)).contiguous()
+        bf16 = self.train_precision == "bf16"
+        if bf16:
+            spect = spect.contiguous()
+            spect_pm = spect_to_posmajor_bf16(spect, Lg)          # one bf16 position-major copy serves all flows
+        else:
+            spect_pad = F.pad(spect, (0, -(-Lg // _TN) * _TN - Lg)).contiguous()
         audio = audio.unfold(1, g, g).permute(0, 2, 1)
         output_audio, log_s_list, log_det_W_list = [], [], []
         for k in range(self.n_flows):
@@ -432,7 +517,10 @@ class WaveGlow(torch.nn.Module):
             audio = torch.einsum('ij,bjl->bil', W, audio)        # 1x1 mixing conv (c <= 8 channels)
             n_half = audio.size(1) // 2
             audio_0, audio_1 = audio[:, :n_half, :], audio[:, n_half:, :]
-            output = _WNFunction.apply(audio_0.contiguous(), spect_pad, *self.WN[k]._plain_weights())
+            if bf16:
+                output = _WNFunctionBf16.apply(audio_0.contiguous(), spect, spect_pm, *self.WN[k]._plain_weights())
+            else:
+                output = _WNFunction.apply(audio_0.contiguous(), spect_pad, *self.WN[k]._plain_weights())
             log_s, b = output[:, n_half:, :], output[:, :n_half, :]
             audio_1 = torch.exp(log_s) * audio_1 + b
             log_s_list.append(log_s)

@@ -166,6 +166,34 @@ int facppg_wn_backward_data(const facppg_wn_weights* w, int n_in, int n_layers, 
                             float* dh_all_dev, float* dskip_dev, float* dspect_dev, float* da0_dev,
                             void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* ---- the same stack with bf16 MFMA operands (BASELINE config 5: bf16 training, fp32 accumulation, fp32 master
+ * weights and fp32 gradients).  Activations are kept POSITION-major ([B][Lr][channels] bf16, Lr =
+ * facppg_wn_bf16_padded_len(L)) because the bf16 MFMA takes 8 consecutive reduction entries per lane; everything --
+ * forward, data gradients AND the weight / bias gradients (NT products over the positions) -- runs in this library. */
+typedef struct facppg_wn_grads {   /* fp32 outputs, same shapes as facppg_wn_weights */
+  float* start_w; float* start_b;
+  float* in_w[8]; float* in_b[8];
+  float* cond_w[8]; float* cond_b[8];
+  float* rs_w[8]; float* rs_b[8];
+  float* end_w; float* end_b;
+} facppg_wn_grads;
+int facppg_wn_bf16_padded_len(int L);
+size_t facppg_wn_bf16_state_bytes(int n_layers, int B, int L);    /* saved activations of one stack (forward -> backward) */
+size_t facppg_wn_bf16_scratch_bytes(int n_layers, int B, int L);  /* per-call scratch (packed bf16 weight images, gradients in flight) */
+/* fp32 channel-major [B][channels][ld] (first L columns) -> bf16 position-major [B][Lr][channels], rows >= L zero */
+int facppg_spect_to_bf16(const float* spect_dev, int B, int channels, int L, int ld, void* out_dev, void* stream);
+/* fp32 position-major [B][Lr][channels] -> fp32 channel-major [B][channels][ld] (first L columns) */
+int facppg_posmajor_to_f32(const float* src_dev, int B, int channels, int L, float* out_dev, int ld, void* stream);
+/* Replaces WN.forward (glow.py:154-175): a0 [B][n_in][L] fp32, spect_pm bf16 [B][Lr][640] -> out [B][2*n_in][L] fp32. */
+int facppg_wn_forward_bf16(const facppg_wn_weights* w, int n_in, int n_layers, const float* a0_dev,
+                           const void* spect_pm_dev, int B, int L, float* out_dev, void* state_dev,
+                           size_t state_bytes, void* scratch_dev, size_t scratch_bytes, void* stream);
+/* Its autograd backward, complete: da0 [B][n_in][L], dspect_pm fp32 [B][Lr][640] (overwritten) and all of `grads`. */
+int facppg_wn_backward_bf16(const facppg_wn_weights* w, const facppg_wn_grads* grads, int n_in, int n_layers,
+                            const float* a0_dev, const void* spect_pm_dev, const float* dout_dev, int B, int L,
+                            const void* state_dev, size_t state_bytes, float* da0_dev, float* dspect_pm_dev,
+                            void* scratch_dev, size_t scratch_bytes, void* stream);
+
 /* Average device time (ms) of the dominant kernel (the fused WN layer) over the launches of
  * the most recent facppg_wg_infer on this handle, measured with hipEvents on the stream the
  * kernels ran on when profiling was enabled with facppg_wg_set_profiling(h, 1).  Synchronises
