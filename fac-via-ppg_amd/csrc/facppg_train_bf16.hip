@@ -67,8 +67,11 @@ struct PackArgs {
 };
 __device__ __forceinline__ int gate_row_src(int mb, int rho) { return (rho >= 16 ? C : 0) + 16 * mb + ((rho >> 3) & 1) * 8 + (rho & 7); }
 
-__global__ void k_pack_bf16(PackArgs p) {
-  const int ng = p.Cin * p.taps / 16;                       // k16 groups written by this call
+constexpr int MAXPACK = 32;
+struct PackBatch { PackArgs e[MAXPACK]; };
+__global__ void k_pack_bf16(PackBatch pb) {
+  const PackArgs& p = pb.e[blockIdx.y];
+  const int ng = p.Cin * p.taps / 16;                       // k16 groups written by this entry
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int MB = (p.M + 31) / 32;
   if (idx >= MB * ng * 64) return;
@@ -185,77 +188,80 @@ __device__ __forceinline__ void bgemm_store4(const BGemmArgs& p, int b, int n, i
   }
 }
 
-template <int MODE>
+// NCB = 32-column blocks per tile: 4 (128 columns) for large products, 2 (64 columns: twice the workgroups, half
+// the LDS and accumulators each) when the launch would otherwise leave the chip with < ~3 workgroups per CU -- these
+// loops are short (a few hundred MFMA cycles per 64-deep chunk), so latency is hidden by resident workgroups and by
+// staging TWO chunks ahead in registers (the loads of chunk c+2 are issued before the MFMAs of chunk c and written
+// to LDS after those of chunk c+1).
+template <int MODE, int NCB>
 __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs p) {
-  __shared__ __attribute__((aligned(16))) bf16_t lds[2][BN * LDB];
+  constexpr int BNt = 32 * NCB;
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2][BNt * LDB];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
-  const int b = blockIdx.z, n0 = blockIdx.x * BN;
+  const int b = blockIdx.z, n0 = blockIdx.x * BNt;
   const int mb = blockIdx.y * 4 + w;
   const bool active = mb * 32 < p.M;
   const uint4* ap = p.A + (size_t)(active ? mb : 0) * p.KG * 64 + lane;
-  // staging: thread -> rows srow + 32*j (j < 4) of the [128 positions][64 k] chunk, 16 bytes at k = 8*sk
+  // staging: thread -> rows srow + 32*j (j < NCB) of the [BNt positions][64 k] chunk, 16 bytes at k = 8*sk
   const int srow = tid >> 3, sk = tid & 7;
   int nchunks = 0;
   for (int s = 0; s < p.nseg; ++s) nchunks += p.seg[s].nch / KC;
 
-  f32x16 acc[4];
+  f32x16 acc[NCB];
 #pragma unroll
-  for (int cb = 0; cb < 4; ++cb)
+  for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
 
-  // chunk c -> (segment, channel offset): walked incrementally
+  // the chunk whose loads are issued next: (segment, channel offset), walked incrementally
   int seg_i = 0, seg_c = 0;
-  auto chunk_src = [&](int rowj) -> const uint4* {
+  auto stage_load = [&](uint4 (&stg)[NCB]) {
     const Seg& sg = p.seg[seg_i];
-    return reinterpret_cast<const uint4*>(sg.x + (size_t)b * sg.bs + (size_t)(sg.row0 + n0 + rowj) * sg.ld + seg_c + 8 * sk);
-  };
-  auto advance = [&]() {
+    const bf16_t* base = sg.x + (size_t)b * sg.bs + (size_t)(sg.row0 + n0 + srow) * sg.ld + seg_c + 8 * sk;
+#pragma unroll
+    for (int j = 0; j < NCB; ++j) stg[j] = *reinterpret_cast<const uint4*>(base + (size_t)(32 * j) * sg.ld);
     seg_c += KC;
-    if (seg_c >= p.seg[seg_i].nch && seg_i + 1 < p.nseg) { ++seg_i; seg_c = 0; }
+    if (seg_c >= sg.nch && seg_i + 1 < p.nseg) { ++seg_i; seg_c = 0; }
   };
-  uint4 stg[4], a_cur[4], a_nxt[4];
-  auto stage_load = [&]() {
+  auto stage_write = [&](int buf, const uint4 (&stg)[NCB]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) stg[j] = *chunk_src(srow + 32 * j);
+    for (int j = 0; j < NCB; ++j) *reinterpret_cast<uint4*>(&lds[buf][(srow + 32 * j) * LDB + 8 * sk]) = stg[j];
   };
-  auto stage_write = [&](int buf) {
+  auto load_a = [&](uint4 (&a)[4], int c) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(&lds[buf][(srow + 32 * j) * LDB + 8 * sk]) = stg[j];
+    for (int s = 0; s < 4; ++s) a[s] = ap[(size_t)(c * 4 + s) * 64];
   };
-  stage_load();
-#pragma unroll
-  for (int s = 0; s < 4; ++s) a_cur[s] = ap[(size_t)s * 64];
-  stage_write(0);
-  advance();
-  __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
-    const bool more = c + 1 < nchunks;
-    if (more) {
-      stage_load();
-#pragma unroll
-      for (int s = 0; s < 4; ++s) a_nxt[s] = ap[(size_t)((c + 1) * 4 + s) * 64];
-    }
+  auto compute = [&](int c, const uint4 (&a)[4]) {
     const bf16_t* lb = &lds[c & 1][li * LDB + 8 * kh];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) {
-        const uint4 bv = *reinterpret_cast<const uint4*>(lb + cb * 32 * LDB + 16 * s);
-        acc[cb] = mfma_bf16(a_cur[s], bv, acc[cb]);
-      }
-    }
-    if (more) {
-      stage_write((c + 1) & 1);
-      advance();
-#pragma unroll
-      for (int s = 0; s < 4; ++s) a_cur[s] = a_nxt[s];
-    }
+      for (int cb = 0; cb < NCB; ++cb)
+        acc[cb] = mfma_bf16(a[s], *reinterpret_cast<const uint4*>(lb + cb * 32 * LDB + 16 * s), acc[cb]);
+  };
+  uint4 st0[NCB], st1[NCB], a0[4], a1[4];
+  stage_load(st0);                      // chunk 0
+  load_a(a0, 0);
+  stage_write(0, st0);
+  if (nchunks > 1) stage_load(st0);     // chunk 1 (in flight)
+  __syncthreads();
+  // iteration c: weights of c+1, activations of c+2 issued; MFMAs of c; activations of c+1 written to LDS
+  auto iter = [&](int c, uint4 (&a_cur)[4], uint4 (&a_nxt)[4], uint4 (&s_nxt)[NCB], uint4 (&s_nxt2)[NCB]) {
+    if (c + 1 < nchunks) load_a(a_nxt, c + 1);
+    if (c + 2 < nchunks) stage_load(s_nxt2);
+    compute(c, a_cur);
+    if (c + 1 < nchunks) stage_write((c + 1) & 1, s_nxt);
     __syncthreads();
+  };
+  int c = 0;
+  for (; c + 1 < nchunks; c += 2) {
+    iter(c, a0, a1, st0, st1);
+    iter(c + 1, a1, a0, st1, st0);
   }
+  if (c < nchunks) iter(c, a0, a1, st0, st1);
   if (!active) return;
 #pragma unroll
-  for (int cb = 0; cb < 4; ++cb) {
+  for (int cb = 0; cb < NCB; ++cb) {
     const int n = n0 + cb * 32 + li;
     if (n >= p.N) continue;
     if constexpr (MODE == EP_GATE) {
@@ -275,6 +281,13 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs p) {
   }
 }
 
+template <int MODE>
+void bgemm_dispatch(const BGemmArgs& a, hipStream_t s) {
+  const long wide = (long)((a.N + 127) / 128) * ((a.M + BM - 1) / BM) * a.B;
+  if (wide >= 3 * 256) k_bgemm<MODE, 4><<<dim3((a.N + 127) / 128, (a.M + BM - 1) / BM, a.B), 256, 0, s>>>(a);
+  else k_bgemm<MODE, 2><<<dim3((a.N + 63) / 64, (a.M + BM - 1) / BM, a.B), 256, 0, s>>>(a);
+}
+
 int bgemm_launch(const BGemmArgs& a, hipStream_t s) {
   int K = 0;
   for (int i = 0; i < a.nseg; ++i) {
@@ -282,13 +295,12 @@ int bgemm_launch(const BGemmArgs& a, hipStream_t s) {
     K += a.seg[i].nch;
   }
   FACPPG_REQUIRE(K == a.KG * 16 && a.M % 32 == 0 && a.nseg >= 1 && a.nseg <= MAXSEG, FACPPG_EINVAL, "bgemm: bad shape K=%d KG=%d M=%d", K, a.KG, a.M);
-  const dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.B);
   switch (a.mode) {
-    case EP_GATE: k_bgemm<EP_GATE><<<grid, 256, 0, s>>>(a); break;
-    case EP_RESSKIP: k_bgemm<EP_RESSKIP><<<grid, 256, 0, s>>>(a); break;
-    case EP_BWD_GATE: k_bgemm<EP_BWD_GATE><<<grid, 256, 0, s>>>(a); break;
-    case EP_BWD_CONV: k_bgemm<EP_BWD_CONV><<<grid, 256, 0, s>>>(a); break;
-    default: k_bgemm<EP_ACC_F32><<<grid, 256, 0, s>>>(a); break;
+    case EP_GATE: bgemm_dispatch<EP_GATE>(a, s); break;
+    case EP_RESSKIP: bgemm_dispatch<EP_RESSKIP>(a, s); break;
+    case EP_BWD_GATE: bgemm_dispatch<EP_BWD_GATE>(a, s); break;
+    case EP_BWD_CONV: bgemm_dispatch<EP_BWD_CONV>(a, s); break;
+    default: bgemm_dispatch<EP_ACC_F32>(a, s); break;
   }
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
@@ -312,6 +324,9 @@ constexpr int MAXPROB = 24;
 struct WgradArgs {
   WgradProb prob[MAXPROB];
   int B, L, Lr;
+  size_t pstride;    // floats per (problem, split) partial = max M * max K of the batch
+  int nsplit;        // the B * ceil(L/64) position chunks are dealt to nsplit workgroups per output tile ...
+  float* part;       // ... which leave partial sums [prob][split][M][K] here (nsplit > 1); k_wgrad_reduce adds them in order
 };
 constexpr int LDP = 64 + 8;   // LDS pitch (positions) of the transposed images
 
@@ -330,15 +345,17 @@ __device__ __forceinline__ void transpose8x8(const uint4 (&r)[8], uint4 (&t)[8])
 }
 
 __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
-  __shared__ __attribute__((aligned(16))) bf16_t lds[2][128 * LDP];   // [A | B][channel][position]; the next chunk waits in registers
-  const WgradProb& p = wa.prob[blockIdx.z];
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2][128 * LDP];   // [A | B][channel][position]; later chunks wait in registers
+  const int pi = blockIdx.z / wa.nsplit, split = blockIdx.z - pi * wa.nsplit;
+  const WgradProb& p = wa.prob[pi];
   const int m0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
   if (m0 >= p.M || k0 >= p.K) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
   const int wm = w >> 1, wk = w & 1;
   // staging role: threads 0..127 transpose dY blocks, 128..255 X blocks; block = (pb: 8 positions, cb: 8 channels)
   const int isx = tid >> 7, blk = tid & 127, pb = blk >> 4, cb8 = blk & 15;
-  const int nlc = (wa.L + 63) / 64, nchunks = wa.B * nlc;
+  const int nlc = (wa.L + 63) / 64, nall = wa.B * nlc;
+  const int c_lo = (int)((long)nall * split / wa.nsplit), c_hi = (int)((long)nall * (split + 1) / wa.nsplit);
   const bf16_t* src;
   long sbs; int sld, srow0, ch0;
   bool live;
@@ -351,14 +368,13 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
     src = p.x; sbs = p.x_bs; sld = p.ldx; srow0 = p.x_row0; ch0 = k0 + 8 * cb8;
     live = k0 + 8 * cb8 < p.K;
   }
-  uint4 stg[8];
-  auto stage_load = [&](int c) {
+  auto stage_load = [&](int c, uint4 (&stg)[8]) {
     const int b = c / nlc, n = (c - b * nlc) * 64 + 8 * pb;
     const bf16_t* s0 = src + (size_t)b * sbs + (size_t)(srow0 + n) * sld + ch0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) stg[i] = live ? *reinterpret_cast<const uint4*>(s0 + (size_t)i * sld) : make_uint4(0, 0, 0, 0);
   };
-  auto stage_write = [&]() {
+  auto stage_write = [&](const uint4 (&stg)[8]) {
     uint4 t[8];
     transpose8x8(stg, t);
     bf16_t* d = &lds[isx][(8 * cb8) * LDP + 8 * pb];
@@ -372,14 +388,18 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  stage_load(0);
-  stage_write();
-  __syncthreads();
   const bf16_t* la = &lds[0][(64 * wm + li) * LDP + 8 * kh];
   const bf16_t* lb = &lds[1][(64 * wk + li) * LDP + 8 * kh];
-  for (int c = 0; c < nchunks; ++c) {
-    const bool more = c + 1 < nchunks;
-    if (more) stage_load(c + 1);
+  uint4 st0[8], st1[8];
+  if (c_lo < c_hi) {
+    stage_load(c_lo, st0);
+    stage_write(st0);
+    if (c_lo + 1 < c_hi) stage_load(c_lo + 1, st0);
+  }
+  __syncthreads();
+  // iteration c: chunk c+2 requested, MFMAs of chunk c from LDS, then chunk c+1 (requested one iteration ago) replaces it
+  auto iter = [&](int c, uint4 (&s_nxt)[8], uint4 (&s_nxt2)[8]) {
+    if (c + 2 < c_hi) stage_load(c + 2, s_nxt2);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       uint4 av[2], bv[2];
@@ -394,9 +414,16 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(av[i], bv[j], acc[i][j]);
     }
     __syncthreads();            // every wave is done reading this chunk
-    if (more) stage_write();
+    if (c + 1 < c_hi) stage_write(s_nxt);
     __syncthreads();
+  };
+  int c = c_lo;
+  for (; c + 1 < c_hi; c += 2) {
+    iter(c, st0, st1);
+    iter(c + 1, st1, st0);
   }
+  if (c < c_hi) iter(c, st0, st1);
+  float* part = wa.nsplit > 1 ? wa.part + ((size_t)pi * wa.nsplit + split) * wa.pstride : nullptr;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -406,25 +433,80 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + 64 * wm + 32 * i + 8 * (r >> 2) + (r & 3) + 4 * kh;
-        if (m < p.M) p.out[m * p.o_sm + k * p.o_sk] = acc[i][j][r];
+        if (m >= p.M) continue;
+        if (part) part[(size_t)m * p.K + k] = acc[i][j][r];
+        else p.out[m * p.o_sm + k * p.o_sk] = acc[i][j][r];
       }
     }
 }
 
-// out[m] = sum_{b, n < L} y[b][row0 + n][m]  (bias gradients), fixed summation order; blockIdx.y = problem
-struct ColsumProb { const bf16_t* y; long bs; int ld, row0, M; float* out; };
-struct ColsumArgs { ColsumProb prob[16]; int B, L; };
-__global__ __launch_bounds__(256) void k_colsum(ColsumArgs ca) {
-  const ColsumProb& p = ca.prob[blockIdx.y];
-  const int m = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+// out[m][k] = sum over the splits, in split order (bit-reproducible)
+__global__ void k_wgrad_reduce(WgradArgs wa) {
+  const WgradProb& p = wa.prob[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.M * p.K) return;
+  const float* part = wa.part + (size_t)blockIdx.y * wa.nsplit * wa.pstride + i;
+  float v = 0.0f;
+  for (int s = 0; s < wa.nsplit; ++s) v += part[(size_t)s * wa.pstride];
+  const int m = i / p.K, k = i - m * p.K;
+  p.out[m * p.o_sm + k * p.o_sk] = v;
+}
+
+constexpr int WG_MAXSPLIT = 8;
+// launches one batch of problems that share (M, K) tile counts; partial buffer: nprob * nsplit * maxM * maxK floats
+int wgrad_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size_t part_bytes, hipStream_t s) {
+  const int tiles = ((maxK + 127) / 128) * ((maxM + 127) / 128) * nprob;
+  const int nall = wa.B * ((wa.L + 63) / 64);
+  int ns = (3 * 256 + tiles - 1) / tiles;       // aim at >= ~3 workgroups per CU
+  ns = std::max(1, std::min(std::min(ns, WG_MAXSPLIT), nall));
+  while (ns > 1 && (size_t)nprob * ns * maxM * maxK * 4 > part_bytes) --ns;
+  wa.nsplit = ns; wa.part = part; wa.pstride = (size_t)maxM * maxK;
+  k_wgrad<<<dim3((maxK + 127) / 128, (maxM + 127) / 128, nprob * ns), 256, 0, s>>>(wa);
+  if (ns > 1) k_wgrad_reduce<<<dim3((maxM * maxK + 255) / 256, nprob), 256, 0, s>>>(wa);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+// out[m] = sum_{b, n < L} y[b][row0 + n][m]  (bias gradients).  Stage 1: workgroup (channel tile, row slice, problem)
+// sums its slice of the B*L rows (4 row lanes x 64 channels per wavefront-row); stage 2 adds the slices in index
+// order -- a fixed summation order whatever the grid, so the result is bit-reproducible.
+constexpr int CS_SLICES = 64, MAXCS = 16;
+struct ColsumProb { const void* y; long bs; int ld, row0, M; float* out; };
+struct ColsumArgs { ColsumProb prob[MAXCS]; int B, L; float* part; };   // part [prob][CS_SLICES][1024]
+template <bool F32>
+__global__ __launch_bounds__(256) void k_colsum_part(ColsumArgs ca) {
+  const ColsumProb& p = ca.prob[blockIdx.z];
+  const int m = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, sl = blockIdx.y;
   __shared__ float red[4][64];
+  const long R = (long)ca.B * ca.L, r0 = R * sl / CS_SLICES, r1 = R * (sl + 1) / CS_SLICES;
   float v = 0.0f;
   if (m < p.M)
-    for (int b = 0; b < ca.B; ++b)
-      for (int n = part; n < ca.L; n += 4) v += bf2f(p.y[(size_t)b * p.bs + (size_t)(p.row0 + n) * p.ld + m]);
-  red[part][threadIdx.x & 63] = v;
+    for (long r = r0 + rl; r < r1; r += 4) {
+      const int b = (int)(r / ca.L), n = (int)(r - (long)b * ca.L);
+      const size_t o = (size_t)b * p.bs + (size_t)(p.row0 + n) * p.ld + m;
+      v += F32 ? reinterpret_cast<const float*>(p.y)[o] : bf2f(reinterpret_cast<const bf16_t*>(p.y)[o]);
+    }
+  red[rl][threadIdx.x & 63] = v;
   __syncthreads();
-  if (part == 0 && m < p.M) p.out[m] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (rl == 0 && m < p.M)
+    ca.part[((size_t)blockIdx.z * CS_SLICES + sl) * 1024 + m] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+// group > 1: out[m / group] also sums `group` adjacent channels (the 8 regrouped samples of one mel channel)
+__global__ void k_colsum_sum(ColsumArgs ca, int group) {
+  const ColsumProb& p = ca.prob[blockIdx.y];
+  const int mo = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mo * group >= p.M) return;
+  float v = 0.0f;
+  for (int g = 0; g < group; ++g)
+    for (int sl = 0; sl < CS_SLICES; ++sl) v += ca.part[((size_t)blockIdx.y * CS_SLICES + sl) * 1024 + mo * group + g];
+  p.out[mo] = v;
+}
+template <bool F32>
+int colsum_launch(ColsumArgs& ca, int nprob, int maxM, int group, hipStream_t s) {
+  k_colsum_part<F32><<<dim3((maxM + 63) / 64, CS_SLICES, nprob), 256, 0, s>>>(ca);
+  k_colsum_sum<<<dim3((maxM / group + 255) / 256, nprob), 256, 0, s>>>(ca, group);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
 }
 
 // ---- the <= 8-channel edges of the stack ----------------------------------------------------------------------
@@ -566,6 +648,69 @@ __global__ void k_from_posmajor_f32(const float* __restrict__ src, float* __rest
   }
 }
 
+// ---- upsampling ConvTranspose1d(80, 80, K, stride hop) + crop + 8-sample regroup (glow.py:184-186, 214-222) -----------
+// forward, straight into the bf16 position-major conditioning operand:
+//   spect[b][l][8m + g] = bu[m] + sum_{m'} sum_{j: 0 <= k = n - (q-j) hop < K} mel[b][m'][q - j] Wu[m'][m][k],  n = 8l + g = q hop + pp
+// One workgroup = (batch, output channel m, block of UQ frames); thread pp owns the hop-phase pp and keeps UQ
+// accumulators so every weight it loads is reused UQ times; the mel values are LDS broadcasts.
+constexpr int UQ = 16, UMAXJ = 8;
+__global__ __launch_bounds__(256) void k_up_fwd(const float* __restrict__ mel, const float* __restrict__ W, const float* __restrict__ bias,
+                                                bf16_t* __restrict__ spect, int T, int nm, int hop, int ksize, int Lr, int n_limit) {
+  extern __shared__ float smel[];  // [nm][UQ + UMAXJ]
+  const int b = blockIdx.z, m = blockIdx.y, q0 = blockIdx.x * UQ;
+  const int nj = (ksize + hop - 1) / hop, SW = UQ + UMAXJ;
+  for (int i = threadIdx.x; i < nm * SW; i += blockDim.x) {
+    const int mp = i / SW, tt = i % SW, t = q0 - (UMAXJ - 1) + tt;
+    smel[i] = (t >= 0 && t < T && tt < SW - 1) ? mel[((size_t)b * nm + mp) * T + t] : 0.0f;
+  }
+  __syncthreads();
+  for (int pp = threadIdx.x; pp < hop; pp += blockDim.x) {
+    float acc[UQ];
+    const float bv = bias[m];
+#pragma unroll
+    for (int q = 0; q < UQ; ++q) acc[q] = bv;
+    for (int j = 0; j < nj; ++j) {
+      const int k = pp + j * hop;
+      if (k < ksize)
+        for (int mp = 0; mp < nm; ++mp) {
+          const float wv = W[((size_t)mp * nm + m) * ksize + k];
+          const float* sm = smel + mp * SW + (UMAXJ - 1) - j;
+#pragma unroll
+          for (int q = 0; q < UQ; ++q) acc[q] = fmaf(sm[q], wv, acc[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < UQ; ++q) {
+      const int n = (q0 + q) * hop + pp;
+      if (q0 + q < T && n < n_limit) spect[((size_t)b * Lr + (n >> 3)) * (nm * 8) + m * 8 + (n & 7)] = f2bf(acc[q]);
+    }
+  }
+}
+// backward w.r.t. the kernel: dWu[m'][m][k] = sum_{b,q} mel[b][m'][q] * dup[b][m][q hop + k], dup[b][m][n] = dspect[b][n/8][8m + n%8]
+// (n < n_limit).  One workgroup = (output channel m, 256 taps k); a thread owns one k and all nm input channels m'.
+template <int NM>
+__global__ __launch_bounds__(256) void k_up_wgrad(const float* __restrict__ mel, const float* __restrict__ dspect, float* __restrict__ dW,
+                                                  int B, int T, int hop, int ksize, int Lr, int n_limit) {
+  __shared__ float smel[NM];
+  const int m = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+  float acc[NM];
+#pragma unroll
+  for (int i = 0; i < NM; ++i) acc[i] = 0.0f;
+  for (int b = 0; b < B; ++b)
+    for (int q = 0; q < T; ++q) {
+      __syncthreads();
+      if (threadIdx.x < NM) smel[threadIdx.x] = mel[((size_t)b * NM + threadIdx.x) * T + q];
+      __syncthreads();
+      const int n = q * hop + k;
+      const float d = (k < ksize && n < n_limit) ? dspect[((size_t)b * Lr + (n >> 3)) * (NM * 8) + m * 8 + (n & 7)] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) acc[i] = fmaf(smel[i], d, acc[i]);
+    }
+  if (k < ksize)
+#pragma unroll
+    for (int i = 0; i < NM; ++i) dW[((size_t)i * NM + m) * ksize + k] = acc[i];
+}
+
 // ---- layouts of the caller-owned buffers -------------------------------------------------------------------------
 struct StateLayout { size_t h, ts, acts, skip, total; size_t h_one, ts_one, acts_one; };
 StateLayout state_layout(int nl, int B, int Lr) {
@@ -578,9 +723,9 @@ StateLayout state_layout(int nl, int B, int Lr) {
   s.total = off;
   return s;
 }
-struct ScratchLayout { size_t w1, w2, rst, int_, condt, dpre, dh, dskip, part, total; size_t w1_one, w2_one, rst_one, int_one, dpre_one, dh_one; };
+struct ScratchLayout { size_t w1, w2, rst, int_, condt, dpre, dh, dskip, part, cspart, wgpart, wgpart_bytes, total; size_t w1_one, w2_one, rst_one, int_one, dpre_one, dh_one; };
 constexpr int K1 = 3 * C + NCOND;   // 1408
-constexpr int SMALL_PARTS = 256;
+constexpr int SMALL_PARTS = 128;
 ScratchLayout scratch_layout(int nl, int B, int Lr) {
   ScratchLayout s;
   const int Lp = HALO + Lr + HALO;
@@ -593,18 +738,29 @@ ScratchLayout scratch_layout(int nl, int B, int Lr) {
   s.condt = take((size_t)(NCOND / 32) * (nl * 2 * C / 16) * 64 * 16);
   s.dpre = take(s.dpre_one * nl); s.dh = take(s.dh_one * (nl + 1)); s.dskip = take(s.dh_one);
   s.part = take((size_t)SMALL_PARTS * 9 * C * 4);
+  s.cspart = take((size_t)MAXCS * CS_SLICES * 1024 * 4);
+  s.wgpart_bytes = (size_t)3 * nl * 4 * (2 * C) * C * 4;      // 4 splits of the largest batch (3 taps x layers x [512 x 256])
+  s.wgpart = take(s.wgpart_bytes);
   s.total = off;
   return s;
 }
 
-int pack_launch(const float* src, uint4* dst, int M, int KG, int k_base, int Cin, int taps, long sm, long sc, long st, long off,
-                int gate_rows, hipStream_t s) {
-  PackArgs p{src, dst, M, KG, k_base, Cin, taps, gate_rows, sm, sc, st, off};
-  const int total = ((M + 31) / 32) * (Cin * taps / 16) * 64;
-  k_pack_bf16<<<(total + 255) / 256, 256, 0, s>>>(p);
-  FACPPG_HIP_CHECK(hipGetLastError());
-  return FACPPG_OK;
-}
+// collects pack jobs and launches them as one grid (blockIdx.y = job)
+struct Packer {
+  PackBatch pb;
+  int n = 0, max_total = 0;
+  void add(const float* src, uint4* dst, int M, int KG, int k_base, int Cin, int taps, long sm, long sc, long st, long off, int gate_rows) {
+    pb.e[n++] = PackArgs{src, dst, M, KG, k_base, Cin, taps, gate_rows, sm, sc, st, off};
+    max_total = std::max(max_total, ((M + 31) / 32) * (Cin * taps / 16) * 64);
+  }
+  int launch(hipStream_t s) {
+    if (!n) return FACPPG_OK;
+    k_pack_bf16<<<dim3((max_total + 255) / 256, n), 256, 0, s>>>(pb);
+    n = 0; max_total = 0;
+    FACPPG_HIP_CHECK(hipGetLastError());
+    return FACPPG_OK;
+  }
+};
 
 int check_wn(const facppg_wn_weights* w, int n_in, int nl, int B, int L) {
   FACPPG_REQUIRE(w && w->start_w && w->start_b && w->end_w && w->end_b, FACPPG_EINVAL, "NULL weight pointer");
@@ -615,9 +771,10 @@ int check_wn(const facppg_wn_weights* w, int n_in, int nl, int B, int L) {
   return FACPPG_OK;
 }
 
-__global__ void k_add2(const float* a, const float* b, float* out, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = a[i] + b[i];
+struct AddBatch { const float* a[8]; const float* b[8]; };
+__global__ void k_add2(AddBatch ab, float* out, int n) {   // out[y][i] = a[y][i] + b[y][i]
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (i < n) out[(size_t)y * n + i] = ab.a[y][i] + ab.b[y][i];
 }
 
 }  // namespace
@@ -653,6 +810,40 @@ extern "C" int facppg_posmajor_to_f32(const float* src_dev, int B, int channels,
   return FACPPG_OK;
 }
 
+extern "C" int facppg_upsample_regroup_bf16(const float* mel_dev, const float* up_w_dev, const float* up_b_dev, int B, int T, int n_mel,
+                                            int hop, int ksize, int L, void* spect_pm_dev, void* stream_) {
+  FACPPG_REQUIRE(mel_dev && up_w_dev && up_b_dev && spect_pm_dev, FACPPG_EINVAL, "NULL argument");
+  FACPPG_REQUIRE(B > 0 && T > 0 && L > 0 && n_mel == 80 && hop % 8 == 0 && hop > 0 && (ksize + hop - 1) / hop <= UMAXJ, FACPPG_EUNSUPPORTED,
+                 "upsample: n_mel must be 80, hop a multiple of 8, kernel/hop <= %d", UMAXJ);
+  FACPPG_REQUIRE((long)(T - 1) * hop + ksize >= (long)L * 8, FACPPG_EINVAL, "upsampled mel is shorter than the audio (glow.py:216)");
+  hipStream_t s = (hipStream_t)stream_;
+  const int Lr = pad_len(L);
+  FACPPG_HIP_CHECK(hipMemsetAsync(spect_pm_dev, 0, (size_t)B * Lr * n_mel * 8 * 2, s));   // rows >= L (and samples no frame reaches) are zero
+  const int Tq = std::min(T, (L * 8 + hop - 1) / hop);     // frames q with q*hop < N produce samples < N
+  k_up_fwd<<<dim3((Tq + UQ - 1) / UQ, n_mel, B), 256, (size_t)n_mel * (UQ + UMAXJ) * 4, s>>>(mel_dev, up_w_dev, up_b_dev, (bf16_t*)spect_pm_dev, T,
+                                                                                          n_mel, hop, ksize, Lr, L * 8);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+extern "C" size_t facppg_upsample_backward_workspace_bytes(void) { return (size_t)MAXCS * CS_SLICES * 1024 * 4; }
+
+extern "C" int facppg_upsample_regroup_backward(const float* mel_dev, const float* dspect_pm_dev, int B, int T, int n_mel, int hop, int ksize,
+                                                int L, float* d_up_w_dev, float* d_up_b_dev, void* ws_dev, size_t ws_bytes, void* stream_) {
+  FACPPG_REQUIRE(mel_dev && dspect_pm_dev && d_up_w_dev && d_up_b_dev && ws_dev, FACPPG_EINVAL, "NULL argument");
+  FACPPG_REQUIRE(B > 0 && T > 0 && L > 0 && n_mel == 80 && hop % 8 == 0 && hop > 0, FACPPG_EUNSUPPORTED, "upsample backward: n_mel must be 80, hop a multiple of 8");
+  FACPPG_REQUIRE(ws_bytes >= facppg_upsample_backward_workspace_bytes(), FACPPG_EWORKSPACE, "workspace too small");
+  hipStream_t s = (hipStream_t)stream_;
+  const int Lr = pad_len(L);
+  k_up_wgrad<80><<<dim3((ksize + 255) / 256, n_mel), 256, 0, s>>>(mel_dev, dspect_pm_dev, d_up_w_dev, B, T, hop, ksize, Lr, L * 8);
+  // d bias[m] = sum over every produced sample of channel m = column sums of dspect over its 8 regrouped channels
+  ColsumArgs ca;
+  memset(&ca, 0, sizeof(ca));
+  ca.B = B; ca.L = L; ca.part = (float*)ws_dev;
+  ca.prob[0] = ColsumProb{dspect_pm_dev, (long)Lr * n_mel * 8, n_mel * 8, 0, n_mel * 8, d_up_b_dev};
+  return colsum_launch<true>(ca, 1, n_mel * 8, 8, s);
+}
+
 // WN.forward (glow.py:154-175) with bf16 MFMA operands, keeping what the backward needs in `state`.
 extern "C" int facppg_wn_forward_bf16(const facppg_wn_weights* wts, int n_in, int nl, const float* a0_dev, const void* spect_pm_dev, int B,
                                       int L, float* out_dev, void* state_dev, size_t state_bytes, void* scratch_dev, size_t scratch_bytes,
@@ -670,14 +861,20 @@ extern "C" int facppg_wn_forward_bf16(const facppg_wn_weights* wts, int n_in, in
   float* b1 = (float*)(W + sc.total);   // [nl][512] summed biases
   FACPPG_HIP_CHECK(hipMemsetAsync(S + st.h, 0, st.h_one * (nl + 1), s));   // zero margins and rows >= L
   FACPPG_HIP_CHECK(hipMemsetAsync(S + st.ts, 0, st.skip - st.ts, s));      // ts, acts: rows >= L meet zero gradients in k_wgrad, but 0 * NaN = NaN
-  for (int i = 0; i < nl; ++i) {
-    const int last = i == nl - 1;
-    uint4* w1 = (uint4*)(W + sc.w1 + sc.w1_one * i);
-    // K order: tap 0 | tap 1 | tap 2 | cond; gate-interleaved rows
-    if (int rc = pack_launch(wts->in_w[i], w1, 2 * C, K1 / 16, 0, C, 3, (long)C * 3, 3, 1, 0, 1, s)) return rc;
-    if (int rc = pack_launch(wts->cond_w[i], w1, 2 * C, K1 / 16, 3 * C, NCOND, 1, NCOND, 1, 0, 0, 1, s)) return rc;
-    if (int rc = pack_launch(wts->rs_w[i], (uint4*)(W + sc.w2 + sc.w2_one * i), last ? C : 2 * C, C / 16, 0, C, 1, C, 1, 0, 0, 0, s)) return rc;
-    k_add2<<<2, 256, 0, s>>>(wts->in_b[i], wts->cond_b[i], b1 + 2 * C * i, 2 * C);
+  {
+    Packer pk;
+    for (int i = 0; i < nl; ++i) {
+      const int last = i == nl - 1;
+      uint4* w1 = (uint4*)(W + sc.w1 + sc.w1_one * i);
+      // K order: tap 0 | tap 1 | tap 2 | cond; gate-interleaved rows
+      pk.add(wts->in_w[i], w1, 2 * C, K1 / 16, 0, C, 3, (long)C * 3, 3, 1, 0, 1);
+      pk.add(wts->cond_w[i], w1, 2 * C, K1 / 16, 3 * C, NCOND, 1, NCOND, 1, 0, 0, 1);
+      pk.add(wts->rs_w[i], (uint4*)(W + sc.w2 + sc.w2_one * i), last ? C : 2 * C, C / 16, 0, C, 1, C, 1, 0, 0, 0);
+    }
+    if (int rc = pk.launch(s)) return rc;
+    AddBatch ab;
+    for (int i = 0; i < nl; ++i) { ab.a[i] = wts->in_b[i]; ab.b[i] = wts->cond_b[i]; }
+    k_add2<<<dim3(2, nl), 256, 0, s>>>(ab, b1, 2 * C);
   }
   const dim3 egrid((L + 3) / 4, B);
   k_t_start<<<egrid, 256, 0, s>>>(a0_dev, wts->start_w, wts->start_b, (bf16_t*)(S + st.h), n_in, L, Lp);
@@ -705,11 +902,12 @@ extern "C" int facppg_wn_forward_bf16(const facppg_wn_weights* wts, int n_in, in
   return FACPPG_OK;
 }
 
-// Complete backward of the stack: da0, dspect (position-major fp32, overwritten) and every weight / bias gradient.
+// Complete backward of the stack: da0, dspect (position-major fp32; overwritten, or added to when accumulate_dspect --
+// the 12 flows of a step share one buffer) and every weight / bias gradient.
 extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facppg_wn_grads* gr, int n_in, int nl, const float* a0_dev,
                                        const void* spect_pm_dev, const float* dout_dev, int B, int L, const void* state_dev,
-                                       size_t state_bytes, float* da0_dev, float* dspect_pm_dev, void* scratch_dev, size_t scratch_bytes,
-                                       void* stream_) {
+                                       size_t state_bytes, float* da0_dev, float* dspect_pm_dev, int accumulate_dspect, void* scratch_dev,
+                                       size_t scratch_bytes, void* stream_) {
   if (int rc = check_wn(wts, n_in, nl, B, L)) return rc;
   FACPPG_REQUIRE(gr && a0_dev && spect_pm_dev && dout_dev && state_dev && da0_dev && dspect_pm_dev && scratch_dev, FACPPG_EINVAL, "NULL argument");
   FACPPG_REQUIRE(gr->start_w && gr->start_b && gr->end_w && gr->end_b, FACPPG_EINVAL, "NULL gradient pointer");
@@ -727,15 +925,18 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
   const int nout = 2 * n_in;
   // transposed operand images
   uint4* condt = (uint4*)(W + sc.condt);
-  for (int i = 0; i < nl; ++i) {
-    const int last = i == nl - 1;
-    // dacts[c] = sum_r Wrs[r][c] * [dh_next (res rows) | dskip (skip rows)][r]; last layer: skip rows only
-    if (int rc = pack_launch(wts->rs_w[i], (uint4*)(W + sc.rst + sc.rst_one * i), C, (last ? C : 2 * C) / 16, 0, last ? C : 2 * C, 1, 1, C, 0, 0, 0, s))
-      return rc;
-    // dh[m] += sum_{tap,o} Win[o][m][tap] * dpre[n - (tap-1) d][o]
-    if (int rc = pack_launch(wts->in_w[i], (uint4*)(W + sc.int_ + sc.int_one * i), C, 3 * 2 * C / 16, 0, 2 * C, 3, 3, (long)C * 3, 1, 0, 0, s)) return rc;
-    // dspect[j] = sum_{i,o} Wcond_i[o][j] * dpre_i[o]: one image, K = nl * 512
-    if (int rc = pack_launch(wts->cond_w[i], condt, NCOND, nl * 2 * C / 16, i * 2 * C, 2 * C, 1, 1, NCOND, 0, 0, 0, s)) return rc;
+  {
+    Packer pk;
+    for (int i = 0; i < nl; ++i) {
+      const int last = i == nl - 1;
+      // dacts[c] = sum_r Wrs[r][c] * [dh_next (res rows) | dskip (skip rows)][r]; last layer: skip rows only
+      pk.add(wts->rs_w[i], (uint4*)(W + sc.rst + sc.rst_one * i), C, (last ? C : 2 * C) / 16, 0, last ? C : 2 * C, 1, 1, C, 0, 0, 0);
+      // dh[m] += sum_{tap,o} Win[o][m][tap] * dpre[n - (tap-1) d][o]
+      pk.add(wts->in_w[i], (uint4*)(W + sc.int_ + sc.int_one * i), C, 3 * 2 * C / 16, 0, 2 * C, 3, 3, (long)C * 3, 1, 0, 0);
+      // dspect[j] = sum_{i,o} Wcond_i[o][j] * dpre_i[o]: one image, K = nl * 512
+      pk.add(wts->cond_w[i], condt, NCOND, nl * 2 * C / 16, i * 2 * C, 2 * C, 1, 1, NCOND, 0, 0, 0);
+    }
+    if (int rc = pk.launch(s)) return rc;
   }
   FACPPG_HIP_CHECK(hipMemsetAsync(W + sc.dpre, 0, sc.dpre_one * nl + 0, s));
   FACPPG_HIP_CHECK(hipMemsetAsync(W + sc.dh, 0, sc.dh_one * (nl + 1), s));
@@ -772,7 +973,7 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
     memset(&c, 0, sizeof(c));
     c.A = condt; c.KG = nl * 2 * C / 16; c.M = NCOND; c.N = L; c.B = B; c.nseg = nl;
     for (int i = 0; i < nl; ++i) c.seg[i] = Seg{(const bf16_t*)(W + sc.dpre + sc.dpre_one * i), (long)Lp * 2 * C, 2 * C, HALO, 2 * C};
-    c.mode = EP_ACC_F32; c.Lr = Lr; c.outf = dspect_pm_dev; c.ldo = NCOND; c.accumulate = 0;
+    c.mode = EP_ACC_F32; c.Lr = Lr; c.outf = dspect_pm_dev; c.ldo = NCOND; c.accumulate = accumulate_dspect != 0;
     if (int rc = bgemm_launch(c, s)) return rc;
   }
   const bf16_t* dh0 = (const bf16_t*)(W + sc.dh);
@@ -794,7 +995,8 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
         p.x = (const bf16_t*)(S + st.h + st.h_one * i); p.x_bs = (long)Lp * C; p.ldx = C; p.x_row0 = HALO + (tp - 1) * (1 << i);
         p.out = gr->in_w[i] + tp; p.o_sm = (long)C * 3; p.o_sk = 3; p.M = 2 * C; p.K = C;
       }
-    k_wgrad<<<dim3(C / 128, 2 * C / 128, nl * 3), 256, 0, s>>>(wa);
+    float* wgpart = (float*)(W + sc.wgpart);
+    if (int rc = wgrad_launch(wa, nl * 3, 2 * C, C, wgpart, sc.wgpart_bytes, s)) return rc;
     memset(&wa.prob, 0, sizeof(wa.prob));
     for (int i = 0; i < nl; ++i) {
       WgradProb& p = wa.prob[i];
@@ -802,7 +1004,7 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
       p.x = (const bf16_t*)spect_pm_dev; p.x_bs = (long)Lr * NCOND; p.ldx = NCOND; p.x_row0 = 0;
       p.out = gr->cond_w[i]; p.o_sm = NCOND; p.o_sk = 1; p.M = 2 * C; p.K = NCOND;
     }
-    k_wgrad<<<dim3(NCOND / 128, 2 * C / 128, nl), 256, 0, s>>>(wa);
+    if (int rc = wgrad_launch(wa, nl, 2 * C, NCOND, wgpart, sc.wgpart_bytes, s)) return rc;
     memset(&wa.prob, 0, sizeof(wa.prob));
     for (int i = 0; i < nl; ++i) {
       const int last = i == nl - 1;
@@ -813,22 +1015,22 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
       p.x = (const bf16_t*)(S + st.acts + st.acts_one * i); p.x_bs = (long)Lr * C; p.ldx = C; p.x_row0 = 0;
       p.out = gr->rs_w[i]; p.o_sm = C; p.o_sk = 1; p.K = C;
     }
-    k_wgrad<<<dim3(C / 128, 2 * C / 128, nl), 256, 0, s>>>(wa);
+    if (int rc = wgrad_launch(wa, nl, 2 * C, C, wgpart, sc.wgpart_bytes, s)) return rc;
   }
   {  // bias gradients: column sums of dpre_i (in + cond biases share them) and of [dh_{i+1} | dskip]
     ColsumArgs ca;
     memset(&ca, 0, sizeof(ca));
-    ca.B = B; ca.L = L;
-    for (int i = 0; i < nl; ++i) ca.prob[i] = ColsumProb{(const bf16_t*)(W + sc.dpre + sc.dpre_one * i), (long)Lp * 2 * C, 2 * C, HALO, 2 * C, gr->in_b[i]};
-    k_colsum<<<dim3(2 * C / 64, nl), 256, 0, s>>>(ca);
+    ca.B = B; ca.L = L; ca.part = (float*)(W + sc.cspart);
+    for (int i = 0; i < nl; ++i) ca.prob[i] = ColsumProb{W + sc.dpre + sc.dpre_one * i, (long)Lp * 2 * C, 2 * C, HALO, 2 * C, gr->in_b[i]};
+    if (int rc = colsum_launch<false>(ca, nl, 2 * C, 1, s)) return rc;
     memset(&ca.prob, 0, sizeof(ca.prob));
     int np = 0;
     for (int i = 0; i < nl; ++i) {
       const int last = i == nl - 1;
-      if (!last) ca.prob[np++] = ColsumProb{(const bf16_t*)(W + sc.dh + sc.dh_one * (i + 1)), (long)Lr * C, C, 0, C, gr->rs_b[i]};
+      if (!last) ca.prob[np++] = ColsumProb{W + sc.dh + sc.dh_one * (i + 1), (long)Lr * C, C, 0, C, gr->rs_b[i]};
       ca.prob[np++] = ColsumProb{dskip, (long)Lr * C, C, 0, C, gr->rs_b[i] + (last ? 0 : C)};
     }
-    k_colsum<<<dim3(C / 64, np), 256, 0, s>>>(ca);
+    if (int rc = colsum_launch<false>(ca, np, C, 1, s)) return rc;
     for (int i = 0; i < nl; ++i) FACPPG_HIP_CHECK(hipMemcpyAsync(gr->cond_b[i], gr->in_b[i], 2 * C * 4, hipMemcpyDeviceToDevice, s));
   }
   FACPPG_HIP_CHECK(hipGetLastError());

@@ -80,7 +80,10 @@ def _declare(lib):
         "facppg_posmajor_to_f32": (c.c_int, [vp, c.c_int, c.c_int, c.c_int, vp, c.c_int, vp]),
         "facppg_wn_forward_bf16": (c.c_int, [c.POINTER(WnWeights), c.c_int, c.c_int, vp, vp, c.c_int, c.c_int, vp, vp, sz, vp, sz, vp]),
         "facppg_wn_backward_bf16": (c.c_int, [c.POINTER(WnWeights), c.POINTER(WnGrads), c.c_int, c.c_int, vp, vp, vp, c.c_int, c.c_int,
-                                              vp, sz, vp, vp, vp, sz, vp]),
+                                              vp, sz, vp, vp, c.c_int, vp, sz, vp]),
+        "facppg_upsample_regroup_bf16": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, vp, vp]),
+        "facppg_upsample_backward_workspace_bytes": (sz, []),
+        "facppg_upsample_regroup_backward": (c.c_int, [vp, vp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, vp, vp, vp, sz, vp]),
         "facppg_wg_set_profiling": (c.c_int, [vp, c.c_int]),
         "facppg_wg_last_layer_ms": (c.c_int, [vp, c.POINTER(f32), c.POINTER(c.c_int)]),
         "facppg_stft_create": (c.c_int, [c.c_int, c.c_int, vp, vp, vp, vp, c.c_int, c.c_int, vp, c.POINTER(vp)]),

@@ -61,7 +61,7 @@ def train(num_gpus, rank, group_name, output_directory, epochs, learning_rate, s
     model = WaveGlow(**waveglow_config).cuda()
     if num_gpus > 1:
         model = apply_gradient_allreduce(model)
-    optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate)
+    optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate, fused=True)   # one multi-tensor kernel per state, not 938 x 4
     iteration = 0
     if checkpoint_path != "":
         model, optimizer, iteration = load_checkpoint(checkpoint_path, model, optimizer)

@@ -155,17 +155,69 @@ def spect_to_posmajor_bf16(spect, Lg):
     return out
 
 
+class _StepShared(object):
+    """What the bf16 flows of one training step share: the fp32 position-major conditioning gradient every flow's
+    backward adds to (one buffer instead of 12 tensors summed by autograd), consumed by the upsampler's backward."""
+
+    def __init__(self):
+        self.dspect_pm = None
+
+
+class _UpsampleBf16Function(torch.autograd.Function):
+    """WaveGlow.upsample + crop + regroup (glow.py:184-186, 214-222) on HIP kernels: forward straight into the bf16
+    position-major conditioning operand; backward = the ConvTranspose1d's weight / bias gradients from the shared
+    conditioning gradient.  Returns (spect_pm, link): ``link`` is a 1-element tensor threaded through every flow so
+    that autograd runs this backward after all of theirs."""
+
+    @staticmethod
+    def forward(ctx, mel, up_w, up_b, shared, hop, Lg):
+        L = _lib.load()
+        dev = mel.device
+        mel = mel.detach().float().contiguous()
+        w, b = up_w.detach().float().contiguous(), up_b.detach().float().contiguous()
+        B, nm, T = mel.shape
+        Lr = L.facppg_wn_bf16_padded_len(Lg)
+        spect_pm = torch.empty(B, Lr, nm * 8, dtype=torch.bfloat16, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.facppg_upsample_regroup_bf16(_lib.ptr(mel), _lib.ptr(w), _lib.ptr(b), B, T, nm, hop, w.shape[2], Lg,
+                                                      _lib.ptr(spect_pm), _lib.current_stream(dev)))
+        ctx.save_for_backward(mel)
+        ctx.shared, ctx.hop, ctx.Lg, ctx.wshape = shared, hop, Lg, tuple(w.shape)
+        ctx.mark_non_differentiable(spect_pm)
+        return spect_pm, torch.zeros(1, device=dev)
+
+    @staticmethod
+    def backward(ctx, _dspect_pm, _dlink):
+        L = _lib.load()
+        (mel,) = ctx.saved_tensors
+        dev = mel.device
+        B, nm, T = mel.shape
+        dw = torch.empty(ctx.wshape, device=dev)
+        db = torch.empty(nm, device=dev)
+        d = ctx.shared.dspect_pm
+        if d is None:                                     # no flow contributed (cannot happen in WaveGlow.forward)
+            return None, torch.zeros_like(dw), torch.zeros_like(db), None, None, None
+        ws = torch.empty(L.facppg_upsample_backward_workspace_bytes(), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.facppg_upsample_regroup_backward(_lib.ptr(mel), _lib.ptr(d), B, T, nm, ctx.hop, ctx.wshape[2], ctx.Lg, _lib.ptr(dw),
+                                                          _lib.ptr(db), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)))
+        ctx.shared.dspect_pm = None
+        return None, dw, db, None, None, None
+
+
 class _WNFunctionBf16(torch.autograd.Function):
     """One flow's WN stack with bf16 MFMA operands, fp32 accumulation and fp32 gradients (BASELINE config 5).
     forward  = facppg_wn_forward_bf16 (fused dilated-conv + conditioning GEMM with the gate in its epilogue, res/skip
                GEMM with the residual / skip update in its epilogue, per layer);
     backward = facppg_wn_backward_bf16: data gradients AND every weight / bias gradient (NT products over the positions,
                batched over layers and taps) -- nothing of the stack's backward runs in torch or rocBLAS.
-    Inputs: a0 [B, n_in, L]; spect [B, 640, >= L] fp32 (only to route its gradient); spect_pm, its bf16 position-major
-    copy (spect_to_posmajor_bf16); then the plain effective weights as in _WNFunction."""
+    Inputs: a0 [B, n_in, L]; ``route``: stand-alone use (shared None) = spect [B, 640, >= L] fp32, which receives the
+    conditioning gradient; inside a training step = the upsampler's ``link`` (the gradient is added to shared.dspect_pm
+    instead); spect_pm, the bf16 position-major conditioning operand; then the plain effective weights as in
+    _WNFunction."""
 
     @staticmethod
-    def forward(ctx, a0, spect, spect_pm, *weights):
+    def forward(ctx, a0, route, shared, spect_pm, *weights):
         L = _lib.load()
         dev = a0.device
         a0 = a0.detach().float().contiguous()
@@ -179,7 +231,7 @@ class _WNFunctionBf16(torch.autograd.Function):
             _lib.check(L.facppg_wn_forward_bf16(st, n_in, n_layers, _lib.ptr(a0), _lib.ptr(spect_pm), B, Lg, _lib.ptr(out),
                                                 _lib.ptr(state), state.numel(), _lib.ptr(work), work.numel(), _lib.current_stream(dev)))
         ctx.save_for_backward(a0, spect_pm, state, *ws_t)
-        ctx.spect_shape = tuple(spect.shape)
+        ctx.shared, ctx.route_shape = shared, tuple(route.shape)
         return out
 
     @staticmethod
@@ -193,16 +245,24 @@ class _WNFunctionBf16(torch.autograd.Function):
         grads = [torch.empty_like(w) for w in ws_t]
         gs, _ = _WNFunction._weights_struct(grads, _lib.WnGrads)
         da0 = torch.empty_like(a0)
-        dspect_pm = torch.empty(spect_pm.shape, dtype=torch.float32, device=dev)
         work = torch.empty(L.facppg_wn_bf16_scratch_bytes(n_layers, B, Lg), dtype=torch.uint8, device=dev)
-        dspect = torch.zeros(ctx.spect_shape, device=dev)
+        shared = ctx.shared
+        accumulate = shared is not None and shared.dspect_pm is not None
+        if shared is None or not accumulate:
+            dspect_pm = torch.empty(spect_pm.shape, dtype=torch.float32, device=dev)
+            if shared is not None:
+                shared.dspect_pm = dspect_pm
+        else:
+            dspect_pm = shared.dspect_pm
+        droute = torch.zeros(ctx.route_shape, device=dev)
         with torch.cuda.device(dev):
             s = _lib.current_stream(dev)
             _lib.check(L.facppg_wn_backward_bf16(st, gs, n_in, n_layers, _lib.ptr(a0), _lib.ptr(spect_pm), _lib.ptr(dout), B, Lg,
-                                                 _lib.ptr(state), state.numel(), _lib.ptr(da0), _lib.ptr(dspect_pm), _lib.ptr(work),
-                                                 work.numel(), s))
-            _lib.check(L.facppg_posmajor_to_f32(_lib.ptr(dspect_pm), B, dspect.shape[1], Lg, _lib.ptr(dspect), dspect.shape[2], s))
-        return (da0, dspect, None, *grads)
+                                                 _lib.ptr(state), state.numel(), _lib.ptr(da0), _lib.ptr(dspect_pm), 1 if accumulate else 0,
+                                                 _lib.ptr(work), work.numel(), s))
+            if shared is None:
+                _lib.check(L.facppg_posmajor_to_f32(_lib.ptr(dspect_pm), B, droute.shape[1], Lg, _lib.ptr(droute), droute.shape[2], s))
+        return (da0, droute, None, None, *grads)
 
 
 def _conv1x1(W, z, transpose=False):
@@ -343,7 +403,7 @@ class WN(torch.nn.Module):
             raise _lib.FacppgError("WN.forward: audio %s and spect %s disagree" % (tuple(audio.shape), tuple(spect.shape)))
         if getattr(self, "train_precision", "fp32") == "bf16":
             spect = spect.float().contiguous()
-            return _WNFunctionBf16.apply(audio.float().contiguous(), spect, spect_to_posmajor_bf16(spect, Lg), *self._plain_weights())
+            return _WNFunctionBf16.apply(audio.float().contiguous(), spect, None, spect_to_posmajor_bf16(spect, Lg), *self._plain_weights())
         spect_pad = torch.nn.functional.pad(spect.float(), (0, -(-Lg // _TN) * _TN - Lg)).contiguous()
         return _WNFunction.apply(audio.float().contiguous(), spect_pad, *self._plain_weights())
 
@@ -487,24 +547,29 @@ class WaveGlow(torch.nn.Module):
                                    % _lib.load().facppg_last_error().decode())
         for wn in self.WN:
             wn._check_kernel_config()
-        # ConvTranspose1d as a matrix product + overlap-add (col2im): both are differentiable torch ops that
-        # run on rocBLAS / a native fold kernel; MIOpen's transposed-conv backward falls back to a naive
-        # kernel here that costs more than the rest of the step together
         hop, ksz = self.upsample.stride[0], self.upsample.kernel_size[0]
-        Bm, nm, Tm = spect.shape
-        cols = torch.einsum('bit,ijk->bjkt', spect, self.upsample.weight).reshape(Bm, nm * ksz, Tm)
-        spect = F.fold(cols, output_size=(1, (Tm - 1) * hop + ksz), kernel_size=(1, ksz), stride=(1, hop)).squeeze(2)
-        spect = spect + self.upsample.bias.view(1, -1, 1)
-        assert spect.size(2) >= audio.size(1)
-        spect = spect[:, :, :audio.size(1)]
-        spect = spect.unfold(2, g, g).permute(0, 2, 1, 3)
-        spect = spect.contiguous().view(spect.size(0), spect.size(1), -1).permute(0, 2, 1)
-        Lg = spect.size(2)
         bf16 = self.train_precision == "bf16"
+        audio = audio[:, :audio.size(1) - audio.size(1) % g]
+        Lg = audio.size(1) // g
         if bf16:
-            spect = spect.contiguous()
-            spect_pm = spect_to_posmajor_bf16(spect, Lg)          # one bf16 position-major copy serves all flows
+            # upsample + crop + regroup on HIP, straight into the bf16 position-major operand every flow reads; the
+            # flows add their conditioning gradients to one shared fp32 buffer that the upsampler's backward consumes
+            if (spect.size(2) - 1) * hop + ksz < audio.size(1):
+                raise _lib.FacppgError("upsampled mel is shorter than the audio (glow.py:216)")
+            shared = _StepShared()
+            spect_pm, link = _UpsampleBf16Function.apply(spect, self.upsample.weight, self.upsample.bias, shared, hop, Lg)
         else:
+            # ConvTranspose1d as a matrix product + overlap-add (col2im): both are differentiable torch ops that
+            # run on rocBLAS / a native fold kernel; MIOpen's transposed-conv backward falls back to a naive
+            # kernel here that costs more than the rest of the step together
+            Bm, nm, Tm = spect.shape
+            cols = torch.einsum('bit,ijk->bjkt', spect, self.upsample.weight).reshape(Bm, nm * ksz, Tm)
+            spect = F.fold(cols, output_size=(1, (Tm - 1) * hop + ksz), kernel_size=(1, ksz), stride=(1, hop)).squeeze(2)
+            spect = spect + self.upsample.bias.view(1, -1, 1)
+            assert spect.size(2) >= audio.size(1)
+            spect = spect[:, :, :audio.size(1)]
+            spect = spect.unfold(2, g, g).permute(0, 2, 1, 3)
+            spect = spect.contiguous().view(spect.size(0), spect.size(1), -1).permute(0, 2, 1)
             spect_pad = F.pad(spect, (0, -(-Lg // _TN) * _TN - Lg)).contiguous()
         audio = audio.unfold(1, g, g).permute(0, 2, 1)
         output_audio, log_s_list, log_det_W_list = [], [], []
@@ -514,11 +579,11 @@ class WaveGlow(torch.nn.Module):
                 audio = audio[:, self.n_early_size:, :]
             W = self.convinv[k].conv.weight.squeeze(-1)
             log_det_W_list.append(audio.size(0) * audio.size(2) * torch.logdet(W))
-            audio = torch.einsum('ij,bjl->bil', W, audio)        # 1x1 mixing conv (c <= 8 channels)
+            audio = _Conv1x1Function.apply(W.float(), audio.contiguous())        # 1x1 mixing conv (c <= 8 channels), HIP fwd + bwd
             n_half = audio.size(1) // 2
             audio_0, audio_1 = audio[:, :n_half, :], audio[:, n_half:, :]
             if bf16:
-                output = _WNFunctionBf16.apply(audio_0.contiguous(), spect, spect_pm, *self.WN[k]._plain_weights())
+                output = _WNFunctionBf16.apply(audio_0.contiguous(), link, shared, spect_pm, *self.WN[k]._plain_weights())
             else:
                 output = _WNFunction.apply(audio_0.contiguous(), spect_pad, *self.WN[k]._plain_weights())
             log_s, b = output[:, n_half:, :], output[:, :n_half, :]

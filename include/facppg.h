@@ -188,11 +188,24 @@ int facppg_posmajor_to_f32(const float* src_dev, int B, int channels, int L, flo
 int facppg_wn_forward_bf16(const facppg_wn_weights* w, int n_in, int n_layers, const float* a0_dev,
                            const void* spect_pm_dev, int B, int L, float* out_dev, void* state_dev,
                            size_t state_bytes, void* scratch_dev, size_t scratch_bytes, void* stream);
-/* Its autograd backward, complete: da0 [B][n_in][L], dspect_pm fp32 [B][Lr][640] (overwritten) and all of `grads`. */
+/* Its autograd backward, complete: da0 [B][n_in][L], dspect_pm fp32 [B][Lr][640] (overwritten, or added to when
+ * accumulate_dspect != 0: the flows of one step share the buffer) and all of `grads`. */
 int facppg_wn_backward_bf16(const facppg_wn_weights* w, const facppg_wn_grads* grads, int n_in, int n_layers,
                             const float* a0_dev, const void* spect_pm_dev, const float* dout_dev, int B, int L,
                             const void* state_dev, size_t state_bytes, float* da0_dev, float* dspect_pm_dev,
-                            void* scratch_dev, size_t scratch_bytes, void* stream);
+                            int accumulate_dspect, void* scratch_dev, size_t scratch_bytes, void* stream);
+/* Replaces WaveGlow.upsample + crop + regroup in the training direction (glow.py:184-186, 214-222), straight into
+ * the bf16 position-major conditioning operand: mel [B][80][T] fp32, up_w [80][80][ksize], up_b [80] ->
+ * spect_pm bf16 [B][Lr][640] for L = N/8 group positions (rows >= L zero). */
+int facppg_upsample_regroup_bf16(const float* mel_dev, const float* up_w_dev, const float* up_b_dev, int B,
+                                 int T, int n_mel, int hop, int ksize, int L, void* spect_pm_dev,
+                                 void* stream);
+/* Its backward w.r.t. the parameters from the accumulated conditioning gradient dspect_pm fp32 [B][Lr][640]:
+ * d_up_w [80][80][ksize], d_up_b [80]. */
+size_t facppg_upsample_backward_workspace_bytes(void);
+int facppg_upsample_regroup_backward(const float* mel_dev, const float* dspect_pm_dev, int B, int T, int n_mel,
+                                     int hop, int ksize, int L, float* d_up_w_dev, float* d_up_b_dev,
+                                     void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* Average device time (ms) of the dominant kernel (the fused WN layer) over the launches of
  * the most recent facppg_wg_infer on this handle, measured with hipEvents on the stream the
