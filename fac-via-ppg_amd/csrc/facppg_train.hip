@@ -98,6 +98,60 @@ __global__ void k_sum_parts(const float* __restrict__ part, float* __restrict__ 
   out[i] = v;
 }
 
+// ---- weight normalisation of EVERY weight-normed conv of the model in one launch (torch.nn.utils.weight_norm, dim 0:
+// w[r][:] = g[r] * v[r][:] / ||v[r][:]||, glow.py:118-146).  One wavefront per output row; the table gives, per tensor,
+// its pointers, row length and first global row.
+struct WnTableEntry { const float* v; const float* g; float* w; float* norm; long row0; int rows, len; };
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ int wn_find(const WnTableEntry* __restrict__ tab, int n, long row) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].row0 <= row) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+__global__ __launch_bounds__(256) void k_weight_norm_fwd(const WnTableEntry* __restrict__ tab, int n, long total_rows) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= total_rows) return;
+  const int lane = threadIdx.x & 63;
+  const WnTableEntry e = tab[wn_find(tab, n, row)];
+  const int r = (int)(row - e.row0);
+  const float* v = e.v + (size_t)r * e.len;
+  float ss = 0.0f;
+  for (int i = lane; i < e.len; i += 64) { const float x = v[i]; ss = fmaf(x, x, ss); }
+  const float norm = sqrtf(wave_sum(ss));
+  const float sc = e.g[r] / norm;
+  float* w = e.w + (size_t)r * e.len;
+  for (int i = lane; i < e.len; i += 64) w[i] = v[i] * sc;
+  if (lane == 0) e.norm[r] = norm;
+}
+// backward: dg[r] = <dw, v> / ||v||;  dv = (g / ||v||) * (dw - v * <dw, v> / ||v||^2).  Table: v, g, w := dw (in), norm (in);
+// outputs dv, dg in a second table of the same order (fields v := dv, g := dg).
+__global__ __launch_bounds__(256) void k_weight_norm_bwd(const WnTableEntry* __restrict__ tab, const WnTableEntry* __restrict__ out, int n,
+                                                         long total_rows) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= total_rows) return;
+  const int lane = threadIdx.x & 63;
+  const int t = wn_find(tab, n, row);
+  const WnTableEntry e = tab[t];
+  const int r = (int)(row - e.row0);
+  const float* v = e.v + (size_t)r * e.len;
+  const float* dw = e.w + (size_t)r * e.len;
+  float dot = 0.0f;
+  for (int i = lane; i < e.len; i += 64) dot = fmaf(dw[i], v[i], dot);
+  dot = wave_sum(dot);
+  const float norm = e.norm[r], gr = e.g[r];
+  const float a = gr / norm, bq = gr * dot / (norm * norm * norm);
+  float* dv = const_cast<float*>(out[t].v) + (size_t)r * e.len;
+  for (int i = lane; i < e.len; i += 64) dv[i] = a * dw[i] - bq * v[i];
+  if (lane == 0) const_cast<float*>(out[t].g)[r] = dot / norm;
+}
+
 template <int C>
 int conv1x1_c(const float* W, const float* z, float* out, int B, int L, bool trans, hipStream_t s) {
   const dim3 grid((L + 1023) / 1024, B);
@@ -107,6 +161,35 @@ int conv1x1_c(const float* W, const float* z, float* out, int B, int L, bool tra
 }
 
 constexpr int kWgradParts = 512;
+
+// affine coupling of a flow in the training direction (glow.py:240-245): y = cat(x0, exp(log_s) * x1 + b) with
+// x = [x0 | x1] (h channels each), wn = [b | log_s]; 4 consecutive positions per thread (<= 8 channels: a few MB per step)
+__global__ __launch_bounds__(256) void k_affine_fwd(const float* __restrict__ x, const float* __restrict__ wn, float* __restrict__ y, int h, int L) {
+  const int b = blockIdx.y;
+  const size_t base = (size_t)b * 2 * h * L;
+  const int l0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+  for (int l = l0; l < min(l0 + 4, L); ++l)
+    for (int j = 0; j < h; ++j) {
+      y[base + (size_t)j * L + l] = x[base + (size_t)j * L + l];
+      y[base + (size_t)(h + j) * L + l] = __expf(wn[base + (size_t)(h + j) * L + l]) * x[base + (size_t)(h + j) * L + l] + wn[base + (size_t)j * L + l];
+    }
+}
+// dx = [dy0 | dy1 * exp(log_s)], dwn = [dy1 | dy1 * exp(log_s) * x1]
+__global__ __launch_bounds__(256) void k_affine_bwd(const float* __restrict__ x, const float* __restrict__ wn, const float* __restrict__ dy,
+                                                    float* __restrict__ dx, float* __restrict__ dwn, int h, int L) {
+  const int b = blockIdx.y;
+  const size_t base = (size_t)b * 2 * h * L;
+  const int l0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+  for (int l = l0; l < min(l0 + 4, L); ++l)
+    for (int j = 0; j < h; ++j) {
+      const size_t o0 = base + (size_t)j * L + l, o1 = base + (size_t)(h + j) * L + l;
+      const float e = __expf(wn[o1]), d1 = dy[o1];
+      dx[o0] = dy[o0];
+      dx[o1] = d1 * e;
+      dwn[o0] = d1;
+      dwn[o1] = d1 * e * x[o1];
+    }
+}
 
 }  // namespace
 }  // namespace facppg
@@ -149,6 +232,36 @@ extern "C" int facppg_conv1x1_wgrad(const float* dout_dev, const float* z_dev, f
     default: FACPPG_REQUIRE(false, FACPPG_EUNSUPPORTED, "channel count %d (built: 2, 4, 6, 8)", c);
   }
   k_sum_parts<<<1, 64, 0, s>>>(part, dw_dev, parts, c * c);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+extern "C" int facppg_affine_forward(const float* x_dev, const float* wn_out_dev, float* y_dev, int B, int h, int L, void* stream) {
+  FACPPG_REQUIRE(x_dev && wn_out_dev && y_dev && B > 0 && h > 0 && L > 0 && B <= 65535, FACPPG_EINVAL, "bad argument");
+  k_affine_fwd<<<dim3((L + 1023) / 1024, B), 256, 0, (hipStream_t)stream>>>(x_dev, wn_out_dev, y_dev, h, L);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+extern "C" int facppg_affine_backward(const float* x_dev, const float* wn_out_dev, const float* dy_dev, float* dx_dev, float* dwn_out_dev, int B,
+                                      int h, int L, void* stream) {
+  FACPPG_REQUIRE(x_dev && wn_out_dev && dy_dev && dx_dev && dwn_out_dev && B > 0 && h > 0 && L > 0 && B <= 65535, FACPPG_EINVAL, "bad argument");
+  k_affine_bwd<<<dim3((L + 1023) / 1024, B), 256, 0, (hipStream_t)stream>>>(x_dev, wn_out_dev, dy_dev, dx_dev, dwn_out_dev, h, L);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+// table entries are 6 x 8 bytes: {v, g, w, norm, row0, (rows | len << 32)} as the host packs them (see facppg.h)
+extern "C" int facppg_weight_norm_forward(const void* table_dev, int n_tensors, long total_rows, void* stream) {
+  FACPPG_REQUIRE(table_dev && n_tensors > 0 && total_rows > 0, FACPPG_EINVAL, "bad argument");
+  k_weight_norm_fwd<<<(unsigned)((total_rows + 3) / 4), 256, 0, (hipStream_t)stream>>>((const WnTableEntry*)table_dev, n_tensors, total_rows);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+extern "C" int facppg_weight_norm_backward(const void* table_dev, const void* out_table_dev, int n_tensors, long total_rows, void* stream) {
+  FACPPG_REQUIRE(table_dev && out_table_dev && n_tensors > 0 && total_rows > 0, FACPPG_EINVAL, "bad argument");
+  k_weight_norm_bwd<<<(unsigned)((total_rows + 3) / 4), 256, 0, (hipStream_t)stream>>>((const WnTableEntry*)table_dev, (const WnTableEntry*)out_table_dev,
+                                                                                      n_tensors, total_rows);
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
 }

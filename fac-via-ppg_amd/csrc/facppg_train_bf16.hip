@@ -21,6 +21,7 @@
 // res/skip, gate backward, transposed-conv accumulate, plain), k_wgrad (NT products batched over layers and taps),
 // k_colsum (bias gradients) and the <= 8-channel start / end convs and their backward as streaming kernels.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "facppg_common.h"
@@ -30,6 +31,11 @@ namespace {
 
 typedef unsigned short bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 nt_load16(const void* p) {
+  const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 
 constexpr int C = 256, NCOND = 640, HALO = 128;
 constexpr int BM = 128, BN = 128, KC = 64;     // k_bgemm tile and K chunk
@@ -189,17 +195,44 @@ __device__ __forceinline__ void bgemm_store4(const BGemmArgs& p, int b, int n, i
 }
 
 // NCB = 32-column blocks per tile: 4 (128 columns) for large products, 2 (64 columns: twice the workgroups, half
-// the LDS and accumulators each) when the launch would otherwise leave the chip with < ~3 workgroups per CU -- these
-// loops are short (a few hundred MFMA cycles per 64-deep chunk), so latency is hidden by resident workgroups and by
-// staging TWO chunks ahead in registers (the loads of chunk c+2 are issued before the MFMAs of chunk c and written
-// to LDS after those of chunk c+1).
+// the LDS and accumulators each) when the launch would otherwise leave the chip with < ~3 workgroups per CU.
+// Measured (B = 12, gate GEMM): removing the activation loads alone cuts the kernel from 81 to 30 us -- a 64-deep chunk
+// is only 8-16 MFMAs (a few hundred cycles) per wave, far less than a memory round trip, so the operands are staged
+// PD = 4 chunks ahead in a register ring (statically indexed: the chunk loop is unrolled by PD), and workgroups that
+// share a column tile (the M tiles) are dealt to the SAME XCD back to back so three of the four find the tile in L2.
+// Measured (rocprofv3, B = 12, gate GEMM 21.6 GFLOP): non-temporal loads for the ACTIVATION operand (streamed once per
+// workgroup) 66 -> 41 us -- they stop evicting the weight images, which every workgroup re-reads, from L1/L2; non-temporal
+// WEIGHT loads are slower (76 us); staging further ahead than one chunk is slower too (PD 1 / 2 / 3 / 4: 68 / 82 / 86 / 91 us).
+#ifndef FACPPG_BG_NT
+#define FACPPG_BG_NT 1
+#endif
+#ifndef FACPPG_WG_NT
+#define FACPPG_WG_NT 0
+#endif
+#ifndef FACPPG_BG_PD
+#define FACPPG_BG_PD 1
+#endif
+#ifndef FACPPG_BG_XCD
+#define FACPPG_BG_XCD 1
+#endif
+constexpr int PD = FACPPG_BG_PD;
 template <int MODE, int NCB>
 __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs p) {
   constexpr int BNt = 32 * NCB;
   __shared__ __attribute__((aligned(16))) bf16_t lds[2][BNt * LDB];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
-  const int b = blockIdx.z, n0 = blockIdx.x * BNt;
-  const int mb = blockIdx.y * 4 + w;
+  // workgroup lin runs on XCD lin % 8; slot = lin / 8 walks (M tile fastest, then this XCD's column tiles)
+  const int nm = (p.M + BM - 1) / BM, ncol = (p.N + BNt - 1) / BNt;
+#if FACPPG_BG_XCD
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int ct = (slot / nm) * 8 + xcd, mt = slot % nm;
+  if (ct >= ncol * p.B) return;
+#else
+  const int mt = blockIdx.x % nm, ct = blockIdx.x / nm;
+  if (ct >= ncol * p.B) return;
+#endif
+  const int b = ct / ncol, n0 = (ct - b * ncol) * BNt;
+  const int mb = mt * 4 + w;
   const bool active = mb * 32 < p.M;
   const uint4* ap = p.A + (size_t)(active ? mb : 0) * p.KG * 64 + lane;
   // staging: thread -> rows srow + 32*j (j < NCB) of the [BNt positions][64 k] chunk, 16 bytes at k = 8*sk
@@ -218,8 +251,19 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs p) {
   auto stage_load = [&](uint4 (&stg)[NCB]) {
     const Seg& sg = p.seg[seg_i];
     const bf16_t* base = sg.x + (size_t)b * sg.bs + (size_t)(sg.row0 + n0 + srow) * sg.ld + seg_c + 8 * sk;
+#if defined(FACPPG_BG_ABLATE) && (FACPPG_BG_ABLATE & 1)
+#pragma unroll
+    for (int j = 0; j < NCB; ++j) stg[j] = make_uint4(0x3c003c00u + seg_c, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);   // ablation: no activation loads
+    (void)base;
+#else
+#if FACPPG_BG_NT & 1
+#pragma unroll
+    for (int j = 0; j < NCB; ++j) stg[j] = nt_load16(base + (size_t)(32 * j) * sg.ld);
+#else
 #pragma unroll
     for (int j = 0; j < NCB; ++j) stg[j] = *reinterpret_cast<const uint4*>(base + (size_t)(32 * j) * sg.ld);
+#endif
+#endif
     seg_c += KC;
     if (seg_c >= sg.nch && seg_i + 1 < p.nseg) { ++seg_i; seg_c = 0; }
   };
@@ -228,8 +272,18 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs p) {
     for (int j = 0; j < NCB; ++j) *reinterpret_cast<uint4*>(&lds[buf][(srow + 32 * j) * LDB + 8 * sk]) = stg[j];
   };
   auto load_a = [&](uint4 (&a)[4], int c) {
+#if defined(FACPPG_BG_ABLATE) && (FACPPG_BG_ABLATE & 2)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a[s] = make_uint4(0x3c003c00u + c, 0x3c003c00u, 0x3c003c00u + s, 0x3c003c00u);   // ablation: no weight loads
+#else
+#if FACPPG_BG_NT & 2
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a[s] = nt_load16(ap + (size_t)(c * 4 + s) * 64);
+#else
 #pragma unroll
     for (int s = 0; s < 4; ++s) a[s] = ap[(size_t)(c * 4 + s) * 64];
+#endif
+#endif
   };
   auto compute = [&](int c, const uint4 (&a)[4]) {
     const bf16_t* lb = &lds[c & 1][li * LDB + 8 * kh];
@@ -239,27 +293,37 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs p) {
       for (int cb = 0; cb < NCB; ++cb)
         acc[cb] = mfma_bf16(a[s], *reinterpret_cast<const uint4*>(lb + cb * 32 * LDB + 16 * s), acc[cb]);
   };
-  uint4 st0[NCB], st1[NCB], a0[4], a1[4];
-  stage_load(st0);                      // chunk 0
-  load_a(a0, 0);
-  stage_write(0, st0);
-  if (nchunks > 1) stage_load(st0);     // chunk 1 (in flight)
+  // rings: chunk c lives in slot c % PD.  Activations of chunk c leave their slot for LDS at the end of iteration c-1,
+  // so iteration c refills that slot with chunk c+PD; weights of chunk c are used during iteration c, so iteration c
+  // refills the slot of chunk c-1 with chunk c+PD-1.
+  uint4 st[PD][NCB], ar[PD][4];
+  stage_load(st[0]);
+  stage_write(0, st[0]);
+#pragma unroll
+  for (int u = 1; u < PD; ++u)
+    if (u < nchunks) stage_load(st[u]);
+#pragma unroll
+  for (int u = 0; u < PD - 1; ++u)
+    if (u < nchunks) load_a(ar[u], u);
   __syncthreads();
-  // iteration c: weights of c+1, activations of c+2 issued; MFMAs of c; activations of c+1 written to LDS
-  auto iter = [&](int c, uint4 (&a_cur)[4], uint4 (&a_nxt)[4], uint4 (&s_nxt)[NCB], uint4 (&s_nxt2)[NCB]) {
-    if (c + 1 < nchunks) load_a(a_nxt, c + 1);
-    if (c + 2 < nchunks) stage_load(s_nxt2);
-    compute(c, a_cur);
-    if (c + 1 < nchunks) stage_write((c + 1) & 1, s_nxt);
-    __syncthreads();
-  };
-  int c = 0;
-  for (; c + 1 < nchunks; c += 2) {
-    iter(c, a0, a1, st0, st1);
-    iter(c + 1, a1, a0, st1, st0);
+  for (int c0 = 0; c0 < nchunks; c0 += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      const int c = c0 + u;
+      if (c < nchunks) {
+        if (c + PD - 1 < nchunks) load_a(ar[(u + PD - 1) % PD], c + PD - 1);
+        if (c + PD < nchunks) stage_load(st[u]);
+        __builtin_amdgcn_sched_barrier(0);   // keep the requests HERE, PD chunks ahead (hipcc otherwise sinks them next to their use)
+        compute(c, ar[u]);
+        if (c + 1 < nchunks) stage_write((c + 1) & 1, st[(u + 1) % PD]);
+        __syncthreads();
+      }
+    }
   }
-  if (c < nchunks) iter(c, a0, a1, st0, st1);
   if (!active) return;
+#if defined(FACPPG_BG_ABLATE) && (FACPPG_BG_ABLATE & 4)
+  if (acc[0][0] != 12345.678f) return;   // ablation: no epilogue
+#endif
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) {
     const int n = n0 + cb * 32 + li;
@@ -283,9 +347,17 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs p) {
 
 template <int MODE>
 void bgemm_dispatch(const BGemmArgs& a, hipStream_t s) {
-  const long wide = (long)((a.N + 127) / 128) * ((a.M + BM - 1) / BM) * a.B;
-  if (wide >= 3 * 256) k_bgemm<MODE, 4><<<dim3((a.N + 127) / 128, (a.M + BM - 1) / BM, a.B), 256, 0, s>>>(a);
-  else k_bgemm<MODE, 2><<<dim3((a.N + 63) / 64, (a.M + BM - 1) / BM, a.B), 256, 0, s>>>(a);
+  const int nm = (a.M + BM - 1) / BM;
+  const long wide = (long)((a.N + 127) / 128) * nm * a.B;
+  static const char* wenv = getenv("FACPPG_BG_WIDE");
+  static const long wide_min = wenv ? atol(wenv) : 384;    // 128-column tiles once they give >= 1.5 workgroups per CU
+  if (wide >= wide_min) {
+    const int ct = ((a.N + 127) / 128) * a.B;
+    k_bgemm<MODE, 4><<<dim3(8 * nm * ((ct + 7) / 8)), 256, 0, s>>>(a);
+  } else {
+    const int ct = ((a.N + 63) / 64) * a.B;
+    k_bgemm<MODE, 2><<<dim3(8 * nm * ((ct + 7) / 8)), 256, 0, s>>>(a);
+  }
 }
 
 int bgemm_launch(const BGemmArgs& a, hipStream_t s) {
@@ -372,7 +444,11 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
     const int b = c / nlc, n = (c - b * nlc) * 64 + 8 * pb;
     const bf16_t* s0 = src + (size_t)b * sbs + (size_t)(srow0 + n) * sld + ch0;
 #pragma unroll
+#if FACPPG_WG_NT
+    for (int i = 0; i < 8; ++i) stg[i] = live ? nt_load16(s0 + (size_t)i * sld) : make_uint4(0, 0, 0, 0);
+#else
     for (int i = 0; i < 8; ++i) stg[i] = live ? *reinterpret_cast<const uint4*>(s0 + (size_t)i * sld) : make_uint4(0, 0, 0, 0);
+#endif
   };
   auto stage_write = [&](const uint4 (&stg)[8]) {
     uint4 t[8];
@@ -400,6 +476,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
   // iteration c: chunk c+2 requested, MFMAs of chunk c from LDS, then chunk c+1 (requested one iteration ago) replaces it
   auto iter = [&](int c, uint4 (&s_nxt)[8], uint4 (&s_nxt2)[8]) {
     if (c + 2 < c_hi) stage_load(c + 2, s_nxt2);
+    __builtin_amdgcn_sched_barrier(0);   // keep the requests two chunks ahead
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       uint4 av[2], bv[2];
@@ -886,6 +963,12 @@ extern "C" int facppg_wn_forward_bf16(const facppg_wn_weights* wts, int n_in, in
     g.A = (const uint4*)(W + sc.w1 + sc.w1_one * i); g.KG = K1 / 16; g.M = 2 * C; g.N = L; g.B = B; g.nseg = 4;
     for (int t = 0; t < 3; ++t) g.seg[t] = Seg{h_in, (long)Lp * C, C, HALO + (t - 1) * d, C};
     g.seg[3] = Seg{(const bf16_t*)spect_pm_dev, (long)Lr * NCOND, NCOND, 0, NCOND};
+    {
+      static const char* ex = getenv("FACPPG_BG_EXP");   // timing experiment (wrong results): 1 = every segment strided like spect, 2 = like h
+      const int exv = ex ? atoi(ex) : 0;
+      if (exv == 1) for (int t = 0; t < 3; ++t) g.seg[t] = Seg{(const bf16_t*)spect_pm_dev, (long)Lr * NCOND, NCOND, 0, C};
+      if (exv == 2) g.seg[3] = Seg{h_in, (long)Lp * C, C, HALO, NCOND};
+    }
     g.mode = EP_GATE; g.bias = b1 + 2 * C * i; g.Lr = Lr;
     g.acts = (bf16_t*)(S + st.acts + st.acts_one * i); g.ts = (bf16_t*)(S + st.ts + st.ts_one * i);
     if (int rc = bgemm_launch(g, s)) return rc;

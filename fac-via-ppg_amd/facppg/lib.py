@@ -84,6 +84,10 @@ def _declare(lib):
         "facppg_upsample_regroup_bf16": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, vp, vp]),
         "facppg_upsample_backward_workspace_bytes": (sz, []),
         "facppg_upsample_regroup_backward": (c.c_int, [vp, vp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, vp, vp, vp, sz, vp]),
+        "facppg_weight_norm_forward": (c.c_int, [vp, c.c_int, c.c_long, vp]),
+        "facppg_weight_norm_backward": (c.c_int, [vp, vp, c.c_int, c.c_long, vp]),
+        "facppg_affine_forward": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, c.c_int, vp]),
+        "facppg_affine_backward": (c.c_int, [vp, vp, vp, vp, vp, c.c_int, c.c_int, c.c_int, vp]),
         "facppg_wg_set_profiling": (c.c_int, [vp, c.c_int]),
         "facppg_wg_last_layer_ms": (c.c_int, [vp, c.POINTER(f32), c.POINTER(c.c_int)]),
         "facppg_stft_create": (c.c_int, [c.c_int, c.c_int, vp, vp, vp, vp, c.c_int, c.c_int, vp, c.POINTER(vp)]),

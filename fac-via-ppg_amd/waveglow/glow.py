@@ -305,6 +305,94 @@ class _Conv1x1Function(torch.autograd.Function):
         return dW, dz
 
 
+class _WeightNormAllFunction(torch.autograd.Function):
+    """w_i = g_i * v_i / ||v_i|| (per output row) for EVERY weight-normed conv of the model in one HIP launch, and the
+    matching backward in one more (torch's weight_norm recomputes each conv with its own two kernels: 288 convs ->
+    ~600 launches per step).  Inputs v_0, g_0, v_1, g_1, ...; outputs w_0, w_1, ..."""
+
+    @staticmethod
+    def _table(entries, dev):
+        import numpy as np
+        t = np.zeros((len(entries), 6), dtype=np.int64)
+        row0 = 0
+        for i, (v, g, w, norm, rows, ln) in enumerate(entries):
+            t[i] = (v, g, w, norm, row0, rows | (ln << 32))
+            row0 += rows
+        return torch.from_numpy(t).to(dev, non_blocking=True), row0
+
+    @staticmethod
+    def forward(ctx, *vg):
+        L = _lib.load()
+        vs = [t.detach().float().contiguous() for t in vg[0::2]]
+        gs = [t.detach().float().contiguous() for t in vg[1::2]]
+        dev = vs[0].device
+        wflat = torch.empty(sum(v.numel() for v in vs), device=dev)
+        nflat = torch.empty(sum(v.shape[0] for v in vs), device=dev)
+        ws, norms, entries, wo, no = [], [], [], 0, 0
+        for v, g in zip(vs, gs):
+            w, nr = wflat[wo:wo + v.numel()].view_as(v), nflat[no:no + v.shape[0]]
+            wo, no = wo + v.numel(), no + v.shape[0]
+            ws.append(w)
+            norms.append(nr)
+            entries.append((v.data_ptr(), g.data_ptr(), w.data_ptr(), nr.data_ptr(), v.shape[0], v.numel() // v.shape[0]))
+        table, total = _WeightNormAllFunction._table(entries, dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.facppg_weight_norm_forward(_lib.ptr(table), len(vs), total, _lib.current_stream(dev)))
+        ctx.save_for_backward(nflat, *vs, *gs)
+        ctx.n = len(vs)
+        return tuple(ws)
+
+    @staticmethod
+    def backward(ctx, *dws):
+        L = _lib.load()
+        nflat, *rest = ctx.saved_tensors
+        vs, gs = rest[:ctx.n], rest[ctx.n:]
+        dev = vs[0].device
+        dws = [d.float().contiguous() for d in dws]
+        dvflat = torch.empty(sum(v.numel() for v in vs), device=dev)
+        dgflat = torch.empty(nflat.numel(), device=dev)
+        ins, outs, out, wo, no = [], [], [], 0, 0
+        for v, g, dw in zip(vs, gs, dws):
+            dv, dg, nr = dvflat[wo:wo + v.numel()].view_as(v), dgflat[no:no + v.shape[0]].view_as(g), nflat[no:no + v.shape[0]]
+            wo, no = wo + v.numel(), no + v.shape[0]
+            ins.append((v.data_ptr(), g.data_ptr(), dw.data_ptr(), nr.data_ptr(), v.shape[0], v.numel() // v.shape[0]))
+            outs.append((dv.data_ptr(), dg.data_ptr(), 0, 0, v.shape[0], v.numel() // v.shape[0]))
+            out += [dv, dg]
+        tin, total = _WeightNormAllFunction._table(ins, dev)
+        tout, _ = _WeightNormAllFunction._table(outs, dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.facppg_weight_norm_backward(_lib.ptr(tin), _lib.ptr(tout), ctx.n, total, _lib.current_stream(dev)))
+        return tuple(out)
+
+
+class _AffineFunction(torch.autograd.Function):
+    """The affine coupling of one flow in the training direction (glow.py:240-245) as one HIP kernel each way:
+    (x = [x0 | x1], wn_out = [b | log_s]) -> cat(x0, exp(log_s) * x1 + b)."""
+
+    @staticmethod
+    def forward(ctx, x, wn_out):
+        L = _lib.load()
+        x, wn_out = x.detach().float().contiguous(), wn_out.detach().float().contiguous()
+        y = torch.empty_like(x)
+        B, c, Lg = x.shape
+        with torch.cuda.device(x.device):
+            _lib.check(L.facppg_affine_forward(_lib.ptr(x), _lib.ptr(wn_out), _lib.ptr(y), B, c // 2, Lg, _lib.current_stream(x.device)))
+        ctx.save_for_backward(x, wn_out)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.load()
+        x, wn_out = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        dx, dwn = torch.empty_like(x), torch.empty_like(wn_out)
+        B, c, Lg = x.shape
+        with torch.cuda.device(x.device):
+            _lib.check(L.facppg_affine_backward(_lib.ptr(x), _lib.ptr(wn_out), _lib.ptr(dy), _lib.ptr(dx), _lib.ptr(dwn), B, c // 2, Lg,
+                                                _lib.current_stream(x.device)))
+        return dx, dwn
+
+
 class Invertible1x1Conv(torch.nn.Module):
     """glow.py:62-102: parameter container for the c x c mixing matrix.  In inference the
     inverse matrix is applied inside k_flow_end (fused with the affine coupling)."""
@@ -372,11 +460,21 @@ class WN(torch.nn.Module):
             rs = 2 * n_channels if i < n_layers - 1 else n_channels
             self.res_skip_layers.append(wn(torch.nn.Conv1d(n_channels, rs, 1), name='weight'))
 
-    def _plain_weights(self):
-        ws = [_effective_weight(self.start), self.start.bias]
+    def _weight_convs(self):
+        """The convs in the order of the plain weight list (minus the un-normed end conv)."""
+        convs = [self.start]
         for i in range(self.n_layers):
-            ws += [_effective_weight(self.in_layers[i]), self.in_layers[i].bias, _effective_weight(self.cond_layers[i]),
-                   self.cond_layers[i].bias, _effective_weight(self.res_skip_layers[i]), self.res_skip_layers[i].bias]
+            convs += [self.in_layers[i], self.cond_layers[i], self.res_skip_layers[i]]
+        return convs
+
+    def _plain_weights(self, effective=None):
+        """[start.w, start.b, (in.w, in.b, cond.w, cond.b, res_skip.w, res_skip.b) per layer, end.w, end.b];
+        ``effective``: the convs' weights already de-normalised (WaveGlow batches that over all flows)."""
+        convs = self._weight_convs()
+        eff = effective if effective is not None else [_effective_weight(c) for c in convs]
+        ws = []
+        for conv, w in zip(convs, eff):
+            ws += [w, conv.bias]
         return ws + [self.end.weight, self.end.bias]
 
     def _check_kernel_config(self):
@@ -536,9 +634,10 @@ class WaveGlow(torch.nn.Module):
     # ---------------------------------------------------------------- the hot path
     def _forward_autograd(self, spect, audio):
         """Training forward with a differentiable graph (train_waveglow.py:126-133).  Per flow the WN
-        stack -- >99 % of the work -- is one HIP autograd node (_WNFunction); the flow edges
-        (c <= 8 channels per position: 1x1 mixing conv and its logdet, affine coupling, early
-        split) and the 0.4 %-of-FLOPs upsampling conv stay as torch ops so autograd links them."""
+        stack -- >99 % of the work -- is one HIP autograd node (_WNFunction fp32 / _WNFunctionBf16); the
+        flow edges are HIP nodes too (1x1 mixing conv: _Conv1x1Function, affine coupling: _AffineFunction; in bf16 mode
+        the upsampler as well: _UpsampleBf16Function).  What stays in torch is bookkeeping on <= 8-channel tensors: the
+        early-output slices, the final cat, logdet of the c x c matrices and the weight-norm parametrisation."""
         F = torch.nn.functional
         g = self.n_group
         self._release()                      # the weights are about to be trained: never serve a stale packed copy
@@ -572,6 +671,15 @@ class WaveGlow(torch.nn.Module):
             spect = spect.contiguous().view(spect.size(0), spect.size(1), -1).permute(0, 2, 1)
             spect_pad = F.pad(spect, (0, -(-Lg // _TN) * _TN - Lg)).contiguous()
         audio = audio.unfold(1, g, g).permute(0, 2, 1)
+        # effective weights of all weight-normed convs in one launch (and one more in the backward)
+        convs = [c for wn in self.WN for c in wn._weight_convs()]
+        if all(hasattr(c, "weight_g") for c in convs):
+            vg = [t for c in convs for t in (c.weight_v, c.weight_g)]
+            eff = list(_WeightNormAllFunction.apply(*vg))
+        else:
+            eff = [_effective_weight(c) for c in convs]
+        per = len(eff) // self.n_flows
+        flow_weights = [self.WN[k]._plain_weights(eff[k * per:(k + 1) * per]) for k in range(self.n_flows)]
         output_audio, log_s_list, log_det_W_list = [], [], []
         for k in range(self.n_flows):
             if k % self.n_early_every == 0 and k > 0:
@@ -581,15 +689,13 @@ class WaveGlow(torch.nn.Module):
             log_det_W_list.append(audio.size(0) * audio.size(2) * torch.logdet(W))
             audio = _Conv1x1Function.apply(W.float(), audio.contiguous())        # 1x1 mixing conv (c <= 8 channels), HIP fwd + bwd
             n_half = audio.size(1) // 2
-            audio_0, audio_1 = audio[:, :n_half, :], audio[:, n_half:, :]
+            audio_0 = audio[:, :n_half, :]
             if bf16:
-                output = _WNFunctionBf16.apply(audio_0.contiguous(), link, shared, spect_pm, *self.WN[k]._plain_weights())
+                output = _WNFunctionBf16.apply(audio_0.contiguous(), link, shared, spect_pm, *flow_weights[k])
             else:
-                output = _WNFunction.apply(audio_0.contiguous(), spect_pad, *self.WN[k]._plain_weights())
-            log_s, b = output[:, n_half:, :], output[:, :n_half, :]
-            audio_1 = torch.exp(log_s) * audio_1 + b
-            log_s_list.append(log_s)
-            audio = torch.cat([audio_0, audio_1], 1)
+                output = _WNFunction.apply(audio_0.contiguous(), spect_pad, *flow_weights[k])
+            log_s_list.append(output[:, n_half:, :])
+            audio = _AffineFunction.apply(audio, output)          # cat(audio_0, exp(log_s) * audio_1 + b), HIP fwd + bwd
         output_audio.append(audio)
         return torch.cat(output_audio, 1), log_s_list, log_det_W_list
 

@@ -138,6 +138,22 @@ size_t facppg_conv1x1_wgrad_workspace_bytes(int c);
 int facppg_conv1x1_wgrad(const float* dout_dev, const float* z_dev, float* dw_dev, int B, int c, int L,
                          void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* Replaces torch.nn.utils.weight_norm's per-conv recomputation (glow.py:118-146: w = g * v / ||v|| per output row) for
+ * ALL weight-normed convs of the model in one launch, and its backward in one more.  table_dev: n_tensors entries of
+ * 6 x 8 bytes {const float* v; const float* g; float* w; float* norm; int64 row0; int32 rows; int32 len} -- row0 = first
+ * global row of the tensor (prefix sum of rows), len = elements per row; forward writes w and norm [rows].
+ * Backward: same table with w := dw (read), norm (read); out_table_dev entries' v := dv, g := dg (written). */
+int facppg_weight_norm_forward(const void* table_dev, int n_tensors, long total_rows, void* stream);
+int facppg_weight_norm_backward(const void* table_dev, const void* out_table_dev, int n_tensors,
+                                long total_rows, void* stream);
+
+/* Replaces the affine coupling of WaveGlow.forward (glow.py:240-245): x = [x0 | x1] and wn_out = [b | log_s], all
+ * [B][2h][L] fp32 -> y = cat(x0, exp(log_s) * x1 + b); and its backward: dx = [dy0 | dy1 exp(log_s)],
+ * dwn_out = [dy1 | dy1 exp(log_s) x1] (the loss's own -sum(log_s) term reaches log_s through autograd separately). */
+int facppg_affine_forward(const float* x_dev, const float* wn_out_dev, float* y_dev, int B, int h, int L, void* stream);
+int facppg_affine_backward(const float* x_dev, const float* wn_out_dev, const float* dy_dev, float* dx_dev,
+                           float* dwn_out_dev, int B, int h, int L, void* stream);
+
 /* ---- WN training primitives (one flow's WN stack; WaveGlow training step, glow.py:154-175 +
  * its autograd backward).  Plain (un-packed, weight-norm already applied) device weights: */
 typedef struct facppg_wn_weights {
