@@ -194,15 +194,17 @@ __device__ __forceinline__ void bgemm_store4(const BGemmArgs& p, int b, int n, i
   }
 }
 
-// NCB = 32-column blocks per tile: 4 (128 columns) for large products, 2 (64 columns: twice the workgroups, half
-// the LDS and accumulators each) when the launch would otherwise leave the chip with < ~3 workgroups per CU.
-// Measured (B = 12, gate GEMM): removing the activation loads alone cuts the kernel from 81 to 30 us -- a 64-deep chunk
-// is only 8-16 MFMAs (a few hundred cycles) per wave, far less than a memory round trip, so the operands are staged
-// PD = 4 chunks ahead in a register ring (statically indexed: the chunk loop is unrolled by PD), and workgroups that
-// share a column tile (the M tiles) are dealt to the SAME XCD back to back so three of the four find the tile in L2.
+// NCB = 32-column blocks per tile: 4 (128 columns) once that gives >= 1.5 workgroups per CU, else 2 (64 columns: twice
+// the workgroups, half the LDS and accumulators each).  The operands of chunk c+PD-1 (weights) / c+PD (activations) are
+// requested before the MFMAs of chunk c and held in a statically indexed register ring (the chunk loop is unrolled by PD);
+// workgroups that share a column tile (the M tiles) are dealt to the SAME XCD back to back, so all but the first find
+// the activation tile in that XCD's L2.
 // Measured (rocprofv3, B = 12, gate GEMM 21.6 GFLOP): non-temporal loads for the ACTIVATION operand (streamed once per
 // workgroup) 66 -> 41 us -- they stop evicting the weight images, which every workgroup re-reads, from L1/L2; non-temporal
-// WEIGHT loads are slower (76 us); staging further ahead than one chunk is slower too (PD 1 / 2 / 3 / 4: 68 / 82 / 86 / 91 us).
+// WEIGHT loads are slower (76 us).  With them: PD 1 / 2 = 41.6 / 40.9 us (gate), 29.1 / 26.6 us (transposed conv); the XCD-aware
+// order 48 -> 41.6 us; before them deeper staging only made things worse (PD 1 / 2 / 3 / 4: 68 / 82 / 86 / 91 us) -- more
+// streaming lines in flight evicted more weights.  k_wgrad's operands are re-read by neighbouring tiles: non-temporal loads
+// there cost 10 % (230 vs 209 us), so it keeps plain loads.
 #ifndef FACPPG_BG_NT
 #define FACPPG_BG_NT 1
 #endif
@@ -210,7 +212,7 @@ __device__ __forceinline__ void bgemm_store4(const BGemmArgs& p, int b, int n, i
 #define FACPPG_WG_NT 0
 #endif
 #ifndef FACPPG_BG_PD
-#define FACPPG_BG_PD 1
+#define FACPPG_BG_PD 2
 #endif
 #ifndef FACPPG_BG_XCD
 #define FACPPG_BG_XCD 1

@@ -65,6 +65,9 @@ constexpr int MAXF = 32;      // max flows
 #define FACPPG_COST16_FULL 105   // microseconds per round of 16-frame tiles: full round / at most one workgroup per CU
 #define FACPPG_COST16_HALF 57
 #endif
+#ifndef FACPPG_WN_NT
+#define FACPPG_WN_NT 0   // bit 0: activation staging loads, bit 1: epilogue stores, bit 2: epilogue loads -- non-temporal
+#endif
 #ifndef FACPPG_NARROW_RING
 #define FACPPG_NARROW_RING 8  // weight prefetch depth (k-groups) of the 32-column tiles, see k_wn_layer
 #endif
@@ -436,7 +439,11 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
       }
 #pragma unroll
       for (int jj = 0; jj < NSTG4; ++jj) {
+#if FACPPG_WN_NT & 1
+        const f4u v = __builtin_nontemporal_load(reinterpret_cast<const f4u*>(base + off[jj]));
+#else
         const f4u v = *reinterpret_cast<const f4u*>(base + off[jj]);
+#endif
         stg[4 * jj + 0] = v.x; stg[4 * jj + 1] = v.y; stg[4 * jj + 2] = v.z; stg[4 * jj + 3] = v.w;
       }
     } else {
@@ -692,10 +699,18 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
         float4 v = *reinterpret_cast<const float4*>(slab + row * TNt + scol4);
         if (nv >= 4) {
           if (add) {
+#if FACPPG_WN_NT & 4
+            const f32x4 x = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rbase + o));
+#else
             const float4 x = *reinterpret_cast<const float4*>(rbase + o);
+#endif
             v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
           }
+#if FACPPG_WN_NT & 2
+          __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(gbase + o));
+#else
           *reinterpret_cast<float4*>(gbase + o) = v;
+#endif
         } else {
           const float vv[4] = {v.x, v.y, v.z, v.w};
           for (int k = 0; k < nv; ++k) gbase[o + k] = vv[k] + (add ? rbase[o + k] : 0.0f);
@@ -1364,6 +1379,99 @@ __global__ __launch_bounds__(256) void k_flow_end(EdgeArgs p) {
 }
 
 
+// k_flow_end4: the throughput shape of k_flow_end on the phase-major layout -- FOUR consecutive frames of one phase
+// per thread, so the 256 skip rows are read and the 256 start-conv rows written as 16-byte accesses (a wave covers
+// 1 KiB of a row per instruction instead of 256 B) and four independent FMA chains run per thread.  The arithmetic per
+// position is exactly k_flow_end's (four 64-channel chains in channel order, then bias + q0 + q1 + q2 + q3; the same
+// fmaf sequences for the 1x1 products), so an utterance gets the same bits from either kernel.
+template <int H, bool EARLY>
+__global__ __launch_bounds__(256) void k_flow_end4(EdgeArgs p) {
+  constexpr int CC = 2 * H, CN = EARLY ? CC + 2 : CC, HN = CN / 2;
+  const int b = blockIdx.y, ph = blockIdx.z, x0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+  const int Tb = p.t_valid ? p.t_valid[b] : p.T;
+  if (x0 >= Tb) return;
+  const int nv = min(4, Tb - x0);                       // live frames among this thread's four
+  const int h_off = ph * p.Tqp + HQ + x0, sk_off = ph * p.Tr + x0;
+  const float* sk = p.skip + (size_t)b * C * p.Lr + sk_off;
+  float o[4][CC];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int j = 0; j < CC; ++j) o[e][j] = p.end_b[j];
+  for (int q = 0; q < 4; ++q) {
+    float acc[4][CC];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int j = 0; j < CC; ++j) acc[e][j] = 0.0f;
+    for (int c0 = q * 64; c0 < q * 64 + 64; c0 += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(sk + (size_t)(c0 + u) * p.Lr);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int j = 0; j < CC; ++j) {
+          const float wv = p.end_w[j * C + c0 + u];
+          acc[0][j] = fmaf(wv, v[u].x, acc[0][j]); acc[1][j] = fmaf(wv, v[u].y, acc[1][j]);
+          acc[2][j] = fmaf(wv, v[u].z, acc[2][j]); acc[3][j] = fmaf(wv, v[u].w, acc[3][j]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int j = 0; j < CC; ++j) o[e][j] += acc[e][j];
+  }
+  float y[4][CN];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int pos = (x0 + (e < nv ? e : 0)) * p.P + ph;   // dead frames recompute frame 0 (never stored)
+    float a[CC];
+#pragma unroll
+    for (int j = 0; j < CC; ++j) a[j] = p.aud_in[((size_t)b * 8 + j) * p.La + pos];
+    const int tr = p.swap ? 0 : H;
+#pragma unroll
+    for (int j = 0; j < H; ++j) a[tr + j] = (a[tr + j] - o[e][j]) / expf(o[e][H + j]);
+    if (EARLY) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) y[e][j] = p.sigma * p.z_early[((size_t)b * 2 + j) * p.L + pos];
+    }
+#pragma unroll
+    for (int i = 0; i < CC; ++i) {
+      float v = 0.0f;
+#pragma unroll
+      for (int j = 0; j < CC; ++j) v = fmaf(p.winv[i * CC + j], a[j], v);
+      y[e][(EARLY ? 2 : 0) + i] = v;
+    }
+    if (e < nv) {
+      if (p.final_flow) {
+        float* dst = p.final_audio + (size_t)b * p.T * p.hop8 * 8 + (size_t)pos * CN;
+#pragma unroll
+        for (int j = 0; j < CN; ++j) dst[j] = y[e][j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < CN; ++j) p.aud_out[((size_t)b * 8 + j) * p.La + pos] = y[e][j];
+      }
+    }
+  }
+  if (p.final_flow) return;
+  // next flow's start conv, four frames per row store
+  const int a0 = p.swap_next ? HN : 0;
+  float* dst = p.h_out + (size_t)b * C * p.Lp + h_off;
+  for (int ch = 0; ch < C; ++ch) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = p.start_b[ch];
+#pragma unroll
+      for (int j = 0; j < HN; ++j) v[e] = fmaf(p.start_w[ch * HN + j], y[e][a0 + j], v[e]);
+    }
+    float* d = dst + (size_t)ch * p.Lp;
+    if (nv == 4) *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+    else for (int e = 0; e < nv; ++e) d[e] = v[e];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Training direction (WaveGlow.forward, glow.py:208-250): audio -> z.  The WN stacks are the same
 // k_wn_layer launches; only the flow edges differ:
@@ -1763,6 +1871,13 @@ extern "C" int facppg_wg_last_layer_ms(facppg_wg* h, float* avg_ms, int* n_launc
 
 template <int H>
 static void launch_flow_end(bool early, bool qs, dim3 grid, hipStream_t s, const EdgeArgs& a) {
+  const char* no4 = getenv("FACPPG_FLOW_END_NO4");   // (read per call: the tests flip it)
+  if (!qs && a.P > 0 && !no4) {   // phase-major, large launch: four frames per thread
+    const dim3 g4((a.T + 1023) / 1024, grid.y, grid.z);
+    if (early) k_flow_end4<H, true><<<g4, 256, 0, s>>>(a);
+    else k_flow_end4<H, false><<<g4, 256, 0, s>>>(a);
+    return;
+  }
   if (qs) {
     if (early) k_flow_end<H, true, true><<<grid, 256, 0, s>>>(a);
     else k_flow_end<H, false, true><<<grid, 256, 0, s>>>(a);

@@ -217,6 +217,23 @@ def test_legacy_glow_old_layout_and_convert_model():
     assert rms((a1 - a2).cpu().numpy()) <= 1e-5
 
 
+@pytest.mark.parametrize("hop,B,T,lengths", [(256, 5, 420, None), (160, 4, 850, [850, 3, 417, 702])])
+def test_flow_end_four_frames_per_thread_same_bits(hop, B, T, lengths, monkeypatch):
+    """k_flow_end4 (16-byte row accesses, four frames per thread; picked for launches of >= 65 536 positions) must give
+    the bits of the one-position-per-thread kernel: same fmaf chains per position.  Ragged lengths exercise its tail
+    stores (frames past an utterance's end must stay untouched: they are the next layer's zero padding)."""
+    m, cfg, sd = build(hop)
+    assert B * T * (hop // 8) >= 65536
+    mel = synth.synthetic_mel(B, T, seed=3).cuda()
+    a4 = m.infer(mel, sigma=0.6, seed=11, lengths=lengths)
+    monkeypatch.setenv("FACPPG_FLOW_END_NO4", "1")
+    a1 = m.infer(mel, sigma=0.6, seed=11, lengths=lengths)
+    assert torch.equal(a4, a1)
+    if lengths:
+        one = m.infer(mel[1:2, :, :3].contiguous(), sigma=0.6, z=None, seed=11)          # smoke: a 3-frame utterance alone runs
+        assert one.shape == (1, 3 * hop)
+
+
 @pytest.mark.parametrize("env", ["FACPPG_WG_UNFOLDED=1", "FACPPG_WN_8W=0", "FACPPG_WN_NO_XCD_MAP=1", "FACPPG_WN_NO_FLAT=1", "FACPPG_WN_TILE16=2",
                                  "FACPPG_WN_TILE16=0"])
 def test_alternate_kernel_paths_match_golden(env):
