@@ -80,6 +80,31 @@ def test_device_noise_is_standard_normal_and_seeded(model160):
     assert torch.equal(m.infer(mel, sigma=0.0, seed=5), m.infer(mel, sigma=0.0, z=z0))
 
 
+def test_full_size_properties_hop256_benched_shape():
+    """The shape bench.py times (BASELINE configs[1] at the metric's rate): B = 8, mel 80 x 1000, hop 256 -> 256 000
+    group positions per launch, 32 phases, 4 000 tiles.  Properties only (the oracle would need minutes): determinism,
+    finiteness, exact output length, noise linearity (sigma = 0 removes every z term: audio = f(mel) alone), batch
+    independence (utterance 5 alone gives the bits it has inside the batch), and per-utterance lengths cutting exactly."""
+    m, cfg = make_model(256)
+    B, T = 8, 1000
+    mel = synth.synthetic_mel(B, T, seed=1234).cuda()
+    a = m.infer(mel, sigma=0.6, seed=5)
+    assert a.shape == (B, T * 256) and torch.isfinite(a).all() and float(a.abs().max()) < 1e3
+    assert torch.equal(a, m.infer(mel, sigma=0.6, seed=5)) and not torch.equal(a, m.infer(mel, sigma=0.6, seed=6))
+    zs = synth.synthetic_z(B, T * 32, cfg, seed=3)
+    full = m.infer(mel, sigma=0.6, z=zs)
+    one = m.infer(mel[5:6].contiguous(), sigma=0.6, z=[z[5:6].contiguous() for z in zs])
+    assert torch.equal(one[0], full[5])
+    a0 = m.infer(mel, sigma=0.0, z=zs)
+    assert torch.equal(a0, m.infer(mel, sigma=0.0, seed=123))                    # sigma = 0: the noise cannot matter
+    lens = [1000, 1, 999, 64, 65, 512, 777, 1000]
+    rag = m.infer(mel, sigma=0.6, z=zs, lengths=lens)
+    for b, n in enumerate(lens):
+        assert torch.equal(rag[b, :n * 256], m.infer(mel[b:b + 1, :, :n].contiguous(), sigma=0.6,
+                                                     z=[z[b:b + 1, :, :n * 32].contiguous() for z in zs])[0])
+        assert torch.count_nonzero(rag[b, n * 256:]) == 0
+
+
 def test_full_size_properties():
     """BASELINE config 2 shape (B=8, 80x1000): size-independent properties -- determinism, batch
     independence (item b of the batch == its own batch-1 run, bit-exact), finite output, and a
@@ -222,7 +247,7 @@ def test_flow_end_four_frames_per_thread_same_bits(hop, B, T, lengths, monkeypat
     """k_flow_end4 (16-byte row accesses, four frames per thread; picked for launches of >= 65 536 positions) must give
     the bits of the one-position-per-thread kernel: same fmaf chains per position.  Ragged lengths exercise its tail
     stores (frames past an utterance's end must stay untouched: they are the next layer's zero padding)."""
-    m, cfg, sd = build(hop)
+    m, cfg = make_model(hop)
     assert B * T * (hop // 8) >= 65536
     mel = synth.synthetic_mel(B, T, seed=3).cuda()
     a4 = m.infer(mel, sigma=0.6, seed=11, lengths=lengths)
