@@ -108,6 +108,64 @@ def end_to_end(log):
         return None
 
 
+def train_step(log):
+    """BASELINE configs[4]'s step (WaveGlow fwd + loss + bwd + Adam, segment 10 000, bf16 MFMA operands) on ONE GPU at the
+    reference's per-GPU batch 3 and at 12, in a child process; secondary figure.  Returns None if the child fails."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--train-worker"], capture_output=True, text=True, timeout=600)
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        for k, v in out.items():
+            log("training step %s: %.1f ms" % (k, v["ms_per_step"]))
+        return out
+    except Exception as e:   # noqa: BLE001
+        log("training-step measurement failed: %r" % (e,))
+        return None
+
+
+def train_worker():
+    import numpy as np
+    from common.layers import TacotronSTFT
+    from facppg import synth
+    from waveglow.glow import WaveGlow, WaveGlowLoss
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    cfg = dict(synth.WAVEGLOW_CONFIG)                      # the reference's training config: hop 160, 16 kHz (config.json)
+    m = WaveGlow(**cfg).to(dev).train()
+    with torch.no_grad():
+        for wn in m.WN:
+            wn.end.weight.normal_(0, 0.02)
+    stft = TacotronSTFT(1024, 160, 1024, 80, 16000, 0.0, 8000.0).to(dev)
+    crit = WaveGlowLoss(0.7071)
+    out = {}
+    for prec, B in (("bf16", 3), ("bf16", 12), ("fp32", 3)):
+        m.train_precision = prec
+        opt = torch.optim.Adam(m.parameters(), lr=1e-5, fused=True)
+        g = np.random.Generator(np.random.PCG64(1))
+        audio = torch.from_numpy(np.clip(g.standard_normal((B, 10000), dtype=np.float32) * 0.1, -1, 1)).to(dev)
+        with torch.no_grad():
+            mel = stft.mel_spectrogram(audio)
+        ts = []
+        for i in range(6):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            m.zero_grad()
+            loss = crit(m((mel, audio)))
+            loss.backward()
+            opt.step()
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t0)
+        t = sorted(ts[1:])[len(ts[1:]) // 2]
+        flops = 3 * 20.26e6 * B * 10000                      # SURVEY.md 8d: fwd 20.3 MFLOP/sample, fwd + bwd ~ 3x
+        peak = 2500.0 if prec == "bf16" else PEAK_F32_MFMA_TFLOPS
+        out["%s_B%d" % (prec, B)] = {
+            "workload": "WaveGlow training step (fwd + WaveGlowLoss + bwd + fused Adam), segment 10000 @16 kHz / hop 160, per-GPU batch %d, "
+                        "%s MFMA operands, fp32 accumulation / master weights / gradients, 1 GPU" % (B, prec),
+            "ms_per_step": t * 1e3, "samples_per_s": B * 10000 / t, "tflops": flops / t / 1e12,
+            "frac_of_mfma_peak": flops / t / 1e12 / peak, "mfma_peak_tflops": peak, "loss_finite": bool(torch.isfinite(loss))}
+    print(json.dumps(out))
+
+
 def stage_rooflines(stages, frames_in, frames_out, batch, hop):
     """Per-stage achieved rates next to the roofline that bounds each (SURVEY.md 8d per-unit figures): the MFMA
     stages in TFLOP/s of the fp32 MFMA peak, the streaming denoiser in GB/s of HBM peak, the autoregressive decoder as
@@ -284,11 +342,15 @@ def main():
     ap.add_argument("--cpu-baseline-worker", nargs=2, type=int, metavar=("THREADS", "FRAMES"), help=argparse.SUPPRESS)
     ap.add_argument("--e2e-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--train-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(*args.cpu_baseline_worker)
     if args.e2e_worker:
         return e2e_worker()
+    if args.train_worker:
+        return train_worker()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus, sys.argv[1:])
     if args.launch_check:
@@ -398,6 +460,10 @@ def main():
         out["end_to_end_batch1"] = e2e.get("batch1")
         out["end_to_end_batch16_ragged"] = e2e.get("batch16_ragged")
         out["reference_rate_config"] = reference_rate_config(dev, mel, log)
+    if rank == 0 and world == 1 and not args.no_train:
+        del model
+        torch.cuda.empty_cache()
+        out["train_step"] = train_step(log)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(log)
     if rank == 0:

@@ -3,7 +3,7 @@
 # (PMC passes are separate runs with --kernel-trace only, as the pool requires.)
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/prof_txt; mkdir -p $O; W=/tmp/facppg_prof; rm -rf $W; mkdir -p $W
-B="python bench.py --no-cpu-baseline --no-e2e"
+B="python bench.py --no-cpu-baseline --no-e2e --no-train"
 timeout 300 rocprofv3 --kernel-trace --stats -d $W/stats -o r -- $B --steps 3 --warmup 1 > $W/stats.log 2>&1; echo "stats rc=$?"
 python tools/rocpd_summary.py stats $W/stats/r_results.db | cut -c1-190 > $O/kernel_stats.txt
 for c in FETCH_SIZE WRITE_SIZE; do

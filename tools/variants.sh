@@ -4,7 +4,7 @@ IFS='|' read -ra VARS <<< "${VARIANTS:-|-DFACPPG_WN_SETPRIO}"
 for v in "${VARS[@]}"; do
   make -s -C fac-via-ppg_amd/csrc clean >/dev/null; make -s -j8 -C fac-via-ppg_amd/csrc EXTRA="$v" 2>/dev/null >/dev/null
   for rep in 1 2; do
-  timeout 200 python bench.py --no-cpu-baseline --no-e2e --steps 3 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('variant [$v] env narrow=${FACPPG_WN_FORCE_NARROW:-0}', 'layer_ms', round(d['roofline']['avg_launch_ms'],3), 'frac', round(d['roofline']['frac'],4), 'ms/step', round(d['ms_per_step'],1))"
+  timeout 200 python bench.py --no-cpu-baseline --no-e2e --no-train --steps 3 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('variant [$v] env narrow=${FACPPG_WN_FORCE_NARROW:-0}', 'layer_ms', round(d['roofline']['avg_launch_ms'],3), 'frac', round(d['roofline']['frac'],4), 'ms/step', round(d['ms_per_step'],1))"
   done
 done
 make -s -C fac-via-ppg_amd/csrc clean >/dev/null; make -s -j8 -C fac-via-ppg_amd/csrc 2>/dev/null >/dev/null
