@@ -1,9 +1,9 @@
 """``get_ppg`` hook of the reference's src/common/data_utils.py:55-59.
 
-The reference computes the PPG of a wav with PyKaldi; that front-end is upstream of the hot path
-and out of scope here.  This build reads a precomputed PPG ([Tin, n_symbols] float array, 10 ms
-frame shift, rows = posteriors): either the given path itself is a ``.npy`` file or a sibling
-``<wav>.ppg.npy`` exists next to the wav.
+The reference computes the PPG of a wav with PyKaldi: features (ppg.compute_feat_for_nnet, built here on HIP kernels) ->
+nnet3 acoustic model (data/am/final.raw, a blob the reference does not ship, and an nnet3 runtime) -> posteriors.  Without
+the model this build reads a precomputed PPG ([Tin, n_symbols] float array, 10 ms frame shift, rows = posteriors): either the
+given path itself is a ``.npy`` file or a sibling ``<wav>.ppg.npy`` exists next to the wav.
 """
 import os
 
@@ -26,5 +26,5 @@ def get_ppg(wav_path, deps=None, is_fmllr=False):
                 raise ValueError("PPG file %s must hold a [Tin, n_symbols] array, got shape %s" % (c, ppg.shape))
             return ppg.astype(np.float32)
     raise NotImplementedError(
-        "PPG extraction from audio (Kaldi nnet3 acoustic model) is upstream of the synthesis hot path and not part "
-        "of this build; provide a precomputed PPG as %s" % " or ".join(candidates))
+        "PPG extraction from audio needs the Kaldi nnet3 acoustic model (data/am/final.raw), which the reference does not ship; "
+        "provide a precomputed PPG as %s (the model's input features are available: ppg.compute_feat_for_nnet)" % " or ".join(candidates))

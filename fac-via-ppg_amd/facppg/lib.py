@@ -108,6 +108,15 @@ def _declare(lib):
         "facppg_taco_draw_dropout": (c.c_int, [vp, vp, c.c_int, c.c_int, c.c_int, vp, vp, vp]),
         "facppg_wg_draw_noise": (c.c_int, [vp, vp, c.c_int, c.c_int, vp, vp]),
         "facppg_taco_postnet": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, c.c_int, vp, vp, sz, vp]),
+        "facppg_mfcc_create": (c.c_int, [c.c_int, c.c_int, c.c_int, vp, vp, c.c_int, vp, c.c_int, c.c_int, vp, c.POINTER(vp)]),
+        "facppg_mfcc_destroy": (None, [vp]),
+        "facppg_mfcc_num_frames": (c.c_int, [vp, c.c_int]),
+        "facppg_mfcc_workspace_bytes": (sz, [vp, c.c_int]),
+        "facppg_mfcc_compute": (c.c_int, [vp, vp, c.c_int, c.c_int, vp, vp, sz, vp]),
+        "facppg_cmn_splice_transform": (c.c_int, [vp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, vp, c.c_int, c.c_int, vp, vp, vp]),
+        "facppg_resample_num_samples": (c.c_int, [c.c_int, c.c_int, c.c_int]),
+        "facppg_resample": (c.c_int, [vp, c.c_int, c.c_int, c.c_int, vp, vp]),
+        "facppg_reduce_ppg": (c.c_int, [vp, vp, c.c_int, c.c_int, c.c_int, vp, vp]),
         "facppg_attention_window_mask": (c.c_int, [vp, c.c_int, c.c_int, c.c_int, c.c_int, vp, vp]),
     }
     for name, (res, args) in sigs.items():

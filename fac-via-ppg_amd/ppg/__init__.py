@@ -1,14 +1,4 @@
-"""Placeholder for the reference's ``ppg`` package (src/ppg/compute_ppg.py).
-
-PPG extraction (Kaldi MFCC -> LDA -> nnet3 acoustic model, needs pykaldi and the missing
-data/am/final.raw blob) sits UPSTREAM of the synthesis hot path and is out of scope for this
-build.  ``DependenciesPPG`` exists so the CLI surface of
-generate_synthesis.py:86 is preserved; PPGs are read from precomputed ``.npy`` files instead
-(see common.data_utils.get_ppg)."""
-
-
-class DependenciesPPG(object):
-    """Stand-in for compute_ppg.DependenciesPPG (compute_ppg.py:205-256): holds nothing."""
-
-    def __init__(self, *args, **kwargs):
-        self.precomputed_only = True
+"""The reference's ``ppg`` package (src/ppg): see compute_ppg.py for what is built (everything around the acoustic
+model, whose nnet3 blob the reference does not ship)."""
+from ppg.compute_ppg import (DependenciesPPG, compute_feat_for_nnet, compute_feat_for_nnet_internal, compute_full_ppg,  # noqa: F401
+                             reduce_ppg_dim)

@@ -366,6 +366,42 @@ int facppg_taco_postnet(facppg_taco* h, const float* mel_dev, const int32_t* out
                         int B, int T, int ld, float* mel_post_dev, void* workspace_dev,
                         size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * PPG front-end, the part that needs no acoustic-model blob (src/ppg/compute_ppg.py, src/common/feat.py; the Kaldi
+ * feature code behind pykaldi): the nnet3 input features and the senone -> monophone reduction.
+ * ---------------------------------------------------------------------------------- */
+typedef struct facppg_mfcc facppg_mfcc;
+/* Replaces kaldi.feat.mfcc.Mfcc(opts) (feat.py:74-100).  The caller folds Kaldi's per-frame linear steps (DC removal,
+ * pre-emphasis, window, zero padding, DFT) into basis_dev [2*nbins][frame_length] (real rows, then imaginary rows) and
+ * supplies the mel bank mel_dev [n_mel][nbins] and the liftered DCT dct_dev [n_ceps][n_mel].  Synchronises `stream`. */
+int facppg_mfcc_create(int frame_length, int frame_shift, int nbins, const float* basis_dev,
+                       const float* mel_dev, int n_mel, const float* dct_dev, int n_ceps, int device,
+                       void* stream, facppg_mfcc** out);
+void facppg_mfcc_destroy(facppg_mfcc* h);
+int facppg_mfcc_num_frames(const facppg_mfcc* h, int n_samples);   /* (n + shift/2) / shift: snip_edges = false */
+size_t facppg_mfcc_workspace_bytes(const facppg_mfcc* h, int n_samples);
+/* Replaces Mfcc.compute_features (feat.py:98): wav_dev [n_samples] (int16-range floats) -> mfcc_dev [T][n_ceps];
+ * frames are cut with Kaldi's snip_edges=false reflection; dither is not applied (deterministic); use_energy != 0
+ * puts the log frame energy in coefficient 0. */
+int facppg_mfcc_compute(facppg_mfcc* h, const float* wav_dev, int n_samples, int use_energy,
+                        float* mfcc_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+/* Replaces Kaldi's DownsampleWaveForm / LinearResample (what frame_opts.allow_downsample = True triggers for inputs above
+ * 16 kHz, feat.py:85-87): windowed-sinc low-pass at 0.99 * min(fs) / 2, 6 zero crossings.  out_dev holds
+ * facppg_resample_num_samples(n_in, fs_in, fs_out) samples. */
+int facppg_resample_num_samples(int n_in, int fs_in, int fs_out);
+int facppg_resample(const float* wav_dev, int n_in, int fs_in, int fs_out, float* out_dev, void* stream);
+/* Replaces apply_cepstral_mean_norm (feat.py:103-118), kaldi.feat.functions.splice_frames(left, right) (edge frames
+ * replicated) and apply_feat_transform (feat.py:121-156) in one pass: feats_dev [T][D] -> out_dev [T][M] with
+ * transform_dev [M][cols], cols = (left+right+1)*D or one more (affine offset column); transform_dev NULL -> the spliced
+ * (and, with do_cmn, mean-normalised) features [T][(left+right+1)*D].  mean_ws_dev: D floats of scratch. */
+int facppg_cmn_splice_transform(const float* feats_dev, int T, int D, int do_cmn, int left, int right,
+                                const float* transform_dev, int M, int cols, float* out_dev,
+                                float* mean_ws_dev, void* stream);
+/* Replaces reduce_ppg_dim (compute_ppg.py:73-94): out[t][m] = sum_k ppg[t][k] * transform_t[k][m]
+ * (transform_t = the densified pdf -> monophone matrix, TRANSPOSED: [K][M], M <= 64). */
+int facppg_reduce_ppg(const float* ppg_dev, const float* transform_t_dev, int T, int K, int M,
+                      float* out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

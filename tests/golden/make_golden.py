@@ -356,6 +356,18 @@ def gen_e2e():
          audio=ac_wav, ac_wav=out)
 
 
+def gen_kaldi_data():
+    """The front-end's DATA files as the reference ships them (data/feats: LDA matrix, pdf -> monophone reduction, splice
+    options; its own tests read the same files through test/data symlinks, test_feat.py:74-87, test_ppg.py:25-27)."""
+    import shutil
+    dst = os.path.join(HERE, "kaldi_feats")
+    os.makedirs(dst, exist_ok=True)
+    for name in ("final.mat", "reduce_dim.mat", "splice_opts"):
+        shutil.copyfile(os.path.join(os.path.dirname(REF), "data", "feats", name), os.path.join(dst, name))
+        os.chmod(os.path.join(dst, name), 0o644)
+    print("copied data/feats ->", dst)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -368,6 +380,7 @@ def main():
     gen_waveglow_train()
     gen_tacotron()
     gen_e2e()
+    gen_kaldi_data()
 
 
 if __name__ == "__main__":
