@@ -52,13 +52,18 @@ def train_step(model, criterion, optimizer, mel, audio, num_gpus=1):
 
 
 def train(num_gpus, rank, group_name, output_directory, epochs, learning_rate, sigma, iters_per_checkpoint, batch_size, seed,
-          checkpoint_path, data_config, dist_config, waveglow_config, max_iterations=None):
+          checkpoint_path, data_config, dist_config, waveglow_config, max_iterations=None, train_precision=None):
+    """train_waveglow.py:66-147.  ``train_precision`` (optional key of the config's train section): 'fp32' (default, the
+    reference's arithmetic) or 'bf16' (bf16 MFMA operands, fp32 accumulation / master weights / gradients); the
+    FACPPG_TRAIN_PRECISION environment variable sets the default."""
     torch.manual_seed(seed)
     torch.cuda.manual_seed(seed)
     if num_gpus > 1:
         init_distributed(rank, num_gpus, group_name, **dist_config)
     criterion = WaveGlowLoss(sigma)
     model = WaveGlow(**waveglow_config).cuda()
+    if train_precision is not None:
+        model.train_precision = train_precision
     if num_gpus > 1:
         model = apply_gradient_allreduce(model)
     optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate, fused=True)   # one multi-tensor kernel per state, not 938 x 4

@@ -33,62 +33,74 @@ def load_wav_to_torch(full_path):
 
 
 class Mel2Samp(torch.utils.data.Dataset):
-    """mel2samp.py:60-113"""
+    """Dataset of fixed-length training segments (mel2samp.py:60-113): item = (mel [n_mel, seg//hop + 1], audio [seg] in
+    [-1, 1]) or, with ``audio_only``, just the audio (script.train_waveglow then computes the mels of a whole batch on the
+    GPU).  Contract kept from the reference: file order = ``random.seed(1234)`` shuffle of the list, one
+    ``random.randint`` draw per long file for the crop start, zero padding of short files, int16 wavs scaled by 1/32768."""
 
     def __init__(self, training_files, segment_length, filter_length, hop_length, win_length, sampling_rate, mel_fmin,
                  mel_fmax, audio_only=False):
         self.audio_files = files_to_list(training_files)
         random.seed(1234)
         random.shuffle(self.audio_files)
+        self.segment_length, self.sampling_rate, self.audio_only = segment_length, sampling_rate, audio_only
         self.stft = TacotronSTFT(filter_length=filter_length, hop_length=hop_length, win_length=win_length,
                                  sampling_rate=sampling_rate, mel_fmin=mel_fmin, mel_fmax=mel_fmax)
-        self.segment_length = segment_length
-        self.sampling_rate = sampling_rate
-        self.audio_only = audio_only      # items are audio segments; the trainer calls mel_batch on the GPU
         self.wav_cache = {}
 
+    def __len__(self):
+        return len(self.audio_files)
+
+    # ---- mel analysis on the GPU STFT kernels
     def mel_batch(self, audio_norm):
         """audio_norm [B, N] in [-1, 1] on the GPU -> mel [B, n_mel, N//hop + 1] (one fused pass)."""
         return self.stft.mel_spectrogram(audio_norm)
 
     def get_mel(self, audio):
         """int16-range audio [N] -> mel [n_mel, N//hop + 1]  (mel2samp.py:79-85)."""
-        audio_norm = (audio / MAX_WAV_VALUE).unsqueeze(0).cuda()
-        return torch.squeeze(self.mel_batch(audio_norm), 0)
+        return self.mel_batch((audio / MAX_WAV_VALUE)[None].cuda())[0]
+
+    # ---- segments
+    def _samples(self, index):
+        """The whole file as int16-range floats (cached), checked against the configured rate."""
+        path = self.audio_files[index]
+        hit = self.wav_cache.get(path)
+        if hit is None:
+            hit = self.wav_cache[path] = load_wav_to_torch(path)
+        samples, rate = hit
+        if rate != self.sampling_rate:
+            raise ValueError("{} SR doesn't match target {} SR".format(rate, self.sampling_rate))
+        return samples
+
+    def _segment(self, samples):
+        """Random crop of long files, right zero padding of short ones."""
+        spare = samples.size(0) - self.segment_length
+        if spare < 0:
+            return torch.nn.functional.pad(samples, (0, -spare))
+        first = random.randint(0, spare)
+        return samples[first:first + self.segment_length]
 
     def __getitem__(self, index):
-        filename = self.audio_files[index]
-        if filename not in self.wav_cache:
-            self.wav_cache[filename] = load_wav_to_torch(filename)
-        audio, sampling_rate = self.wav_cache[filename]
-        if sampling_rate != self.sampling_rate:
-            raise ValueError("{} SR doesn't match target {} SR".format(sampling_rate, self.sampling_rate))
-        if audio.size(0) >= self.segment_length:
-            start = random.randint(0, audio.size(0) - self.segment_length)
-            audio = audio[start:start + self.segment_length]
-        else:
-            audio = torch.nn.functional.pad(audio, (0, self.segment_length - audio.size(0)), 'constant').data
-        if self.audio_only:
-            return audio / MAX_WAV_VALUE
-        mel = self.get_mel(audio).cpu()
-        return (mel, audio / MAX_WAV_VALUE)
-
-    def __len__(self):
-        return len(self.audio_files)
+        segment = self._segment(self._samples(index))
+        audio = segment / MAX_WAV_VALUE
+        return audio if self.audio_only else (self.get_mel(segment).cpu(), audio)
 
 
-if __name__ == "__main__":     # directory of clean audio -> directory of mel .pt files (mel2samp.py:115-147)
-    parser = argparse.ArgumentParser()
-    parser.add_argument('-f', "--filelist_path", required=True)
-    parser.add_argument('-c', '--config', type=str, help='JSON file for configuration')
-    parser.add_argument('-o', '--output_dir', type=str, help='Output directory')
-    args = parser.parse_args()
-    with open(args.config) as f:
-        data_config = json.load(f)["data_config"]
-    mel2samp = Mel2Samp(**data_config)
-    os.makedirs(args.output_dir, exist_ok=True)
-    for filepath in files_to_list(args.filelist_path):
-        audio, sr = load_wav_to_torch(filepath)
-        new_filepath = args.output_dir + '/' + os.path.basename(filepath) + '.pt'
-        print(new_filepath)
-        torch.save(mel2samp.get_mel(audio).cpu(), new_filepath)
+def export_mels(filelist_path, config_path, output_dir):
+    """Clean audio files -> ``<output_dir>/<name>.pt`` mel tensors (the reference's ``__main__``, mel2samp.py:115-147)."""
+    with open(config_path) as f:
+        dataset = Mel2Samp(**json.load(f)["data_config"])
+    os.makedirs(output_dir, exist_ok=True)
+    for wav_path in files_to_list(filelist_path):
+        target = os.path.join(output_dir, os.path.basename(wav_path) + '.pt')
+        print(target)
+        torch.save(dataset.get_mel(load_wav_to_torch(wav_path)[0]).cpu(), target)
+
+
+if __name__ == "__main__":
+    cli = argparse.ArgumentParser()
+    cli.add_argument('-f', "--filelist_path", required=True)
+    cli.add_argument('-c', '--config', type=str, help='JSON file for configuration')
+    cli.add_argument('-o', '--output_dir', type=str, help='Output directory')
+    opts = cli.parse_args()
+    export_mels(opts.filelist_path, opts.config, opts.output_dir)
