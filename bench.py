@@ -291,8 +291,22 @@ def spawn_ranks(n, argv):
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0 = procs[0].communicate()[0]
+    # watch all ranks: one that dies must take the others down with it (they would sit in a barrier until RCCL's timeout)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        failed = next((r for r, p in enumerate(procs) if p.poll() not in (None, 0)), None)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
     rcs = [p.wait() for p in procs]
+    reader.join(5)
+    out0 = "".join(c for c in chunks if c)
     if any(rcs):
         sys.stderr.write(out0)
         raise SystemExit("bench.py: rank exit codes %s" % rcs)

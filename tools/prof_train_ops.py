@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""torch.profiler view of one bf16 training step (which host ops launch the small kernels): python tools/prof_train_ops.py [B]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "fac-via-ppg_amd"), os.path.join(ROOT, "tests")]
+import numpy as np
+import torch
+from torch.profiler import ProfilerActivity, profile
+from facppg import synth
+from test_gpu_e2e import weightnorm_state_dict
+from waveglow.glow import WaveGlow, WaveGlowLoss
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+cfg = dict(synth.WAVEGLOW_CONFIG)
+m = WaveGlow(**cfg)
+m.load_state_dict(weightnorm_state_dict(synth.waveglow_state_dict(cfg)), strict=True)
+m = m.cuda().train()
+m.train_precision = "bf16"
+opt = torch.optim.Adam(m.parameters(), lr=1e-5, fused=True)
+crit = WaveGlowLoss(0.7071)
+g = np.random.Generator(np.random.PCG64(1))
+audio = torch.from_numpy(np.clip(g.standard_normal((B, 10000), dtype=np.float32) * 0.1, -1, 1)).cuda()
+mel = synth.synthetic_mel(B, 63, seed=1).cuda()
+
+
+def step():
+    m.zero_grad()
+    loss = crit(m((mel, audio)))
+    loss.backward()
+    opt.step()
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    step()
+    torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="count", row_limit=40, max_name_column_width=60))
