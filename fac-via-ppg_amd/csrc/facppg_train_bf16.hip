@@ -419,7 +419,8 @@ __device__ __forceinline__ void transpose8x8(const uint4 (&r)[8], uint4 (&t)[8])
 }
 
 __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
-  __shared__ __attribute__((aligned(16))) bf16_t lds[2][128 * LDP];   // [A | B][channel][position]; later chunks wait in registers
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds_dyn[];      // [buffer][A | B][channel][position], double-buffered: one barrier per chunk
+  bf16_t (*lds)[2][128 * LDP] = reinterpret_cast<bf16_t (*)[2][128 * LDP]>(lds_dyn);
   const int pi = blockIdx.z / wa.nsplit, split = blockIdx.z - pi * wa.nsplit;
   const WgradProb& p = wa.prob[pi];
   const int m0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
@@ -452,10 +453,12 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
     for (int i = 0; i < 8; ++i) stg[i] = live ? *reinterpret_cast<const uint4*>(s0 + (size_t)i * sld) : make_uint4(0, 0, 0, 0);
 #endif
   };
-  auto stage_write = [&](const uint4 (&stg)[8]) {
+  auto stage_write = [&](int buf, const uint4 (&stg)[8]) {
     uint4 t[8];
     transpose8x8(stg, t);
-    bf16_t* d = &lds[isx][(8 * cb8) * LDP + 8 * pb];
+    // position block pb of channel block cb8 sits at column block (pb + (cb8 >> 1)) & 7: with the row pitch of 144 B, the
+    // 16 lanes of a store group (cb8 = 0..15, same pb) would otherwise hit only 2 x 4 banks each (8-way conflict)
+    bf16_t* d = &lds[buf][isx][(8 * cb8) * LDP + 8 * ((pb + (cb8 >> 1)) & 7)];
 #pragma unroll
     for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(d + c * LDP) = t[c];
   };
@@ -466,12 +469,13 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  const bf16_t* la = &lds[0][(64 * wm + li) * LDP + 8 * kh];
-  const bf16_t* lb = &lds[1][(64 * wk + li) * LDP + 8 * kh];
+  // fragment rows 64*w? + 32*i + li: their column swizzle (row >> 4) & 7 = (4*w? + 2*i + (li >> 4)) & 7
+  const int la_row = (64 * wm + li) * LDP, lb_row = (64 * wk + li) * LDP;
+  const int la_sw = 4 * wm + (li >> 4), lb_sw = 4 * wk + (li >> 4);
   uint4 st0[8], st1[8];
   if (c_lo < c_hi) {
     stage_load(c_lo, st0);
-    stage_write(st0);
+    stage_write(0, st0);
     if (c_lo + 1 < c_hi) stage_load(c_lo + 1, st0);
   }
   __syncthreads();
@@ -479,21 +483,24 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
   auto iter = [&](int c, uint4 (&s_nxt)[8], uint4 (&s_nxt2)[8]) {
     if (c + 2 < c_hi) stage_load(c + 2, s_nxt2);
     __builtin_amdgcn_sched_barrier(0);   // keep the requests two chunks ahead
+    const int buf = (c - c_lo) & 1;
+    const bf16_t* la = &lds[buf][0][la_row];
+    const bf16_t* lb = &lds[buf][1][lb_row];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       uint4 av[2], bv[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        av[i] = *reinterpret_cast<const uint4*>(la + i * 32 * LDP + 16 * s);
-        bv[i] = *reinterpret_cast<const uint4*>(lb + i * 32 * LDP + 16 * s);
+        av[i] = *reinterpret_cast<const uint4*>(la + i * 32 * LDP + 8 * ((2 * s + kh + la_sw + 2 * i) & 7));
+        bv[i] = *reinterpret_cast<const uint4*>(lb + i * 32 * LDP + 8 * ((2 * s + kh + lb_sw + 2 * i) & 7));
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(av[i], bv[j], acc[i][j]);
     }
-    __syncthreads();            // every wave is done reading this chunk
-    if (c + 1 < c_hi) stage_write(s_nxt);
+    // chunk c+1 goes to the OTHER buffer (last read in iteration c-1, which every wave left through the barrier below)
+    if (c + 1 < c_hi) stage_write(buf ^ 1, s_nxt);
     __syncthreads();
   };
   int c = c_lo;
@@ -540,7 +547,13 @@ int wgrad_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size
   ns = std::max(1, std::min(std::min(ns, WG_MAXSPLIT), nall));
   while (ns > 1 && (size_t)nprob * ns * maxM * maxK * 4 > part_bytes) --ns;
   wa.nsplit = ns; wa.part = part; wa.pstride = (size_t)maxM * maxK;
-  k_wgrad<<<dim3((maxK + 127) / 128, (maxM + 127) / 128, nprob * ns), 256, 0, s>>>(wa);
+  constexpr size_t kWgradLds = (size_t)2 * 2 * 128 * LDP * sizeof(bf16_t);   // 73 728 B
+  static bool attr_set = false;
+  if (!attr_set) {
+    FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgradLds));
+    attr_set = true;
+  }
+  k_wgrad<<<dim3((maxK + 127) / 128, (maxM + 127) / 128, nprob * ns), 256, kWgradLds, s>>>(wa);
   if (ns > 1) k_wgrad_reduce<<<dim3((maxM * maxK + 255) / 256, nprob), 256, 0, s>>>(wa);
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
@@ -549,26 +562,42 @@ int wgrad_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size
 // out[m] = sum_{b, n < L} y[b][row0 + n][m]  (bias gradients).  Stage 1: workgroup (channel tile, row slice, problem)
 // sums its slice of the B*L rows (4 row lanes x 64 channels per wavefront-row); stage 2 adds the slices in index
 // order -- a fixed summation order whatever the grid, so the result is bit-reproducible.
-constexpr int CS_SLICES = 64, MAXCS = 16;
+constexpr int CS_SLICES = 256, MAXCS = 16;
 struct ColsumProb { const void* y; long bs; int ld, row0, M; float* out; };
 struct ColsumArgs { ColsumProb prob[MAXCS]; int B, L; float* part; };   // part [prob][CS_SLICES][1024]
 template <bool F32>
 __global__ __launch_bounds__(256) void k_colsum_part(ColsumArgs ca) {
+  // a thread owns TWO adjacent channels (one 4-byte load of bf16, 8 bytes of fp32), the 256 threads cover M / 2 channel
+  // pairs x 512 / M row lanes: every row is read as whole contiguous segments
   const ColsumProb& p = ca.prob[blockIdx.z];
-  const int m = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, sl = blockIdx.y;
-  __shared__ float red[4][64];
+  const int npair = p.M / 2, lanes = 256 / npair > 0 ? 256 / npair : 1;       // M <= 512, even
+  const int pr = threadIdx.x % npair, rl = threadIdx.x / npair, sl = blockIdx.y;
+  __shared__ float red[512];
   const long R = (long)ca.B * ca.L, r0 = R * sl / CS_SLICES, r1 = R * (sl + 1) / CS_SLICES;
-  float v = 0.0f;
-  if (m < p.M)
-    for (long r = r0 + rl; r < r1; r += 4) {
+  float v0 = 0.0f, v1 = 0.0f;
+  if (rl < lanes)
+#pragma unroll 4
+    for (long r = r0 + rl; r < r1; r += lanes) {
       const int b = (int)(r / ca.L), n = (int)(r - (long)b * ca.L);
-      const size_t o = (size_t)b * p.bs + (size_t)(p.row0 + n) * p.ld + m;
-      v += F32 ? reinterpret_cast<const float*>(p.y)[o] : bf2f(reinterpret_cast<const bf16_t*>(p.y)[o]);
+      const size_t o = (size_t)b * p.bs + (size_t)(p.row0 + n) * p.ld + 2 * pr;
+      if (F32) {
+        const float2 x = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(p.y) + o);
+        v0 += x.x; v1 += x.y;
+      } else {
+        const unsigned x = *reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16_t*>(p.y) + o);
+        v0 += lo2f(x); v1 += hi2f(x);
+      }
     }
-  red[rl][threadIdx.x & 63] = v;
-  __syncthreads();
-  if (rl == 0 && m < p.M)
-    ca.part[((size_t)blockIdx.z * CS_SLICES + sl) * 1024 + m] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  // row lanes meet in LDS in lane order
+  float* part = ca.part + ((size_t)blockIdx.z * CS_SLICES + sl) * 1024;
+  for (int l = 0; l < lanes; ++l) {
+    if (rl == l) {
+      if (l == 0) { red[2 * pr] = v0; red[2 * pr + 1] = v1; }
+      else { red[2 * pr] += v0; red[2 * pr + 1] += v1; }
+    }
+    __syncthreads();
+  }
+  for (int m = threadIdx.x; m < p.M; m += 256) part[m] = red[m];
 }
 // group > 1: out[m / group] also sums `group` adjacent channels (the 8 regrouped samples of one mel channel)
 __global__ void k_colsum_sum(ColsumArgs ca, int group) {
@@ -582,7 +611,7 @@ __global__ void k_colsum_sum(ColsumArgs ca, int group) {
 }
 template <bool F32>
 int colsum_launch(ColsumArgs& ca, int nprob, int maxM, int group, hipStream_t s) {
-  k_colsum_part<F32><<<dim3((maxM + 63) / 64, CS_SLICES, nprob), 256, 0, s>>>(ca);
+  k_colsum_part<F32><<<dim3(1, CS_SLICES, nprob), 256, 0, s>>>(ca);
   k_colsum_sum<<<dim3((maxM / group + 255) / 256, nprob), 256, 0, s>>>(ca, group);
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
@@ -639,30 +668,58 @@ __global__ void k_t_end_bwd(const float* __restrict__ dout, const float* __restr
 template <bool WIDE_BF16>
 __global__ __launch_bounds__(256) void k_small_wgrad_part(const float* __restrict__ small, const void* __restrict__ wide, long wide_bs,
                                                           int wide_row0, float* __restrict__ part, int nj, int B, int L, int nparts) {
+  // workgroup = a contiguous range of the B*L rows; its slice of `small` (<= 8 x SW values) is staged in LDS first so the
+  // main loop is one coalesced row of `wide` + LDS broadcasts per row
+  constexpr int SW = 128;
+  __shared__ float ssm[8][SW];
   const int c = threadIdx.x;
+  const long total = (long)B * L, i0 = total * blockIdx.x / nparts, i1 = total * (blockIdx.x + 1) / nparts;
   float acc[9];
 #pragma unroll
   for (int j = 0; j < 9; ++j) acc[j] = 0.0f;
-  const long total = (long)B * L;
-  for (long i = blockIdx.x; i < total; i += nparts) {
-    const int b = (int)(i / L), n = (int)(i - (long)b * L);
-    float wv;
-    if constexpr (WIDE_BF16) wv = bf2f(reinterpret_cast<const bf16_t*>(wide)[(size_t)b * wide_bs + (size_t)(wide_row0 + n) * C + c]);
-    else wv = reinterpret_cast<const float*>(wide)[(size_t)b * wide_bs + (size_t)(wide_row0 + n) * C + c];
+  for (long base = i0; base < i1; base += SW) {
+    const int cnt = (int)((i1 - base) < SW ? (i1 - base) : SW);
+    __syncthreads();
+    for (int e = threadIdx.x; e < nj * cnt; e += 256) {
+      const int j = e / cnt, r = e - j * cnt;
+      const long i = base + r;
+      const int b = (int)(i / L), n = (int)(i - (long)b * L);
+      ssm[j][r] = small[((size_t)b * nj + j) * L + n];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < cnt; ++r) {
+      const long i = base + r;
+      const int b = (int)(i / L), n = (int)(i - (long)b * L);
+      float wv;
+      if constexpr (WIDE_BF16) wv = bf2f(reinterpret_cast<const bf16_t*>(wide)[(size_t)b * wide_bs + (size_t)(wide_row0 + n) * C + c]);
+      else wv = reinterpret_cast<const float*>(wide)[(size_t)b * wide_bs + (size_t)(wide_row0 + n) * C + c];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (j < nj) acc[j] = fmaf(small[((size_t)b * nj + j) * L + n], wv, acc[j]);
-    acc[8] += wv;
+      for (int j = 0; j < 8; ++j)
+        if (j < nj) acc[j] = fmaf(ssm[j][r], wv, acc[j]);
+      acc[8] += wv;
+    }
   }
 #pragma unroll
   for (int j = 0; j < 9; ++j) part[((size_t)blockIdx.x * 9 + j) * C + c] = acc[j];
 }
 // out_w[(j, c)] laid out by (o_sj, o_sc); out_wsum[c] = column sums of wide (may be null)
-__global__ void k_small_wgrad_sum(const float* __restrict__ part, int nparts, int nj, float* __restrict__ out_w, int o_sj, int o_sc,
-                                  float* __restrict__ out_wsum) {
-  const int c = threadIdx.x, j = blockIdx.x;
-  float v = 0.0f;
-  for (int p = 0; p < nparts; ++p) v += part[((size_t)p * 9 + j) * C + c];
+__global__ __launch_bounds__(1024) void k_small_wgrad_sum(const float* __restrict__ part, int nparts, int nj, float* __restrict__ out_w, int o_sj,
+                                                           int o_sc, float* __restrict__ out_wsum) {
+  // 1024 threads = 256 channels x 4 quarters of the partials; eight interleaved chains per thread so the loads overlap;
+  // chains, then quarters, are combined in a fixed order
+  __shared__ float red[4][C];
+  const int c = threadIdx.x & (C - 1), q = threadIdx.x >> 8, j = blockIdx.x;
+  const int p0 = nparts * q / 4, p1 = nparts * (q + 1) / 4;
+  float v8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int p = p0; p < p1; p += 8)
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (p + u < p1) v8[u] += part[((size_t)(p + u) * 9 + j) * C + c];
+  red[q][c] = ((v8[0] + v8[1]) + (v8[2] + v8[3])) + ((v8[4] + v8[5]) + (v8[6] + v8[7]));
+  __syncthreads();
+  if (q) return;
+  const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
   if (j < nj) out_w[j * o_sj + c * o_sc] = v;
   else if (j == 8 && out_wsum) out_wsum[c] = v;
 }
@@ -804,7 +861,7 @@ StateLayout state_layout(int nl, int B, int Lr) {
 }
 struct ScratchLayout { size_t w1, w2, rst, int_, condt, dpre, dh, dskip, part, cspart, wgpart, wgpart_bytes, total; size_t w1_one, w2_one, rst_one, int_one, dpre_one, dh_one; };
 constexpr int K1 = 3 * C + NCOND;   // 1408
-constexpr int SMALL_PARTS = 128;
+constexpr int SMALL_PARTS = 256;
 ScratchLayout scratch_layout(int nl, int B, int Lr) {
   ScratchLayout s;
   const int Lp = HALO + Lr + HALO;
@@ -919,8 +976,11 @@ extern "C" int facppg_upsample_regroup_backward(const float* mel_dev, const floa
   ColsumArgs ca;
   memset(&ca, 0, sizeof(ca));
   ca.B = B; ca.L = L; ca.part = (float*)ws_dev;
-  ca.prob[0] = ColsumProb{dspect_pm_dev, (long)Lr * n_mel * 8, n_mel * 8, 0, n_mel * 8, d_up_b_dev};
-  return colsum_launch<true>(ca, 1, n_mel * 8, 8, s);
+  // 640 channels as two problems of 320 (k_colsum_part covers <= 512 channels per problem)
+  const int half = n_mel * 4;
+  ca.prob[0] = ColsumProb{dspect_pm_dev, (long)Lr * n_mel * 8, n_mel * 8, 0, half, d_up_b_dev};
+  ca.prob[1] = ColsumProb{dspect_pm_dev + half, (long)Lr * n_mel * 8, n_mel * 8, 0, half, d_up_b_dev + half / 8};
+  return colsum_launch<true>(ca, 2, half, 8, s);
 }
 
 // WN.forward (glow.py:154-175) with bf16 MFMA operands, keeping what the backward needs in `state`.
@@ -1032,7 +1092,7 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
   {  // end conv: weight [nout][256] and bias gradients
     float* part = (float*)(W + sc.part);
     k_small_wgrad_part<false><<<SMALL_PARTS, 256, 0, s>>>(dout_dev, S + st.skip, (long)Lr * C, 0, part, nout, B, L, SMALL_PARTS);
-    k_small_wgrad_sum<<<9, 256, 0, s>>>(part, SMALL_PARTS, nout, gr->end_w, C, 1, nullptr);
+    k_small_wgrad_sum<<<9, 1024, 0, s>>>(part, SMALL_PARTS, nout, gr->end_w, C, 1, nullptr);
     k_small_rowsum<<<nout, 256, 0, s>>>(dout_dev, gr->end_b, nout, B, L);
   }
   for (int i = nl - 1; i >= 0; --i) {
@@ -1066,7 +1126,7 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
   {  // start conv: weight [256][n_in] and bias [256] gradients
     float* part = (float*)(W + sc.part);
     k_small_wgrad_part<true><<<SMALL_PARTS, 256, 0, s>>>(a0_dev, dh0, (long)Lr * C, 0, part, n_in, B, L, SMALL_PARTS);
-    k_small_wgrad_sum<<<9, 256, 0, s>>>(part, SMALL_PARTS, n_in, gr->start_w, 1, n_in, gr->start_b);
+    k_small_wgrad_sum<<<9, 1024, 0, s>>>(part, SMALL_PARTS, n_in, gr->start_w, 1, n_in, gr->start_b);
   }
   // weight gradients of the three convs of every layer: NT products over positions, batched over layers (x taps)
   {
