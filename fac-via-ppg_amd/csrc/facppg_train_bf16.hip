@@ -428,7 +428,10 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
   const int wm = w >> 1, wk = w & 1;
   // staging role: threads 0..127 transpose dY blocks, 128..255 X blocks; block = (pb: 8 positions, cb: 8 channels)
-  const int isx = tid >> 7, blk = tid & 127, pb = blk >> 4, cb8 = blk & 15;
+  // (the 8 lanes of an LDS store group take the 8 position blocks of ONE channel block: 128 contiguous bytes per row, no bank
+  //  conflict; SQ_LDS_BANK_CONFLICT was 50 % of the LDS-active cycles with channel blocks fastest, and a column swizzle that fixed
+  //  the stores broke the ds_read_b128 lane groups instead)
+  const int isx = tid >> 7, blk = tid & 127, pb = blk & 7, cb8 = blk >> 3;
   const int nlc = (wa.L + 63) / 64, nall = wa.B * nlc;
   const int c_lo = (int)((long)nall * split / wa.nsplit), c_hi = (int)((long)nall * (split + 1) / wa.nsplit);
   const bf16_t* src;
@@ -456,9 +459,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
   auto stage_write = [&](int buf, const uint4 (&stg)[8]) {
     uint4 t[8];
     transpose8x8(stg, t);
-    // position block pb of channel block cb8 sits at column block (pb + (cb8 >> 1)) & 7: with the row pitch of 144 B, the
-    // 16 lanes of a store group (cb8 = 0..15, same pb) would otherwise hit only 2 x 4 banks each (8-way conflict)
-    bf16_t* d = &lds[buf][isx][(8 * cb8) * LDP + 8 * ((pb + (cb8 >> 1)) & 7)];
+    bf16_t* d = &lds[buf][isx][(8 * cb8) * LDP + 8 * pb];
 #pragma unroll
     for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(d + c * LDP) = t[c];
   };
@@ -469,9 +470,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  // fragment rows 64*w? + 32*i + li: their column swizzle (row >> 4) & 7 = (4*w? + 2*i + (li >> 4)) & 7
-  const int la_row = (64 * wm + li) * LDP, lb_row = (64 * wk + li) * LDP;
-  const int la_sw = 4 * wm + (li >> 4), lb_sw = 4 * wk + (li >> 4);
+  const int la_row = (64 * wm + li) * LDP + 8 * kh, lb_row = (64 * wk + li) * LDP + 8 * kh;
   uint4 st0[8], st1[8];
   if (c_lo < c_hi) {
     stage_load(c_lo, st0);
@@ -491,8 +490,8 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
       uint4 av[2], bv[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        av[i] = *reinterpret_cast<const uint4*>(la + i * 32 * LDP + 8 * ((2 * s + kh + la_sw + 2 * i) & 7));
-        bv[i] = *reinterpret_cast<const uint4*>(lb + i * 32 * LDP + 8 * ((2 * s + kh + lb_sw + 2 * i) & 7));
+        av[i] = *reinterpret_cast<const uint4*>(la + i * 32 * LDP + 16 * s);
+        bv[i] = *reinterpret_cast<const uint4*>(lb + i * 32 * LDP + 16 * s);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
