@@ -428,10 +428,12 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
   const int wm = w >> 1, wk = w & 1;
   // staging role: threads 0..127 transpose dY blocks, 128..255 X blocks; block = (pb: 8 positions, cb: 8 channels)
-  // (the 8 lanes of an LDS store group take the 8 position blocks of ONE channel block: 128 contiguous bytes per row, no bank
-  //  conflict; SQ_LDS_BANK_CONFLICT was 50 % of the LDS-active cycles with channel blocks fastest, and a column swizzle that fixed
-  //  the stores broke the ds_read_b128 lane groups instead)
-  const int isx = tid >> 7, blk = tid & 127, pb = blk & 7, cb8 = blk >> 3;
+  // LDS image [channel][position], row pitch 144 B.  Position block pb of a channel row sits at column block (pb + f) & 7 with
+  // f = (row >> 5) & 3: constant inside every 32-row fragment block, so the ds_read_b128 lane groups stay conflict-free, while the
+  // 8 lanes of a store group take channel blocks 0,4,8,12,1,5,9,13 (or 2,6,.. / 3,7,..) -- four different f per bank half.
+  // Measured: channel blocks in lane order, no swizzle: SQ_LDS_BANK_CONFLICT = 50 % of the LDS-active cycles, 202 us; position
+  // blocks fastest (conflict-free but 16-byte pieces of 8 rows per 8 lanes on the global side): 168 us.
+  const int isx = tid >> 7, blk = tid & 127, pb = blk >> 4, l16 = blk & 15, cb8 = 4 * (l16 & 3) + (l16 >> 2);
   const int nlc = (wa.L + 63) / 64, nall = wa.B * nlc;
   const int c_lo = (int)((long)nall * split / wa.nsplit), c_hi = (int)((long)nall * (split + 1) / wa.nsplit);
   const bf16_t* src;
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
   auto stage_write = [&](int buf, const uint4 (&stg)[8]) {
     uint4 t[8];
     transpose8x8(stg, t);
-    bf16_t* d = &lds[buf][isx][(8 * cb8) * LDP + 8 * pb];
+    bf16_t* d = &lds[buf][isx][(8 * cb8) * LDP + 8 * ((pb + (cb8 >> 2)) & 7)];
 #pragma unroll
     for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(d + c * LDP) = t[c];
   };
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  const int la_row = (64 * wm + li) * LDP + 8 * kh, lb_row = (64 * wk + li) * LDP + 8 * kh;
+  const int la_row = (64 * wm + li) * LDP, lb_row = (64 * wk + li) * LDP;
   uint4 st0[8], st1[8];
   if (c_lo < c_hi) {
     stage_load(c_lo, st0);
@@ -490,8 +492,8 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
       uint4 av[2], bv[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        av[i] = *reinterpret_cast<const uint4*>(la + i * 32 * LDP + 16 * s);
-        bv[i] = *reinterpret_cast<const uint4*>(lb + i * 32 * LDP + 16 * s);
+        av[i] = *reinterpret_cast<const uint4*>(la + i * 32 * LDP + 8 * ((2 * s + kh + 2 * wm + i) & 7));
+        bv[i] = *reinterpret_cast<const uint4*>(lb + i * 32 * LDP + 8 * ((2 * s + kh + 2 * wk + i) & 7));
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
