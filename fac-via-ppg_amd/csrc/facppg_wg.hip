@@ -348,7 +348,13 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   if constexpr (PM) {
     const int lin = blockIdx.x;
     int tile;
-    if (p.xcd_map) { const int r = lin >> 3; ph = (r / p.nt) * 8 + (lin & 7); tile = r % p.nt; }
+    if (p.xcd_map == 1) { const int r = lin >> 3; ph = (r / p.nt) * 8 + (lin & 7); tile = r % p.nt; }
+    else if (p.xcd_map >= 2) {
+      // an XCD walks its phase group (all P/8 phases, or pairs of them) tile by tile: the rows two phases of one XCD share
+      // (taps at +-d for d a multiple of 8) are then re-read while still in that XCD's L2
+      const int r = lin >> 3, npg = p.xcd_map == 2 ? p.P / 8 : 2, per = npg * p.nt, grp = r / per, q = r % per;
+      ph = (grp * npg + q % npg) * 8 + (lin & 7); tile = q / npg;
+    }
     else { ph = lin / p.nt; tile = lin % p.nt; }
     if (ph >= p.P) return;
     // this lane's four columns (staging loads and epilogue stores use the same lane -> column map):
@@ -767,7 +773,13 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
   {
     const int lin = blockIdx.x;
     int tile;
-    if (p.xcd_map) { const int r = lin >> 3; ph = (r / p.nt) * 8 + (lin & 7); tile = r % p.nt; }
+    if (p.xcd_map == 1) { const int r = lin >> 3; ph = (r / p.nt) * 8 + (lin & 7); tile = r % p.nt; }
+    else if (p.xcd_map >= 2) {
+      // an XCD walks its phase group (all P/8 phases, or pairs of them) tile by tile: the rows two phases of one XCD share
+      // (taps at +-d for d a multiple of 8) are then re-read while still in that XCD's L2
+      const int r = lin >> 3, npg = p.xcd_map == 2 ? p.P / 8 : 2, per = npg * p.nt, grp = r / per, q = r % per;
+      ph = (grp * npg + q % npg) * 8 + (lin & 7); tile = q / npg;
+    }
     else { ph = lin / p.nt; tile = lin % p.nt; }
     if (ph >= p.P) return;
     int qcol;
@@ -958,7 +970,13 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
   int ph, tile;
   {
     const int lin = blockIdx.x;
-    if (p.xcd_map) { const int r = lin >> 3; ph = (r / p.nt) * 8 + (lin & 7); tile = r % p.nt; }
+    if (p.xcd_map == 1) { const int r = lin >> 3; ph = (r / p.nt) * 8 + (lin & 7); tile = r % p.nt; }
+    else if (p.xcd_map >= 2) {
+      // an XCD walks its phase group (all P/8 phases, or pairs of them) tile by tile: the rows two phases of one XCD share
+      // (taps at +-d for d a multiple of 8) are then re-read while still in that XCD's L2
+      const int r = lin >> 3, npg = p.xcd_map == 2 ? p.P / 8 : 2, per = npg * p.nt, grp = r / per, q = r % per;
+      ph = (grp * npg + q % npg) * 8 + (lin & 7); tile = q / npg;
+    }
     else { ph = lin / p.nt; tile = lin % p.nt; }
     if (ph >= p.P) return;
   }
@@ -1974,7 +1992,9 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   a.nch = NCHH + h->kcp / KCH; a.ngc = h->kcp / 8; a.kc = h->kc; a.hop = c.hop_length; a.ksize = c.upsample_kernel;
   // workgroup i lands on XCD i % 8: give every XCD its own phases so a phase's weight image lives in one L2
   static const char* no_xcd = getenv("FACPPG_WN_NO_XCD_MAP");
-  a.xcd_map = (w.P % 8 == 0) && !no_xcd;
+  static const char* tord = getenv("FACPPG_WN_TILE_ORDER");   // 1 phase-slowest (default), 2 tile-slowest, 3 tile-slowest within phase pairs
+  a.xcd_map = ((w.P % 8 == 0) && !no_xcd) ? (tord ? atoi(tord) : 1) : 0;
+  if (a.xcd_map == 3 && (w.P / 8) % 2) a.xcd_map = 1;
   const unsigned lgrid = (unsigned)(w.P * a.nt);
   {
     static const char* st_env = getenv("FACPPG_WN_STAGGER");   // experiment: sleeps (of ~3.4 us) for odd-slot first-round tiles
