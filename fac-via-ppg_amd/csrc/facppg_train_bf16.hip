@@ -266,8 +266,11 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs p) {
     for (int j = 0; j < NCB; ++j) stg[j] = *reinterpret_cast<const uint4*>(base + (size_t)(32 * j) * sg.ld);
 #endif
 #endif
-    seg_c += KC;
-    if (seg_c >= sg.nch && seg_i + 1 < p.nseg) { ++seg_i; seg_c = 0; }
+    // advance to the next chunk; at the very end stay on the last one: the requests of the last iterations are issued
+    // UNCONDITIONALLY (they re-read the last chunk, nothing consumes them) -- a branch around a load makes hipcc's waitcnt pass
+    // merge the two paths to vmcnt(0) at the next use, which drains every prefetch and exposes a full memory round trip per chunk
+    if (seg_c + KC < sg.nch) seg_c += KC;
+    else if (seg_i + 1 < p.nseg) { ++seg_i; seg_c = 0; }
   };
   auto stage_write = [&](int buf, const uint4 (&stg)[NCB]) {
 #pragma unroll
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs p) {
     for (int s = 0; s < 4; ++s) a[s] = nt_load16(ap + (size_t)(c * 4 + s) * 64);
 #else
 #pragma unroll
-    for (int s = 0; s < 4; ++s) a[s] = ap[(size_t)(c * 4 + s) * 64];
+    for (int s = 0; s < 4; ++s) a[s] = ap[(size_t)(min(c, nchunks - 1) * 4 + s) * 64];
 #endif
 #endif
   };
@@ -302,24 +305,23 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs p) {
   stage_load(st[0]);
   stage_write(0, st[0]);
 #pragma unroll
-  for (int u = 1; u < PD; ++u)
-    if (u < nchunks) stage_load(st[u]);
+  for (int u = 1; u < PD; ++u) stage_load(st[u]);
 #pragma unroll
-  for (int u = 0; u < PD - 1; ++u)
-    if (u < nchunks) load_a(ar[u], u);
+  for (int u = 0; u < PD - 1; ++u) load_a(ar[u], u);
   __syncthreads();
+  // the chunk loop runs in whole groups of PD iterations (static ring indices); iterations past the last chunk multiply the
+  // re-read last chunk by ... nothing: their MFMAs are skipped by a uniform branch that contains no memory operation
   for (int c0 = 0; c0 < nchunks; c0 += PD) {
 #pragma unroll
     for (int u = 0; u < PD; ++u) {
       const int c = c0 + u;
-      if (c < nchunks) {
-        if (c + PD - 1 < nchunks) load_a(ar[(u + PD - 1) % PD], c + PD - 1);
-        if (c + PD < nchunks) stage_load(st[u]);
-        __builtin_amdgcn_sched_barrier(0);   // keep the requests HERE, PD chunks ahead (hipcc otherwise sinks them next to their use)
-        compute(c, ar[u]);
-        if (c + 1 < nchunks) stage_write((c + 1) & 1, st[(u + 1) % PD]);
-        __syncthreads();
-      }
+      load_a(ar[(u + PD - 1) % PD], c + PD - 1);
+      stage_load(st[u]);
+      __builtin_amdgcn_sched_barrier(0);   // keep the requests HERE, PD chunks ahead (hipcc otherwise sinks them next to their use)
+      if (c < nchunks) compute(c, ar[u]);
+      __builtin_amdgcn_sched_barrier(0);
+      stage_write((c + 1) & 1, st[(u + 1) % PD]);
+      __syncthreads();
     }
   }
   if (!active) return;
@@ -347,12 +349,137 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs p) {
   }
 }
 
+// k_bgemm2: the large-product shape.  256 rows x 128 columns per workgroup on EIGHT waves (4 along M x 2 along N, 64 x 64 each):
+// both operands go through LDS -- the weight tile is the packed image copied verbatim (it is already in fragment order: a lane
+// reads back its own 16 bytes, lane-linear, conflict-free), so the two column waves of a row block share ONE copy from L2, and
+// the activation tile is shared by the four row waves.  16 MFMAs per wave per 64-deep chunk, 100 KB of LDS (one workgroup per CU,
+// two waves per SIMD), operands of chunk c+2 in flight in registers while chunk c computes.
+constexpr int B2_M = 256, B2_N = 128;
+constexpr size_t B2_LDS_A = (size_t)8 * 4 * 64 * 16, B2_LDS_B = (size_t)B2_N * LDB * 2, B2_LDS = 2 * (B2_LDS_A + B2_LDS_B);
+template <int MODE>
+__global__ __launch_bounds__(512) void k_bgemm2(BGemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
+  uint4* ldsA = reinterpret_cast<uint4*>(lds2);                                     // [2][8 row blocks][4 k16][64 lanes]
+  bf16_t* ldsB = reinterpret_cast<bf16_t*>(lds2 + 2 * B2_LDS_A);                    // [2][128 columns][LDB]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
+  const int wm = w >> 1, wn = w & 1;
+  const int nm = (p.M + B2_M - 1) / B2_M, ncol = (p.N + B2_N - 1) / B2_N;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int ct = (slot / nm) * 8 + xcd, mt = slot % nm;
+  if (ct >= ncol * p.B) return;
+  const int b = ct / ncol, n0 = (ct - b * ncol) * B2_N;
+  const int nrb = p.M / 32;                                                          // row blocks in the image
+  // wave w copies row block mt*8 + w of the weight tile (clamped: blocks past M are never used)
+  const uint4* ap = p.A + (size_t)min(mt * 8 + w, nrb - 1) * p.KG * 64 + lane;
+  const int srow = tid >> 3, sk = tid & 7;                                           // activation staging: rows srow, srow + 64
+  int nchunks = 0;
+  for (int s = 0; s < p.nseg; ++s) nchunks += p.seg[s].nch / KC;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  int seg_i = 0, seg_c = 0;
+  auto stage_load = [&](u32x4 (&sb)[2], u32x4 (&sa)[4], int c) {
+    const Seg& sg = p.seg[seg_i];
+    const bf16_t* base = sg.x + (size_t)b * sg.bs + (size_t)(sg.row0 + n0 + srow) * sg.ld + seg_c + 8 * sk;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) sb[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + (size_t)(64 * j) * sg.ld));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sa[s] = *reinterpret_cast<const u32x4*>(ap + (size_t)(min(c, nchunks - 1) * 4 + s) * 64);
+    if (seg_c + KC < sg.nch) seg_c += KC;                       // (stays on the last chunk at the end: see k_bgemm)
+    else if (seg_i + 1 < p.nseg) { ++seg_i; seg_c = 0; }
+  };
+  auto stage_write = [&](int buf, const u32x4 (&sb)[2], const u32x4 (&sa)[4]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x4*>(&ldsB[(size_t)buf * B2_N * LDB + (srow + 64 * j) * LDB + 8 * sk]) = sb[j];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4*>(ldsA + (size_t)buf * (8 * 4 * 64) + (w * 4 + s) * 64 + lane) = sa[s];
+  };
+  auto compute = [&](int buf) {
+    const uint4* la = ldsA + (size_t)buf * (8 * 4 * 64) + (2 * wm) * 4 * 64 + lane;
+    const bf16_t* lb = ldsB + (size_t)buf * B2_N * LDB + (64 * wn + li) * LDB + 8 * kh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      uint4 av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        av[i] = la[(i * 4 + s) * 64];
+        bv[i] = *reinterpret_cast<const uint4*>(lb + i * 32 * LDB + 16 * s);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(av[i], bv[j], acc[i][j]);
+    }
+  };
+  u32x4 sb0[2], sa0[4], sb1[2], sa1[4];
+  stage_load(sb0, sa0, 0);
+  stage_write(0, sb0, sa0);
+  stage_load(sb0, sa0, 1);
+  __syncthreads();
+  // every request and LDS store is unconditional (see k_bgemm); only the MFMAs of a padding iteration are skipped
+  auto iter = [&](int c, u32x4 (&sb_n)[2], u32x4 (&sa_n)[4], u32x4 (&sb_n2)[2], u32x4 (&sa_n2)[4]) {
+    stage_load(sb_n2, sa_n2, c + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (c < nchunks) compute(c & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_write((c + 1) & 1, sb_n, sa_n);
+    __syncthreads();
+  };
+  for (int c = 0; c < nchunks; c += 2) {
+    iter(c, sb0, sa0, sb1, sa1);
+    iter(c + 1, sb1, sa1, sb0, sa0);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int mb = mt * 8 + 2 * wm + i;
+    if (mb * 32 >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + 64 * wn + 32 * j + li;
+      if (n >= p.N) continue;
+      if constexpr (MODE == EP_GATE) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          const float v2[4] = {acc[i][j][8 + 4 * q], acc[i][j][8 + 4 * q + 1], acc[i][j][8 + 4 * q + 2], acc[i][j][8 + 4 * q + 3]};
+          bgemm_store4<MODE>(p, b, n, mb, q, kh, v, v2);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          bgemm_store4<MODE>(p, b, n, mb, q, kh, v, v);
+        }
+      }
+    }
+  }
+}
+
 template <int MODE>
 void bgemm_dispatch(const BGemmArgs& a, hipStream_t s) {
   const int nm = (a.M + BM - 1) / BM;
   const long wide = (long)((a.N + 127) / 128) * nm * a.B;
   static const char* wenv = getenv("FACPPG_BG_WIDE");
   static const long wide_min = wenv ? atol(wenv) : 384;    // 128-column tiles once they give >= 1.5 workgroups per CU
+  static const char* b2env = getenv("FACPPG_BG2_MIN");
+  static const long b2_min = b2env ? atol(b2env) : (1L << 40);   // 256 x 128 / 8-wave tiles: measured slower than k_bgemm in every mode
+                                                                  // (profiles/r02_experiments.txt), so opt-in only
+  const int nm2 = (a.M + B2_M - 1) / B2_M, ct2 = ((a.N + B2_N - 1) / B2_N) * a.B;
+  if ((long)nm2 * ct2 >= b2_min && a.M >= 128) {
+    static bool attr_set[8] = {false, false, false, false, false, false, false, false};
+    if (!attr_set[MODE]) {
+      (void)hipFuncSetAttribute((const void*)k_bgemm2<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B2_LDS);
+      attr_set[MODE] = true;
+    }
+    k_bgemm2<MODE><<<dim3(8 * nm2 * ((ct2 + 7) / 8)), 512, B2_LDS, s>>>(a);
+    return;
+  }
   if (wide >= wide_min) {
     const int ct = ((a.N + 127) / 128) * a.B;
     k_bgemm<MODE, 4><<<dim3(8 * nm * ((ct + 7) / 8)), 256, 0, s>>>(a);
@@ -438,24 +565,21 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
   const int c_lo = (int)((long)nall * split / wa.nsplit), c_hi = (int)((long)nall * (split + 1) / wa.nsplit);
   const bf16_t* src;
   long sbs; int sld, srow0, ch0;
-  bool live;
   if (!isx) {
     const bool second = p.dy1 && m0 >= p.msplit;
     src = second ? p.dy1 : p.dy0; sbs = p.dy_bs; sld = p.ldy; srow0 = p.dy_row0;
     ch0 = (second ? m0 - p.msplit : m0) + 8 * cb8;
-    live = m0 + 8 * cb8 < p.M;
   } else {
     src = p.x; sbs = p.x_bs; sld = p.ldx; srow0 = p.x_row0; ch0 = k0 + 8 * cb8;
-    live = k0 + 8 * cb8 < p.K;
   }
   auto stage_load = [&](int c, uint4 (&stg)[8]) {
     const int b = c / nlc, n = (c - b * nlc) * 64 + 8 * pb;
     const bf16_t* s0 = src + (size_t)b * sbs + (size_t)(srow0 + n) * sld + ch0;
 #pragma unroll
 #if FACPPG_WG_NT
-    for (int i = 0; i < 8; ++i) stg[i] = live ? nt_load16(s0 + (size_t)i * sld) : make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < 8; ++i) stg[i] = nt_load16(s0 + (size_t)i * sld);
 #else
-    for (int i = 0; i < 8; ++i) stg[i] = live ? *reinterpret_cast<const uint4*>(s0 + (size_t)i * sld) : make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < 8; ++i) stg[i] = *reinterpret_cast<const uint4*>(s0 + (size_t)i * sld);   // (M, K multiples of 128: no guard, no branch)
 #endif
   };
   auto stage_write = [&](int buf, const uint4 (&stg)[8]) {
@@ -474,15 +598,15 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   const int la_row = (64 * wm + li) * LDP, lb_row = (64 * wk + li) * LDP;
   uint4 st0[8], st1[8];
-  if (c_lo < c_hi) {
-    stage_load(c_lo, st0);
-    stage_write(0, st0);
-    if (c_lo + 1 < c_hi) stage_load(c_lo + 1, st0);
-  }
+  if (c_lo >= c_hi) return;          // (uniform per workgroup)
+  const int c_last = c_hi - 1;
+  stage_load(c_lo, st0);
+  stage_write(0, st0);
+  stage_load(min(c_lo + 1, c_last), st0);
   __syncthreads();
   // iteration c: chunk c+2 requested, MFMAs of chunk c from LDS, then chunk c+1 (requested one iteration ago) replaces it
   auto iter = [&](int c, uint4 (&s_nxt)[8], uint4 (&s_nxt2)[8]) {
-    if (c + 2 < c_hi) stage_load(c + 2, s_nxt2);
+    stage_load(min(c + 2, c_last), s_nxt2);   // unconditional (see k_bgemm): the last two iterations re-read the last chunk
     __builtin_amdgcn_sched_barrier(0);   // keep the requests two chunks ahead
     const int buf = (c - c_lo) & 1;
     const bf16_t* la = &lds[buf][0][la_row];
@@ -501,7 +625,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(av[i], bv[j], acc[i][j]);
     }
     // chunk c+1 goes to the OTHER buffer (last read in iteration c-1, which every wave left through the barrier below)
-    if (c + 1 < c_hi) stage_write(buf ^ 1, s_nxt);
+    stage_write(buf ^ 1, s_nxt);
     __syncthreads();
   };
   int c = c_lo;
@@ -542,6 +666,7 @@ __global__ void k_wgrad_reduce(WgradArgs wa) {
 constexpr int WG_MAXSPLIT = 8;
 // launches one batch of problems that share (M, K) tile counts; partial buffer: nprob * nsplit * maxM * maxK floats
 int wgrad_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size_t part_bytes, hipStream_t s) {
+  FACPPG_REQUIRE(maxM % 128 == 0 && maxK % 128 == 0, FACPPG_EINVAL, "k_wgrad: M and K must be multiples of 128 (got %d, %d)", maxM, maxK);
   const int tiles = ((maxK + 127) / 128) * ((maxM + 127) / 128) * nprob;
   const int nall = wa.B * ((wa.L + 63) / 64);
   int ns = (3 * 256 + tiles - 1) / tiles;       // aim at >= ~3 workgroups per CU
