@@ -223,6 +223,68 @@ __global__ void k_add_bias(const float* a, const float* b, float* out, int n) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Folded flow edges (inference, phase-major).  Both ends of a WN stack are linear maps next to linear maps:
+//
+// * glow.py:175 applies the `end` 1x1 conv (256 -> 2*n_half channels) to the SUM of the layers' skip outputs
+//   (glow.py:167-174), so layer i's 256 skip rows are only ever seen through W_end:
+//     end(sum_i (Ws_i a_i + bs_i)) = sum_i (W_end Ws_i) a_i + (W_end sum_i bs_i + b_end).
+//   The res_skip GEMM of a layer therefore needs its 256 res rows plus 2*n_half <= 8 "end" rows, not 512 rows,
+//   and the [B][256][L] skip accumulator becomes [B][8][L].  Image `we`: float index ((s*64 + lane)*8 + g) =
+//   (W_end Ws_i)[lane % 16][32 s + 4 g + lane / 16]: the A operands of v_mfma_f32_16x16x4_f32, K slice s.
+// * glow.py:156-160: the first layer's dilated conv is applied straight to start(x_a) = W_start x_a + b_start, a
+//   1x1 conv of the n_half conditioning audio channels.  Composed: a 3-tap conv over n_half + 1 channels (the
+//   extra one is 1 inside the utterance and 0 in the zero padding, carrying b_start exactly where the reference
+//   pads h with zeros).  K = 24 instead of 768 for the first layer.  Matrix F0 [512][64]: column 8*tap + ch.
+// The products are formed once in fp64 and rounded to fp32.
+// ------------------------------------------------------------------------------------------
+__global__ void k_fold_end_rows(const float* __restrict__ end_w,   // [cc][256]
+                                const float* __restrict__ ws,      // [256][256] skip rows of res_skip_layers[i]
+                                float* __restrict__ out, int cc) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (s*64 + lane)*8 + g
+  if (idx >= 8 * 64 * 8) return;
+  const int g = idx & 7, lane = (idx >> 3) & 63, sl = idx >> 9;
+  const int row = lane & 15, k = 32 * sl + 4 * g + (lane >> 4);
+  double v = 0.0;
+  if (row < cc)
+    for (int c = 0; c < C; ++c) v += (double)end_w[row * C + c] * (double)ws[c * C + k];
+  out[idx] = (float)v;
+}
+
+// endb[j] = end_b[j] + sum_c W_end[j][c] * sum_i bs_i[c];  bs_all = the layers' skip biases, [n_layers][256]
+__global__ void k_fold_end_bias(const float* end_w, const float* end_b, const float* bs_all, int n_layers, float* out, int cc) {
+  const int j = threadIdx.x;
+  if (j >= 8) return;
+  double v = 0.0;
+  if (j < cc) {
+    v = end_b[j];
+    for (int c = 0; c < C; ++c) {
+      double sb = 0.0;
+      for (int i = 0; i < n_layers; ++i) sb += (double)bs_all[i * C + c];
+      v += (double)end_w[j * C + c] * sb;
+    }
+  }
+  out[j] = (float)v;
+}
+
+__global__ void k_fold_first(const float* __restrict__ in_w,      // [512][256][3]
+                             const float* __restrict__ start_w,   // [256][hh]
+                             const float* __restrict__ start_b,   // [256]
+                             float* __restrict__ F0, int hh) {     // [512][64]
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 2 * C * 64) return;
+  const int o = idx >> 6, kk = idx & 63, tap = kk >> 3, ch = kk & 7;
+  double v = 0.0;
+  if (tap < 3 && ch <= hh)
+    for (int c = 0; c < C; ++c) v += (double)in_w[((size_t)o * C + c) * 3 + tap] * (double)(ch < hh ? start_w[c * hh + ch] : start_b[c]);
+  F0[idx] = (float)v;
+}
+
+__global__ void k_copy_rows(const float* __restrict__ src, float* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------
 // k_wn_layer
 // ------------------------------------------------------------------------------------------
 struct WnArgs {
@@ -243,6 +305,11 @@ struct WnArgs {
   int P, Tr, Tqp, ntq, nt, nch, ngc, kc, xcd_map;
   int hop, ksize;      // upsampler stride / kernel size: late phases reach fewer mel frames (pm_chunks)
   int flat_cols;       // > 0: uniform batch, tiles cut from the B*T frames of a phase laid end to end (no ragged last tile per utterance)
+  // folded flow edges (EF kernels): skip = the [B][8][P*Tr] end-row accumulator
+  const float* xa;     // [B][8][P][Tqp] conditioning audio channels + the in-utterance indicator, zero margins (first layer's operand)
+  const float* we;     // end-row image of this layer (k_fold_end_rows)
+  const float* endb;   // [8] folded end bias (seeds the accumulator in the first layer)
+  int nconv;           // K chunks before the conditioning rows: 12 (three taps of 256 channels) or 1 (folded first layer)
   int stagger_first, stagger_sleeps;   // FACPPG_STAGGER experiment
 };
 
@@ -307,12 +374,16 @@ __device__ __forceinline__ float gate_tanh_sigmoid(float a, float b) {
 // for phases >= 8; hop 256: always 5).
 __device__ __forceinline__ int pm_chunks(const WnArgs& p, int ph) {
   const int nj = (p.ksize - 1 - 8 * ph) / p.hop + 1;
-  return min(p.nch, NCHH + (nj * NMEL + KCH - 1) / KCH);
+  return min(p.nch, p.nconv + (nj * NMEL + KCH - 1) / KCH);
 }
 
-template <bool LAST, int NCB, bool SAVE = false, bool PM = false>
+// EF (with PM): folded flow edges, see k_fold_end_rows -- the second GEMM has the 256 res rows only (none in the last
+// layer), 8 end rows come from v_mfma_f32_16x16x4_f32 over the gated activations, and the first layer (p.nconv == 1)
+// takes its taps from p.xa.
+template <bool LAST, int NCB, bool SAVE = false, bool PM = false, bool EF = false>
 __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
-  // LDS: 2 staging buffers [64 k][TNt] then the gated activations [256][TNt] (aliased)
+  static_assert(!EF || PM, "folded flow edges exist on the phase-major layout only");
+  // LDS: 2 staging buffers [64 k][TNt] then the gated activations [256][TNt] (aliased); EF: + end rows [8][TNt]
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TNt = 32 * NCB;          // positions per tile: 64 (throughput) or 32 (small problems)
   constexpr int RPL = 64 / TNt;          // k-rows covered by one wave-wide staging load
@@ -420,7 +491,8 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   const int nch = PM ? pm_chunks(p, ph) : NCH1;
   constexpr int F4R = TNt / 4, RPL4 = 64 / F4R, NSTG4 = 16 / RPL4;   // PM staging: float4 per row, rows per wave load, loads
   const int srow4 = lane / F4R, scol4 = (lane % F4R) * 4;
-  const float* hb4 = p.h_in + (size_t)b * C * p.Lp;                         // PM: tapo[] carry the lane's column
+  const bool folded_first = EF && p.nconv == 1;
+  const float* hb4 = folded_first ? p.xa + (size_t)b * 8 * p.Lp : p.h_in + (size_t)b * C * p.Lp;   // PM: tapo[] carry the lane's column
   const float* sb4 = PM ? p.melp + (size_t)b * NMEL * p.Tqp + in_off - ph * p.Tqp : nullptr;   // = HQ + qcol
   float stg[NSTG];
   auto stage_load = [&](int c) {
@@ -432,16 +504,19 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
       // both kinds of chunk reduce to "base + per-row offset" so the loads themselves are branch-free.
       // Phase rows are contiguous in frames, so a lane fetches 4 columns at once (16-byte loads at
       // 4-byte alignment: tap offsets are arbitrary) -- 4 VMEM instructions per chunk instead of 16.
-      const bool conv = c < NCHH;
+      const bool conv = c < p.nconv;
       const float* base = conv ? hb4 : sb4;
       int off[NSTG4];
 #pragma unroll
       for (int jj = 0; jj < NSTG4; ++jj) {
         const int r0 = w * 16 + srow4 + jj * RPL4;
         // folded conditioning rows r = j*80 + m' <- mel[m'][q - j]; rows past kc (K padding) meet zero weights
-        const int r = min((c - NCHH) * 64 + r0, p.kc - 1);
+        const int r = min((c - p.nconv) * 64 + r0, p.kc - 1);
         const int j = r / NMEL, m = r - j * NMEL;
-        off[jj] = conv ? ((c & 3) * 64 + r0) * p.Lp + (c < 4 ? tapo[0] : c < 8 ? tapo[1] : tapo[2]) : m * p.Tqp - j;
+        // conv rows: channel (c % 4)*64 + r0 of tap c / 4 -- or, folded first layer, row 8*tap + ch of p.xa (rows >= 24: zero weights)
+        const int tp = folded_first ? min(r0 >> 3, 2) : c >> 2;
+        const int chn = folded_first ? (r0 & 7) : (c & 3) * 64 + r0;
+        off[jj] = conv ? chn * p.Lp + (tp == 0 ? tapo[0] : tp == 1 ? tapo[1] : tapo[2]) : m * p.Tqp - j;
       }
 #pragma unroll
       for (int jj = 0; jj < NSTG4; ++jj) {
@@ -469,7 +544,8 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   // A operand of k-group gg (PM: the convolution image, then this phase's conditioning image)
   auto load_a1 = [&](float4 (&a)[4], const float4* ap_, int gg) {
     if constexpr (PM) {
-      const float4* src = gg < NGH ? ap_ + (size_t)gg * 1024 : wave_c_ptr + (size_t)(gg - NGH) * 1024;
+      const int ngh = 8 * p.nconv;
+      const float4* src = gg < ngh ? ap_ + (size_t)gg * 1024 : wave_c_ptr + (size_t)(gg - ngh) * 1024;
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) a[rb] = src[rb * 64];
     } else {
@@ -623,11 +699,13 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
       }
   __syncthreads();
 
-  // res_skip 1x1 conv: [512 (256 if LAST)] x 256; accumulators start at bias (+ h_in for res rows)
-  constexpr int NRB2 = LAST ? 2 : 4;
+  // res_skip 1x1 conv: [512 (256 if LAST)] x 256; accumulators start at bias (+ h_in for res rows).
+  // EF: the 256 res rows only (image and bias laid out like a LAST layer's 256 rows), nothing in the last layer.
+  constexpr int NRB2 = EF ? (LAST ? 0 : 2) : LAST ? 2 : 4;
+  constexpr bool ROWS256 = LAST || EF;
 #pragma unroll
   for (int rb = 0; rb < NRB2; ++rb) {
-    const int base = (LAST ? w * 64 + rb * 32 : (rb >> 1) * C + w * 64 + (rb & 1) * 32) + 4 * kh;
+    const int base = (ROWS256 ? w * 64 + rb * 32 : (rb >> 1) * C + w * 64 + (rb & 1) * 32) + 4 * kh;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float4 bv = *reinterpret_cast<const float4*>(p.b2 + base + 8 * q);
@@ -644,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
       }
     }
   }
-  {
+  if constexpr (NRB2 > 0) {
     const float4* ap2 = p.w2 + (size_t)(w * NRB2) * NG2 * 64 + lane;
     const float* lb = smem + (4 * kh) * TNt + li;
 #pragma unroll
@@ -673,15 +751,61 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
     }
   }
 
+  if constexpr (EF) {
+    // end rows: (W_end Ws_i)[8 x 256] . gated[256 x TNt] on 16x16x4 MFMAs, one 16-column block per wave.  Eight K
+    // slices of 32, each a chain of 8 MFMAs from zero, summed in slice order: every tile width does exactly this, so
+    // a tile gets the same bits from k_wn_layer, k_wn_layer8 and k_wn_layer16.
+    if (w < TNt / 16) {
+      const int pl = lane & 15, kq = lane >> 4;
+      const float4* wimg = reinterpret_cast<const float4*>(p.we) + lane * 2;
+      const float* gb = smem + kq * TNt + 16 * w + pl;
+      float4 a0[8], a1[8];
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) { a0[sl] = wimg[sl * 128]; a1[sl] = wimg[sl * 128 + 1]; }
+      f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) {
+        const float av[8] = {a0[sl].x, a0[sl].y, a0[sl].z, a0[sl].w, a1[sl].x, a1[sl].y, a1[sl].z, a1[sl].w};
+        f32x4 e = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 8; ++g) e = mfma16x16x4(av[g], gb[(32 * sl + 4 * g) * TNt], e);
+        if (sl == 0) tot = e;
+        else { tot[0] += e[0]; tot[1] += e[1]; tot[2] += e[2]; tot[3] += e[3]; }
+      }
+      if (kq < 2) {
+        float* endl = smem + C * TNt + (4 * kq) * TNt + 16 * w + pl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) endl[r * TNt] = tot[r];
+      }
+    }
+  }
+
   if constexpr (PM) {
     // epilogue, phase-major: the MFMA result layout gives a lane one column of 16 rows, i.e. 4-byte
     // accesses.  Each wave transposes its 64 res rows, then its 64 skip rows, through a private
     // [64][TNt] LDS slab and touches HBM with 16-byte row segments instead (4x fewer VMEM instructions).
     __syncthreads();   // every wave is done reading the gated activations
+    if constexpr (EF) {
+      // end rows: 8 rows x TNt columns, accumulated over the layers of the flow (seeded with the folded end bias)
+      const int row = w * RPL4 + srow4;
+      if (row < 8 && nvalid > 0) {
+        const float4 v4 = *reinterpret_cast<const float4*>(smem + C * TNt + row * TNt + scol4);
+        float* g = p.skip + ((size_t)b * 8 + row) * p.Lr + sk_off;
+        const float bias = p.endb[row];
+        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        if (nvalid >= 4) {
+          float4 x = make_float4(bias, bias, bias, bias);
+          if (!p.first) x = *reinterpret_cast<const float4*>(g);
+          *reinterpret_cast<float4*>(g) = make_float4(x.x + vv[0], x.y + vv[1], x.z + vv[2], x.w + vv[3]);
+        } else {
+          for (int k = 0; k < nvalid; ++k) g[k] = (p.first ? bias : g[k]) + vv[k];
+        }
+      }
+    }
     float* slab = smem + w * (64 * TNt);
 #pragma unroll
     for (int half = 0; half < NRB2 / 2; ++half) {
-      const bool is_res = !LAST && half == 0;
+      const bool is_res = EF || (!LAST && half == 0);
 #pragma unroll
       for (int rbh = 0; rbh < 2; ++rbh)
 #pragma unroll
@@ -762,7 +886,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
 // (one short utterance) a 4-wave tile leaves every SIMD with a single wave, and each barrier, LDS
 // round trip and weight load is fully exposed.
 // ------------------------------------------------------------------------------------------
-template <bool LAST, int NCB>
+template <bool LAST, int NCB, bool EF = false>
 __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TNt = 32 * NCB;
@@ -819,18 +943,21 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
   const int nch = pm_chunks(p, ph);
   constexpr int F4R = TNt / 4, RPL4 = 64 / F4R, NSTG4 = 8 / RPL4;
   const int srow4 = lane / F4R, scol4 = (lane % F4R) * 4;
-  const float* hb4 = p.h_in + (size_t)b * C * p.Lp;
+  const bool folded_first = EF && p.nconv == 1;
+  const float* hb4 = folded_first ? p.xa + (size_t)b * 8 * p.Lp : p.h_in + (size_t)b * C * p.Lp;
   const float* sb4 = p.melp + (size_t)b * NMEL * p.Tqp + in_off - ph * p.Tqp;
   float4 stg[NSTG4];
   auto stage_load = [&](int c) {
-    const bool conv = c < NCHH;
+    const bool conv = c < p.nconv;
     const float* base = conv ? hb4 : sb4;
 #pragma unroll
     for (int jj = 0; jj < NSTG4; ++jj) {
       const int r0 = w8 * 8 + srow4 + jj * RPL4;
-      const int r = min((c - NCHH) * 64 + r0, p.kc - 1);
+      const int r = min((c - p.nconv) * 64 + r0, p.kc - 1);
       const int j = r / NMEL, m = r - j * NMEL;
-      const int off = conv ? ((c & 3) * 64 + r0) * p.Lp + (c < 4 ? tapo[0] : c < 8 ? tapo[1] : tapo[2]) : m * p.Tqp - j;
+      const int tp = folded_first ? min(r0 >> 3, 2) : c >> 2;
+      const int chn = folded_first ? (r0 & 7) : (c & 3) * 64 + r0;
+      const int off = conv ? chn * p.Lp + (tp == 0 ? tapo[0] : tp == 1 ? tapo[1] : tapo[2]) : m * p.Tqp - j;
       const f4u v = *reinterpret_cast<const f4u*>(base + off);
       stg[jj] = make_float4(v.x, v.y, v.z, v.w);
     }
@@ -841,7 +968,8 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
     for (int jj = 0; jj < NSTG4; ++jj) *reinterpret_cast<float4*>(dst + jj * RPL4 * TNt) = stg[jj];
   };
   auto load_a1 = [&](float4 (&a)[2], int gg) {
-    const float4* src = gg < NGH ? wave_a + (size_t)gg * 1024 : wave_c + (size_t)(gg - NGH) * 1024;
+    const int ngh = 8 * p.nconv;
+    const float4* src = gg < ngh ? wave_a + (size_t)gg * 1024 : wave_c + (size_t)(gg - ngh) * 1024;
     a[0] = src[0];
     a[1] = src[128];
   };
@@ -885,24 +1013,25 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
       smem[(chb + 8 * (r >> 2) + (r & 3) + 4 * kh) * TNt + cb * 32 + li] = gate_tanh_sigmoid(acc[0][cb][r], acc[1][cb][r]);
   __syncthreads();
   // res_skip 1x1 conv
-  constexpr int NRB2 = LAST ? 1 : 2;
+  constexpr int NRB2 = EF ? (LAST ? 0 : 1) : LAST ? 1 : 2;   // EF: res rows only (image laid out like a LAST layer's 256 rows)
+  constexpr bool ROWS256 = LAST || EF;
 #pragma unroll
   for (int rb = 0; rb < NRB2; ++rb) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 bv = *reinterpret_cast<const float4*>(p.b2 + (LAST ? 0 : rb * C) + chb + 4 * kh + 8 * q);
+      const float4 bv = *reinterpret_cast<const float4*>(p.b2 + (ROWS256 ? 0 : rb * C) + chb + 4 * kh + 8 * q);
       acc[rb][0][4 * q + 0] = bv.x; acc[rb][0][4 * q + 1] = bv.y; acc[rb][0][4 * q + 2] = bv.z; acc[rb][0][4 * q + 3] = bv.w;
     }
 #pragma unroll
     for (int cb = 1; cb < NCB; ++cb) acc[rb][cb] = acc[rb][0];
   }
-  {
+  if constexpr (NRB2 > 0) {
     // w2 image: float4 index ((wq*nrb + rb4)*NG2 + g)*64 + lane, nrb = 2 (LAST) or 4
-    const float4* ap2 = p.w2 + (size_t)(LAST ? wq * 2 + sub : wq * 4 + sub) * NG2 * 64 + lane;
+    const float4* ap2 = p.w2 + (size_t)(ROWS256 ? wq * 2 + sub : wq * 4 + sub) * NG2 * 64 + lane;
     const float* lb = smem + (4 * kh) * TNt + li;
     auto load_a2 = [&](float4 (&a)[2], int g) {
       a[0] = ap2[g * 64];
-      if constexpr (!LAST) a[1] = ap2[(size_t)2 * NG2 * 64 + g * 64];
+      if constexpr (!ROWS256) a[1] = ap2[(size_t)2 * NG2 * 64 + g * 64];
     };
 #pragma unroll
     for (int i = 0; i < RING - 1; ++i) load_a2(ar[i], i);
@@ -917,12 +1046,53 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
       }
     }
   }
+  if constexpr (EF) {   // end rows, exactly as in k_wn_layer<EF>
+    if (w8 < TNt / 16) {
+      const int pl = lane & 15, kq = lane >> 4;
+      const float4* wimg = reinterpret_cast<const float4*>(p.we) + lane * 2;
+      const float* gb = smem + kq * TNt + 16 * w8 + pl;
+      float4 a0[8], a1[8];
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) { a0[sl] = wimg[sl * 128]; a1[sl] = wimg[sl * 128 + 1]; }
+      f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) {
+        const float av[8] = {a0[sl].x, a0[sl].y, a0[sl].z, a0[sl].w, a1[sl].x, a1[sl].y, a1[sl].z, a1[sl].w};
+        f32x4 e = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 8; ++g) e = mfma16x16x4(av[g], gb[(32 * sl + 4 * g) * TNt], e);
+        if (sl == 0) tot = e;
+        else { tot[0] += e[0]; tot[1] += e[1]; tot[2] += e[2]; tot[3] += e[3]; }
+      }
+      if (kq < 2) {
+        float* endl = smem + C * TNt + (4 * kq) * TNt + 16 * w8 + pl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) endl[r * TNt] = tot[r];
+      }
+    }
+  }
   // epilogue through a private [32][TNt] LDS slab per wave, 16-byte row segments to HBM
   __syncthreads();
+  if constexpr (EF) {
+    const int row = w8 * RPL4 + srow4;
+    if (row < 8 && nvalid > 0) {
+      const float4 v4 = *reinterpret_cast<const float4*>(smem + C * TNt + row * TNt + scol4);
+      float* g = p.skip + ((size_t)b * 8 + row) * p.Lr + sk_off;
+      const float bias = p.endb[row];
+      const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+      if (nvalid >= 4) {
+        float4 x = make_float4(bias, bias, bias, bias);
+        if (!p.first) x = *reinterpret_cast<const float4*>(g);
+        *reinterpret_cast<float4*>(g) = make_float4(x.x + vv[0], x.y + vv[1], x.z + vv[2], x.w + vv[3]);
+      } else {
+        for (int k = 0; k < nvalid; ++k) g[k] = (p.first ? bias : g[k]) + vv[k];
+      }
+    }
+  }
   float* slab = smem + w8 * (32 * TNt);
 #pragma unroll
   for (int half = 0; half < NRB2; ++half) {
-    const bool is_res = !LAST && half == 0;
+    const bool is_res = EF || (!LAST && half == 0);
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -961,7 +1131,7 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
 // ------------------------------------------------------------------------------------------
 constexpr int TN16 = 16;
 
-template <bool LAST>
+template <bool LAST, bool EF = false>
 __global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6;
@@ -999,18 +1169,21 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
   }
   const float4* wave_a = p.w1 + (w8 * 4) * 64 + lane;                                    // + g16 * 2048 + rbl * 64
   const float4* wave_c = p.wc + (size_t)ph * (p.ngc / 2) * 2048 + (w8 * 4) * 64 + lane;   // ngc counts 8-wide groups
-  const int nch = pm_chunks(p, ph), NGH16 = NCHH * 4;
+  const int nch = pm_chunks(p, ph), NGH16 = p.nconv * 4;
   // staging: a chunk is 64 k-rows x 16 frames = 1024 floats, two per thread
   const int srow = tid >> 3, scol = (tid & 7) * 2;
-  const float* hb = p.h_in + (size_t)b * C * p.Lp + scol;
+  const bool folded_first = EF && p.nconv == 1;
+  const float* hb = (folded_first ? p.xa + (size_t)b * 8 * p.Lp : p.h_in + (size_t)b * C * p.Lp) + scol;
   const float* sb = p.melp + (size_t)b * NMEL * p.Tqp + HQ + q0 + scol;
   typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
   float2 stg;
   auto stage_load = [&](int c) {
-    const bool conv = c < NCHH;
-    const int r = min((c - NCHH) * 64 + srow, p.kc - 1);
+    const bool conv = c < p.nconv;
+    const int r = min((c - p.nconv) * 64 + srow, p.kc - 1);
     const int j = r / NMEL, m = r - j * NMEL;
-    const float* src = conv ? hb + (size_t)((c & 3) * 64 + srow) * p.Lp + (c < 4 ? tapo[0] : c < 8 ? tapo[1] : tapo[2])
+    const int tp = folded_first ? min(srow >> 3, 2) : c >> 2;
+    const int chn = folded_first ? (srow & 7) : (c & 3) * 64 + srow;
+    const float* src = conv ? hb + (size_t)chn * p.Lp + (tp == 0 ? tapo[0] : tp == 1 ? tapo[1] : tapo[2])
                             : sb + m * p.Tqp - j;
     const f2u v = *reinterpret_cast<const f2u*>(src);
     stg = make_float2(v.x, v.y);
@@ -1056,13 +1229,14 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
     for (int r = 0; r < 4; ++r) smem[(chb + 16 * rbl + 4 * kq + r) * TN16 + pl] = gate_tanh_sigmoid(acc[rbl][r], acc[rbl + 2][r]);
   __syncthreads();
   // res_skip 1x1 conv: blocks rbl 0,1 = res rows chb.., rbl 2,3 = skip rows 256+chb.. (LAST: rbl 0,1 = skip rows chb..)
-  constexpr int NB2 = LAST ? 2 : 4;
+  constexpr int NB2 = EF ? (LAST ? 0 : 2) : LAST ? 2 : 4;   // EF: res rows only (image laid out like a LAST layer's 256 rows)
+  constexpr bool ROWS256 = LAST || EF;
 #pragma unroll
   for (int rbl = 0; rbl < NB2; ++rbl) {
-    const float4 bv = *reinterpret_cast<const float4*>(p.b2 + (LAST ? 0 : (rbl >> 1) * C) + chb + (rbl & 1) * 16 + 4 * kq);
+    const float4 bv = *reinterpret_cast<const float4*>(p.b2 + (ROWS256 ? 0 : (rbl >> 1) * C) + chb + (rbl & 1) * 16 + 4 * kq);
     acc[rbl][0] = bv.x; acc[rbl][1] = bv.y; acc[rbl][2] = bv.z; acc[rbl][3] = bv.w;
   }
-  {
+  if constexpr (NB2 > 0) {
     const float4* ap2 = p.w2 + (w8 * NB2) * 64 + lane;   // [g16][NB2*8 blocks][64]
     const float* lb = smem + k16(0, kq) * TN16 + pl;
     auto load_a2 = [&](float4 (&a)[4], int g) {
@@ -1089,13 +1263,53 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
       }
     }
   }
+  if constexpr (EF) {
+    // end rows (see k_wn_layer<EF>): wave w8 forms K slice w8 of the single 16-column block; the slices meet in LDS
+    // and are summed in slice order below -- the same sums, in the same order, as the wider tiles
+    const float4* wimg = reinterpret_cast<const float4*>(p.we) + w8 * 128 + lane * 2;
+    const float4 a0 = wimg[0], a1 = wimg[1];
+    const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const float* gb = smem + (32 * w8 + kq) * TN16 + pl;
+    f32x4 e = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 8; ++g) e = mfma16x16x4(av[g], gb[(4 * g) * TN16], e);
+    if (kq < 2) {
+      float* part = smem + C * TN16 + (w8 * 8 + 4 * kq) * TN16 + pl;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[r * TN16] = e[r];
+    }
+  }
   // epilogue through a private [32][16] LDS slab per wave, 16-byte row segments to HBM
   __syncthreads();
+  if constexpr (EF) {
+    if (tid < 32) {
+      const int row = tid >> 2, c4 = (tid & 3) * 4, nv = nvalid - c4;
+      if (nv > 0) {
+        const float* part = smem + C * TN16 + row * TN16 + c4;
+        float4 t = *reinterpret_cast<const float4*>(part);
+#pragma unroll
+        for (int sl = 1; sl < 8; ++sl) {
+          const float4 x = *reinterpret_cast<const float4*>(part + sl * 8 * TN16);
+          t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
+        }
+        float* g = p.skip + ((size_t)b * 8 + row) * p.Lr + sk_off + c4;
+        const float bias = p.endb[row];
+        const float vv[4] = {t.x, t.y, t.z, t.w};
+        if (nv >= 4) {
+          float4 x = make_float4(bias, bias, bias, bias);
+          if (!p.first) x = *reinterpret_cast<const float4*>(g);
+          *reinterpret_cast<float4*>(g) = make_float4(x.x + vv[0], x.y + vv[1], x.z + vv[2], x.w + vv[3]);
+        } else {
+          for (int k = 0; k < nv; ++k) g[k] = (p.first ? bias : g[k]) + vv[k];
+        }
+      }
+    }
+  }
   float* slab = smem + w8 * (32 * TN16);
   const int erow = lane >> 2, ecol = (lane & 3) * 4;   // 16 rows x 4 float4 per pass, two passes
 #pragma unroll
   for (int half = 0; half < NB2 / 2; ++half) {
-    const bool is_res = !LAST && half == 0;
+    const bool is_res = EF || (!LAST && half == 0);
 #pragma unroll
     for (int rbl = 0; rbl < 2; ++rbl)
 #pragma unroll
@@ -1262,7 +1476,19 @@ struct EdgeArgs {
   int swap, swap_next;     // legacy layout (glow_old.py:224-240): odd flows condition on the SECOND half
   int La;                  // channel pitch of aud_in / aud_out (always position-major)
   int P, Tr, Tqp;          // P > 0: h and skip are phase-major (k_wn_layer<PM>), grid = (frames/256, B, P)
+  // folded flow edges (k_wn_layer<EF>): `skip` holds the end conv's output already, [B][8][Lr]; the next flow's
+  // conditioning channels also go to xa_out [B][8][Lp] (+ the in-utterance indicator channel) for its folded first layer
+  int folded;
+  float* xa_out;
 };
+
+// rows 0..HN-1 = the conditioning audio channels, row HN = 1 (inside the utterance), rows above = 0
+template <int HN>
+__device__ __forceinline__ void write_xa(const EdgeArgs& p, int b, int h_off, const float* a0) {
+  float* dst = p.xa_out + (size_t)b * 8 * p.Lp + h_off;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dst[(size_t)j * p.Lp] = j < HN ? a0[j] : j == HN ? 1.0f : 0.0f;
+}
 
 // This thread's position: natural index `pos` (into aud / z / the output audio) and the offsets of
 // that position inside a channel row of h and of skip.
@@ -1302,6 +1528,7 @@ __global__ __launch_bounds__(256) void k_begin(EdgeArgs p) {
     p.aud_out[((size_t)b * 8 + j) * p.La + pos] = a[j];
   }
   start_conv<HN>(p, b, h_off, a + (p.swap_next ? HN : 0));
+  if (p.folded) write_xa<HN>(p, b, h_off, a + (p.swap_next ? HN : 0));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1338,7 +1565,11 @@ __global__ __launch_bounds__(256) void k_flow_end(EdgeArgs p) {
         for (int j = 0; j < CC; ++j) acc[j] = fmaf(p.end_w[j * C + c0 + u], v[u], acc[j]);
     }
   };
-  if constexpr (QS) {
+  if (p.folded) {
+    if (!valid) return;
+#pragma unroll
+    for (int j = 0; j < CC; ++j) o[j] = p.skip[((size_t)b * 8 + j) * p.Lr + sk_off];
+  } else if constexpr (QS) {
 #pragma unroll
     for (int j = 0; j < CC; ++j) o[j] = 0.0f;
     if (valid) quarter(qtr, o);
@@ -1393,6 +1624,7 @@ __global__ __launch_bounds__(256) void k_flow_end(EdgeArgs p) {
       for (int j = 0; j < CN; ++j) p.aud_out[((size_t)b * 8 + j) * p.La + pos] = y[j];
     }
     start_conv<CN / 2>(p, b, h_off, y + (p.swap_next ? CN / 2 : 0), qtr * CQ, CQ);
+    if (p.folded && qtr == 0) write_xa<CN / 2>(p, b, h_off, y + (p.swap_next ? CN / 2 : 0));
   }
 }
 
@@ -1416,7 +1648,14 @@ __global__ __launch_bounds__(256) void k_flow_end4(EdgeArgs p) {
   for (int e = 0; e < 4; ++e)
 #pragma unroll
     for (int j = 0; j < CC; ++j) o[e][j] = p.end_b[j];
-  for (int q = 0; q < 4; ++q) {
+  if (p.folded) {
+#pragma unroll
+    for (int j = 0; j < CC; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(p.skip + ((size_t)b * 8 + j) * p.Lr + sk_off);
+      o[0][j] = v.x; o[1][j] = v.y; o[2][j] = v.z; o[3][j] = v.w;
+    }
+  }
+  for (int q = 0; q < (p.folded ? 0 : 4); ++q) {
     float acc[4][CC];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -1487,6 +1726,18 @@ __global__ __launch_bounds__(256) void k_flow_end4(EdgeArgs p) {
     float* d = dst + (size_t)ch * p.Lp;
     if (nv == 4) *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
     else for (int e = 0; e < nv; ++e) d[e] = v[e];
+  }
+  if (p.folded) {
+    float* xd = p.xa_out + (size_t)b * 8 * p.Lp + h_off;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = j < HN ? y[e][a0 + j] : j == HN ? 1.0f : 0.0f;
+      float* d = xd + (size_t)j * p.Lp;
+      if (nv == 4) *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+      else for (int e = 0; e < nv; ++e) d[e] = v[e];
+    }
   }
 }
 
@@ -1609,6 +1860,12 @@ struct facppg_wg {
   float4* wcpm[MAXF][8];
   float* b1pm[MAXF][8];
   float4 *w1_16[MAXF][8], *wc_16[MAXF][8], *w2_16[MAXF][8];   // the same weights as k_wn_layer16's 16x16x4 images
+  // folded flow edges (k_fold_end_rows / k_fold_first): end-row image per layer, folded end bias per flow, the first layer's
+  // folded tap image (both lane orders), res-rows-only images of the non-last res_skip convs (both lane orders)
+  float* we[MAXF][8];
+  float* endb[MAXF];
+  float4 *w1f[MAXF], *w1f_16[MAXF];
+  float4 *w2r[MAXF][8], *w2r_16[MAXF][8];
   int profiling;
   std::vector<hipEvent_t> ev;  // pairs around each k_wn_layer launch
   int ev_used;
@@ -1683,7 +1940,8 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   const size_t nm = cfg->n_mel_channels;
   const size_t w1_bytes = (size_t)(16 * NG1 + 8) * 64 * sizeof(float4);
   auto w2_bytes = [&](int last) { return (size_t)(4 * (last ? 2 : 4) * NG2 + 8) * 64 * sizeof(float4); };
-  struct Off { size_t start_w, start_b, end_w, end_b, winv, wfwd, w1[8], w2[8], b1[8], b2[8], w1pm[8], wcpm[8], b1pm[8], w1_16[8], wc_16[8], w2_16[8]; } fo[MAXF];
+  struct Off { size_t start_w, start_b, end_w, end_b, winv, wfwd, w1[8], w2[8], b1[8], b2[8], w1pm[8], wcpm[8], b1pm[8], w1_16[8], wc_16[8], w2_16[8],
+               we[8], endb, w1f, w1f_16, w2r[8], w2r_16[8]; } fo[MAXF];
   h->P = cfg->hop_length / 8;
   h->nj = (cfg->upsample_kernel + cfg->hop_length - 1) / cfg->hop_length;
   h->kc = h->nj * NMEL;
@@ -1702,7 +1960,12 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
       fo[k].w1_16[i] = take(w1pm_bytes);                      // same floats, other lane order
       fo[k].wc_16[i] = take(wcpm_bytes);                      // (the +8 groups of look-ahead padding cover 4 16-wide groups)
       fo[k].w2_16[i] = take((size_t)(C / 16 + 4) * (last ? 16 : 32) * 64 * sizeof(float4));   // 16 K groups + 4 of look-ahead
+      fo[k].we[i] = take(8 * 64 * 8 * 4);
+      fo[k].w2r[i] = last ? 0 : take(w2_bytes(1));
+      fo[k].w2r_16[i] = last ? 0 : take((size_t)(C / 16 + 4) * 16 * 64 * sizeof(float4));
     }
+    fo[k].endb = take(8 * 4);
+    fo[k].w1f = take((size_t)8 * 1024 * sizeof(float4)); fo[k].w1f_16 = take((size_t)4 * 2048 * sizeof(float4));
     fo[k].end_w = take(cc * C * 4); fo[k].end_b = take(cc * 4); fo[k].winv = take(cc * cc * 4); fo[k].wfwd = take(cc * cc * 4);
   }
   h->arena_bytes = off;
@@ -1714,7 +1977,8 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   // scratch for folding the upsampler into the conditioning convs: U, one layer's folded matrices, packed Wc
   const size_t ncol = (size_t)h->P * h->kcp;
   const size_t t_u = 0, t_f = t_u + NCOND * ncol * 4, t_a = t_f + (size_t)2 * C * ncol * 4;
-  const size_t tmp_bytes = t_a + packed_a_float4s(2 * C, NCOND) * sizeof(float4);
+  const size_t t_f0 = t_a + packed_a_float4s(2 * C, NCOND) * sizeof(float4), t_bs = t_f0 + (size_t)2 * C * 64 * 4;
+  const size_t tmp_bytes = t_bs + (size_t)8 * C * 4;
   char* tmp = nullptr;
   if (hipMalloc((void**)&tmp, tmp_bytes) != hipSuccess) {
     set_error("hipMalloc(%zu) for weight folding scratch failed", tmp_bytes);
@@ -1742,6 +2006,7 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   }
   for (int k = 0; k < cfg->n_flows; ++k) {
     const size_t hh = h->n_half[k], cc = 2 * hh;
+    const float* h_flow_src = src;
     h->start_w[k] = F(fo[k].start_w); h->start_b[k] = F(fo[k].start_b);
     WG_TRY(cpy(h->start_w[k], src, C * hh)); src += C * hh;
     WG_TRY(cpy(h->start_b[k], src, C)); src += C;
@@ -1783,10 +2048,39 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
         k_pack_cond_16<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const float*)(tmp + t_f), h->wc_16[k][i], h->P, h->kcp);
       }
       k_pack_w2_16<<<((C / 16) * (last ? 16 : 32) * 64 + 255) / 256, 256, 0, stream>>>(rs_w, h->w2_16[k][i], last);
+      // folded flow edges: res rows alone (the first 256 rows of a non-last res_skip conv, packed like a last layer's
+      // 256 rows); this layer's skip bias for the folded end bias; the first layer's taps through the start conv
+      h->w2r[k][i] = last ? nullptr : (float4*)(h->arena + fo[k].w2r[i]);
+      h->w2r_16[k][i] = last ? nullptr : (float4*)(h->arena + fo[k].w2r_16[i]);
+      if (!last) {
+        k_pack_w2<<<(4 * 2 * NG2 * 64 + 255) / 256, 256, 0, stream>>>(rs_w, h->w2r[k][i], 1);
+        k_pack_w2_16<<<((C / 16) * 16 * 64 + 255) / 256, 256, 0, stream>>>(rs_w, h->w2r_16[k][i], 1);
+      }
+      k_copy_rows<<<1, 256, 0, stream>>>(rs_b + (last ? 0 : C), (float*)(tmp + t_bs) + i * C, C);
+      if (i == 0) {
+        h->w1f[k] = (float4*)(h->arena + fo[k].w1f); h->w1f_16[k] = (float4*)(h->arena + fo[k].w1f_16);
+        k_fold_first<<<(2 * C * 64 + 255) / 256, 256, 0, stream>>>(in_w, h->start_w[k], h->start_b[k], (float*)(tmp + t_f0), (int)hh);
+        k_pack_cond_pm<<<(8 * 1024 + 255) / 256, 256, 0, stream>>>((const float*)(tmp + t_f0), h->w1f[k], 1, 64);
+        k_pack_cond_16<<<(4 * 2048 + 255) / 256, 256, 0, stream>>>((const float*)(tmp + t_f0), h->w1f_16[k], 1, 64);
+      }
     }
     h->end_w[k] = F(fo[k].end_w); h->end_b[k] = F(fo[k].end_b); h->winv[k] = F(fo[k].winv);
     WG_TRY(cpy(h->end_w[k], src, cc * C)); src += cc * C;
     WG_TRY(cpy(h->end_b[k], src, cc)); src += cc;
+    {
+      // the skip rows of every layer of this flow seen through the end conv (src has moved past them: walk again)
+      const float* q = h_flow_src;
+      q += C * hh + C;
+      for (int i = 0; i < cfg->wn_layers; ++i) {
+        const int last = i == cfg->wn_layers - 1;
+        q += (size_t)2 * C * C * 3 + 2 * C + (size_t)2 * C * NCOND + 2 * C;
+        const float* rs_w = q; q += (last ? C : 2 * C) * C + (last ? C : 2 * C);
+        h->we[k][i] = F(fo[k].we[i]);
+        k_fold_end_rows<<<(8 * 64 * 8 + 255) / 256, 256, 0, stream>>>(h->end_w[k], rs_w + (last ? 0 : (size_t)C * C), h->we[k][i], (int)cc);
+      }
+      h->endb[k] = F(fo[k].endb);
+      k_fold_end_bias<<<1, 64, 0, stream>>>(h->end_w[k], h->end_b[k], (const float*)(tmp + t_bs), cfg->wn_layers, h->endb[k], (int)cc);
+    }
     WG_TRY(cpy(h->winv[k], src, cc * cc)); src += cc * cc;
     h->wfwd[k] = F(fo[k].wfwd);
     WG_TRY(cpy(h->wfwd[k], src, cc * cc)); src += cc * cc;
@@ -1799,6 +2093,10 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<true, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer8<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer8<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<false, 2, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<true, 2, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer8<false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer8<true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipFree(tmp);
 #undef WG_TRY
   *out = h;
@@ -1838,7 +2136,7 @@ WsLayout ws_layout(const facppg_wg_config& c, int B, int T) {
 // phase-major layout (k_wn_layer<PM>): frames are the contiguous axis of every phase row
 struct PmLayout {
   int L, La, Tr, Tqp, P;
-  size_t h0, h1, skip, melp, aud0, aud1, z, total;
+  size_t h0, h1, xa, skip, melp, aud0, aud1, z, total;
 };
 PmLayout pm_layout(const facppg_wg_config& c, int B, int T) {
   PmLayout w;
@@ -1851,6 +2149,7 @@ PmLayout pm_layout(const facppg_wg_config& c, int B, int T) {
   auto take = [&](size_t floats) { size_t o = off; off += (floats * 4 + 255) / 256 * 256; return o; };
   w.h0 = take((size_t)B * C * w.P * w.Tqp);
   w.h1 = take((size_t)B * C * w.P * w.Tqp);
+  w.xa = take((size_t)B * 8 * w.P * w.Tqp);     // right behind h0 | h1: one memset zeroes the margins of all three
   w.skip = take((size_t)B * C * w.P * w.Tr);
   w.melp = take((size_t)B * NMEL * w.Tqp);
   w.aud0 = take((size_t)B * 8 * w.La);
@@ -1920,8 +2219,12 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   float* aud[2] = {(float*)(ws + w.aud0), (float*)(ws + w.aud1)};
   float* zbuf = (float*)(ws + w.z);
   const int nf = c.n_flows;
-  // zero margins of h (the convolution's zero padding) and the frames past each utterance's end
-  FACPPG_HIP_CHECK(hipMemsetAsync(ws + w.h0, 0, (size_t)B * C * w.P * w.Tqp * 4 * 2, s));
+  // FACPPG_WG_EDGE_FOLD=0 runs the layers without the folded flow edges (512-row res_skip GEMM, 256-channel skip sum)
+  const char* fold_env = getenv("FACPPG_WG_EDGE_FOLD");   // (read per call: the tests flip it)
+  const bool fold = !fold_env || atoi(fold_env) != 0;
+  float* xa = (float*)(ws + w.xa);
+  // zero margins of h and xa (the convolution's zero padding) and the frames past each utterance's end
+  FACPPG_HIP_CHECK(hipMemsetAsync(ws + w.h0, 0, w.skip - w.h0, s));
   k_mel_pad<<<dim3((w.Tqp + 255) / 256, B * NMEL), 256, 0, s>>>(mel_dev, melp, T_valid_dev, T, w.Tqp);
   const float* z = z_dev;
   const size_t zn = (size_t)B * 8 * w.L;
@@ -1934,6 +2237,7 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   e.skip = skip; e.t_valid = T_valid_dev; e.sigma = sigma; e.T = T; e.hop8 = w.P; e.Lp = w.P * w.Tqp; e.Lr = w.P * w.Tr; e.L = w.L;
   e.La = w.La; e.P = w.P; e.Tr = w.Tr; e.Tqp = w.Tqp;
   e.final_audio = audio_dev;
+  e.folded = fold; e.xa_out = xa;
   const dim3 egrid((T + 255) / 256, B, w.P);
   const bool fqs = (long)B * w.L < 65536;   // k_flow_end: split channels over the waves when positions are few
   const dim3 fgrid(fqs ? (T + 63) / 64 : (T + 255) / 256, B, w.P);
@@ -1989,7 +2293,8 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   // uniform batch: cut tiles from the B*T frames of a phase laid end to end, so only the very last tile is ragged
   static const char* no_flat = getenv("FACPPG_WN_NO_FLAT");
   if (!T_valid_dev && T % 4 == 0 && !no_flat && !tile16) { a.flat_cols = B * T; a.nt = (B * T + tn - 1) / tn; }
-  a.nch = NCHH + h->kcp / KCH; a.ngc = h->kcp / 8; a.kc = h->kc; a.hop = c.hop_length; a.ksize = c.upsample_kernel;
+  a.ngc = h->kcp / 8; a.kc = h->kc; a.hop = c.hop_length; a.ksize = c.upsample_kernel;
+  a.xa = xa;
   // workgroup i lands on XCD i % 8: give every XCD its own phases so a phase's weight image lives in one L2
   static const char* no_xcd = getenv("FACPPG_WN_NO_XCD_MAP");
   static const char* tord = getenv("FACPPG_WN_TILE_ORDER");   // 1 phase-slowest (default), 2 tile-slowest, 3 tile-slowest within phase pairs
@@ -2012,25 +2317,36 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
       if (tile16) { a.w1 = h->w1_16[k][i]; a.wc = h->wc_16[k][i]; a.w2 = h->w2_16[k][i]; }
       a.dil = 1 << i; a.first = (i == 0);
       const bool last = i == c.wn_layers - 1;
-      if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
-      if (tile16) {
-        if (last) k_wn_layer16<true><<<lgrid, 512, 16384, s>>>(a);
-        else k_wn_layer16<false><<<lgrid, 512, 16384, s>>>(a);
-      } else if (narrow) {
-        if (w8mode == 0) {
-          if (last) k_wn_layer<true, 1, false, true><<<lgrid, 256, 32768, s>>>(a);
-          else k_wn_layer<false, 1, false, true><<<lgrid, 256, 32768, s>>>(a);
-        } else {
-          if (last) k_wn_layer8<true, 1><<<lgrid, 512, 32768, s>>>(a);
-          else k_wn_layer8<false, 1><<<lgrid, 512, 32768, s>>>(a);
-        }
-      } else if (w8mode == 2) {
-        if (last) k_wn_layer8<true, 2><<<lgrid, 512, 65536, s>>>(a);
-        else k_wn_layer8<false, 2><<<lgrid, 512, 65536, s>>>(a);
-      } else {
-        if (last) k_wn_layer<true, 2, false, true><<<lgrid, 256, 65536, s>>>(a);
-        else k_wn_layer<false, 2, false, true><<<lgrid, 256, 65536, s>>>(a);
+      a.nconv = NCHH;
+      if (fold) {
+        a.we = h->we[k][i]; a.endb = h->endb[k];
+        a.w2 = tile16 ? h->w2r_16[k][i] : h->w2r[k][i];
+        if (i == 0) { a.nconv = 1; a.w1 = tile16 ? h->w1f_16[k] : h->w1f[k]; }
       }
+      a.nch = a.nconv + h->kcp / KCH;
+      if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
+      // folded flow edges need 8 more LDS rows per tile (the end rows; 16-frame tiles: their 8 K-slice partials)
+#define WN_LAUNCH(KERNEL_LAST, KERNEL_MID, THREADS, LDS)              \
+  do {                                                                 \
+    if (last) KERNEL_LAST<<<lgrid, THREADS, LDS, s>>>(a);              \
+    else KERNEL_MID<<<lgrid, THREADS, LDS, s>>>(a);                    \
+  } while (0)
+      if (fold) {
+        if (tile16) WN_LAUNCH((k_wn_layer16<true, true>), (k_wn_layer16<false, true>), 512, 16384 + 4096);
+        else if (narrow) {
+          if (w8mode == 0) WN_LAUNCH((k_wn_layer<true, 1, false, true, true>), (k_wn_layer<false, 1, false, true, true>), 256, 32768 + 1024);
+          else WN_LAUNCH((k_wn_layer8<true, 1, true>), (k_wn_layer8<false, 1, true>), 512, 32768 + 1024);
+        } else if (w8mode == 2) WN_LAUNCH((k_wn_layer8<true, 2, true>), (k_wn_layer8<false, 2, true>), 512, 65536 + 2048);
+        else WN_LAUNCH((k_wn_layer<true, 2, false, true, true>), (k_wn_layer<false, 2, false, true, true>), 256, 65536 + 2048);
+      } else {
+        if (tile16) WN_LAUNCH((k_wn_layer16<true>), (k_wn_layer16<false>), 512, 16384);
+        else if (narrow) {
+          if (w8mode == 0) WN_LAUNCH((k_wn_layer<true, 1, false, true>), (k_wn_layer<false, 1, false, true>), 256, 32768);
+          else WN_LAUNCH((k_wn_layer8<true, 1>), (k_wn_layer8<false, 1>), 512, 32768);
+        } else if (w8mode == 2) WN_LAUNCH((k_wn_layer8<true, 2>), (k_wn_layer8<false, 2>), 512, 65536);
+        else WN_LAUNCH((k_wn_layer<true, 2, false, true>), (k_wn_layer<false, 2, false, true>), 256, 65536);
+      }
+#undef WN_LAUNCH
       if (!last) hi ^= 1;
       if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
     }
