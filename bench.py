@@ -35,17 +35,35 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 BATCH, FRAMES, HOP, SR = 8, 1000, 256, 22050
 
 
-def layer_flops_per_position(n_layers=8, C=256, ncond=None):
-    """Algorithmic FLOPs of one k_wn_layer launch per group position, averaged over a flow's
-    layers: in_layer 2*C*2C*3 + cond 2*ncond*2C + res_skip 2*C*2C (C last).
-    The inference kernels fold the upsampling ConvTranspose1d into the conditioning conv, which
-    shrinks its reduction from 640 (= 80 mel x 8 group) to ceil(1024/hop)*80 = 320 rows: the FLOPs
-    counted here are those of the folded formulation that actually runs (FACPPG_WG_UNFOLDED=1
-    runs, and counts, the reference's 640)."""
+def layer_flops_per_position(n_layers=8, C=256, ncond=None, edge_fold=None, n_flows=12, n_early_every=4, n_early_size=2,
+                             n_group=8):
+    """Algorithmic FLOPs of one k_wn_layer launch per group position, averaged over all layers of all flows
+    (SURVEY.md Appendix D): in_layer 2*C*2C*3 + cond 2*ncond*2C + res_skip 2*C*2C (C in a flow's last layer).
+    The FLOPs counted are those of the formulation that actually runs:
+    * the upsampling ConvTranspose1d is folded into the conditioning conv, whose reduction shrinks from 640
+      (= 80 mel x 8 group) to ceil(1024/hop)*80 = 320 rows (FACPPG_WG_UNFOLDED=1 runs, and counts, the reference's 640);
+    * the flow edges are folded into the layers (FACPPG_WG_EDGE_FOLD=0 runs, and counts, the unfolded form): the end
+      conv is applied through every layer's skip rows, so res_skip is 256 res rows (none in the last layer) plus
+      2*n_half end rows, and the first layer's three taps act on the n_half conditioning channels + 1 through the start
+      conv (K = 3*(n_half+1) instead of 768).  Zero padding of these small operands to MFMA tile sizes is NOT counted.
+    ncond=640 with edge_fold=False is the reference's own formulation."""
+    unfolded = os.environ.get("FACPPG_WG_UNFOLDED", "0") not in ("", "0")
     if ncond is None:
-        ncond = 640 if os.environ.get("FACPPG_WG_UNFOLDED", "0") not in ("", "0") else -(-1024 // HOP) * 80
+        ncond = 640 if unfolded else -(-1024 // HOP) * 80
+    if edge_fold is None:
+        edge_fold = not unfolded and os.environ.get("FACPPG_WG_EDGE_FOLD", "1") not in ("0",)
     g1 = 2 * (3 * C + ncond) * 2 * C
-    return ((n_layers - 1) * (g1 + 2 * C * 2 * C) + (g1 + 2 * C * C)) / n_layers
+    if not edge_fold:
+        return ((n_layers - 1) * (g1 + 2 * C * 2 * C) + (g1 + 2 * C * C)) / n_layers
+    total, hh = 0, n_group // 2
+    for k in range(n_flows):
+        if k % n_early_every == 0 and k > 0:
+            hh -= n_early_size // 2
+        for i in range(n_layers):
+            taps = 2 * (3 * (hh + 1) + ncond) * 2 * C if i == 0 else g1
+            res = 0 if i == n_layers - 1 else 2 * C * C
+            total += taps + res + 2 * (2 * hh) * C
+    return total / (n_flows * n_layers)
 
 
 def cpu_baseline_worker(threads, frames):
@@ -448,8 +466,8 @@ def main():
     flops = layer_flops_per_position() * positions
     achieved = flops / (layer_ms * 1e-3) / 1e12 if layer_ms > 0 else 0.0
     # the same launch priced at the reference formulation's FLOPs (2*(3*256+640)*512 + res_skip per
-    # position); it can exceed the fp32 MFMA peak because the folded kernel executes 19 % fewer FLOPs
-    flops_ref = layer_flops_per_position(ncond=640) * positions
+    # position); it can exceed the fp32 MFMA peak because the folded kernels execute a third fewer FLOPs
+    flops_ref = layer_flops_per_position(ncond=640, edge_fold=False) * positions
     achieved_ref = flops_ref / (layer_ms * 1e-3) / 1e12 if layer_ms > 0 else 0.0
     traffic, traffic_src = pmc_traffic()
     out = {
