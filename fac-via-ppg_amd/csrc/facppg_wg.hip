@@ -927,16 +927,6 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
     }
   }
   f32x16 acc[2][NCB];   // [0] tanh rows / res rows, [1] sigmoid rows / skip rows of channels chb..chb+31
-#pragma unroll
-  for (int rb = 0; rb < 2; ++rb) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 bv = *reinterpret_cast<const float4*>(p.b1 + rb * C + chb + 4 * kh + 8 * q);
-      acc[rb][0][4 * q + 0] = bv.x; acc[rb][0][4 * q + 1] = bv.y; acc[rb][0][4 * q + 2] = bv.z; acc[rb][0][4 * q + 3] = bv.w;
-    }
-#pragma unroll
-    for (int cb = 1; cb < NCB; ++cb) acc[rb][cb] = acc[rb][0];
-  }
   // images are [k-group][16 row blocks][64 lanes]; row block index = wq*4 + sub (+2 for the second half)
   const float4* wave_a = p.w1 + (wq * 4 + sub) * 64 + lane;
   const float4* wave_c = p.wc + (size_t)ph * p.ngc * 1024 + (wq * 4 + sub) * 64 + lane;
@@ -948,6 +938,10 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
   const float* sb4 = p.melp + (size_t)b * NMEL * p.Tqp + in_off - ph * p.Tqp;
   float4 stg[NSTG4];
   auto stage_load = [&](int c) {
+#if defined(FACPPG_ABLATE8) && (FACPPG_ABLATE8 & 2)
+    for (int jj = 0; jj < NSTG4; ++jj) stg[jj] = make_float4(0.001f * c, 0.f, 0.f, 0.f);   // ablation: no activation loads
+    return;
+#endif
     const bool conv = c < p.nconv;
     const float* base = conv ? hb4 : sb4;
 #pragma unroll
@@ -969,7 +963,11 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
   };
   auto load_a1 = [&](float4 (&a)[2], int gg) {
     const int ngh = 8 * p.nconv;
+#if defined(FACPPG_ABLATE8) && (FACPPG_ABLATE8 & 4)
+    const float4* src = wave_a + (size_t)(gg & 7) * 1024;   // ablation: the weight stream stays in L1/L2
+#else
     const float4* src = gg < ngh ? wave_a + (size_t)gg * 1024 : wave_c + (size_t)(gg - ngh) * 1024;
+#endif
     a[0] = src[0];
     a[1] = src[128];
   };
@@ -989,6 +987,17 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
   stage_load(0);
 #pragma unroll
   for (int i = 0; i < RING - 1; ++i) load_a1(ar[i], i);
+  // accumulators start at the bias; loaded behind the first operand loads so the prologue is one memory round trip, not two
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 bv = *reinterpret_cast<const float4*>(p.b1 + rb * C + chb + 4 * kh + 8 * q);
+      acc[rb][0][4 * q + 0] = bv.x; acc[rb][0][4 * q + 1] = bv.y; acc[rb][0][4 * q + 2] = bv.z; acc[rb][0][4 * q + 3] = bv.w;
+    }
+#pragma unroll
+    for (int cb = 1; cb < NCB; ++cb) acc[rb][cb] = acc[rb][0];
+  }
   stage_write(0);
   __syncthreads();
   for (int c = 0; c < nch; ++c) {
@@ -1003,7 +1012,9 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
       mfma2(ar[g % RING], bq, 2);
     }
     stage_write((c + 1) & 1);
-    __syncthreads();
+#if !(defined(FACPPG_ABLATE8) && (FACPPG_ABLATE8 & 1))
+    __syncthreads();   // (ablation bit 1: no barrier per chunk -- racy, timing only)
+#endif
   }
   // gate -> LDS [256][TNt]
 #pragma unroll
@@ -1015,6 +1026,17 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
   // res_skip 1x1 conv
   constexpr int NRB2 = EF ? (LAST ? 0 : 1) : LAST ? 1 : 2;   // EF: res rows only (image laid out like a LAST layer's 256 rows)
   constexpr bool ROWS256 = LAST || EF;
+  // narrow tiles run one workgroup per CU: nothing hides the epilogue's read of h_in (the residual), so fetch it here,
+  // ahead of the second GEMM
+  constexpr bool HPRE = !LAST && NCB == 1;
+  float4 hpre[HPRE ? 32 / RPL4 : 1];
+  if constexpr (HPRE) {
+    if (nvalid >= 4) {
+      const float* rb0 = p.h_in + (size_t)b * C * p.Lp + in_off;
+#pragma unroll
+      for (int i = 0; i < 32 / RPL4; ++i) hpre[i] = *reinterpret_cast<const float4*>(rb0 + (size_t)(chb + i * RPL4 + srow4) * p.Lp);
+    }
+  }
 #pragma unroll
   for (int rb = 0; rb < NRB2; ++rb) {
 #pragma unroll
@@ -1103,14 +1125,16 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
     const float* rbase = is_res ? p.h_in + (size_t)b * C * p.Lp + in_off : gbase;
     const int pitch = is_res ? p.Lp : p.Lr;
     const bool add = is_res || !p.first;
-#pragma unroll 4
+#pragma unroll
     for (int i = 0; i < 32 / RPL4; ++i) {
       const int row = i * RPL4 + srow4;
       const size_t o = (size_t)(chb + row) * pitch;
       float4 v = *reinterpret_cast<const float4*>(slab + row * TNt + scol4);
       if (nv >= 4) {
         if (add) {
-          const float4 x = *reinterpret_cast<const float4*>(rbase + o);
+          float4 x;
+          if (HPRE && is_res) x = hpre[i];
+          else x = *reinterpret_cast<const float4*>(rbase + o);
           v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
         }
         *reinterpret_cast<float4*>(gbase + o) = v;
@@ -1162,11 +1186,6 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
     tapo[tp] = (pp - qsh * p.P) * p.Tqp + HQ + q0 + qsh;
   }
   f32x4 acc[4];
-#pragma unroll
-  for (int rbl = 0; rbl < 4; ++rbl) {
-    const float4 bv = *reinterpret_cast<const float4*>(p.b1 + (rbl >> 1) * C + chb + (rbl & 1) * 16 + 4 * kq);
-    acc[rbl][0] = bv.x; acc[rbl][1] = bv.y; acc[rbl][2] = bv.z; acc[rbl][3] = bv.w;
-  }
   const float4* wave_a = p.w1 + (w8 * 4) * 64 + lane;                                    // + g16 * 2048 + rbl * 64
   const float4* wave_c = p.wc + (size_t)ph * (p.ngc / 2) * 2048 + (w8 * 4) * 64 + lane;   // ngc counts 8-wide groups
   const int nch = pm_chunks(p, ph), NGH16 = p.nconv * 4;
@@ -1199,6 +1218,11 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
   stage_load(0);
 #pragma unroll
   for (int i = 0; i < RING - 1; ++i) load_a(ar[i], i);
+#pragma unroll
+  for (int rbl = 0; rbl < 4; ++rbl) {
+    const float4 bv = *reinterpret_cast<const float4*>(p.b1 + (rbl >> 1) * C + chb + (rbl & 1) * 16 + 4 * kq);
+    acc[rbl][0] = bv.x; acc[rbl][1] = bv.y; acc[rbl][2] = bv.z; acc[rbl][3] = bv.w;
+  }
   stage_write(0);
   __syncthreads();
   for (int c = 0; c < nch; ++c) {
@@ -1231,6 +1255,15 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
   // res_skip 1x1 conv: blocks rbl 0,1 = res rows chb.., rbl 2,3 = skip rows 256+chb.. (LAST: rbl 0,1 = skip rows chb..)
   constexpr int NB2 = EF ? (LAST ? 0 : 2) : LAST ? 2 : 4;   // EF: res rows only (image laid out like a LAST layer's 256 rows)
   constexpr bool ROWS256 = LAST || EF;
+  // the residual h_in of this wave's 32 res rows, fetched ahead of the second GEMM (see k_wn_layer8)
+  float4 hpre[2];
+  if constexpr (!LAST) {
+    if (nvalid - (lane & 3) * 4 >= 4) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+        hpre[it] = *reinterpret_cast<const float4*>(p.h_in + ((size_t)b * C + chb + it * 16 + (lane >> 2)) * p.Lp + in_off + (lane & 3) * 4);
+    }
+  }
 #pragma unroll
   for (int rbl = 0; rbl < NB2; ++rbl) {
     const float4 bv = *reinterpret_cast<const float4*>(p.b2 + (ROWS256 ? 0 : (rbl >> 1) * C) + chb + (rbl & 1) * 16 + 4 * kq);
@@ -1327,7 +1360,9 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
       float4 v = *reinterpret_cast<const float4*>(slab + row * TN16 + ecol);
       if (nv >= 4) {
         if (add) {
-          const float4 x = *reinterpret_cast<const float4*>(rbase + o);
+          float4 x;
+          if (!LAST && is_res) x = hpre[it];
+          else x = *reinterpret_cast<const float4*>(rbase + o);
           v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
         }
         *reinterpret_cast<float4*>(gbase + o) = v;
