@@ -284,6 +284,44 @@ __global__ void k_copy_rows(const float* __restrict__ src, float* __restrict__ d
   if (i < n) dst[i] = src[i];
 }
 
+// Ragged batches: the tiles of a phase are cut from the utterances' valid frames laid end to end, each utterance rounded
+// up to a multiple of 4 frames (a lane moves 4 frames at a time), instead of per utterance -- no half-empty last tile per
+// utterance.  k_group_offsets: off[b] = sum_{b' < b} round_up(T_b', 4) / 4 (one block; chunked scan).  k_group_table:
+// entry g = (b, first frame, live frames from there on, 0) for the g-th 4-frame group, zeros past the end.
+__global__ __launch_bounds__(1024) void k_group_offsets(const int* __restrict__ t_valid, int B, int* __restrict__ off) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x, per = (B + 1023) / 1024, b0 = t * per, b1 = min(B, b0 + per);
+  int sum = 0;
+  for (int b = b0; b < b1; ++b) sum += (t_valid[b] + 3) / 4;
+  part[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - sum;   // exclusive prefix of this thread's chunk
+  for (int b = b0; b < b1; ++b) { off[b] = run; run += (t_valid[b] + 3) / 4; }
+  if (t == 1023) off[B] = part[1023];
+}
+
+__global__ void k_group_table(const int* __restrict__ t_valid, const int* __restrict__ off, int B, int4* __restrict__ table, int n) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  int4 e = make_int4(0, 0, 0, 0);
+  if (g < off[B]) {
+    int lo = 0, hi = B - 1;   // the last b with off[b] <= g (utterances of zero frames own no group and are skipped)
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (off[mid] <= g) lo = mid; else hi = mid - 1;
+    }
+    const int q = 4 * (g - off[lo]);
+    e = make_int4(lo, q, t_valid[lo] - q, 0);
+  }
+  table[g] = e;
+}
+
 // ------------------------------------------------------------------------------------------
 // k_wn_layer
 // ------------------------------------------------------------------------------------------
@@ -305,6 +343,8 @@ struct WnArgs {
   int P, Tr, Tqp, ntq, nt, nch, ngc, kc, xcd_map;
   int hop, ksize;      // upsampler stride / kernel size: late phases reach fewer mel frames (pm_chunks)
   int flat_cols;       // > 0: uniform batch, tiles cut from the B*T frames of a phase laid end to end (no ragged last tile per utterance)
+  const int4* groups;  // ragged batch: tiles cut from the utterances' valid frames laid end to end (each rounded up to 4 frames);
+                       // entry per 4-frame group = (b, first frame, live frames from there on, -), dead groups have .z <= 0
   // folded flow edges (EF kernels): skip = the [B][8][P*Tr] end-row accumulator
   const float* xa;     // [B][8][P][Tqp] conditioning audio channels + the in-utterance indicator, zero margins (first layer's operand)
   const float* we;     // end-row image of this layer (k_fold_end_rows)
@@ -432,7 +472,11 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
     // batch b, first frame qcol, nvalid = live columns from qcol on (may be <= 0)
     int qcol;
     t0 = 0;
-    if (p.flat_cols > 0) {
+    if (p.groups) {
+      const int4 e = p.groups[tile * (TNt / 4) + lane % (TNt / 4)];
+      if (__builtin_amdgcn_readfirstlane(e.z) <= 0) return;   // lane 0 holds the tile's first group: the whole tile is past the end
+      b = e.x; qcol = e.y; nvalid = e.z;
+    } else if (p.flat_cols > 0) {
       const int c0 = tile * TNt + (lane % (TNt / 4)) * 4;
       const int cl = min(c0, p.flat_cols - 4);
       b = cl / p.T; qcol = cl - b * p.T; nvalid = p.flat_cols - c0;
@@ -907,7 +951,11 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
     else { ph = lin / p.nt; tile = lin % p.nt; }
     if (ph >= p.P) return;
     int qcol;
-    if (p.flat_cols > 0) {
+    if (p.groups) {
+      const int4 e = p.groups[tile * (TNt / 4) + lane % (TNt / 4)];
+      if (__builtin_amdgcn_readfirstlane(e.z) <= 0) return;   // lane 0 holds the tile's first group: the whole tile is past the end
+      b = e.x; qcol = e.y; nvalid = e.z;
+    } else if (p.flat_cols > 0) {
       const int c0 = tile * TNt + (lane % (TNt / 4)) * 4;
       const int cl = min(c0, p.flat_cols - 4);
       b = cl / p.T; qcol = cl - b * p.T; nvalid = p.flat_cols - c0;
@@ -2171,7 +2219,8 @@ WsLayout ws_layout(const facppg_wg_config& c, int B, int T) {
 // phase-major layout (k_wn_layer<PM>): frames are the contiguous axis of every phase row
 struct PmLayout {
   int L, La, Tr, Tqp, P;
-  size_t h0, h1, xa, skip, melp, aud0, aud1, z, total;
+  size_t h0, h1, xa, skip, melp, aud0, aud1, z, goff, gtab, total;
+  int ngroups;   // 4-frame groups a ragged batch can have at most (table entries; a multiple of 16 = one 64-frame tile)
 };
 PmLayout pm_layout(const facppg_wg_config& c, int B, int T) {
   PmLayout w;
@@ -2190,6 +2239,9 @@ PmLayout pm_layout(const facppg_wg_config& c, int B, int T) {
   w.aud0 = take((size_t)B * 8 * w.La);
   w.aud1 = take((size_t)B * 8 * w.La);
   w.z = take((size_t)B * 8 * w.L + 4);
+  w.ngroups = round_up(B * ((T + 3) / 4), 16);
+  w.goff = take((size_t)B + 1);
+  w.gtab = take((size_t)w.ngroups * 4);
   w.total = off;
   return w;
 }
@@ -2328,6 +2380,14 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   // uniform batch: cut tiles from the B*T frames of a phase laid end to end, so only the very last tile is ragged
   static const char* no_flat = getenv("FACPPG_WN_NO_FLAT");
   if (!T_valid_dev && T % 4 == 0 && !no_flat && !tile16) { a.flat_cols = B * T; a.nt = (B * T + tn - 1) / tn; }
+  if (T_valid_dev && B > 1 && !no_flat && !tile16) {
+    // ragged batch: the group table maps every lane's 4 frames to (utterance, frame); tiles past the end exit at once
+    int* goff = (int*)(ws + w.goff);
+    int4* gtab = (int4*)(ws + w.gtab);
+    k_group_offsets<<<1, 1024, 0, s>>>(T_valid_dev, B, goff);
+    k_group_table<<<(w.ngroups + 255) / 256, 256, 0, s>>>(T_valid_dev, goff, B, gtab, w.ngroups);
+    a.groups = gtab; a.nt = w.ngroups * 4 / tn;
+  }
   a.ngc = h->kcp / 8; a.kc = h->kc; a.hop = c.hop_length; a.ksize = c.upsample_kernel;
   a.xa = xa;
   // workgroup i lands on XCD i % 8: give every XCD its own phases so a phase's weight image lives in one L2

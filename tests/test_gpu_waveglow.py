@@ -260,11 +260,11 @@ def test_flow_end_four_frames_per_thread_same_bits(hop, B, T, lengths, monkeypat
 
 
 @pytest.mark.parametrize("env", ["FACPPG_WG_UNFOLDED=1", "FACPPG_WN_8W=0", "FACPPG_WN_NO_XCD_MAP=1", "FACPPG_WN_NO_FLAT=1", "FACPPG_WN_TILE16=2",
-                                 "FACPPG_WN_TILE16=0"])
+                                 "FACPPG_WN_TILE16=0", "FACPPG_WG_EDGE_FOLD=0"])
 def test_alternate_kernel_paths_match_golden(env):
     """The A/B switches select other kernels for the same call (the unfolded K=1408 layer the training
     direction uses; 4-wave tiles for small launches; no XCD-aware phase mapping; per-utterance tiles; 16-frame
-    tiles always / never).  They
+    tiles always / never; layers without the folded flow edges).  They
     are read once per process, so each runs the golden comparison in its own interpreter."""
     import os, subprocess, sys
     k, v = env.split("=")
@@ -273,3 +273,21 @@ def test_alternate_kernel_paths_match_golden(env):
                         "test_infer_matches_reference_golden or test_ragged_batch"], env=e, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("hop,B,T,lengths", [(256, 2, 300, None), (256, 3, 90, [90, 41, 7]), (160, 1, 64, None)])
+def test_folded_flow_edges_agree_with_unfolded_layers(hop, B, T, lengths, monkeypatch):
+    """The default inference path folds the flow edges into the WN layers (end conv through each layer's skip rows, the
+    first layer's taps through the start conv: csrc/facppg_wg.hip k_fold_end_rows / k_fold_first).  It is the same linear
+    algebra re-associated, so it must agree with the layer-by-layer form (FACPPG_WG_EDGE_FOLD=0: 512-row res_skip GEMM,
+    256-channel skip sum, end conv in k_flow_end) to fp32 round-off -- across tile widths (64 / 32 / 16 frames) and at the
+    ragged ends, where the folded start bias must vanish exactly where the reference zero-pads h."""
+    m, cfg = make_model(hop)
+    mel = synth.synthetic_mel(B, T, seed=5).cuda()
+    folded = m.infer(mel, sigma=0.6, seed=3, lengths=lengths)
+    monkeypatch.setenv("FACPPG_WG_EDGE_FOLD", "0")
+    plain = m.infer(mel, sigma=0.6, seed=3, lengths=lengths)
+    err = (folded - plain).cpu().numpy()
+    print("rms", rms(err), "max", np.abs(err).max(), "rms audio", rms(plain.cpu().numpy()))
+    assert rms(err) <= 2e-5 and np.abs(err).max() <= 5e-4
+    assert not torch.equal(folded, plain)   # (the switch did select another path)
