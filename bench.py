@@ -156,31 +156,40 @@ def train_worker():
     stft = TacotronSTFT(1024, 160, 1024, 80, 16000, 0.0, 8000.0).to(dev)
     crit = WaveGlowLoss(0.7071)
     out = {}
-    for prec, B in (("bf16", 3), ("bf16", 12), ("fp32", 3)):
+    from waveglow.graphed import GraphedTrainStep
+    for prec, B, graphed in (("bf16", 3, True), ("bf16", 12, True), ("bf16", 3, False), ("bf16", 12, False), ("fp32", 3, False)):
         m.train_precision = prec
-        opt = torch.optim.Adam(m.parameters(), lr=1e-5, fused=True)
+        # graphed: the step replayed as one captured HIP graph, as script.train_waveglow runs it by default under bf16
+        opt = torch.optim.Adam(m.parameters(), lr=1e-5, fused=True, capturable=graphed)
         g = np.random.Generator(np.random.PCG64(1))
         audio = torch.from_numpy(np.clip(g.standard_normal((B, 10000), dtype=np.float32) * 0.1, -1, 1)).to(dev)
         with torch.no_grad():
             mel = stft.mel_spectrogram(audio)
+        stepper = GraphedTrainStep(m, crit, opt, warmup=2) if graphed else None
         ts = []
-        for i in range(6):
+        for i in range(9 if graphed else 6):
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
-            m.zero_grad()
-            loss = crit(m((mel, audio)))
-            loss.backward()
-            opt.step()
+            if graphed:
+                loss = stepper(mel, audio)
+            else:
+                m.zero_grad()
+                loss = crit(m((mel, audio)))
+                loss.backward()
+                opt.step()
             torch.cuda.synchronize(dev)
             ts.append(time.perf_counter() - t0)
-        t = sorted(ts[1:])[len(ts[1:]) // 2]
+        steady = ts[4:] if graphed else ts[1:]              # graphed: 2 warm-up steps, the capturing step, one more
+        t = sorted(steady)[len(steady) // 2]
         flops = 3 * 20.26e6 * B * 10000                      # fwd 20.3 MFLOP/sample, fwd + bwd ~ 3x
         peak = 2500.0 if prec == "bf16" else PEAK_F32_MFMA_TFLOPS
-        out["%s_B%d" % (prec, B)] = {
+        out["%s_B%d%s" % (prec, B, "_graph" if graphed else "")] = {
             "workload": "WaveGlow training step (fwd + WaveGlowLoss + bwd + fused Adam), segment 10000 @16 kHz / hop 160, per-GPU batch %d, "
-                        "%s MFMA operands, fp32 accumulation / master weights / gradients, 1 GPU" % (B, prec),
+                        "%s MFMA operands, fp32 accumulation / master weights / gradients, 1 GPU, %s" % (
+                            B, prec, "one replayed HIP graph per step" if graphed else "launch by launch"),
             "ms_per_step": t * 1e3, "samples_per_s": B * 10000 / t, "tflops": flops / t / 1e12,
             "frac_of_mfma_peak": flops / t / 1e12 / peak, "mfma_peak_tflops": peak, "loss_finite": bool(torch.isfinite(loss))}
+        del stepper, opt
     print(json.dumps(out))
 
 

@@ -16,8 +16,10 @@ import torch
 from torch.utils.data import DataLoader
 from torch.utils.data.distributed import DistributedSampler
 
-from waveglow.distributed import init_distributed, apply_gradient_allreduce, reduce_tensor
+from waveglow.distributed import (init_distributed, apply_gradient_allreduce, allreduce_gradients, broadcast_parameters,
+                                  reduce_tensor)
 from waveglow.glow import WaveGlow, WaveGlowLoss
+from waveglow.graphed import GraphedTrainStep
 from waveglow.mel2samp import Mel2Samp
 
 
@@ -52,10 +54,11 @@ def train_step(model, criterion, optimizer, mel, audio, num_gpus=1):
 
 
 def train(num_gpus, rank, group_name, output_directory, epochs, learning_rate, sigma, iters_per_checkpoint, batch_size, seed,
-          checkpoint_path, data_config, dist_config, waveglow_config, max_iterations=None, train_precision=None):
+          checkpoint_path, data_config, dist_config, waveglow_config, max_iterations=None, train_precision=None, hip_graph=None):
     """train_waveglow.py:66-147.  ``train_precision`` (optional key of the config's train section): 'fp32' (default, the
     reference's arithmetic) or 'bf16' (bf16 MFMA operands, fp32 accumulation / master weights / gradients); the
-    FACPPG_TRAIN_PRECISION environment variable sets the default."""
+    FACPPG_TRAIN_PRECISION environment variable sets the default.  ``hip_graph`` (optional key): replay the step as one
+    captured HIP graph (waveglow.graphed); default: on for bf16 (FACPPG_TRAIN_GRAPH=0 turns it off), off for fp32."""
     torch.manual_seed(seed)
     torch.cuda.manual_seed(seed)
     if num_gpus > 1:
@@ -64,9 +67,20 @@ def train(num_gpus, rank, group_name, output_directory, epochs, learning_rate, s
     model = WaveGlow(**waveglow_config).cuda()
     if train_precision is not None:
         model.train_precision = train_precision
+    if hip_graph is None:
+        hip_graph = model.train_precision == "bf16" and os.environ.get("FACPPG_TRAIN_GRAPH", "1") != "0"
     if num_gpus > 1:
-        model = apply_gradient_allreduce(model)
-    optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate, fused=True)   # one multi-tensor kernel per state, not 938 x 4
+        # eager: the exchange hangs off the backward pass; graphed: it follows each replay (no autograd runs then)
+        if hip_graph:
+            broadcast_parameters(model, 0)
+        else:
+            model = apply_gradient_allreduce(model)
+    # one multi-tensor kernel per Adam state, not 938 x 4; inside the graph when there is no gradient exchange
+    optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate, fused=True, capturable=bool(hip_graph and num_gpus == 1))
+    stepper = None
+    if hip_graph:
+        stepper = GraphedTrainStep(model, criterion, optimizer,
+                                   sync_gradients=(lambda: allreduce_gradients(model)) if num_gpus > 1 else None)
     iteration = 0
     if checkpoint_path != "":
         model, optimizer, iteration = load_checkpoint(checkpoint_path, model, optimizer)
@@ -86,7 +100,11 @@ def train(num_gpus, rank, group_name, output_directory, epochs, learning_rate, s
             audio = audio.cuda(non_blocking=True)
             with torch.no_grad():
                 mel = trainset.mel_batch(audio)           # GPU STFT -> mel, no host round trip
-            reduced_loss = train_step(model, criterion, optimizer, mel, audio, num_gpus)
+            if stepper is not None:
+                loss = stepper(mel, audio)
+                reduced_loss = reduce_tensor(loss, num_gpus).item() if num_gpus > 1 else loss.item()
+            else:
+                reduced_loss = train_step(model, criterion, optimizer, mel, audio, num_gpus)
             print("{}:\t{:.9f}".format(iteration, reduced_loss))
             if iteration % iters_per_checkpoint == 0 and rank == 0:
                 save_checkpoint(model, optimizer, learning_rate, iteration, "{}/waveglow_{}".format(output_directory, iteration),

@@ -305,20 +305,57 @@ class _Conv1x1Function(torch.autograd.Function):
         return dW, dz
 
 
+_PINNED = {"arenas": [], "used": 0}
+
+
+def _pinned_like(array):
+    """A pinned host copy of a small int64 numpy table, carved from arenas allocated OUTSIDE graph capture (pinning memory
+    is not permitted while a stream is capturing; call `reserve_pinned()` before capturing a training step)."""
+    n = array.size
+    arenas = _PINNED["arenas"]
+    if not arenas or _PINNED["used"] + n > arenas[-1].numel():
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("pinned table arena exhausted during graph capture: call waveglow.glow.reserve_pinned() first")
+        arenas.append(torch.empty(max(1 << 18, n), dtype=torch.int64).pin_memory())
+        _PINNED["used"] = 0
+    out = arenas[-1][_PINNED["used"]:_PINNED["used"] + n].view(array.shape)
+    _PINNED["used"] += n
+    out.copy_(torch.from_numpy(array))
+    return out
+
+
+def reserve_pinned():
+    """Make sure a fresh 2 MiB pinned arena is available (enough for every table of a captured training step)."""
+    _PINNED["arenas"].append(torch.empty(1 << 18, dtype=torch.int64).pin_memory())
+    _PINNED["used"] = 0
+
+
 class _WeightNormAllFunction(torch.autograd.Function):
     """w_i = g_i * v_i / ||v_i|| (per output row) for EVERY weight-normed conv of the model in one HIP launch, and the
     matching backward in one more (torch's weight_norm recomputes each conv with its own two kernels: 288 convs ->
     ~600 launches per step).  Inputs v_0, g_0, v_1, g_1, ...; outputs w_0, w_1, ..."""
 
+    _tables = {}   # (device, entries) -> (pinned host table, device table, total rows)
+
     @staticmethod
     def _table(entries, dev):
+        """Device table of one launch.  The caching allocator hands a training loop the same buffers step after step, so
+        the table is almost always a cache hit (no upload).  A miss uploads from PINNED memory that the cache keeps alive:
+        an upload recorded while a HIP graph is being captured stays valid for every replay."""
         import numpy as np
-        t = np.zeros((len(entries), 6), dtype=np.int64)
-        row0 = 0
-        for i, (v, g, w, norm, rows, ln) in enumerate(entries):
-            t[i] = (v, g, w, norm, row0, rows | (ln << 32))
-            row0 += rows
-        return torch.from_numpy(t).to(dev, non_blocking=True), row0
+        key = (str(dev), tuple(entries))
+        hit = _WeightNormAllFunction._tables.get(key)
+        if hit is None:
+            t = np.zeros((len(entries), 6), dtype=np.int64)
+            row0 = 0
+            for i, (v, g, w, norm, rows, ln) in enumerate(entries):
+                t[i] = (v, g, w, norm, row0, rows | (ln << 32))
+                row0 += rows
+            if len(_WeightNormAllFunction._tables) >= 64 and not torch.cuda.is_current_stream_capturing():
+                _WeightNormAllFunction._tables.clear()
+            host = _pinned_like(t)
+            hit = _WeightNormAllFunction._tables[key] = (host, host.to(dev, non_blocking=True), row0)
+        return hit[1], hit[2]
 
     @staticmethod
     def forward(ctx, *vg):

@@ -35,7 +35,18 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     step()
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="count", row_limit=40, max_name_column_width=60))
+# who issues the fills / copies: aggregate by the innermost Python frames of this repo
+from collections import Counter
+for op in ("aten::fill_", "aten::zero_", "aten::copy_", "aten::zeros", "aten::zeros_like"):
+    c = Counter()
+    for ev in prof.events():
+        if ev.name == op:
+            frames = [f for f in (ev.stack or []) if "fac-via-ppg_amd" in f or "tools/" in f or "optim" in f or "autograd" in f]
+            c[" <- ".join(frames[:3]) or "(no python frame: autograd engine / C++)"] += 1
+    print("==", op, sum(c.values()))
+    for k, v in c.most_common(8):
+        print("   %5d  %s" % (v, k[:260]))
