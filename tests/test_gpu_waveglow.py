@@ -291,3 +291,26 @@ def test_folded_flow_edges_agree_with_unfolded_layers(hop, B, T, lengths, monkey
     print("rms", rms(err), "max", np.abs(err).max(), "rms audio", rms(plain.cpu().numpy()))
     assert rms(err) <= 2e-5 and np.abs(err).max() <= 5e-4
     assert not torch.equal(folded, plain)   # (the switch did select another path)
+
+
+@pytest.mark.parametrize("hop,n_flows,n_early_every,n_layers,T", [(256, 3, 2, 1, 40), (160, 2, 4, 3, 70), (256, 5, 4, 2, 9)])
+def test_other_stack_depths_match_oracle(hop, n_flows, n_early_every, n_layers, T):
+    """The folded flow edges distinguish first / middle / last layers of a stack: stacks of 1 (first = last), 2 (no middle
+    layer) and 3 layers, with early outputs at other flows, against the oracle."""
+    from oracle import waveglow as owg
+    from waveglow.glow import WaveGlow
+    cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=hop, n_flows=n_flows, n_early_every=n_early_every,
+               WN_config=dict(synth.WAVEGLOW_CONFIG["WN_config"], n_layers=n_layers))
+    sd = synth.waveglow_state_dict(cfg)
+    m = WaveGlow.remove_weightnorm(WaveGlow(**cfg))
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    B = 2
+    mel = synth.synthetic_mel(B, T, seed=21)
+    zs = synth.synthetic_z(B, T * hop // 8, cfg, seed=22)
+    out = m.infer(mel.cuda(), sigma=0.6, z=zs).cpu()
+    with torch.no_grad():
+        ref = owg.infer(sd, cfg, mel, 0.6, zs)
+    err = (out - ref).numpy()
+    print("rms err", rms(err), "rms ref", rms(ref.numpy()))
+    assert rms(err) <= RMS_TOL and np.abs(err).max() <= 5e-3
