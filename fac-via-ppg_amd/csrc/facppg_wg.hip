@@ -362,13 +362,28 @@ __device__ __forceinline__ void load_a(float4 (&a)[4], const float4* __restrict_
 }
 
 // B operand of one k-group (4 K-steps x NCB column blocks) from the LDS image [k][32*NCB].
-template <int NCB>
+// K4 (phase-major kernels): the image is [k/4][32*NCB][k%4] -- the four K-steps a lane feeds into one k-group's MFMAs
+// (rows 8g + 4kh + 0..3 of its column) are 16 contiguous bytes, ONE ds_read_b128 per column block instead of four
+// ds_read_b32.  With the row-major image hipcc, short of registers, sinks every 4-byte read next to its MFMAs and waits
+// for each (lgkmcnt(0) every 8 MFMAs); lb = image + (kh * 32*NCB + li) * 4.
+template <int NCB, bool K4 = false>
 __device__ __forceinline__ void load_b(float (&bv)[4][NCB], const float* lb, int g) {
+  if constexpr (K4) {
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
+    for (int cb = 0; cb < NCB; ++cb) {
+      const float4 v = *reinterpret_cast<const float4*>(lb + ((2 * g) * (32 * NCB) + 32 * cb) * 4);
+      bv[0][cb] = v.x; bv[1][cb] = v.y; bv[2][cb] = v.z; bv[3][cb] = v.w;
+    }
+  } else {
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) bv[s][cb] = lb[(8 * g + s) * (32 * NCB) + 32 * cb];
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) bv[s][cb] = lb[(8 * g + s) * (32 * NCB) + 32 * cb];
+  }
 }
+
+// K4 image: float index of (k, col)
+__device__ __forceinline__ int k4_index(int k, int col, int tnt) { return ((k >> 2) * tnt + col) * 4 + (k & 3); }
 
 // 4 K-steps (one k-group of 8) for NRB row blocks x NCB column blocks.
 template <int NRB, int NCB>
@@ -433,7 +448,9 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   const int srow = lane / TNt, scol = lane % TNt;   // this lane's slot inside a staging load
   // tile coordinates: batch b, first column t0 (position, or frame of phase ph), nvalid live columns,
   // in_off / sk_off = offset of column 0 inside a channel row of h / skip, tapo[] = same for the 3 taps
-  int b, t0, nvalid, ph = 0, in_off, sk_off, tapo[3];
+  // PM: tap0..2 are wave-uniform (three named scalars, NOT an array: hipcc turns the per-chunk select over an array into an
+  // indexed scratch load behind a vmcnt(0)), the lane's column is lane_q
+  int b, t0, nvalid, ph = 0, in_off, sk_off, tap0 = 0, tap1 = 0, tap2 = 0, lane_q = 0;
 #ifdef FACPPG_STAGGER
   // experiment: the two workgroups of a CU start in lock step, so their gate / epilogue / prologue phases (no MFMA)
   // coincide; delaying the one in the odd wave slot of the first round by a fraction of a tile lets each phase hide
@@ -488,19 +505,19 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
     }
     in_off = ph * p.Tqp + HQ + qcol;
     sk_off = ph * p.Tr + qcol;
-#pragma unroll
-    for (int tp = 0; tp < 3; ++tp) {
-      const int pp = ph + (tp - 1) * p.dil;
-      const int qsh = pp >= 0 ? pp / p.P : -((p.P - 1 - pp) / p.P);   // floor(pp / P)
-      tapo[tp] = (pp - qsh * p.P) * p.Tqp + HQ + qcol + qsh;
+    lane_q = HQ + qcol;
+    {
+      const int pm = ph - p.dil, qm = pm >= 0 ? pm / p.P : -((p.P - 1 - pm) / p.P);   // floor((ph - d) / P)
+      const int pq = ph + p.dil, qp = pq / p.P;
+      tap0 = (pm - qm * p.P) * p.Tqp + qm;
+      tap1 = ph * p.Tqp;
+      tap2 = (pq - qp * p.P) * p.Tqp + qp;
     }
   } else {
     b = blockIdx.y; t0 = blockIdx.x * TNt;
     nvalid = (p.t_valid ? p.t_valid[b] : p.T) * p.hop8 - t0;
     in_off = HALO + t0;
     sk_off = t0;
-#pragma unroll
-    for (int tp = 0; tp < 3; ++tp) tapo[tp] = in_off + (tp - 1) * p.dil;
   }
   if (!PM && nvalid <= 0) return;
 
@@ -538,8 +555,17 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   const bool folded_first = EF && p.nconv == 1;
   const float* hb4 = folded_first ? p.xa + (size_t)b * 8 * p.Lp : p.h_in + (size_t)b * C * p.Lp;   // PM: tapo[] carry the lane's column
   const float* sb4 = PM ? p.melp + (size_t)b * NMEL * p.Tqp + in_off - ph * p.Tqp : nullptr;   // = HQ + qcol
+  // folded first layer: conv row r0 = 8*tap + ch of p.xa (rows >= 24 meet zero weights); computed once, outside the K loop
+  int first_off[NSTG4];
+#pragma unroll
+  for (int jj = 0; jj < NSTG4; ++jj) {
+    const int r0 = w * 16 + NSTG4 * srow4 + jj, tp = min(r0 >> 3, 2);
+    first_off[jj] = (r0 & 7) * p.Lp + (tp == 0 ? tap0 : tp == 1 ? tap1 : tap2) + lane_q;
+  }
   float stg[NSTG];
-  auto stage_load = [&](int c) {
+  // first0: the prologue's call for chunk 0 of a folded first layer (the only one that needs first_off[]: every chunk the
+  // K loop stages for such a layer is a conditioning chunk, so first_off[] is dead once the loop starts)
+  auto stage_load = [&](int c, bool first0 = false) __attribute__((always_inline)) {
 #if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 16)
     for (int jj = 0; jj < NSTG; ++jj) stg[jj] = 0.001f * c;   // ablation: no activation loads
     return;
@@ -548,19 +574,20 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
       // both kinds of chunk reduce to "base + per-row offset" so the loads themselves are branch-free.
       // Phase rows are contiguous in frames, so a lane fetches 4 columns at once (16-byte loads at
       // 4-byte alignment: tap offsets are arbitrary) -- 4 VMEM instructions per chunk instead of 16.
+      // (a lane stages NSTG4 CONSECUTIVE k-rows of its 4 columns: they are neighbours in the K4 image)
       const bool conv = c < p.nconv;
       const float* base = conv ? hb4 : sb4;
+      const int tapc = tap0 + (int)(c >= 4) * (tap1 - tap0) + (int)(c >= 8) * (tap2 - tap1) + lane_q;
       int off[NSTG4];
 #pragma unroll
       for (int jj = 0; jj < NSTG4; ++jj) {
-        const int r0 = w * 16 + srow4 + jj * RPL4;
+        const int r0 = w * 16 + NSTG4 * srow4 + jj;
         // folded conditioning rows r = j*80 + m' <- mel[m'][q - j]; rows past kc (K padding) meet zero weights
         const int r = min((c - p.nconv) * 64 + r0, p.kc - 1);
         const int j = r / NMEL, m = r - j * NMEL;
-        // conv rows: channel (c % 4)*64 + r0 of tap c / 4 -- or, folded first layer, row 8*tap + ch of p.xa (rows >= 24: zero weights)
-        const int tp = folded_first ? min(r0 >> 3, 2) : c >> 2;
-        const int chn = folded_first ? (r0 & 7) : (c & 3) * 64 + r0;
-        off[jj] = conv ? chn * p.Lp + (tp == 0 ? tapo[0] : tp == 1 ? tapo[1] : tapo[2]) : m * p.Tqp - j;
+        // conv rows: channel (c % 4)*64 + r0 of tap c / 4; the folded first layer's only conv chunk has its offsets in first_off[]
+        const int conv_off = first0 ? first_off[jj] : ((c & 3) * 64 + r0) * p.Lp + tapc;
+        off[jj] = conv ? conv_off : m * p.Tqp - j;
       }
 #pragma unroll
       for (int jj = 0; jj < NSTG4; ++jj) {
@@ -586,7 +613,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
     }
   };
   // A operand of k-group gg (PM: the convolution image, then this phase's conditioning image)
-  auto load_a1 = [&](float4 (&a)[4], const float4* ap_, int gg) {
+  auto load_a1 = [&](float4 (&a)[4], const float4* ap_, int gg) __attribute__((always_inline)) {
     if constexpr (PM) {
       const int ngh = 8 * p.nconv;
       const float4* src = gg < ngh ? ap_ + (size_t)gg * 1024 : wave_c_ptr + (size_t)(gg - ngh) * 1024;
@@ -596,12 +623,15 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
       load_a<4>(a, ap_, NG1 * 64, gg);
     }
   };
-  auto stage_write = [&](int buf) {
+  auto stage_write = [&](int buf) __attribute__((always_inline)) {
     if constexpr (PM) {
-      float* dst = smem + buf * (KCH * TNt) + (w * 16 + srow4) * TNt + scol4;
+      // K4 image [k/4][TNt][k%4]: this lane's NSTG4 consecutive rows of column scol4 + cc are contiguous
+      float* dst = smem + buf * (KCH * TNt) + k4_index(w * 16 + NSTG4 * srow4, scol4, TNt);
 #pragma unroll
-      for (int jj = 0; jj < NSTG4; ++jj)
-        *reinterpret_cast<float4*>(dst + jj * RPL4 * TNt) = make_float4(stg[4 * jj], stg[4 * jj + 1], stg[4 * jj + 2], stg[4 * jj + 3]);
+      for (int cc = 0; cc < 4; ++cc) {
+        if constexpr (NSTG4 == 4) *reinterpret_cast<float4*>(dst + 4 * cc) = make_float4(stg[cc], stg[4 + cc], stg[8 + cc], stg[12 + cc]);
+        else *reinterpret_cast<float2*>(dst + 4 * cc) = make_float2(stg[cc], stg[4 + cc]);
+      }
     } else {
       float* dst = smem + buf * (KCH * TNt) + (w * 16) * TNt + lane;   // (row srow, col scol) = + lane
 #pragma unroll
@@ -619,7 +649,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   constexpr int CPI = RING == 3 ? 3 : 1;   // chunks per unrolled iteration
   const float4* ap = wave_a_ptr;
   float4 ar[RING][4];
-  stage_load(0);
+  stage_load(0, folded_first);
 #pragma unroll
   for (int i = 0; i < RING - 1; ++i) load_a1(ar[i], ap, i);
   stage_write(0);
@@ -630,21 +660,21 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   // loads (vmcnt of the shorter path) at the very first A use -- an HBM round trip per chunk.
   // So the staging load is unconditional (the last chunk re-stages itself, harmlessly) and the
   // tail chunk is peeled instead of guarded.
-  auto do_chunk = [&](int c, auto jc) {
+  auto do_chunk = [&](int c, auto jc) __attribute__((always_inline)) {
     constexpr int j = decltype(jc)::value;
     stage_load(c + 1 < nch ? c + 1 : c);
-    const float* lb = smem + (c & 1) * (KCH * TNt) + (4 * kh) * TNt + li;
+    const float* lb = smem + (c & 1) * (KCH * TNt) + (PM ? (kh * TNt + li) * 4 : (4 * kh) * TNt + li);
     const int G = c * 8;
     if constexpr (NCB == 1) {
       // narrow tiles run ~1 wave/SIMD with registers to spare: read the B values one k-group ahead
       // (double-buffered) so no ds_read -> s_waitcnt -> MFMA chain is exposed
       float bq[2][4][NCB];
-      load_b<NCB>(bq[0], lb, 0);
+      load_b<NCB, PM>(bq[0], lb, 0);
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         const int gi = j * 8 + g;
         load_a1(ar[(gi + RING - 1) % RING], ap, G + g + RING - 1);
-        if (g + 1 < 8) load_b<NCB>(bq[(g + 1) & 1], lb, g + 1);
+        if (g + 1 < 8) load_b<NCB, PM>(bq[(g + 1) & 1], lb, g + 1);
         __builtin_amdgcn_sched_barrier(0);
         mfma_group<4, NCB>(acc, ar[gi % RING], bq[g & 1]);
       }
@@ -658,7 +688,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch PD groups ahead (hipcc sinks it otherwise)
 #endif
         float bq[4][NCB];
-        load_b<NCB>(bq, lb, g);
+        load_b<NCB, PM>(bq, lb, g);
 #ifdef FACPPG_WN_SETPRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
@@ -739,7 +769,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
           v = gate_tanh_sigmoid(acc[rb][cb][r], acc[rb + 2][cb][r]);
         }
 #endif
-        smem[ch * TNt + cb * 32 + li] = v;
+        smem[PM ? k4_index(ch, cb * 32 + li, TNt) : ch * TNt + cb * 32 + li] = v;
       }
   __syncthreads();
 
@@ -768,11 +798,11 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   }
   if constexpr (NRB2 > 0) {
     const float4* ap2 = p.w2 + (size_t)(w * NRB2) * NG2 * 64 + lane;
-    const float* lb = smem + (4 * kh) * TNt + li;
+    const float* lb = smem + (PM ? (kh * TNt + li) * 4 : (4 * kh) * TNt + li);
 #pragma unroll
     for (int i = 0; i < RING - 1; ++i) load_a<NRB2>(ar[i], ap2, NG2 * 64, i);
     constexpr int NCH2 = NG2 / 8;
-    auto do_chunk2 = [&](int c, auto jc) {
+    auto do_chunk2 = [&](int c, auto jc) __attribute__((always_inline)) {
       constexpr int j = decltype(jc)::value;
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
@@ -780,7 +810,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
         load_a<NRB2>(ar[(gi + RING - 1) % RING], ap2, NG2 * 64, c * 8 + g + RING - 1);
         __builtin_amdgcn_sched_barrier(0);
         float bq[4][NCB];
-        load_b<NCB>(bq, lb, c * 8 + g);
+        load_b<NCB, PM>(bq, lb, c * 8 + g);
         mfma_group<NRB2, NCB>(acc, ar[gi % RING], bq);
       }
     };
@@ -802,7 +832,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
     if (w < TNt / 16) {
       const int pl = lane & 15, kq = lane >> 4;
       const float4* wimg = reinterpret_cast<const float4*>(p.we) + lane * 2;
-      const float* gb = smem + kq * TNt + 16 * w + pl;
+      const float* gb = smem + (16 * w + pl) * 4 + kq;   // K4 image: row 32 sl + 4 g + kq of column 16 w + pl
       float4 a0[8], a1[8];
 #pragma unroll
       for (int sl = 0; sl < 8; ++sl) { a0[sl] = wimg[sl * 128]; a1[sl] = wimg[sl * 128 + 1]; }
@@ -812,7 +842,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
         const float av[8] = {a0[sl].x, a0[sl].y, a0[sl].z, a0[sl].w, a1[sl].x, a1[sl].y, a1[sl].z, a1[sl].w};
         f32x4 e = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int g = 0; g < 8; ++g) e = mfma16x16x4(av[g], gb[(32 * sl + 4 * g) * TNt], e);
+        for (int g = 0; g < 8; ++g) e = mfma16x16x4(av[g], gb[(8 * sl + g) * TNt * 4], e);
         if (sl == 0) tot = e;
         else { tot[0] += e[0]; tot[1] += e[1]; tot[2] += e[2]; tot[3] += e[3]; }
       }
@@ -937,7 +967,7 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, wq = w8 >> 1, sub = w8 & 1;
   const int li = lane & 31, kh = lane >> 5;
   const int chb = wq * 64 + sub * 32;   // first channel of this wave's block
-  int b, nvalid, ph, in_off, sk_off, tapo[3];
+  int b, nvalid, ph, in_off, sk_off, tap0, tap1, tap2, lane_q;   // tap0..2 are wave-uniform, the lane's column is lane_q (see k_wn_layer)
   {
     const int lin = blockIdx.x;
     int tile;
@@ -967,11 +997,13 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
     }
     in_off = ph * p.Tqp + HQ + qcol;
     sk_off = ph * p.Tr + qcol;
-#pragma unroll
-    for (int tp = 0; tp < 3; ++tp) {
-      const int pp = ph + (tp - 1) * p.dil;
-      const int qsh = pp >= 0 ? pp / p.P : -((p.P - 1 - pp) / p.P);
-      tapo[tp] = (pp - qsh * p.P) * p.Tqp + HQ + qcol + qsh;
+    lane_q = HQ + qcol;
+    {
+      const int pm = ph - p.dil, qm = pm >= 0 ? pm / p.P : -((p.P - 1 - pm) / p.P);   // floor((ph - d) / P)
+      const int pq = ph + p.dil, qp = pq / p.P;
+      tap0 = (pm - qm * p.P) * p.Tqp + qm;
+      tap1 = ph * p.Tqp;
+      tap2 = (pq - qp * p.P) * p.Tqp + qp;
     }
   }
   f32x16 acc[2][NCB];   // [0] tanh rows / res rows, [1] sigmoid rows / skip rows of channels chb..chb+31
@@ -984,32 +1016,42 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
   const bool folded_first = EF && p.nconv == 1;
   const float* hb4 = folded_first ? p.xa + (size_t)b * 8 * p.Lp : p.h_in + (size_t)b * C * p.Lp;
   const float* sb4 = p.melp + (size_t)b * NMEL * p.Tqp + in_off - ph * p.Tqp;
+  int first_off[NSTG4];   // folded first layer: conv row r0 = 8*tap + ch of p.xa
+#pragma unroll
+  for (int jj = 0; jj < NSTG4; ++jj) {
+    const int r0 = w8 * 8 + NSTG4 * srow4 + jj, tp = min(r0 >> 3, 2);
+    first_off[jj] = (r0 & 7) * p.Lp + (tp == 0 ? tap0 : tp == 1 ? tap1 : tap2) + lane_q;
+  }
   float4 stg[NSTG4];
-  auto stage_load = [&](int c) {
+  auto stage_load = [&](int c, bool first0 = false) __attribute__((always_inline)) {   // first0: see k_wn_layer
 #if defined(FACPPG_ABLATE8) && (FACPPG_ABLATE8 & 2)
     for (int jj = 0; jj < NSTG4; ++jj) stg[jj] = make_float4(0.001f * c, 0.f, 0.f, 0.f);   // ablation: no activation loads
     return;
 #endif
     const bool conv = c < p.nconv;
     const float* base = conv ? hb4 : sb4;
+    const int tapc = tap0 + (int)(c >= 4) * (tap1 - tap0) + (int)(c >= 8) * (tap2 - tap1) + lane_q;
 #pragma unroll
     for (int jj = 0; jj < NSTG4; ++jj) {
-      const int r0 = w8 * 8 + srow4 + jj * RPL4;
+      const int r0 = w8 * 8 + NSTG4 * srow4 + jj;   // consecutive k-rows per lane: neighbours in the K4 image (see load_b)
       const int r = min((c - p.nconv) * 64 + r0, p.kc - 1);
       const int j = r / NMEL, m = r - j * NMEL;
-      const int tp = folded_first ? min(r0 >> 3, 2) : c >> 2;
-      const int chn = folded_first ? (r0 & 7) : (c & 3) * 64 + r0;
-      const int off = conv ? chn * p.Lp + (tp == 0 ? tapo[0] : tp == 1 ? tapo[1] : tapo[2]) : m * p.Tqp - j;
+      const int conv_off = first0 ? first_off[jj] : ((c & 3) * 64 + r0) * p.Lp + tapc;
+      const int off = conv ? conv_off : m * p.Tqp - j;
       const f4u v = *reinterpret_cast<const f4u*>(base + off);
       stg[jj] = make_float4(v.x, v.y, v.z, v.w);
     }
   };
-  auto stage_write = [&](int buf) {
-    float* dst = smem + buf * (KCH * TNt) + (w8 * 8 + srow4) * TNt + scol4;
-#pragma unroll
-    for (int jj = 0; jj < NSTG4; ++jj) *reinterpret_cast<float4*>(dst + jj * RPL4 * TNt) = stg[jj];
+  auto stage_write = [&](int buf) __attribute__((always_inline)) {
+    float* dst = smem + buf * (KCH * TNt) + k4_index(w8 * 8 + NSTG4 * srow4, scol4, TNt);
+    if constexpr (NSTG4 == 2) {
+      dst[0] = stg[0].x; dst[1] = stg[1].x; dst[4] = stg[0].y; dst[5] = stg[1].y;
+      dst[8] = stg[0].z; dst[9] = stg[1].z; dst[12] = stg[0].w; dst[13] = stg[1].w;
+    } else {
+      dst[0] = stg[0].x; dst[4] = stg[0].y; dst[8] = stg[0].z; dst[12] = stg[0].w;
+    }
   };
-  auto load_a1 = [&](float4 (&a)[2], int gg) {
+  auto load_a1 = [&](float4 (&a)[2], int gg) __attribute__((always_inline)) {
     const int ngh = 8 * p.nconv;
 #if defined(FACPPG_ABLATE8) && (FACPPG_ABLATE8 & 4)
     const float4* src = wave_a + (size_t)(gg & 7) * 1024;   // ablation: the weight stream stays in L1/L2
@@ -1019,7 +1061,7 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
     a[0] = src[0];
     a[1] = src[128];
   };
-  auto mfma2 = [&](const float4 (&a)[2], const float (&bv)[4][NCB], int nrb) {
+  auto mfma2 = [&](const float4 (&a)[2], const float (&bv)[4][NCB], int nrb) __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -1032,7 +1074,7 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
   };
   constexpr int RING = 4;
   float4 ar[RING][2];
-  stage_load(0);
+  stage_load(0, folded_first);
 #pragma unroll
   for (int i = 0; i < RING - 1; ++i) load_a1(ar[i], i);
   // accumulators start at the bias; loaded behind the first operand loads so the prologue is one memory round trip, not two
@@ -1050,13 +1092,13 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
   __syncthreads();
   for (int c = 0; c < nch; ++c) {
     stage_load(c + 1 < nch ? c + 1 : c);
-    const float* lb = smem + (c & 1) * (KCH * TNt) + (4 * kh) * TNt + li;
+    const float* lb = smem + (c & 1) * (KCH * TNt) + (kh * TNt + li) * 4;
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
       load_a1(ar[(g + RING - 1) % RING], c * 8 + g + RING - 1);
       __builtin_amdgcn_sched_barrier(0);
       float bq[4][NCB];
-      load_b<NCB>(bq, lb, g);
+      load_b<NCB, true>(bq, lb, g);
       mfma2(ar[g % RING], bq, 2);
     }
     stage_write((c + 1) & 1);
@@ -1069,7 +1111,7 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
   for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      smem[(chb + 8 * (r >> 2) + (r & 3) + 4 * kh) * TNt + cb * 32 + li] = gate_tanh_sigmoid(acc[0][cb][r], acc[1][cb][r]);
+      smem[k4_index(chb + 8 * (r >> 2) + (r & 3) + 4 * kh, cb * 32 + li, TNt)] = gate_tanh_sigmoid(acc[0][cb][r], acc[1][cb][r]);
   __syncthreads();
   // res_skip 1x1 conv
   constexpr int NRB2 = EF ? (LAST ? 0 : 1) : LAST ? 1 : 2;   // EF: res rows only (image laid out like a LAST layer's 256 rows)
@@ -1098,8 +1140,8 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
   if constexpr (NRB2 > 0) {
     // w2 image: float4 index ((wq*nrb + rb4)*NG2 + g)*64 + lane, nrb = 2 (LAST) or 4
     const float4* ap2 = p.w2 + (size_t)(ROWS256 ? wq * 2 + sub : wq * 4 + sub) * NG2 * 64 + lane;
-    const float* lb = smem + (4 * kh) * TNt + li;
-    auto load_a2 = [&](float4 (&a)[2], int g) {
+    const float* lb = smem + (kh * TNt + li) * 4;
+    auto load_a2 = [&](float4 (&a)[2], int g) __attribute__((always_inline)) {
       a[0] = ap2[g * 64];
       if constexpr (!ROWS256) a[1] = ap2[(size_t)2 * NG2 * 64 + g * 64];
     };
@@ -1111,7 +1153,7 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
         load_a2(ar[(g + RING - 1) % RING], c * 8 + g + RING - 1);
         __builtin_amdgcn_sched_barrier(0);
         float bq[4][NCB];
-        load_b<NCB>(bq, lb, c * 8 + g);
+        load_b<NCB, true>(bq, lb, c * 8 + g);
         mfma2(ar[g % RING], bq, NRB2);
       }
     }
@@ -1120,7 +1162,7 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
     if (w8 < TNt / 16) {
       const int pl = lane & 15, kq = lane >> 4;
       const float4* wimg = reinterpret_cast<const float4*>(p.we) + lane * 2;
-      const float* gb = smem + kq * TNt + 16 * w8 + pl;
+      const float* gb = smem + (16 * w8 + pl) * 4 + kq;   // K4 image
       float4 a0[8], a1[8];
 #pragma unroll
       for (int sl = 0; sl < 8; ++sl) { a0[sl] = wimg[sl * 128]; a1[sl] = wimg[sl * 128 + 1]; }
@@ -1130,7 +1172,7 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
         const float av[8] = {a0[sl].x, a0[sl].y, a0[sl].z, a0[sl].w, a1[sl].x, a1[sl].y, a1[sl].z, a1[sl].w};
         f32x4 e = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int g = 0; g < 8; ++g) e = mfma16x16x4(av[g], gb[(32 * sl + 4 * g) * TNt], e);
+        for (int g = 0; g < 8; ++g) e = mfma16x16x4(av[g], gb[(8 * sl + g) * TNt * 4], e);
         if (sl == 0) tot = e;
         else { tot[0] += e[0]; tot[1] += e[1]; tot[2] += e[2]; tot[3] += e[3]; }
       }
@@ -1244,7 +1286,7 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
   const float* sb = p.melp + (size_t)b * NMEL * p.Tqp + HQ + q0 + scol;
   typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
   float2 stg;
-  auto stage_load = [&](int c) {
+  auto stage_load = [&](int c) __attribute__((always_inline)) {
     const bool conv = c < p.nconv;
     const int r = min((c - p.nconv) * 64 + srow, p.kc - 1);
     const int j = r / NMEL, m = r - j * NMEL;
@@ -1255,8 +1297,8 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
     const f2u v = *reinterpret_cast<const f2u*>(src);
     stg = make_float2(v.x, v.y);
   };
-  auto stage_write = [&](int buf) { *reinterpret_cast<float2*>(smem + buf * (KCH * TN16) + srow * TN16 + scol) = stg; };
-  auto load_a = [&](float4 (&a)[4], int gg) {   // gg = 16-wide K group over [conv | cond]
+  auto stage_write = [&](int buf) __attribute__((always_inline)) { *reinterpret_cast<float2*>(smem + buf * (KCH * TN16) + srow * TN16 + scol) = stg; };
+  auto load_a = [&](float4 (&a)[4], int gg) __attribute__((always_inline)) {   // gg = 16-wide K group over [conv | cond]
     const float4* src = gg < NGH16 ? wave_a + (size_t)gg * 2048 : wave_c + (size_t)(gg - NGH16) * 2048;
 #pragma unroll
     for (int rbl = 0; rbl < 4; ++rbl) a[rbl] = src[rbl * 64];
@@ -1320,7 +1362,7 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
   if constexpr (NB2 > 0) {
     const float4* ap2 = p.w2 + (w8 * NB2) * 64 + lane;   // [g16][NB2*8 blocks][64]
     const float* lb = smem + k16(0, kq) * TN16 + pl;
-    auto load_a2 = [&](float4 (&a)[4], int g) {
+    auto load_a2 = [&](float4 (&a)[4], int g) __attribute__((always_inline)) {
 #pragma unroll
       for (int rbl = 0; rbl < NB2; ++rbl) a[rbl] = ap2[(size_t)g * (NB2 * 8 * 64) + rbl * 64];
     };
@@ -1635,7 +1677,7 @@ __global__ __launch_bounds__(256) void k_flow_end(EdgeArgs p) {
   // gets the same bits whichever shape its batch selects.
   float o[CC];
   const float* sk = p.skip + (size_t)b * C * p.Lr + sk_off;
-  auto quarter = [&](int q, float (&acc)[CC]) {
+  auto quarter = [&](int q, float (&acc)[CC]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < CC; ++j) acc[j] = 0.0f;
     for (int c0 = q * 64; c0 < q * 64 + 64; c0 += 16) {
