@@ -68,6 +68,15 @@ constexpr int MAXF = 32;      // max flows
 #ifndef FACPPG_WN_NT
 #define FACPPG_WN_NT 0   // bit 0: activation staging loads, bit 1: epilogue stores, bit 2: epilogue loads -- non-temporal
 #endif
+#ifndef FACPPG_WN_W128_DEFAULT
+#define FACPPG_WN_W128_DEFAULT 0
+#endif
+#ifndef FACPPG_WN_RING
+#define FACPPG_WN_RING 3     // weight ring of the 64-frame phase-major tiles (3 or 4 register sets)
+#endif
+#ifndef FACPPG_WN_SPREAD
+#define FACPPG_WN_SPREAD 0   // 1: weight prefetch loads interleaved with the MFMA clusters (see k_wn_layer's K loop)
+#endif
 #ifndef FACPPG_NARROW_RING
 #define FACPPG_NARROW_RING 8  // weight prefetch depth (k-groups) of the 32-column tiles, see k_wn_layer
 #endif
@@ -623,6 +632,18 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
       load_a<4>(a, ap_, NG1 * 64, gg);
     }
   };
+#if FACPPG_WN_SPREAD
+  // one row block of k-group gg
+  auto load_a1_rb = [&](float4& a, const float4* ap_, int gg, int rb) __attribute__((always_inline)) {
+    if constexpr (PM) {
+      const int ngh = 8 * p.nconv;
+      const float4* src = gg < ngh ? ap_ + (size_t)gg * 1024 : wave_c_ptr + (size_t)(gg - ngh) * 1024;
+      a = src[rb * 64];
+    } else {
+      a = ap_[(size_t)rb * NG1 * 64 + gg * 64];
+    }
+  };
+#endif
   auto stage_write = [&](int buf) __attribute__((always_inline)) {
     if constexpr (PM) {
       // K4 image [k/4][TNt][k%4]: this lane's NSTG4 consecutive rows of column scol4 + cc are contiguous
@@ -645,7 +666,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   // chunk stalled ~1 us on that; PD >= 2 gives the staging loads 3+ k-groups (>= 6144 cycles) to
   // land before the first younger A load is needed.  RING = 3 needs the group loop unrolled by
   // lcm(8, 3) = 24 groups = 3 chunks; 22 chunks = 7 x 3 + 1 and 168 % 3 == 0 keeps the phase static.
-  constexpr int RING = NCB == 1 ? (PM ? FACPPG_NARROW_RING : 4) : 3;
+  constexpr int RING = NCB == 1 ? (PM ? FACPPG_NARROW_RING : 4) : (PM ? FACPPG_WN_RING : 3);
   constexpr int CPI = RING == 3 ? 3 : 1;   // chunks per unrolled iteration
   const float4* ap = wave_a_ptr;
   float4 ar[RING][4];
@@ -683,18 +704,32 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
       for (int g = 0; g < 8; ++g) {
         const int gi = j * 8 + g;   // position inside the unrolled iteration (ring phase is static)
         // padded groups exist past the end of the packed image (RING-1 of them)
+#if FACPPG_WN_SPREAD
+        // Experiment (measured SLOWER here, 0.80 vs 0.83; profiles/r02_experiments.txt): the four weight loads of the group
+        // prefetched here issued one per K-step, between the MFMA clusters.  In tools/probes/mfma_probe.hip four back-to-back
+        // global_load_dwordx4 per 32 MFMAs cost 11 % of the MFMA rate and one per 8 MFMAs 3 %; it does not carry over.
+        float bq[4][NCB];
+        load_b<NCB, PM>(bq, lb, g);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) {
+            const float4& a4 = ar[gi % RING][rb];
+            const float av = s == 0 ? a4.x : s == 1 ? a4.y : s == 2 ? a4.z : a4.w;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mfma32x32x2(av, bq[s][cb], acc[rb][cb]);
+          }
+          load_a1_rb(ar[(gi + RING - 1) % RING][s], ap, G + g + RING - 1, s);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#else
         load_a1(ar[(gi + RING - 1) % RING], ap, G + g + RING - 1);
 #ifndef FACPPG_WN_NOSCHEDBAR
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch PD groups ahead (hipcc sinks it otherwise)
 #endif
         float bq[4][NCB];
         load_b<NCB, PM>(bq, lb, g);
-#ifdef FACPPG_WN_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
         mfma_group<4, NCB>(acc, ar[gi % RING], bq);
-#ifdef FACPPG_WN_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
 #endif
       }
     }
@@ -807,11 +842,28 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         const int gi = j * 8 + g;
+#if FACPPG_WN_SPREAD
+        float bq[4][NCB];
+        load_b<NCB, PM>(bq, lb, c * 8 + g);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {   // weight loads one per K-step, see the first GEMM
+#pragma unroll
+          for (int rb = 0; rb < NRB2; ++rb) {
+            const float4& a4 = ar[gi % RING][rb];
+            const float av = s == 0 ? a4.x : s == 1 ? a4.y : s == 2 ? a4.z : a4.w;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mfma32x32x2(av, bq[s][cb], acc[rb][cb]);
+          }
+          if (s < NRB2) ar[(gi + RING - 1) % RING][s] = ap2[(size_t)s * NG2 * 64 + (c * 8 + g + RING - 1) * 64];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#else
         load_a<NRB2>(ar[(gi + RING - 1) % RING], ap2, NG2 * 64, c * 8 + g + RING - 1);
         __builtin_amdgcn_sched_barrier(0);
         float bq[4][NCB];
         load_b<NCB, PM>(bq, lb, c * 8 + g);
         mfma_group<NRB2, NCB>(acc, ar[gi % RING], bq);
+#endif
       }
     };
     if constexpr (CPI == 3) {
@@ -960,8 +1012,11 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
 // (one short utterance) a 4-wave tile leaves every SIMD with a single wave, and each barrier, LDS
 // round trip and weight load is fully exposed.
 // ------------------------------------------------------------------------------------------
+// NCB = 4 (128-frame tiles, ONE workgroup per CU, 256 VGPRs): each weight load then feeds four column blocks -- 2 global
+// loads per 32 MFMAs instead of k_wn_layer's 4.  tools/probes/mfma_probe.hip: with 2 waves per SIMD the fp32 MFMA stream
+// runs at 0.95 of peak next to 2 global_load_dwordx4 per 32 MFMAs and at 0.85 next to 4.
 template <bool LAST, int NCB, bool EF = false>
-__global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
+__global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TNt = 32 * NCB;
   const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, wq = w8 >> 1, sub = w8 & 1;
@@ -1044,7 +1099,12 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer8(WnArgs p) {
   };
   auto stage_write = [&](int buf) __attribute__((always_inline)) {
     float* dst = smem + buf * (KCH * TNt) + k4_index(w8 * 8 + NSTG4 * srow4, scol4, TNt);
-    if constexpr (NSTG4 == 2) {
+    if constexpr (NSTG4 == 4) {
+      *reinterpret_cast<float4*>(dst) = make_float4(stg[0].x, stg[1].x, stg[2].x, stg[3].x);
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(stg[0].y, stg[1].y, stg[2].y, stg[3].y);
+      *reinterpret_cast<float4*>(dst + 8) = make_float4(stg[0].z, stg[1].z, stg[2].z, stg[3].z);
+      *reinterpret_cast<float4*>(dst + 12) = make_float4(stg[0].w, stg[1].w, stg[2].w, stg[3].w);
+    } else if constexpr (NSTG4 == 2) {
       dst[0] = stg[0].x; dst[1] = stg[1].x; dst[4] = stg[0].y; dst[5] = stg[1].y;
       dst[8] = stg[0].z; dst[9] = stg[1].z; dst[12] = stg[0].w; dst[13] = stg[1].w;
     } else {
@@ -2222,6 +2282,8 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<true, 2, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer8<false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer8<true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer8<false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer8<true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipFree(tmp);
 #undef WG_TRY
   *out = h;
@@ -2262,7 +2324,7 @@ WsLayout ws_layout(const facppg_wg_config& c, int B, int T) {
 struct PmLayout {
   int L, La, Tr, Tqp, P;
   size_t h0, h1, xa, skip, melp, aud0, aud1, z, goff, gtab, total;
-  int ngroups;   // 4-frame groups a ragged batch can have at most (table entries; a multiple of 16 = one 64-frame tile)
+  int ngroups;   // 4-frame groups a ragged batch can have at most (table entries; a multiple of 32 = one 128-frame tile)
 };
 PmLayout pm_layout(const facppg_wg_config& c, int B, int T) {
   PmLayout w;
@@ -2281,7 +2343,7 @@ PmLayout pm_layout(const facppg_wg_config& c, int B, int T) {
   w.aud0 = take((size_t)B * 8 * w.La);
   w.aud1 = take((size_t)B * 8 * w.La);
   w.z = take((size_t)B * 8 * w.L + 4);
-  w.ngroups = round_up(B * ((T + 3) / 4), 16);
+  w.ngroups = round_up(B * ((T + 3) / 4), 32);
   w.goff = take((size_t)B + 1);
   w.gtab = take((size_t)w.ngroups * 4);
   w.total = off;
@@ -2414,7 +2476,12 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   const long cost_best = narrow ? launch_cost(tiles_n, 181, 94) : launch_cost(tiles_w, 331, 185);
   const bool tile16 = tile16_mode == 2 || (tile16_mode == 1 && !force_narrow && cost_16 < cost_best);
   if (tile16) narrow = false;
-  const int tn = tile16 ? TN16 : narrow ? 32 : TN;
+  // 128-frame tiles on eight waves, one workgroup per CU (k_wn_layer8<NCB = 4>): half the weight loads per MFMA.  For
+  // launches of several rounds of 256 such tiles; FACPPG_WN_W128 = 0 never, 1 by size (default), 2 whenever possible
+  static const char* w128_env = getenv("FACPPG_WN_W128");
+  const int w128_mode = w128_env ? atoi(w128_env) : FACPPG_WN_W128_DEFAULT;
+  const bool wide128 = fold && !narrow && !tile16 && !force_narrow && (w128_mode == 2 || (w128_mode == 1 && tiles_w >= 4 * 512));
+  const int tn = tile16 ? TN16 : narrow ? 32 : wide128 ? 128 : TN;
   WnArgs a;
   memset(&a, 0, sizeof(a));
   a.melp = melp; a.skip = skip; a.t_valid = T_valid_dev; a.T = T; a.hop8 = w.P; a.Lp = w.P * w.Tqp; a.Lr = w.P * w.Tr;
@@ -2469,7 +2536,8 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
     else KERNEL_MID<<<lgrid, THREADS, LDS, s>>>(a);                    \
   } while (0)
       if (fold) {
-        if (tile16) WN_LAUNCH((k_wn_layer16<true, true>), (k_wn_layer16<false, true>), 512, 16384 + 4096);
+        if (wide128) WN_LAUNCH((k_wn_layer8<true, 4, true>), (k_wn_layer8<false, 4, true>), 512, 131072 + 4096);
+        else if (tile16) WN_LAUNCH((k_wn_layer16<true, true>), (k_wn_layer16<false, true>), 512, 16384 + 4096);
         else if (narrow) {
           if (w8mode == 0) WN_LAUNCH((k_wn_layer<true, 1, false, true, true>), (k_wn_layer<false, 1, false, true, true>), 256, 32768 + 1024);
           else WN_LAUNCH((k_wn_layer8<true, 1, true>), (k_wn_layer8<false, 1, true>), 512, 32768 + 1024);

@@ -260,11 +260,11 @@ def test_flow_end_four_frames_per_thread_same_bits(hop, B, T, lengths, monkeypat
 
 
 @pytest.mark.parametrize("env", ["FACPPG_WG_UNFOLDED=1", "FACPPG_WN_8W=0", "FACPPG_WN_NO_XCD_MAP=1", "FACPPG_WN_NO_FLAT=1", "FACPPG_WN_TILE16=2",
-                                 "FACPPG_WN_TILE16=0", "FACPPG_WG_EDGE_FOLD=0"])
+                                 "FACPPG_WN_TILE16=0", "FACPPG_WG_EDGE_FOLD=0", "FACPPG_WN_W128=2"])
 def test_alternate_kernel_paths_match_golden(env):
     """The A/B switches select other kernels for the same call (the unfolded K=1408 layer the training
     direction uses; 4-wave tiles for small launches; no XCD-aware phase mapping; per-utterance tiles; 16-frame
-    tiles always / never; layers without the folded flow edges).  They
+    tiles always / never; layers without the folded flow edges; 128-frame tiles).  They
     are read once per process, so each runs the golden comparison in its own interpreter."""
     import os, subprocess, sys
     k, v = env.split("=")
