@@ -418,7 +418,8 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 __device__ __forceinline__ float gate_tanh_sigmoid(float a, float b) {
   const float ea = __expf(-2.0f * fminf(fmaxf(a, -15.0f), 15.0f));
   const float eb = __expf(-b);
-  return __fdividef(1.0f - ea, (1.0f + ea) * (1.0f + eb));
+  // v_rcp_f32 directly: hipcc expands __fdividef to the full IEEE division sequence (v_div_scale x2, v_div_fmas, v_div_fixup)
+  return (1.0f - ea) * __builtin_amdgcn_rcpf((1.0f + ea) * (1.0f + eb));
 }
 
 // PM = true is the phase-major inference variant.  The upsampling ConvTranspose1d (glow.py:253) is
