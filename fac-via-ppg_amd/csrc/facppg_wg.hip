@@ -2072,9 +2072,9 @@ static int wg_check_cfg(const facppg_wg_config* c) {
   FACPPG_REQUIRE(c->upsample_kernel >= c->hop_length && (c->upsample_kernel + c->hop_length - 1) / c->hop_length <= UP_MAXJ,
                  FACPPG_EUNSUPPORTED, "upsample kernel/hop ratio must be in [1, %d]", UP_MAXJ);
   FACPPG_REQUIRE(c->n_early_size == 2 && c->n_early_every >= 1, FACPPG_EUNSUPPORTED, "n_early_size must be 2");
-  int n_half = c->n_group / 2, n_rem = c->n_group;
+  int n_half = c->n_group / 2;
   for (int k = 0; k < c->n_flows; ++k) {
-    if (k % c->n_early_every == 0 && k > 0) { n_half -= c->n_early_size / 2; n_rem -= c->n_early_size; }
+    if (k % c->n_early_every == 0 && k > 0) n_half -= c->n_early_size / 2;
     FACPPG_REQUIRE(n_half >= 1, FACPPG_EUNSUPPORTED, "flow %d has no channels left", k);
   }
   return FACPPG_OK;
