@@ -1005,6 +1005,22 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   }
 }
 
+// FACPPG_WN8_PROF: phase stamps of k_wn_layer8 (workgroup 0, thread 0; clock64 ticks summed over launches), read back with
+// facppg_debug_wn8_prof -- where a narrow launch spends its time outside the K loop (tools/prof_wn8.py)
+#ifdef FACPPG_WN8_PROF
+__device__ unsigned long long g_wn8_prof[8];
+#define WN8_STAMP_DECL long long wn8_t = clock64()
+#define WN8_STAMP(i)                                                                           \
+  do {                                                                                         \
+    const long long now__ = clock64();                                                         \
+    if (blockIdx.x == 0 && threadIdx.x == 0) { atomicAdd(&g_wn8_prof[i], (unsigned long long)(now__ - wn8_t)); if ((i) == 5) atomicAdd(&g_wn8_prof[6], 1ull); } \
+    wn8_t = now__;                                                                             \
+  } while (0)
+#else
+#define WN8_STAMP_DECL
+#define WN8_STAMP(i)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // k_wn_layer8: the phase-major layer with EIGHT waves per tile.  Wave w8 owns one 32-channel block:
 // its tanh rows and the matching sigmoid rows in the first GEMM (2 row blocks instead of 4), its res
@@ -1020,6 +1036,7 @@ template <bool LAST, int NCB, bool EF = false>
 __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TNt = 32 * NCB;
+  WN8_STAMP_DECL;
   const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, wq = w8 >> 1, sub = w8 & 1;
   const int li = lane & 31, kh = lane >> 5;
   const int chb = wq * 64 + sub * 32;   // first channel of this wave's block
@@ -1151,6 +1168,7 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
   }
   stage_write(0);
   __syncthreads();
+  WN8_STAMP(0);   // prologue
   for (int c = 0; c < nch; ++c) {
     stage_load(c + 1 < nch ? c + 1 : c);
     const float* lb = smem + (c & 1) * (KCH * TNt) + (kh * TNt + li) * 4;
@@ -1167,6 +1185,7 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
     __syncthreads();   // (ablation bit 1: no barrier per chunk -- racy, timing only)
 #endif
   }
+  WN8_STAMP(1);   // K loop
   // gate -> LDS [256][TNt]
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb)
@@ -1174,11 +1193,21 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
     for (int r = 0; r < 16; ++r)
       smem[k4_index(chb + 8 * (r >> 2) + (r & 3) + 4 * kh, cb * 32 + li, TNt)] = gate_tanh_sigmoid(acc[0][cb][r], acc[1][cb][r]);
   __syncthreads();
+  WN8_STAMP(2);   // gate
   // res_skip 1x1 conv
   constexpr int NRB2 = EF ? (LAST ? 0 : 1) : LAST ? 1 : 2;   // EF: res rows only (image laid out like a LAST layer's 256 rows)
   constexpr bool ROWS256 = LAST || EF;
   // narrow tiles run one workgroup per CU: nothing hides the epilogue's read of h_in (the residual), so fetch it here,
   // ahead of the second GEMM
+  // NCB = 1 (one workgroup per CU, nothing to hide behind): the end rows are split by K slice over the eight waves, as in
+  // k_wn_layer16 -- wave w8 forms slice w8 of both 16-column blocks; its 32 bytes of the image are fetched here, ahead of
+  // the second GEMM.  (One wave per column block doing all eight slices cost 3.9 us of a 75 us launch, six waves idle.)
+  constexpr bool ESPLIT = EF && NCB == 1;
+  float4 es0, es1;
+  if constexpr (ESPLIT) {
+    const float4* wimg = reinterpret_cast<const float4*>(p.we) + w8 * 128 + lane * 2;
+    es0 = wimg[0]; es1 = wimg[1];
+  }
   constexpr bool HPRE = !LAST && NCB == 1;
   float4 hpre[HPRE ? 32 / RPL4 : 1];
   if constexpr (HPRE) {
@@ -1219,7 +1248,23 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
       }
     }
   }
-  if constexpr (EF) {   // end rows, exactly as in k_wn_layer<EF>
+  WN8_STAMP(3);   // second GEMM
+  if constexpr (ESPLIT) {
+    const int pl = lane & 15, kq = lane >> 4;
+    const float av[8] = {es0.x, es0.y, es0.z, es0.w, es1.x, es1.y, es1.z, es1.w};
+#pragma unroll
+    for (int blk = 0; blk < TNt / 16; ++blk) {
+      const float* gb = smem + (16 * blk + pl) * 4 + kq + (8 * w8) * TNt * 4;   // K4 image, rows 32 w8 + 4 g + kq
+      f32x4 e = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 8; ++g) e = mfma16x16x4(av[g], gb[g * TNt * 4], e);
+      if (kq < 2) {
+        float* part = smem + C * TNt + (w8 * 8 + 4 * kq) * TNt + 16 * blk + pl;   // [slice][row][column]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[r * TNt] = e[r];
+      }
+    }
+  } else if constexpr (EF) {   // end rows, exactly as in k_wn_layer<EF>
     if (w8 < TNt / 16) {
       const int pl = lane & 15, kq = lane >> 4;
       const float4* wimg = reinterpret_cast<const float4*>(p.we) + lane * 2;
@@ -1246,10 +1291,18 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
   }
   // epilogue through a private [32][TNt] LDS slab per wave, 16-byte row segments to HBM
   __syncthreads();
+  WN8_STAMP(4);   // end rows
   if constexpr (EF) {
     const int row = w8 * RPL4 + srow4;
     if (row < 8 && nvalid > 0) {
-      const float4 v4 = *reinterpret_cast<const float4*>(smem + C * TNt + row * TNt + scol4);
+      float4 v4 = *reinterpret_cast<const float4*>(smem + C * TNt + row * TNt + scol4);
+      if constexpr (ESPLIT) {   // the slices meet here, added in slice order (the order every tile width uses)
+#pragma unroll
+        for (int sl = 1; sl < 8; ++sl) {
+          const float4 x = *reinterpret_cast<const float4*>(smem + C * TNt + (sl * 8 + row) * TNt + scol4);
+          v4.x += x.x; v4.y += x.y; v4.z += x.z; v4.w += x.w;
+        }
+      }
       float* g = p.skip + ((size_t)b * 8 + row) * p.Lr + sk_off;
       const float bias = p.endb[row];
       const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
@@ -1295,6 +1348,7 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
       }
     }
   }
+  WN8_STAMP(5);   // epilogue
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2358,6 +2412,17 @@ extern "C" size_t facppg_wg_workspace_bytes(const facppg_wg* h, int B, int T) {
   return a > b ? a : b;
 }
 
+#ifdef FACPPG_WN8_PROF
+extern "C" int facppg_debug_wn8_prof(unsigned long long* out8, int reset) {
+  FACPPG_HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_wn8_prof), 8 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    FACPPG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_wn8_prof), z, sizeof(z)));
+  }
+  return FACPPG_OK;
+}
+#endif
+
 extern "C" int facppg_wg_set_profiling(facppg_wg* h, int enable) {
   FACPPG_REQUIRE(h, FACPPG_EINVAL, "handle is NULL");
   h->profiling = enable ? 1 : 0;
@@ -2541,7 +2606,7 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
         else if (tile16) WN_LAUNCH((k_wn_layer16<true, true>), (k_wn_layer16<false, true>), 512, 16384 + 4096);
         else if (narrow) {
           if (w8mode == 0) WN_LAUNCH((k_wn_layer<true, 1, false, true, true>), (k_wn_layer<false, 1, false, true, true>), 256, 32768 + 1024);
-          else WN_LAUNCH((k_wn_layer8<true, 1, true>), (k_wn_layer8<false, 1, true>), 512, 32768 + 1024);
+          else WN_LAUNCH((k_wn_layer8<true, 1, true>), (k_wn_layer8<false, 1, true>), 512, 32768 + 8 * 1024);   // + the end rows' 8 K-slice partials
         } else if (w8mode == 2) WN_LAUNCH((k_wn_layer8<true, 2, true>), (k_wn_layer8<false, 2, true>), 512, 65536 + 2048);
         else WN_LAUNCH((k_wn_layer<true, 2, false, true, true>), (k_wn_layer<false, 2, false, true, true>), 256, 65536 + 2048);
       } else {
