@@ -196,6 +196,55 @@ __global__ __launch_bounds__(256) void k_affine_bwd(const float* __restrict__ x,
 
 using namespace facppg;
 
+// log det W and W^-T of one small mixing matrix (c <= 8) by LU with partial pivoting, one thread: what torch.logdet and its
+// backward do through rocSOLVER in ~22 tiny launches per flow and direction (glow.py:100: log_det_W = B * L * logdet(W)).
+// det <= 0 follows torch.logdet: NaN for a negative determinant, -inf for a singular matrix.
+__global__ void k_logdet(const float* __restrict__ W, int c, float* __restrict__ logdet, float* __restrict__ winv_t) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float a[8][8], inv[8][8];
+  for (int i = 0; i < c; ++i)
+    for (int j = 0; j < c; ++j) { a[i][j] = W[i * c + j]; inv[i][j] = i == j ? 1.0f : 0.0f; }
+  float sign = 1.0f, logabs = 0.0f;
+  bool singular = false;
+  for (int k = 0; k < c; ++k) {
+    int piv = k;
+    float best = fabsf(a[k][k]);
+    for (int i = k + 1; i < c; ++i)
+      if (fabsf(a[i][k]) > best) { best = fabsf(a[i][k]); piv = i; }
+    if (best == 0.0f) { singular = true; break; }
+    if (piv != k) {
+      for (int j = 0; j < c; ++j) { float t = a[k][j]; a[k][j] = a[piv][j]; a[piv][j] = t; t = inv[k][j]; inv[k][j] = inv[piv][j]; inv[piv][j] = t; }
+      sign = -sign;
+    }
+    const float d = a[k][k];
+    if (d < 0.0f) sign = -sign;
+    logabs += logf(fabsf(d));
+    const float r = 1.0f / d;
+    for (int j = 0; j < c; ++j) { a[k][j] *= r; inv[k][j] *= r; }   // Gauss-Jordan on [A | I]
+    for (int i = 0; i < c; ++i) {
+      if (i == k) continue;
+      const float f = a[i][k];
+      for (int j = 0; j < c; ++j) { a[i][j] = fmaf(-f, a[k][j], a[i][j]); inv[i][j] = fmaf(-f, inv[k][j], inv[i][j]); }
+    }
+  }
+  if (singular) {
+    *logdet = -INFINITY;
+    for (int i = 0; i < c * c; ++i) winv_t[i] = NAN;
+    return;
+  }
+  *logdet = sign > 0.0f ? logabs : NAN;
+  for (int i = 0; i < c; ++i)
+    for (int j = 0; j < c; ++j) winv_t[i * c + j] = inv[j][i];
+}
+
+extern "C" int facppg_logdet(const float* w_dev, int c, float* logdet_dev, float* winv_t_dev, void* stream) {
+  FACPPG_REQUIRE(w_dev && logdet_dev && winv_t_dev, FACPPG_EINVAL, "NULL argument");
+  FACPPG_REQUIRE(c >= 1 && c <= 8, FACPPG_EUNSUPPORTED, "mixing matrices are at most 8 x 8 (got %d)", c);
+  k_logdet<<<1, 64, 0, (hipStream_t)stream>>>(w_dev, c, logdet_dev, winv_t_dev);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
 extern "C" int facppg_conv1x1(const float* w_dev, const float* z_dev, float* out_dev, int B, int c, int L, int transpose_w,
                               void* stream) {
   FACPPG_REQUIRE(w_dev && z_dev && out_dev, FACPPG_EINVAL, "NULL argument");

@@ -278,6 +278,28 @@ def _conv1x1(W, z, transpose=False):
     return out
 
 
+class _LogDetFunction(torch.autograd.Function):
+    """torch.logdet(W) of the mixing matrix (glow.py:100) as ONE HIP launch (LU with partial pivoting, c <= 8), with its
+    gradient W^-T from the same launch -- torch.logdet and its backward go through rocSOLVER in ~22 small launches per flow
+    and direction.  NaN / -inf for a negative / zero determinant, as torch.logdet."""
+
+    @staticmethod
+    def forward(ctx, W):
+        L = _lib.load()
+        Wc = W.detach().float().contiguous()
+        out = torch.empty(1 + Wc.numel(), device=Wc.device)
+        with torch.cuda.device(Wc.device):
+            _lib.check(L.facppg_logdet(_lib.ptr(Wc), Wc.shape[0], _lib.ptr(out), _lib.ptr(out[1:]), _lib.current_stream(Wc.device)))
+        ctx.save_for_backward(out)
+        ctx.shape = Wc.shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        return g * out[1:].view(ctx.shape)
+
+
 class _Conv1x1Function(torch.autograd.Function):
     """The mixing conv of Invertible1x1Conv.forward (glow.py:98-102) as an autograd node on HIP kernels:
     forward W z, backward dz = W^T dout (same kernel, transposed matrix) and dW = sum_{b,l} dout z^T."""
@@ -464,7 +486,7 @@ class Invertible1x1Conv(torch.nn.Module):
         W = self.conv.weight.squeeze(-1)
         if reverse:
             return _conv1x1(self.inverse_matrix(), z)
-        log_det_W = z.size(0) * z.size(2) * torch.logdet(W.float())
+        log_det_W = z.size(0) * z.size(2) * _LogDetFunction.apply(W.float())
         if torch.is_grad_enabled() and (W.requires_grad or z.requires_grad):
             return _Conv1x1Function.apply(W.float(), z.float()), log_det_W
         return _conv1x1(W, z), log_det_W
@@ -723,7 +745,7 @@ class WaveGlow(torch.nn.Module):
                 output_audio.append(audio[:, :self.n_early_size, :])
                 audio = audio[:, self.n_early_size:, :]
             W = self.convinv[k].conv.weight.squeeze(-1)
-            log_det_W_list.append(audio.size(0) * audio.size(2) * torch.logdet(W))
+            log_det_W_list.append(audio.size(0) * audio.size(2) * _LogDetFunction.apply(W.float()))   # glow.py:100, one HIP launch
             audio = _Conv1x1Function.apply(W.float(), audio.contiguous())        # 1x1 mixing conv (c <= 8 channels), HIP fwd + bwd
             n_half = audio.size(1) // 2
             audio_0 = audio[:, :n_half, :]
@@ -773,7 +795,7 @@ class WaveGlow(torch.nn.Module):
             log_s_list.append(log_s_flat[off:off + n].view(B, hk, Lg))
             off += n
             W = self.convinv[k].conv.weight.squeeze(-1).float()
-            log_det_W_list.append(B * Lg * torch.logdet(W))          # glow.py:100
+            log_det_W_list.append(B * Lg * _LogDetFunction.apply(W))  # glow.py:100
         return z, log_s_list, log_det_W_list
 
     def draw_noise(self, utterance_seeds, T, device=None):

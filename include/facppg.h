@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FACPPG_VERSION 101 /* 0.1.1 */
+#define FACPPG_VERSION 102 /* 0.1.1 */
 
 #define FACPPG_OK 0
 #define FACPPG_EINVAL (-1)       /* bad argument (NULL pointer, non-positive size, ...) */
@@ -137,6 +137,11 @@ int facppg_conv1x1(const float* w_dev, const float* z_dev, float* out_dev, int B
 size_t facppg_conv1x1_wgrad_workspace_bytes(int c);
 int facppg_conv1x1_wgrad(const float* dout_dev, const float* z_dev, float* dw_dev, int B, int c, int L,
                          void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Replaces torch.logdet(W) of Invertible1x1Conv.forward (glow.py:100) and, through winv_t = W^-T, its gradient
+ * (d logdet / dW = W^-T): LU with partial pivoting of one c x c matrix (c <= 8) in one launch.  logdet_dev [1],
+ * winv_t_dev [c][c].  NaN for a negative determinant, -inf for a singular matrix, as torch.logdet. */
+int facppg_logdet(const float* w_dev, int c, float* logdet_dev, float* winv_t_dev, void* stream);
 
 /* Replaces torch.nn.utils.weight_norm's per-conv recomputation (glow.py:118-146: w = g * v / ||v|| per output row) for
  * ALL weight-normed convs of the model in one launch, and its backward in one more.  table_dev: n_tensors entries of

@@ -189,3 +189,29 @@ def test_two_handles_on_two_streams_concurrently():
             a = wg.infer(mel, sigma=0.6, seed=1)
         torch.cuda.synchronize()
         assert torch.equal(outs[0], serial[0]) and torch.equal(outs[1], serial[1]) and torch.equal(a, a_serial)
+
+
+def test_logdet_kernel_matches_torch():
+    """facppg_logdet (LU with partial pivoting in one launch) vs torch.logdet and its gradient W^-T, for the mixing-matrix
+    sizes the flows use, a matrix that needs pivoting, a negative determinant (NaN) and a singular matrix (-inf)."""
+    import torch
+    from waveglow.glow import _LogDetFunction
+    g = torch.Generator().manual_seed(7)
+    for c in (2, 4, 6, 8):
+        W = torch.linalg.qr(torch.randn(c, c, generator=g))[0] * 1.3 + 0.05 * torch.randn(c, c, generator=g)
+        if torch.det(W) < 0:
+            W[:, 0] = -W[:, 0]
+        Wg = W.cuda().requires_grad_(True)
+        out = _LogDetFunction.apply(Wg)
+        out.backward()
+        Wr = W.double().requires_grad_(True)
+        ref = torch.logdet(Wr)
+        ref.backward()
+        assert abs(float(out) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+        assert torch.allclose(Wg.grad.cpu().double(), Wr.grad, rtol=1e-4, atol=1e-5)
+    P = torch.tensor([[0.0, 2.0, 0.0], [0.0, 0.0, 3.0], [4.0, 0.0, 0.0]])       # zero diagonal: needs row exchanges, det = +24
+    assert abs(float(_LogDetFunction.apply(P.cuda())) - float(torch.log(torch.tensor(24.0)))) < 1e-5
+    N = torch.diag(torch.tensor([1.0, -2.0, 3.0]))
+    assert torch.isnan(_LogDetFunction.apply(N.cuda()))
+    S = torch.tensor([[1.0, 2.0], [2.0, 4.0]])
+    assert float(_LogDetFunction.apply(S.cuda())) == float("-inf")
