@@ -53,3 +53,46 @@ def test_train_loop_checkpoint_and_resume(tmp_path):
     tw.train(1, 0, "", str(out), epochs=100, learning_rate=1e-4, sigma=0.7071, iters_per_checkpoint=1000, batch_size=2, seed=1,
              checkpoint_path=str(out / "waveglow_10"), data_config=data, dist_config=dist_cfg, waveglow_config=cfg,
              max_iterations=13)
+
+
+def test_train_script_bf16_runs_as_replayed_graph(tmp_path, capsys):
+    """script.train_waveglow with train_precision='bf16': the step runs through waveglow.graphed.GraphedTrainStep (three
+    ordinary steps, capture, replays), writes a loadable checkpoint in between, resumes from it (the capturable optimizer
+    state loads), and walks the same losses as the launch-by-launch loop (hip_graph=False) on the same data order."""
+    from common.utils import load_waveglow_model
+    from facppg import synth
+    from script import train_waveglow as tw
+    g = np.random.Generator(np.random.PCG64(11))
+    files = []
+    for i in range(4):
+        t = np.arange(12000 + 400 * i) / 16000.0
+        wav = 0.3 * np.sin(2 * np.pi * (150 + 30 * i) * t) + 0.02 * g.standard_normal(t.shape)
+        path = tmp_path / ("utt%d.wav" % i)
+        wavfile.write(path, 16000, (wav * 32767).astype(np.int16))
+        files.append(str(path))
+    (tmp_path / "files.txt").write_text("\n".join(files) + "\n")
+    cfg = dict(synth.WAVEGLOW_CONFIG, n_flows=4)
+    data = dict(training_files=str(tmp_path / "files.txt"), segment_length=4000, sampling_rate=16000, filter_length=1024,
+                hop_length=160, win_length=1024, mel_fmin=0.0, mel_fmax=8000.0)
+    dist_cfg = dict(dist_backend="nccl", dist_url="tcp://127.0.0.1:54322")
+
+    def run(out, graph, iters, ckpt=""):
+        import random
+        random.seed(5)                     # Mel2Samp's segment crops
+        tw.train(1, 0, "", str(out), epochs=100, learning_rate=1e-4, sigma=0.7071, iters_per_checkpoint=4, batch_size=2, seed=16807,
+                 checkpoint_path=ckpt, data_config=data, dist_config=dist_cfg, waveglow_config=cfg, max_iterations=iters,
+                 train_precision="bf16", hip_graph=graph)
+        lines = [l for l in capsys.readouterr().out.splitlines() if ":\t" in l]
+        return [float(l.split("\t")[1]) for l in lines]
+
+    graphed = run(tmp_path / "g", True, 9)
+    eager = run(tmp_path / "e", False, 9)
+    print("graphed", ["%.4f" % v for v in graphed])
+    print("eager  ", ["%.4f" % v for v in eager])
+    assert len(graphed) == 9 and all(np.isfinite(graphed))
+    assert np.allclose(graphed, eager, rtol=0, atol=5e-4)
+    wg = load_waveglow_model(str(tmp_path / "g" / "waveglow_8"))
+    audio = wg.infer(synth.synthetic_mel(1, 10, seed=1).cuda(), sigma=0.6, seed=1)
+    assert audio.shape == (1, 1600) and torch.isfinite(audio).all()
+    resumed = run(tmp_path / "g", True, 12, ckpt=str(tmp_path / "g" / "waveglow_8"))
+    assert len(resumed) == 3 and all(np.isfinite(resumed))
