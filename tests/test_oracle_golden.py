@@ -119,3 +119,34 @@ def test_hparams_surface():
         hparams.create_hparams_stage(bogus=1)
     with pytest.raises(ValueError):
         hparams.create_hparams(is_large_set=True)           # stage-only key
+
+
+def test_folded_flow_edges_are_the_same_linear_algebra():
+    """The identities the inference kernels rely on (csrc/facppg_wg.hip, k_fold_end_rows / k_fold_first), checked on the
+    oracle in fp64: (i) end(sum_i (Ws_i a_i + bs_i)) = sum_i (W_end Ws_i) a_i + (W_end sum_i bs_i + b_end)  (glow.py:167-175);
+    (ii) the first layer's dilated conv over start(x) = W_start x + b_start equals a 3-tap conv over [x; 1_inside] with
+    weights [W_in[tap] W_start | W_in[tap] b_start] -- including the two edge positions, where the reference zero-pads h,
+    so b_start must NOT arrive through the tap that falls outside (glow.py:156-160)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    nc, nh, nl, L = 16, 3, 4, 23
+    r = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    # (i)
+    W_end, b_end = r(2 * nh, nc), r(2 * nh)
+    acts = [r(1, nc, L) for _ in range(nl)]
+    Ws, bs = [r(nc, nc) for _ in range(nl)], [r(nc) for _ in range(nl)]
+    skip_sum = sum(F.conv1d(a, W[:, :, None], b) for a, W, b in zip(acts, Ws, bs))
+    ref = F.conv1d(skip_sum, W_end[:, :, None], b_end)
+    folded = sum(F.conv1d(a, (W_end @ W)[:, :, None]) for a, W in zip(acts, Ws)) + (W_end @ sum(bs) + b_end)[None, :, None]
+    assert torch.allclose(ref, folded, rtol=1e-12, atol=1e-12)
+    # (ii)
+    W_start, b_start, W_in, b_in = r(nc, nh), r(nc), r(2 * nc, nc, 3), r(2 * nc)
+    x = r(1, nh, L)
+    h = F.conv1d(x, W_start[:, :, None], b_start)
+    ref = F.conv1d(h, W_in, b_in, dilation=1, padding=1)
+    xa = torch.cat([x, torch.ones(1, 1, L, dtype=torch.float64)], 1)                  # indicator channel: 1 inside the utterance
+    W_fold = torch.cat([torch.einsum("oct,cj->ojt", W_in, W_start), torch.einsum("oct,c->ot", W_in, b_start)[:, None, :]], 1)
+    folded = F.conv1d(xa, W_fold, b_in, dilation=1, padding=1)                        # zero padding of xa = zero padding of h
+    assert torch.allclose(ref, folded, rtol=1e-12, atol=1e-12)
+    naive = F.conv1d(x, W_fold[:, :nh], b_in + torch.einsum("oct,c->o", W_in, b_start), dilation=1, padding=1)
+    assert not torch.allclose(ref[..., 0], naive[..., 0]) and torch.allclose(ref[..., 1:-1], naive[..., 1:-1])
