@@ -199,42 +199,56 @@ using namespace facppg;
 // log det W and W^-T of one small mixing matrix (c <= 8) by LU with partial pivoting, one thread: what torch.logdet and its
 // backward do through rocSOLVER in ~22 tiny launches per flow and direction (glow.py:100: log_det_W = B * L * logdet(W)).
 // det <= 0 follows torch.logdet: NaN for a negative determinant, -inf for a singular matrix.
-__global__ void k_logdet(const float* __restrict__ W, int c, float* __restrict__ logdet, float* __restrict__ winv_t) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  float a[8][8], inv[8][8];
-  for (int i = 0; i < c; ++i)
-    for (int j = 0; j < c; ++j) { a[i][j] = W[i * c + j]; inv[i][j] = i == j ? 1.0f : 0.0f; }
-  float sign = 1.0f, logabs = 0.0f;
-  bool singular = false;
+__global__ __launch_bounds__(64) void k_logdet(const float* __restrict__ W, int c, float* __restrict__ logdet, float* __restrict__ winv_t) {
+  // one wave; lane (i, j) owns element [i][j] of the matrix and of the accumulating inverse (Gauss-Jordan on [A | I] with
+  // partial pivoting).  (A one-thread version with the two 8 x 8 arrays in scratch took 72 us per call.)
+  __shared__ float A[8][8], Iv[8][8];
+  __shared__ int s_piv, s_singular;
+  __shared__ float s_sign, s_log;
+  const int tid = threadIdx.x, i = tid >> 3, j = tid & 7;
+  const bool in = i < c && j < c;
+  A[i][j] = in ? W[i * c + j] : (i == j ? 1.0f : 0.0f);
+  Iv[i][j] = i == j ? 1.0f : 0.0f;
+  if (tid == 0) { s_sign = 1.0f; s_log = 0.0f; s_singular = 0; }
+  __syncthreads();
   for (int k = 0; k < c; ++k) {
-    int piv = k;
-    float best = fabsf(a[k][k]);
-    for (int i = k + 1; i < c; ++i)
-      if (fabsf(a[i][k]) > best) { best = fabsf(a[i][k]); piv = i; }
-    if (best == 0.0f) { singular = true; break; }
-    if (piv != k) {
-      for (int j = 0; j < c; ++j) { float t = a[k][j]; a[k][j] = a[piv][j]; a[piv][j] = t; t = inv[k][j]; inv[k][j] = inv[piv][j]; inv[piv][j] = t; }
-      sign = -sign;
+    if (tid == 0) {
+      int piv = k;
+      float best = fabsf(A[k][k]);
+      for (int r = k + 1; r < c; ++r)
+        if (fabsf(A[r][k]) > best) { best = fabsf(A[r][k]); piv = r; }
+      s_piv = piv;
+      if (best == 0.0f) s_singular = 1;
     }
-    const float d = a[k][k];
-    if (d < 0.0f) sign = -sign;
-    logabs += logf(fabsf(d));
-    const float r = 1.0f / d;
-    for (int j = 0; j < c; ++j) { a[k][j] *= r; inv[k][j] *= r; }   // Gauss-Jordan on [A | I]
-    for (int i = 0; i < c; ++i) {
-      if (i == k) continue;
-      const float f = a[i][k];
-      for (int j = 0; j < c; ++j) { a[i][j] = fmaf(-f, a[k][j], a[i][j]); inv[i][j] = fmaf(-f, inv[k][j], inv[i][j]); }
+    __syncthreads();
+    if (s_singular) break;
+    const int piv = s_piv;
+    if (piv != k && i == k) {   // row k's lanes exchange rows k and piv
+      float t = A[k][j]; A[k][j] = A[piv][j]; A[piv][j] = t;
+      t = Iv[k][j]; Iv[k][j] = Iv[piv][j]; Iv[piv][j] = t;
     }
+    __syncthreads();
+    const float d = A[k][k];
+    __syncthreads();
+    if (tid == 0) {
+      if (piv != k) s_sign = -s_sign;
+      if (d < 0.0f) s_sign = -s_sign;
+      s_log += logf(fabsf(d));
+    }
+    if (i == k) { const float r = 1.0f / d; A[k][j] *= r; Iv[k][j] *= r; }
+    __syncthreads();
+    const float f = A[i][k], akj = A[k][j], ikj = Iv[k][j];
+    __syncthreads();
+    if (i != k) { A[i][j] = fmaf(-f, akj, A[i][j]); Iv[i][j] = fmaf(-f, ikj, Iv[i][j]); }
+    __syncthreads();
   }
-  if (singular) {
-    *logdet = -INFINITY;
-    for (int i = 0; i < c * c; ++i) winv_t[i] = NAN;
+  if (s_singular) {
+    if (tid == 0) *logdet = -INFINITY;
+    if (in) winv_t[i * c + j] = NAN;
     return;
   }
-  *logdet = sign > 0.0f ? logabs : NAN;
-  for (int i = 0; i < c; ++i)
-    for (int j = 0; j < c; ++j) winv_t[i * c + j] = inv[j][i];
+  if (tid == 0) *logdet = s_sign > 0.0f ? s_log : NAN;
+  if (in) winv_t[i * c + j] = Iv[j][i];
 }
 
 extern "C" int facppg_logdet(const float* w_dev, int c, float* logdet_dev, float* winv_t_dev, void* stream) {
