@@ -689,7 +689,7 @@ int wgrad_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size
 // sums its slice of the B*L rows (4 row lanes x 64 channels per wavefront-row); stage 2 adds the slices in index
 // order -- a fixed summation order whatever the grid, so the result is bit-reproducible.
 constexpr int CS_SLICES = 256, MAXCS = 16;
-struct ColsumProb { const void* y; long bs; int ld, row0, M; float* out; };
+struct ColsumProb { const void* y; long bs; int ld, row0, M; float* out; float* out2; };   // out2: optional second copy of the sums
 struct ColsumArgs { ColsumProb prob[MAXCS]; int B, L; float* part; };   // part [prob][CS_SLICES][1024]
 template <bool F32>
 __global__ __launch_bounds__(256) void k_colsum_part(ColsumArgs ca) {
@@ -734,6 +734,7 @@ __global__ void k_colsum_sum(ColsumArgs ca, int group) {
   for (int g = 0; g < group; ++g)
     for (int sl = 0; sl < CS_SLICES; ++sl) v += ca.part[((size_t)blockIdx.y * CS_SLICES + sl) * 1024 + mo * group + g];
   p.out[mo] = v;
+  if (p.out2) p.out2[mo] = v;
 }
 template <bool F32>
 int colsum_launch(ColsumArgs& ca, int nprob, int maxM, int group, hipStream_t s) {
@@ -1313,7 +1314,8 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
     ColsumArgs ca;
     memset(&ca, 0, sizeof(ca));
     ca.B = B; ca.L = L; ca.part = (float*)(W + sc.cspart);
-    for (int i = 0; i < nl; ++i) ca.prob[i] = ColsumProb{W + sc.dpre + sc.dpre_one * i, (long)Lp * 2 * C, 2 * C, HALO, 2 * C, gr->in_b[i]};
+    // (the conditioning conv's bias sees the same pre-activations: its gradient is the same sums, written by the same launch)
+    for (int i = 0; i < nl; ++i) ca.prob[i] = ColsumProb{W + sc.dpre + sc.dpre_one * i, (long)Lp * 2 * C, 2 * C, HALO, 2 * C, gr->in_b[i], gr->cond_b[i]};
     if (int rc = colsum_launch<false>(ca, nl, 2 * C, 1, s)) return rc;
     memset(&ca.prob, 0, sizeof(ca.prob));
     int np = 0;
@@ -1323,7 +1325,6 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
       ca.prob[np++] = ColsumProb{dskip, (long)Lr * C, C, 0, C, gr->rs_b[i] + (last ? 0 : C)};
     }
     if (int rc = colsum_launch<false>(ca, np, C, 1, s)) return rc;
-    for (int i = 0; i < nl; ++i) FACPPG_HIP_CHECK(hipMemcpyAsync(gr->cond_b[i], gr->in_b[i], 2 * C * 4, hipMemcpyDeviceToDevice, s));
   }
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
