@@ -988,7 +988,10 @@ StateLayout state_layout(int nl, int B, int Lr) {
 }
 struct ScratchLayout { size_t w1, w2, rst, int_, condt, dpre, dh, dskip, part, cspart, wgpart, wgpart_bytes, total; size_t w1_one, w2_one, rst_one, int_one, dpre_one, dh_one; };
 constexpr int K1 = 3 * C + NCOND;   // 1408
-constexpr int SMALL_PARTS = 256;
+#ifndef FACPPG_SMALL_PARTS
+#define FACPPG_SMALL_PARTS 256
+#endif
+constexpr int SMALL_PARTS = FACPPG_SMALL_PARTS;   // partial sums of the <= 8-channel weight gradients (one block each)
 ScratchLayout scratch_layout(int nl, int B, int Lr) {
   ScratchLayout s;
   const int Lp = HALO + Lr + HALO;

@@ -53,7 +53,8 @@ class GraphedTrainStep:
         self.optimizer.zero_grad(set_to_none=True)   # the captured backward allocates the gradients in the graph's pool
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: the DataLoader's pin-memory thread may allocate pinned memory while this thread captures
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.static_loss = self._forward_backward(self.static_mel, self.static_audio).detach()
             if self.sync_gradients is None:
                 self.optimizer.step()
