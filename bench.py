@@ -1,26 +1,40 @@
 #!/usr/bin/env python3
 """Throughput bench of the PPG->wav hot path on MI355X (driver contract: see the task brief).
 
-A "step" is one WaveGlow.infer over one batch of synthetic mels = BASELINE.json configs[1]:
-batch 8, mel 80x1000, fp32, noise generated on the device, inputs resident in HBM.  The metric is
-BASELINE.json's: 22.05 kHz audio samples per second (hop 256), whole job over all ranks.
-With --gpus N > 1 it runs one rank per GPU: either launched under torch.distributed.run (RANK /
-LOCAL_RANK / WORLD_SIZE / MASTER_* in the env), or -- when WORLD_SIZE is not set -- it spawns the N
-ranks itself (the one-process-per-GPU launcher pattern of the reference's distributed.py:145-170).
-Utterance batches are independent, so each rank synthesises its own batch (weak scaling, no
-data-path collective; RCCL is used only for the barrier and the max-over-ranks of the elapsed
-time).  The world size and the number of ranks RCCL actually sees are asserted to equal --gpus.
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload infer|e2e|corpus|train]
+
+--workload (what one "step" is, and what `value` counts; every workload names its BASELINE.json config):
+  infer   (default) WaveGlow.infer over one batch of synthetic mels = configs[1]: batch 8, mel 80x1000, fp32, noise
+          generated on the device, inputs resident in HBM.  Each rank its own batch (weak scaling).
+  e2e     end-to-end PPG -> mel -> wav (Tacotron2 + WaveGlow + Denoiser) on configs[2]: 16 variable-length utterances
+          per rank (--e2e-batch 1: the metric's "batch = 1" case), host PPG in, device wav out.  Weak scaling.
+  corpus  configs[3]: offline synthesis of --utterances (1024) ragged monophone-PPG utterances sharded over the ranks
+          (facppg.shard, script.synthesize_corpus), INCLUDING the all_gather of lengths and the padded gather of the audio to
+          rank 0.  One step = the whole corpus once.  Strong scaling.
+  train   configs[4]: the bf16 WaveGlow training step (fwd + loss + bwd + Adam, segment 10 000) replayed as a HIP graph,
+          data parallel with the bucketed RCCL gradient all-reduce of waveglow.distributed; reports the exchange's share.
+The metric is BASELINE.json's: 22.05 kHz (hop 256) audio samples per second, whole job over all ranks.
+
+With --gpus N > 1 it runs one rank per GPU: either launched under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* in the env), or -- when WORLD_SIZE is not set -- it spawns the N ranks itself (the one-process-per-GPU launcher
+pattern of the reference's distributed.py:145-170).  The world size and the number of ranks RCCL actually sees are asserted
+to equal --gpus.  An N > 1 `infer` run also carries short `train_dp` and `corpus_dp` entries (the two configs whose
+collectives matter), so one 8-GPU invocation measures them too; --no-extra skips them.
 
 Adds to the JSON line:
-  roofline      fp32-MFMA roofline of the dominant kernel (k_wn_layer): algorithmic FLOPs per
-                launch / its average launch duration measured live with hipEvents on the launch
-                stream during the timed steps (facppg_wg_last_layer_ms).
-  cpu_baseline  the CPU oracle (a port of the reference's PyTorch-CPU path) timed on this host's
-                cores on a bounded sample (rank 0, N=1 only).
+  roofline      fp32-MFMA roofline of the dominant kernel (k_wn_layer): algorithmic FLOPs per launch / its average launch
+                duration measured live with hipEvents on the launch stream during the timed steps.
+  end_to_end_*  the metric's own configurations (batch 1 and the 16-utterance ragged batch) timed in THIS process: K steps
+                between synchronisations on the host clock (`steps`, `ms_per_step`) plus a hipEvent stage breakdown.
+  cpu_baseline  the CPU oracle (a port of the reference's PyTorch-CPU path) timed on this host's cores on a bounded sample
+                (rank 0, N=1 only): end to end on config 1 and a config-3 subset, median of 3 after a warm-up.
 """
 import argparse
+import contextlib
+import hashlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -32,11 +46,24 @@ for _p in (ROOT, os.path.join(ROOT, "fac-via-ppg_amd")):
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0
 BATCH, FRAMES, HOP, SR = 8, 1000, 256, 22050
+METRIC = "22.05 kHz audio samples/sec end-to-end PPG→wav; real-time factor at batch=1"   # BASELINE.json, verbatim
+WG_KERNEL_SOURCE = os.path.join(ROOT, "fac-via-ppg_amd", "csrc", "facppg_wg.hip")
+
+
+def kernel_source_id(path=WG_KERNEL_SOURCE):
+    """Identity of the WaveGlow kernel source a measurement belongs to: sha1 of the file with comments and blank
+    space removed.  profiles/rNN_pmc.json records it (tools/make_pmc_json.py); a PMC summary taken from another
+    build of the kernels is not quoted as this build's traffic."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    return hashlib.sha1(re.sub(r"\s+", "", src).encode()).hexdigest()[:16]
 
 
 def layer_flops_per_position(n_layers=8, C=256, ncond=None, edge_fold=None, n_flows=12, n_early_every=4, n_early_size=2,
-                             n_group=8):
+                             n_group=8, hop=HOP):
     """Algorithmic FLOPs of one k_wn_layer launch per group position, averaged over all layers of all flows
     (SURVEY.md Appendix D): in_layer 2*C*2C*3 + cond 2*ncond*2C + res_skip 2*C*2C (C in a flow's last layer).
     The FLOPs counted are those of the formulation that actually runs:
@@ -49,7 +76,7 @@ def layer_flops_per_position(n_layers=8, C=256, ncond=None, edge_fold=None, n_fl
     ncond=640 with edge_fold=False is the reference's own formulation."""
     unfolded = os.environ.get("FACPPG_WG_UNFOLDED", "0") not in ("", "0")
     if ncond is None:
-        ncond = 640 if unfolded else -(-1024 // HOP) * 80
+        ncond = 640 if unfolded else -(-1024 // hop) * 80
     if edge_fold is None:
         edge_fold = not unfolded and os.environ.get("FACPPG_WG_EDGE_FOLD", "1") not in ("0",)
     g1 = 2 * (3 * C + ncond) * 2 * C
@@ -66,66 +93,120 @@ def layer_flops_per_position(n_layers=8, C=256, ncond=None, edge_fold=None, n_fl
     return total / (n_flows * n_layers)
 
 
-def cpu_baseline_worker(threads, frames):
-    """Oracle WaveGlow.infer (a port of the reference's PyTorch-CPU path, validated against the
-    reference's golden vectors) on `threads` host cores; prints one JSON line."""
+# ---------------------------------------------------------------------------------------------- CPU baseline (oracle)
+def config3_lengths(n=16, seed=7):
+    """Tin_i = 100 + PCG64(seed).integers(0, 301) frames (1-4 s)."""
+    import numpy as np
+    return (100 + np.random.Generator(np.random.PCG64(seed)).integers(0, 301, size=n)).tolist()
+
+
+def cpu_baseline_worker(threads, mode):
+    """The oracle (a port of the reference's PyTorch-CPU path, validated against the reference's golden vectors) on
+    `threads` host cores; prints one JSON line.  Modes: wg600 = WaveGlow.infer alone, B = 1 x 600 frames, one run;
+    e2e1 = config 1 end to end (PPG [200 x 5816] -> Tacotron2 -> WaveGlow -> Denoiser), e2e3 = the two shortest
+    utterances of config 3 one after the other (the reference synthesises batch 1 only): warm-up + median of 3."""
+    import numpy as np
+    from common.hparams import create_hparams_stage
     from facppg import synth
-    from oracle import waveglow as owg
+    from oracle import dsp, tacotron as otac, waveglow as owg
     torch.set_num_threads(threads)
     cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=HOP)
     sd = synth.waveglow_state_dict(cfg)
-    mel = synth.synthetic_mel(1, frames, seed=1234)
-    zs = synth.synthetic_z(1, frames * HOP // 8, cfg, seed=4321)
+
+    def z_for(frames, seed):
+        return synth.synthetic_z(1, frames * HOP // 8, cfg, seed=seed)
+
     with torch.no_grad():
-        owg.infer(sd, cfg, mel[:, :, :20], 0.6, [z[:, :, :20 * HOP // 8] for z in zs])   # warm-up
-        t0 = time.perf_counter()
-        owg.infer(sd, cfg, mel, 0.6, zs)
-        t = time.perf_counter() - t0
-    print(json.dumps({"threads": threads, "frames": frames, "seconds": t, "value": frames * HOP / t}))
+        owg.infer(sd, cfg, synth.synthetic_mel(1, 20, seed=1), 0.6, z_for(20, 2))   # warm-up (thread pool, oneDNN primitives)
+        if mode == "wg600":
+            frames = 600
+            mel, zs = synth.synthetic_mel(1, frames, seed=1234), z_for(frames, 4321)
+            t0 = time.perf_counter()
+            owg.infer(sd, cfg, mel, 0.6, zs)
+            t = time.perf_counter() - t0
+            print(json.dumps({"threads": threads, "mode": mode, "seconds": t, "samples": frames * HOP, "runs": 1}))
+            return
+        lens = [200] if mode == "e2e1" else sorted(config3_lengths())[:2]
+        hp = create_hparams_stage(max_decoder_steps=max(lens))
+        tsd = synth.tacotron_state_dict(hp, gate_bias=-10.0)
+        nb = 88 * HOP // 8
+        bias = owg.infer(sd, cfg, torch.zeros(1, 80, 88), 0.0, [torch.zeros(1, 4, nb), torch.zeros(1, 2, nb), torch.zeros(1, 2, nb)])
+        den = dsp.DenoiserOracle(bias, hop_length=HOP)
+        g = np.random.Generator(np.random.PCG64(3))
+        utts = []
+        for i, n in enumerate(lens):
+            x = torch.from_numpy(synth.synthetic_ppg(n, 5816, seed=i)).t().unsqueeze(0)
+            em = torch.from_numpy((g.random((2, 1, n, hp.symbols_embedding_dim)) < 0.5).astype(np.float32))
+            dm = torch.from_numpy((g.random((n, 2, 1, hp.prenet_dim)) < 0.5).astype(np.float32))
+            utts.append((n, x, em, dm, z_for(n, 50 + i)))
+
+        def run():
+            out = 0
+            for n, x, em, dm, zs in utts:
+                hp_n = create_hparams_stage(max_decoder_steps=n)
+                _, mel_post, _, _ = otac.inference(tsd, hp_n, x, em, dm)
+                wav = den(owg.infer(sd, cfg, mel_post, 0.6, zs), 0.005)
+                out += wav.shape[-1]
+            return out
+        run()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            samples = run()
+            ts.append(time.perf_counter() - t0)
+    print(json.dumps({"threads": threads, "mode": mode, "seconds": sorted(ts)[1], "samples": samples, "runs": 3, "frames": lens}))
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(log):
-    """Bounded CPU sample in subprocesses (a 256-thread oneDNN run of these small convs is
-    pathologically slow, so a few thread counts are tried under a timeout and the best is reported)."""
+    """Bounded CPU sample in subprocesses (configs 1-3 end to end, median of 3 after a warm-up, core count
+    and CPU model stated).  A 256-thread oneDNN run of these small convolutions is pathologically slow, so the thread
+    count is fixed at 16 (round 2 measured 16 / 32 threads: 16 is 2.4x faster)."""
     import subprocess
-    frames, best = 600, None
-    for threads in (16, 32):
-        if threads > (os.cpu_count() or 1):
-            continue
+    threads = min(16, os.cpu_count() or 1)
+    res = {}
+    for mode, limit in (("e2e1", 240), ("e2e3", 240), ("wg600", 120)):
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(threads), str(frames)],
-                               capture_output=True, text=True, timeout=120)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(threads), mode],
+                               capture_output=True, text=True, timeout=limit)
             d = json.loads(r.stdout.strip().splitlines()[-1])
-            log("cpu baseline: %d threads -> %.0f samples/s (%.1f s)" % (threads, d["value"], d["seconds"]))
-            if best is None or d["value"] > best["value"]:
-                best = d
-        except Exception as e:  # timeout or parse failure: report what we have
-            log("cpu baseline with %d threads failed: %r" % (threads, e))
-    if best is None:
+            d["value"] = d["samples"] / d["seconds"]
+            log("cpu baseline %s: %d threads -> %.0f samples/s (%.1f s per run)" % (mode, threads, d["value"], d["seconds"]))
+            res[mode] = d
+        except Exception as e:  # noqa: BLE001  (timeout or parse failure: report what we have)
+            log("cpu baseline %s failed: %r" % (mode, e))
+    if not res:
         return None
-    return {"value": best["value"], "unit": "samples/s", "cores": best["threads"], "kind": "port",
-            "host_cpus": os.cpu_count(),
-            "sample": "oracle (torch-CPU fp32 port of the reference path) WaveGlow.infer B=1 mel 80x%d hop=%d = %d samples, "
-                      "%.1f s on %d threads (best of 16/32 threads)" % (frames, HOP, frames * HOP, best["seconds"], best["threads"])}
+    head = res.get("e2e1") or res.get("e2e3") or res["wg600"]
+    out = {"value": head["value"], "unit": "samples/s", "cores": threads, "kind": "port", "host_cpus": os.cpu_count(),
+           "cpu_model": cpu_model_name(),
+           "sample": "oracle (torch-CPU fp32 port of the reference path, pinned to reference-generated golden vectors) on %d of %d "
+                     "host threads; value = config 1 end to end: PPG [200 x 5816] -> Tacotron2 -> WaveGlow -> Denoiser at hop %d = "
+                     "%d samples, median of 3 runs after a warm-up (%.1f s per run)" % (
+                         threads, os.cpu_count() or 0, HOP, head["samples"], head["seconds"]),
+           "realtime_factor": head["value"] / SR}
+    if "e2e3" in res:
+        d = res["e2e3"]
+        out["config3_subset"] = {"value": d["value"], "seconds": d["seconds"], "samples": d["samples"],
+                                 "sample": "the two shortest utterances of config 3 (%s frames), synthesised one after the other as "
+                                           "the reference does (batch 1), median of 3 after a warm-up" % d.get("frames")}
+    if "wg600" in res:
+        d = res["wg600"]
+        out["waveglow_only"] = {"value": d["value"], "seconds": d["seconds"], "samples": d["samples"],
+                                "sample": "oracle WaveGlow.infer alone, B=1, mel 80x600, hop=%d, one run after a warm-up" % HOP}
+    return out
 
 
-def end_to_end(log):
-    """The metric's own configurations (PPG -> mel -> wav: Tacotron2 + WaveGlow + Denoiser), batch=1 (its
-    "real-time factor at batch=1") and BASELINE configs[2] (16 variable-length utterances), measured in a child
-    process (e2e_worker) so that nothing it does -- it uses cooperative launches, which rocprofv3 on this stack
-    does not survive -- can take the primary measurement down with it.  Returns None if the child fails."""
-    import subprocess
-    try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--e2e-worker"], capture_output=True, text=True, timeout=600)
-        out = json.loads(r.stdout.strip().splitlines()[-1])
-        for k, v in out.items():
-            log("end-to-end %s: %d samples in %.2f ms = %.0fx real time" % (k, v["samples"], v["ms"], v["realtime_factor"]))
-        return out
-    except Exception as e:   # noqa: BLE001  (secondary figure: report its absence, never fail the bench)
-        log("end-to-end measurement failed: %r" % (e,))
-        return None
-
-
+# ---------------------------------------------------------------------------------------------- secondary figures
 def train_step(log):
     """BASELINE configs[4]'s step (WaveGlow fwd + loss + bwd + Adam, segment 10 000, bf16 MFMA operands) on ONE GPU at the
     reference's per-GPU batch 3 and at 12, in a child process; secondary figure.  Returns None if the child fails."""
@@ -141,30 +222,43 @@ def train_step(log):
         return None
 
 
-def train_worker():
+def train_batch(dev, B, seed=1):
+    """A synthetic training batch: audio [B, 10000] ~ N(0, 0.1^2) clipped to +-1 and its mel
+    from the build's own GPU mel analysis (hop 160, 16 kHz: the reference's training config, config.json)."""
     import numpy as np
     from common.layers import TacotronSTFT
+    stft = TacotronSTFT(1024, 160, 1024, 80, 16000, 0.0, 8000.0).to(dev)
+    g = np.random.Generator(np.random.PCG64(seed))
+    audio = torch.from_numpy(np.clip(g.standard_normal((B, 10000), dtype=np.float32) * 0.1, -1, 1)).to(dev)
+    with torch.no_grad():
+        mel = stft.mel_spectrogram(audio)
+    return mel, audio
+
+
+def make_train_model(dev, prec="bf16"):
+    """WaveGlow in training mode (weight-normed, non-trivial coupling: WN.end ~ N(0, 0.02^2)) and its loss."""
     from facppg import synth
     from waveglow.glow import WaveGlow, WaveGlowLoss
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
-    cfg = dict(synth.WAVEGLOW_CONFIG)                      # the reference's training config: hop 160, 16 kHz (config.json)
-    m = WaveGlow(**cfg).to(dev).train()
+    torch.manual_seed(16807)
+    m = WaveGlow(**dict(synth.WAVEGLOW_CONFIG)).to(dev).train()
     with torch.no_grad():
         for wn in m.WN:
             wn.end.weight.normal_(0, 0.02)
-    stft = TacotronSTFT(1024, 160, 1024, 80, 16000, 0.0, 8000.0).to(dev)
-    crit = WaveGlowLoss(0.7071)
-    out = {}
+    m.train_precision = prec
+    return m, WaveGlowLoss(0.7071)
+
+
+def train_worker():
     from waveglow.graphed import GraphedTrainStep
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    out = {}
+    m, crit = make_train_model(dev)
     for prec, B, graphed in (("bf16", 3, True), ("bf16", 12, True), ("bf16", 3, False), ("bf16", 12, False), ("fp32", 3, False)):
         m.train_precision = prec
+        mel, audio = train_batch(dev, B)
         # graphed: the step replayed as one captured HIP graph, as script.train_waveglow runs it by default under bf16
         opt = torch.optim.Adam(m.parameters(), lr=1e-5, fused=True, capturable=graphed)
-        g = np.random.Generator(np.random.PCG64(1))
-        audio = torch.from_numpy(np.clip(g.standard_normal((B, 10000), dtype=np.float32) * 0.1, -1, 1)).to(dev)
-        with torch.no_grad():
-            mel = stft.mel_spectrogram(audio)
         stepper = GraphedTrainStep(m, crit, opt, warmup=2) if graphed else None
         ts = []
         for i in range(9 if graphed else 6):
@@ -182,7 +276,7 @@ def train_worker():
         steady = ts[4:] if graphed else ts[1:]              # graphed: 2 warm-up steps, the capturing step, one more
         t = sorted(steady)[len(steady) // 2]
         flops = 3 * 20.26e6 * B * 10000                      # fwd 20.3 MFLOP/sample, fwd + bwd ~ 3x
-        peak = 2500.0 if prec == "bf16" else PEAK_F32_MFMA_TFLOPS
+        peak = PEAK_BF16_MFMA_TFLOPS if prec == "bf16" else PEAK_F32_MFMA_TFLOPS
         out["%s_B%d%s" % (prec, B, "_graph" if graphed else "")] = {
             "workload": "WaveGlow training step (fwd + WaveGlowLoss + bwd + fused Adam), segment 10000 @16 kHz / hop 160, per-GPU batch %d, "
                         "%s MFMA operands, fp32 accumulation / master weights / gradients, 1 GPU, %s" % (
@@ -199,7 +293,7 @@ def stage_rooflines(stages, frames_in, frames_out, batch, hop):
     microseconds per frame (latency-bound: neither roofline applies)."""
     out = {}
     pos = frames_out * hop // 8
-    flop = {"encoder": 22.8e6 * frames_in, "postnet": 8.68e6 * frames_out, "waveglow": 96 * layer_flops_per_position() * pos}
+    flop = {"encoder": 22.8e6 * frames_in, "postnet": 8.68e6 * frames_out, "waveglow": 96 * layer_flops_per_position(hop=hop) * pos}
     for k, f in flop.items():
         if stages.get(k):
             t = f / (stages[k] * 1e-3) / 1e12
@@ -214,53 +308,72 @@ def stage_rooflines(stages, frames_in, frames_out, batch, hop):
     return out
 
 
-def e2e_worker():
-    """PPG -> mel -> wav (Tacotron2.inference + WaveGlow.infer + Denoiser) with inputs on the host (the PPG upload is
-    part of the path), timed with hipEvents on the launch stream (facppg.pipeline.StageTimer): total and per stage.
-    Median of 5 after 2 warm-ups.  Prints one JSON line {config: {...}}."""
-    import contextlib
-    import numpy as np
-    from common.hparams import create_hparams_stage
-    from facppg import pipeline, synth
-    from script.train_ppg2mel import load_model
-    from waveglow.denoiser import Denoiser
-    from waveglow.glow import WaveGlow
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
-    cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=HOP)
-    waveglow = WaveGlow.remove_weightnorm(WaveGlow(**cfg))
-    waveglow.load_state_dict(synth.waveglow_state_dict(cfg))
-    waveglow = waveglow.to(dev).eval()
-    den = Denoiser(waveglow, hop_length=HOP, mode="zeros")
-    g = np.random.Generator(np.random.PCG64(7))
-    configs = {"batch1": [200], "batch16_ragged": (100 + g.integers(0, 301, size=16)).tolist()}     # SURVEY.md 8d configs 1 / 3
-    out = {}
-    with contextlib.redirect_stdout(sys.stderr):     # the model prints the reference's "Reached max decoder steps"
-        for name, lens in configs.items():
-            hp = create_hparams_stage(max_decoder_steps=max(lens))
-            taco = load_model(hp)
-            taco.load_state_dict(synth.tacotron_state_dict(hp, gate_bias=-10.0))
-            taco.eval()
-            ppgs = [synth.synthetic_ppg(n, 5816, seed=i) for i, n in enumerate(lens)]
-            runs = []
-            for i in range(7):
-                timer = pipeline.StageTimer()
-                wavs, tout = pipeline.synthesize(ppgs, taco, waveglow, den, sigma=0.6, strength=0.005, seed=i, return_device=True,
-                                                 step_limits=lens if len(lens) > 1 else None, timer=timer)
-                runs.append(timer.stages_ms())
-            runs = sorted(runs[2:], key=lambda r: r["total"])
-            st = runs[len(runs) // 2]
-            n = sum(tout) * HOP
-            out[name] = {"workload": "PPG [%s x 5816] -> mel -> wav, hop=%d, batch=%d%s (Tacotron2 + WaveGlow + Denoiser), host PPG in, "
-                                     "device wav out" % ("200" if len(lens) == 1 else "100..400", HOP, len(lens),
-                                                         "" if len(lens) == 1 else " ragged, max_decoder_steps = Tin_i"),
-                         "timing": "hipEvents on the launch stream, median of 5 after 2 warm-ups",
-                         "ms": st["total"], "samples": n, "samples_per_s": n / (st["total"] * 1e-3),
-                         "realtime_factor": n / (st["total"] * 1e-3) / SR, "frames": sum(tout),
-                         "stage_ms": {k: v for k, v in st.items() if k != "total"},
-                         "stage_roofline": stage_rooflines(st, sum(lens), sum(tout), len(lens), HOP)}
-            del taco
-    print(json.dumps(out))
+class EndToEnd(object):
+    """PPG -> mel -> wav (Tacotron2.inference + WaveGlow.infer + Denoiser) on synthetic utterances, inputs on the host (the
+    PPG upload is part of the path).  SURVEY.md 8d: config 1 = one 200-frame utterance, config 3 = 16 utterances of
+    Tin_i = 100 + PCG64(7).integers(0, 301) frames with max_decoder_steps = Tin_i."""
+
+    def __init__(self, dev, lens, n_symbols=5816, seed0=0, waveglow=None, denoiser=None):
+        from common.hparams import create_hparams_stage
+        from facppg import synth
+        from script.train_ppg2mel import load_model
+        from waveglow.denoiser import Denoiser
+        from waveglow.glow import WaveGlow
+        self.dev, self.lens = dev, list(lens)
+        if waveglow is None:
+            cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=HOP)
+            waveglow = WaveGlow.remove_weightnorm(WaveGlow(**cfg))
+            waveglow.load_state_dict(synth.waveglow_state_dict(cfg))
+            waveglow = waveglow.to(dev).eval()
+        self.waveglow = waveglow
+        self.denoiser = denoiser if denoiser is not None else Denoiser(waveglow, hop_length=HOP, mode="zeros")
+        with contextlib.redirect_stdout(sys.stderr):
+            hp = create_hparams_stage(max_decoder_steps=max(self.lens), n_symbols=n_symbols)
+            self.tacotron = load_model(hp)
+            self.tacotron.load_state_dict(synth.tacotron_state_dict(hp, gate_bias=-10.0))
+            self.tacotron.eval()
+        self.ppgs = [synth.synthetic_ppg(n, n_symbols, seed=seed0 + i, alpha=0.002 if n_symbols > 100 else 0.1)
+                     for i, n in enumerate(self.lens)]
+        self.samples = sum(self.lens) * HOP
+
+    def step(self, i, timer=None):
+        from facppg import pipeline
+        with contextlib.redirect_stdout(sys.stderr):     # the model prints the reference's "Reached max decoder steps"
+            return pipeline.synthesize(self.ppgs, self.tacotron, self.waveglow, self.denoiser, sigma=0.6, strength=0.005, seed=i,
+                                       return_device=True, step_limits=self.lens if len(self.lens) > 1 else None, timer=timer)
+
+    def describe(self):
+        n = len(self.lens)
+        return ("PPG [%s x %d] -> mel -> wav, hop=%d (%d Hz), batch=%d%s (Tacotron2 + WaveGlow + Denoiser), fp32, host PPG in, "
+                "device wav out; seeded synthetic weights" % ("200" if n == 1 else "100..400", self.ppgs[0].shape[1], HOP, SR, n,
+                                                              "" if n == 1 else " ragged, max_decoder_steps = Tin_i"))
+
+
+def time_end_to_end(dev, lens, steps, warmup, log, name, **kw):
+    """K steps between two synchronisations on the host clock (the driver-checkable figure) + one more step under a
+    hipEvent StageTimer for the per-stage breakdown."""
+    from facppg import pipeline
+    e = EndToEnd(dev, lens, **kw)
+    for i in range(warmup):
+        e.step(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        wavs, tout = e.step(warmup + i)
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    timer = pipeline.StageTimer()
+    e.step(warmup + steps, timer=timer)
+    st = timer.stages_ms()
+    assert [int(t) for t in tout] == e.lens and all(torch.isfinite(w).all() for w in wavs)
+    ms = el / steps * 1e3
+    log("end-to-end %s: %d samples in %.2f ms/step = %.0fx real time" % (name, e.samples, ms, e.samples / (ms * 1e-3) / SR))
+    return {"workload": e.describe(), "timing": "host clock around %d steps between device synchronisations, after %d warm-ups; "
+            "stage_ms: hipEvents on the launch stream, one further step" % (steps, warmup),
+            "steps": steps, "warmup": warmup, "ms_per_step": ms, "ms": ms, "samples": e.samples, "samples_per_s": e.samples / (ms * 1e-3),
+            "realtime_factor": e.samples / (ms * 1e-3) / SR, "frames": sum(e.lens), "stage_ms_total": st["total"],
+            "stage_ms": {k: v for k, v in st.items() if k != "total"},
+            "stage_roofline": stage_rooflines(st, sum(e.lens), sum(e.lens), len(e.lens), HOP)}
 
 
 def reference_rate_config(dev, mel, log):
@@ -288,20 +401,27 @@ def reference_rate_config(dev, mel, log):
 
 
 def pmc_traffic():
-    """HBM bytes per k_wn_layer launch, READ FROM the committed rocprofv3 PMC passes of this same command
-    (newest profiles/rNN_pmc.json; FETCH_SIZE doubled per the gfx950 correction, calibrated on k_flow_end) -- PMC
-    counters cannot be collected from inside the timed run.  Returns (bytes, provenance) or (None, None)."""
+    """HBM bytes per k_wn_layer launch, READ FROM the committed rocprofv3 PMC passes of this same command (newest
+    profiles/rNN_pmc.json; FETCH_SIZE doubled per the gfx950 correction, calibrated on k_flow_end) -- PMC counters cannot
+    be collected from inside the timed run.  The summary records the identity of the kernel source it was taken from
+    (tools/make_pmc_json.py); one taken from ANOTHER build of the kernels is refused (traffic = null and the reason in
+    traffic_source) instead of being passed off as this build's.  Returns (bytes or None, provenance)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)["k_wn_layer"]
+            have, want = d.get("kernel_source_id"), kernel_source_id()
+            if have != want:
+                return None, "STALE: %s was taken from kernel source %s, this build is %s -- re-run tools/profile_bench.sh" % (
+                    os.path.basename(path), have, want)
             return d["hbm_bytes_per_launch"], "static: %s (%s)" % (os.path.basename(path), d.get("build", "separate rocprofv3 --pmc passes"))
-        except Exception:
+        except Exception:   # noqa: BLE001
             continue
     return None, None
 
 
+# ---------------------------------------------------------------------------------------------- launch plumbing
 def spawn_ranks(n, argv):
     """--gpus N without a launcher: start N copies of this script, one per GPU, with the env torch.distributed.run
     would give them (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1, a free MASTER_PORT), wait for all, and pass
@@ -353,9 +473,20 @@ def rank_census(dist, dev, backend):
     return int(one.item()), [int(t.item()) for t in all_dev]
 
 
+class FakeCorpusSynthesizer(object):
+    """CPU stand-in for facppg.pipeline.Synthesizer in --launch-check (the HIP path needs a GPU): utterance i of n frames
+    -> a ramp of n * HOP samples whose values encode (seed, n)."""
+
+    def __call__(self, ppgs, utterance_seeds=None, step_limits=None, return_device=False, **kw):
+        wavs = [torch.arange(p.shape[0] * HOP, dtype=torch.float32) * 1e-6 + float(s % 1000) for p, s in zip(ppgs, utterance_seeds)]
+        return wavs, [p.shape[0] for p in ppgs]
+
+
 def launch_check(args):
     """CPU-runnable check of the N-rank launch path (tests/test_bench_launch.py): rendezvous, census, barrier, one JSON
-    line from rank 0 -- everything bench.py does around the timed region, without the GPU work."""
+    line from rank 0 -- everything bench.py does around the timed region, without the GPU work.  With --workload corpus /
+    train the workload's own data path runs too, on CPU stand-ins: the sharding + all_gather + padded gather of the
+    corpus, the bucketed gradient exchange of the training step."""
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
@@ -365,10 +496,241 @@ def launch_check(args):
     dist.barrier()
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    out = {"launch_check": True, "workload": args.workload, "n_gpus": world, "world_size": dist.get_world_size(), "ranks_connected": n,
+           "max_over_ranks": float(t.item())}
+    if args.workload == "corpus":
+        corpus = CorpusWorkload(None, rank, world, args, dist, synthesizer=FakeCorpusSynthesizer())
+        got = corpus.step(0)
+        if rank == 0:
+            out["utterances"] = len(got)
+            out["samples"] = int(sum(v.numel() for v in got.values()))
+            out["expected_samples"] = corpus.samples
+            out["lengths_ok"] = all(got[i].numel() == n_ * HOP for i, n_ in enumerate(corpus.lengths))
+    if args.workload == "train":
+        from waveglow.distributed import GradientExchange, broadcast_parameters
+        torch.manual_seed(rank)
+        m = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Tanh(), torch.nn.Linear(8, 2))
+        broadcast_parameters(m, 0)
+        ex = GradientExchange(m, n_buckets=2)
+        m(torch.full((4, 8), float(rank + 1))).sum().backward()
+        local = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+        ex.exchange()
+        mean = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        out["exchange_ok"] = bool(torch.allclose(mean, sum(gathered) / world, atol=1e-6))
+        out["exchange_bytes"] = ex.bytes_per_exchange()
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": world, "world_size": dist.get_world_size(), "ranks_connected": n,
-                          "max_over_ranks": float(t.item())}))
+        print(json.dumps(out))
     dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------- workloads
+class InferWorkload(object):
+    """configs[1]: WaveGlow.infer batch 8 x 80x1000 per rank."""
+    name, scaling, dtype = "infer", "weak", "f32"
+
+    def __init__(self, dev, rank, world, args, dist):
+        from facppg import lib as flib, synth
+        from waveglow.glow import WaveGlow
+        self.dev, self.world, self.flib = dev, world, flib
+        cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=HOP)
+        model = WaveGlow.remove_weightnorm(WaveGlow(**cfg))
+        model.load_state_dict(synth.waveglow_state_dict(cfg))
+        self.model = model.to(dev).eval()
+        self.mel = synth.synthetic_mel(BATCH, FRAMES, seed=1234 + rank).to(dev)
+        self.samples = world * BATCH * FRAMES * HOP
+        self.audio = None
+
+    def step(self, i):
+        self.audio = self.model.infer(self.mel, sigma=0.6, seed=1000 + i)
+
+    def start_timed(self):
+        L = self.flib.load()
+        self.flib.check(L.facppg_wg_set_profiling(self.model._handle(self.dev), 1))
+
+    def finish(self, out, elapsed, steps):
+        flib, L = self.flib, self.flib.load()
+        ms, n = flib.ctypes.c_float(), flib.ctypes.c_int()
+        flib.check(L.facppg_wg_last_layer_ms(self.model._handle(self.dev), flib.ctypes.byref(ms), flib.ctypes.byref(n)))
+        layer_ms, layer_n = ms.value, n.value
+        assert os.environ.get("FACPPG_BENCH_NO_CHECK") or torch.isfinite(self.audio).all()
+        positions = BATCH * FRAMES * HOP // 8
+        flops = layer_flops_per_position() * positions
+        achieved = flops / (layer_ms * 1e-3) / 1e12 if layer_ms > 0 else 0.0
+        # the same launch priced at the reference formulation's FLOPs (SURVEY.md 8d: 2*(3*256+640)*512 + res_skip per
+        # position); it can exceed the fp32 MFMA peak because the folded kernels execute a third fewer FLOPs
+        flops_ref = layer_flops_per_position(ncond=640, edge_fold=False) * positions
+        achieved_ref = flops_ref / (layer_ms * 1e-3) / 1e12 if layer_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic()
+        tile = self.model.last_launch_shape()
+        out["config"] = {"workload": "BASELINE configs[1]: WaveGlow.infer batch=%d, mel 80x%d, hop=%d (%d Hz), fp32, sigma=0.6, device "
+                                     "Philox noise; the vocoder stage (98.8 %% of the FLOPs) of the PPG->wav path; seeded synthetic weights "
+                                     "(no checkpoints ship with the reference); the metric's end-to-end configurations are in "
+                                     "end_to_end_batch1 / end_to_end_batch16_ragged" % (BATCH, FRAMES, HOP, SR),
+                         "per_gpu_batch": BATCH, "global_batch": BATCH * self.world, "parallelism": "dp%d" % self.world}
+        out["roofline"] = {"bound": "mfma", "kernel": "k_wn_layer", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                           "avg_launch_ms": layer_ms, "launches_timed": layer_n, "flops_per_launch": flops,
+                           "tile_frames": tile[0], "waves_per_workgroup": tile[1], "workgroups_per_launch": tile[2],
+                           "kernel_source_id": kernel_source_id(),
+                           "reference_formulation": {"flops_per_launch": flops_ref, "achieved": achieved_ref,
+                                                     "frac": achieved_ref / PEAK_F32_MFMA_TFLOPS}}
+
+
+class E2EWorkload(object):
+    """configs[2] (or, --e2e-batch 1, the metric's batch-1 case): end-to-end PPG -> wav per rank."""
+    name, scaling, dtype = "e2e", "weak", "f32"
+
+    def __init__(self, dev, rank, world, args, dist):
+        lens = [200] if args.e2e_batch == 1 else config3_lengths(args.e2e_batch, 7 + rank)
+        self.e = EndToEnd(dev, lens, seed0=1000 * rank)
+        self.world, self.dev = world, dev
+        # every rank has the same number of utterances but its own lengths: count what was really synthesised
+        n = torch.tensor([float(self.e.samples)], dtype=torch.float64)
+        if dist is not None:
+            n = n.to(dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(n)
+        self.samples = int(n.item())
+
+    def step(self, i):
+        self.out = self.e.step(i)
+
+    def start_timed(self):
+        pass
+
+    def finish(self, out, elapsed, steps):
+        from facppg import pipeline
+        timer = pipeline.StageTimer()
+        self.e.step(10 ** 6, timer=timer)
+        st = timer.stages_ms()
+        out["config"] = {"workload": "BASELINE configs[2]: " + self.e.describe() if len(self.e.lens) > 1 else
+                         "the metric's batch = 1 case (SURVEY.md 8d config 1): " + self.e.describe(),
+                         "per_gpu_batch": len(self.e.lens), "global_batch": len(self.e.lens) * self.world, "parallelism": "dp%d" % self.world}
+        out["stage_ms"] = {k: v for k, v in st.items() if k != "total"}
+        out["stage_roofline"] = stage_rooflines(st, sum(self.e.lens), sum(self.e.lens), len(self.e.lens), HOP)
+
+
+class CorpusWorkload(object):
+    """configs[3]: --utterances ragged monophone-PPG utterances (Tin_i = 100 + PCG64(11).integers(0, 301)
+    frames, 40 symbols = config "1m") sharded over the ranks by facppg.shard.partition; every rank synthesises its shard
+    in batches of 16 through script.synthesize_corpus.synthesize_shard; the audio comes back to rank 0 through
+    script.synthesize_corpus.collect (an all_gather of lengths + one padded gather over RCCL).  No files: the PPGs are
+    generated in memory and the waveforms stay in memory on rank 0."""
+    name, scaling, dtype = "corpus", "strong", "f32"
+
+    def __init__(self, dev, rank, world, args, dist, synthesizer=None):
+        import numpy as np
+        from facppg import synth
+        self.rank, self.world, self.dev = rank, world, dev
+        self.lengths = config3_lengths(args.utterances, 11)
+        self.samples = sum(self.lengths) * HOP
+        self.args = argparse.Namespace(batch_size=16, sigma=0.6, denoiser_strength=0.005, seed=0, limit_steps_to_input=True)
+        from facppg import shard
+        mine = set(shard.partition(self.lengths, world)[rank])
+        nsym = 40
+        # only this rank's utterances are materialised (the others are never touched by synthesize_shard)
+        self.ppgs = [synth.synthetic_ppg(n, nsym, seed=5000 + i, alpha=0.1) if i in mine else np.zeros((n, 0), np.float32)
+                     for i, n in enumerate(self.lengths)]
+        if synthesizer is None:
+            e = EndToEnd(dev, [max(self.lengths)], n_symbols=nsym)
+            from facppg import pipeline
+
+            def synthesizer(ppgs, **kw):
+                with contextlib.redirect_stdout(sys.stderr):
+                    return pipeline.synthesize(ppgs, e.tacotron, e.waveglow, e.denoiser, **kw)
+        self.synthesizer = synthesizer
+        self.gathered = None
+
+    def step(self, i):
+        from script import synthesize_corpus as sc
+        wavs, ids = sc.synthesize_shard(self.synthesizer, self.ppgs, self.lengths, self.rank, self.world, self.args)
+        self.gathered = sc.collect(wavs, ids, self.world)
+        return self.gathered
+
+    def start_timed(self):
+        pass
+
+    def finish(self, out, elapsed, steps):
+        if self.rank == 0:
+            assert sorted(self.gathered) == list(range(len(self.lengths))), "an utterance was lost or duplicated in the gather"
+            assert all(self.gathered[i].numel() == n * HOP for i, n in enumerate(self.lengths))
+        out["config"] = {"workload": "BASELINE configs[3]: offline corpus synthesis, %d ragged utterances (100..400 frames, 40-symbol "
+                                     "monophone PPGs) -> wav at hop=%d, sharded length-sorted round-robin over %d rank(s), batches of 16, "
+                                     "per-utterance seeds and decoder limits; one step = the whole corpus incl. the all_gather of lengths "
+                                     "and the padded gather of the audio to rank 0" % (len(self.lengths), HOP, self.world),
+                         "utterances": len(self.lengths), "per_gpu_utterances": -(-len(self.lengths) // self.world),
+                         "global_batch": len(self.lengths), "parallelism": "dp%d" % self.world}
+
+
+class TrainWorkload(object):
+    """configs[4]: the bf16 WaveGlow training step, one replayed HIP graph per step, data parallel."""
+    name, scaling, dtype = "train", "weak", "bf16"
+
+    def __init__(self, dev, rank, world, args, dist):
+        from waveglow.distributed import GradientExchange, broadcast_parameters
+        from waveglow.graphed import GraphedTrainStep
+        self.dev, self.world, self.B = dev, world, args.train_batch
+        self.model, crit = make_train_model(dev, "bf16")
+        self.mel, self.audio = train_batch(dev, self.B, seed=1 + rank)
+        self.exchange = None
+        if world > 1:
+            broadcast_parameters(self.model, 0)
+            self.exchange = GradientExchange(self.model, n_buckets=args.grad_buckets,
+                                             grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else None)
+        opt = torch.optim.Adam(self.model.parameters(), lr=1e-5, fused=True, capturable=world == 1)
+        self.stepper = GraphedTrainStep(self.model, crit, opt, warmup=2, exchange=self.exchange)
+        self.samples = world * self.B * 10000
+        self.loss = None
+
+    def step(self, i):
+        self.loss = self.stepper(self.mel, self.audio)
+
+    def start_timed(self):
+        assert self.stepper.graph is not None or self.stepper.capture_failed, "need >= 3 warm-up steps before the timed region (capture)"
+
+    def finish(self, out, elapsed, steps):
+        assert bool(torch.isfinite(self.loss))
+        ms = elapsed / steps * 1e3
+        flops = 3 * 20.26e6 * self.B * 10000 * self.world
+        out["config"] = {"workload": "BASELINE configs[4]: WaveGlow training step (fwd + WaveGlowLoss + bwd + fused Adam), segment 10000 "
+                                     "@16 kHz / hop 160, per-GPU batch %d, bf16 MFMA operands, fp32 accumulation / master weights / "
+                                     "gradients, one replayed HIP graph per step%s" % (
+                                         self.B, "" if self.world == 1 else ", data parallel: bucketed gradient all-reduce after each replay"),
+                         "per_gpu_batch": self.B, "global_batch": self.B * self.world, "parallelism": "dp%d" % self.world,
+                         "graph_captured": self.stepper.graph is not None}
+        out["tflops"] = flops / (ms * 1e-3) / 1e12
+        out["frac_of_mfma_peak"] = out["tflops"] / (PEAK_BF16_MFMA_TFLOPS * self.world)
+        if self.exchange is not None:
+            ex_ms = self.exchange.exchange_ms()
+            nbytes = self.exchange.bytes_per_exchange()
+            out["gradient_exchange"] = {
+                "buckets": len(self.exchange.buckets), "bytes": nbytes, "dtype": str(self.exchange.comm_dtype).replace("torch.", ""),
+                "ms": ex_ms, "fraction_of_step": ex_ms / ms if ex_ms else None,
+                # bus bandwidth in the NCCL-tests convention: algorithm bytes x 2 (N - 1) / N per second
+                "bus_GBps": (nbytes * 2 * (self.world - 1) / self.world / (ex_ms * 1e-3) / 1e9) if ex_ms else None,
+                "timing": "hipEvents on the compute stream around the last step's exchange (pack + all_reduce + scale)"}
+
+
+WORKLOADS = {"infer": InferWorkload, "e2e": E2EWorkload, "corpus": CorpusWorkload, "train": TrainWorkload}
+
+
+def timed_run(wl, steps, warmup, fence, dist, dev, backend):
+    for i in range(warmup):
+        wl.step(i)
+    torch.cuda.synchronize(dev)
+    wl.start_timed()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        wl.step(warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
 
 
 def main():
@@ -376,20 +738,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="infer")
+    ap.add_argument("--utterances", type=int, default=1024, help="corpus workload: utterances in the corpus")
+    ap.add_argument("--e2e-batch", type=int, default=16, help="e2e workload: utterances per rank (1 = the metric's batch-1 case)")
+    ap.add_argument("--train-batch", type=int, default=3, help="train workload: per-GPU batch (config.json: 3)")
+    ap.add_argument("--grad-buckets", type=int, default=3)
+    ap.add_argument("--grad-dtype", choices=("fp32", "bf16"), default="fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the secondary batch-1 end-to-end measurement")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the secondary end-to-end measurements (they use cooperative launches, "
+                    "which rocprofv3 on this stack does not survive)")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
+    ap.add_argument("--no-extra", action="store_true", help="N > 1 infer runs: skip the train_dp / corpus_dp entries")
     ap.add_argument("--dist-backend", default="nccl", help=argparse.SUPPRESS)   # "gloo" + --share-gpu: 1-GPU dry run of the N>1 path
     ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-baseline-worker", nargs=2, type=int, metavar=("THREADS", "FRAMES"), help=argparse.SUPPRESS)
-    ap.add_argument("--e2e-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-worker", nargs=2, metavar=("THREADS", "MODE"), help=argparse.SUPPRESS)
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--train-worker", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
-        return cpu_baseline_worker(*args.cpu_baseline_worker)
-    if args.e2e_worker:
-        return e2e_worker()
+        return cpu_baseline_worker(int(args.cpu_baseline_worker[0]), args.cpu_baseline_worker[1])
     if args.train_worker:
         return train_worker()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -422,19 +789,6 @@ def main():
     if not args.share_gpu:
         assert len(set(rank_devices)) == world, "ranks share a GPU: %s" % rank_devices
 
-    from facppg import lib as flib, synth
-    from waveglow.glow import WaveGlow
-    cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=HOP)
-    sd = synth.waveglow_state_dict(cfg)
-    model = WaveGlow.remove_weightnorm(WaveGlow(**cfg))
-    model.load_state_dict(sd)
-    model = model.to(dev).eval()
-    mel = synth.synthetic_mel(BATCH, FRAMES, seed=1234 + rank).to(dev)
-    L = flib.load()
-
-    def step(i):
-        return model.infer(mel, sigma=0.6, seed=1000 + i)
-
     def fence():
         if dist is not None:
             dist.barrier()
@@ -444,68 +798,68 @@ def main():
         if rank == 0:
             print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
-    log("model ready; warmup")
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize(dev)
-    log("warmup done")
-    handle = model._handle(dev)
-    flib.check(L.facppg_wg_set_profiling(handle, 1))
-    layer_ms, layer_n = [], 0
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        audio = step(args.warmup + i)
-    fence()
-    elapsed = time.perf_counter() - t0
+    if args.workload == "train":
+        args.warmup = max(args.warmup, 4)      # 2 eager warm-ups + the capturing step + one replay before the clock starts
+    wl = WORKLOADS[args.workload](dev, rank, world, args, dist)
+    log("%s workload ready; warmup" % args.workload)
+    elapsed = timed_run(wl, args.steps, args.warmup, fence, dist, dev, args.dist_backend)
     log("timed region done: %.3f s" % elapsed)
-    ms = flib.ctypes.c_float()
-    n = flib.ctypes.c_int()
-    flib.check(L.facppg_wg_last_layer_ms(handle, flib.ctypes.byref(ms), flib.ctypes.byref(n)))
-    layer_ms, layer_n = ms.value, n.value
-    assert os.environ.get("FACPPG_BENCH_NO_CHECK") or torch.isfinite(audio).all()
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    samples_per_step = world * BATCH * FRAMES * HOP
-    value = samples_per_step * args.steps / elapsed
-    positions = BATCH * FRAMES * HOP // 8
-    flops = layer_flops_per_position() * positions
-    achieved = flops / (layer_ms * 1e-3) / 1e12 if layer_ms > 0 else 0.0
-    # the same launch priced at the reference formulation's FLOPs (2*(3*256+640)*512 + res_skip per
-    # position); it can exceed the fp32 MFMA peak because the folded kernels execute a third fewer FLOPs
-    flops_ref = layer_flops_per_position(ncond=640, edge_fold=False) * positions
-    achieved_ref = flops_ref / (layer_ms * 1e-3) / 1e12 if layer_ms > 0 else 0.0
-    traffic, traffic_src = pmc_traffic()
+    value = wl.samples * args.steps / elapsed
+    train = args.workload == "train"
     out = {
-        "metric": "22.05 kHz audio samples/sec, WaveGlow.infer (mel->wav) of the PPG->wav path",
+        "metric": METRIC if not train else "16 kHz audio samples/sec through the WaveGlow training step (BASELINE configs[4])",
         "value": value, "unit": "samples/s", "n_gpus": world, "world_size": world, "ranks_connected": ranks_connected,
-        "rank_devices": rank_devices, "collective_backend": ("RCCL (torch.distributed nccl)" if args.dist_backend == "nccl" else args.dist_backend) if world > 1 else None, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "WaveGlow.infer batch=%d, mel 80x%d, hop=%d (%d Hz), fp32, sigma=0.6, device Philox noise; "
-                               "seeded synthetic weights (no checkpoints ship with the reference)" % (BATCH, FRAMES, HOP, SR),
-                   "per_gpu_batch": BATCH, "global_batch": BATCH * world, "parallelism": "dp%d" % world},
-        "realtime_factor": value / SR,
-        "roofline": {"bound": "mfma", "kernel": "k_wn_layer", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                     "avg_launch_ms": layer_ms, "launches_timed": layer_n,
-                     "flops_per_launch": flops,
-                     "reference_formulation": {"flops_per_launch": flops_ref, "achieved": achieved_ref,
-                                               "frac": achieved_ref / PEAK_F32_MFMA_TFLOPS}},
+        "rank_devices": rank_devices,
+        "collective_backend": ("RCCL (torch.distributed nccl)" if args.dist_backend == "nccl" else args.dist_backend) if world > 1 else None,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": wl.scaling, "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic", "workload": args.workload,
+        "realtime_factor": value / (16000 if train else SR),
     }
-    if rank == 0 and world == 1 and not args.no_e2e:
-        e2e = end_to_end(log) or {}
-        out["end_to_end_batch1"] = e2e.get("batch1")
-        out["end_to_end_batch16_ragged"] = e2e.get("batch16_ragged")
-        out["reference_rate_config"] = reference_rate_config(dev, mel, log)
-    if rank == 0 and world == 1 and not args.no_train:
-        del model
+    wl.finish(out, elapsed, args.steps)
+    secondary_ok = rank == 0 and world == 1 and args.workload == "infer"
+    if secondary_ok and not args.no_e2e:
+        for key, lens in (("end_to_end_batch1", [200]), ("end_to_end_batch16_ragged", config3_lengths())):
+            try:
+                out[key] = time_end_to_end(dev, lens, 5, 2, log, key, waveglow=wl.model)
+            except Exception as e:   # noqa: BLE001  (secondary figure: report its absence, never fail the bench)
+                log("%s failed: %r" % (key, e))
+                out[key] = None
+        out["reference_rate_config"] = reference_rate_config(dev, wl.mel, log)
+    if world > 1 and args.workload == "infer" and not args.no_extra:
+        # the two configs whose collectives matter, measured in the same multi-GPU invocation (short runs; a failure
+        # is reported as null and never takes the primary figure down)
+        del wl
+        torch.cuda.empty_cache()
+        for key, name, steps, warm in (("train_dp", "train", 10, 4), ("corpus_dp", "corpus", 1, 1)):
+            sub, err = None, None
+            try:
+                sub = WORKLOADS[name](dev, rank, world, argparse.Namespace(**vars(args)), dist)
+            except Exception as e:   # noqa: BLE001
+                err = e
+            # every rank must enter the sub-workload's collectives or none: agree on whether all of them got this far
+            ready = torch.tensor([0 if sub is None else 1], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.int32)
+            dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+            if int(ready.item()) == 0:
+                log("%s skipped: a rank could not set it up (%r)" % (key, err))
+                out[key] = None
+                continue
+            try:
+                el = timed_run(sub, steps, warm, fence, dist, dev, args.dist_backend)
+                entry = {"steps": steps, "warmup": warm, "ms_per_step": el / steps * 1e3, "value": sub.samples * steps / el,
+                         "unit": "samples/s", "scaling": sub.scaling, "dtype": sub.dtype}
+                sub.finish(entry, el, steps)
+                out[key] = entry
+                log("%s: %.1f ms/step" % (key, entry["ms_per_step"]))
+            except Exception as e:   # noqa: BLE001
+                log("%s failed: %r" % (key, e))
+                out[key] = None
+            del sub
+            torch.cuda.empty_cache()
+    if secondary_ok and not args.no_train:
+        wl = None
         torch.cuda.empty_cache()
         out["train_step"] = train_step(log)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if secondary_ok and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(log)
     if rank == 0:
         print(json.dumps(out))

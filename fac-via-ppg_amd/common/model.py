@@ -167,16 +167,21 @@ class Tacotron2(nn.Module):
         return torch.cat([sd[k].detach().float().reshape(-1) for k in keys])
 
     def _release(self):
+        self.__dict__.pop("_facppg_dicts", None)      # (the module tree may be about to change: re-collected with the next handle)
         h = self.__dict__.pop("_facppg_handle", None)
         if h is not None:
             _lib.load().facppg_taco_destroy(h[0])
 
     def _fingerprint(self):
         """Identity + in-place version of every tensor the packed handle was built from: optimizer steps and in-place
-        ops bump ``_version``, re-assignment changes ``data_ptr``.  Writes through the ``.data`` alias bypass the
+        ops bump ``_version``, re-assigning a Parameter changes its identity.  Writes through the ``.data`` alias bypass the
         version counter by design; the handle is also dropped on every ``train()`` / ``eval()`` switch, and
         ``invalidate_packed_weights()`` covers code that pokes ``.data`` within one mode."""
-        return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values() if torch.is_tensor(t))
+        dicts = self.__dict__.get("_facppg_dicts")
+        if dicts is None:       # the live _parameters / _buffers dicts of every submodule, collected once per handle
+            dicts = [d for m in self.modules() for d in (m._parameters, m._buffers)]
+            self.__dict__["_facppg_dicts"] = dicts
+        return tuple((id(t), t._version) for d in dicts for t in d.values() if t is not None)
 
     def invalidate_packed_weights(self):
         self._release()
@@ -214,6 +219,7 @@ class Tacotron2(nn.Module):
     def __getstate__(self):
         d = dict(self.__dict__)
         d.pop("_facppg_handle", None)
+        d.pop("_facppg_dicts", None)
         return d
 
     def __del__(self):

@@ -65,17 +65,11 @@ constexpr int MAXF = 32;      // max flows
 #define FACPPG_COST16_FULL 105   // microseconds per round of 16-frame tiles: full round / at most one workgroup per CU
 #define FACPPG_COST16_HALF 57
 #endif
-#ifndef FACPPG_WN_NT
-#define FACPPG_WN_NT 0   // bit 0: activation staging loads, bit 1: epilogue stores, bit 2: epilogue loads -- non-temporal
-#endif
 #ifndef FACPPG_WN_W128_DEFAULT
 #define FACPPG_WN_W128_DEFAULT 0
 #endif
 #ifndef FACPPG_WN_RING
 #define FACPPG_WN_RING 3     // weight ring of the 64-frame phase-major tiles (3 or 4 register sets)
-#endif
-#ifndef FACPPG_WN_SPREAD
-#define FACPPG_WN_SPREAD 0   // 1: weight prefetch loads interleaved with the MFMA clusters (see k_wn_layer's K loop)
 #endif
 #ifndef FACPPG_NARROW_RING
 #define FACPPG_NARROW_RING 8  // weight prefetch depth (k-groups) of the 32-column tiles, see k_wn_layer
@@ -359,7 +353,6 @@ struct WnArgs {
   const float* we;     // end-row image of this layer (k_fold_end_rows)
   const float* endb;   // [8] folded end bias (seeds the accumulator in the first layer)
   int nconv;           // K chunks before the conditioning rows: 12 (three taps of 256 channels) or 1 (folded first layer)
-  int stagger_first, stagger_sleeps;   // FACPPG_STAGGER experiment
 };
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
@@ -461,38 +454,10 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   // PM: tap0..2 are wave-uniform (three named scalars, NOT an array: hipcc turns the per-chunk select over an array into an
   // indexed scratch load behind a vmcnt(0)), the lane's column is lane_q
   int b, t0, nvalid, ph = 0, in_off, sk_off, tap0 = 0, tap1 = 0, tap2 = 0, lane_q = 0;
-#ifdef FACPPG_STAGGER
-  // experiment: the two workgroups of a CU start in lock step, so their gate / epilogue / prologue phases (no MFMA)
-  // coincide; delaying the one in the odd wave slot of the first round by a fraction of a tile lets each phase hide
-  // under the other workgroup's MFMA stream (later workgroups inherit the offset: they start when a slot frees).
-  if constexpr (PM && NCB == 2) {
-    // stagger_first selects which first-round workgroups wait: 1 = the second half of the first 512 (if the dispatcher
-    // fills every CU once before doubling up), 2 = odd (lin / 8), 3 = odd hardware wave slot
-    bool delay = false;
-    if (blockIdx.x < 512u) {
-      if (p.stagger_first == 1) delay = blockIdx.x >= 256u;
-      else if (p.stagger_first == 2) delay = (blockIdx.x >> 3) & 1;
-      else {
-        int* sd = reinterpret_cast<int*>(smem);
-        if (tid == 0) sd[0] = __builtin_amdgcn_s_getreg(6148) & 1;   // HW_ID.WAVE_ID[3:0]
-        __syncthreads();
-        delay = sd[0];
-        __syncthreads();
-      }
-    }
-    if (delay) for (int i = 0; i < p.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-#endif
   if constexpr (PM) {
     const int lin = blockIdx.x;
     int tile;
     if (p.xcd_map == 1) { const int r = lin >> 3; ph = (r / p.nt) * 8 + (lin & 7); tile = r % p.nt; }
-    else if (p.xcd_map >= 2) {
-      // an XCD walks its phase group (all P/8 phases, or pairs of them) tile by tile: the rows two phases of one XCD share
-      // (taps at +-d for d a multiple of 8) are then re-read while still in that XCD's L2
-      const int r = lin >> 3, npg = p.xcd_map == 2 ? p.P / 8 : 2, per = npg * p.nt, grp = r / per, q = r % per;
-      ph = (grp * npg + q % npg) * 8 + (lin & 7); tile = q / npg;
-    }
     else { ph = lin / p.nt; tile = lin % p.nt; }
     if (ph >= p.P) return;
     // this lane's four columns (staging loads and epilogue stores use the same lane -> column map):
@@ -548,17 +513,9 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
     for (int cb = 1; cb < NCB; ++cb) acc[rb][cb] = acc[rb][0];
   }
 
-#if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 4)
-  const float4* wave_a_ptr = p.w1 + lane;   // ablation: every wave streams the same rows (L1 hits)
-#else
   // PM images are [k-group][16 row blocks][64 lanes]: a k-group's four row blocks sit 1 KiB apart
   const float4* wave_a_ptr = PM ? p.w1 + w * 256 + lane : p.w1 + (size_t)(w * 4) * NG1 * 64 + lane;
-#endif
-#if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 4)
-  const float4* wave_c_ptr = PM ? p.wc + lane : nullptr;
-#else
   const float4* wave_c_ptr = PM ? p.wc + (size_t)ph * p.ngc * 1024 + w * 256 + lane : nullptr;
-#endif
   const int nch = PM ? pm_chunks(p, ph) : NCH1;
   constexpr int F4R = TNt / 4, RPL4 = 64 / F4R, NSTG4 = 16 / RPL4;   // PM staging: float4 per row, rows per wave load, loads
   const int srow4 = lane / F4R, scol4 = (lane % F4R) * 4;
@@ -576,10 +533,6 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   // first0: the prologue's call for chunk 0 of a folded first layer (the only one that needs first_off[]: every chunk the
   // K loop stages for such a layer is a conditioning chunk, so first_off[] is dead once the loop starts)
   auto stage_load = [&](int c, bool first0 = false) __attribute__((always_inline)) {
-#if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 16)
-    for (int jj = 0; jj < NSTG; ++jj) stg[jj] = 0.001f * c;   // ablation: no activation loads
-    return;
-#endif
     if constexpr (PM) {
       // both kinds of chunk reduce to "base + per-row offset" so the loads themselves are branch-free.
       // Phase rows are contiguous in frames, so a lane fetches 4 columns at once (16-byte loads at
@@ -601,11 +554,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
       }
 #pragma unroll
       for (int jj = 0; jj < NSTG4; ++jj) {
-#if FACPPG_WN_NT & 1
-        const f4u v = __builtin_nontemporal_load(reinterpret_cast<const f4u*>(base + off[jj]));
-#else
         const f4u v = *reinterpret_cast<const f4u*>(base + off[jj]);
-#endif
         stg[4 * jj + 0] = v.x; stg[4 * jj + 1] = v.y; stg[4 * jj + 2] = v.z; stg[4 * jj + 3] = v.w;
       }
     } else {
@@ -633,18 +582,6 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
       load_a<4>(a, ap_, NG1 * 64, gg);
     }
   };
-#if FACPPG_WN_SPREAD
-  // one row block of k-group gg
-  auto load_a1_rb = [&](float4& a, const float4* ap_, int gg, int rb) __attribute__((always_inline)) {
-    if constexpr (PM) {
-      const int ngh = 8 * p.nconv;
-      const float4* src = gg < ngh ? ap_ + (size_t)gg * 1024 : wave_c_ptr + (size_t)(gg - ngh) * 1024;
-      a = src[rb * 64];
-    } else {
-      a = ap_[(size_t)rb * NG1 * 64 + gg * 64];
-    }
-  };
-#endif
   auto stage_write = [&](int buf) __attribute__((always_inline)) {
     if constexpr (PM) {
       // K4 image [k/4][TNt][k%4]: this lane's NSTG4 consecutive rows of column scol4 + cc are contiguous
@@ -705,43 +642,15 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
       for (int g = 0; g < 8; ++g) {
         const int gi = j * 8 + g;   // position inside the unrolled iteration (ring phase is static)
         // padded groups exist past the end of the packed image (RING-1 of them)
-#if FACPPG_WN_SPREAD
-        // Experiment (measured SLOWER here, 0.80 vs 0.83; profiles/r02_experiments.txt): the four weight loads of the group
-        // prefetched here issued one per K-step, between the MFMA clusters.  In tools/probes/mfma_probe.hip four back-to-back
-        // global_load_dwordx4 per 32 MFMAs cost 11 % of the MFMA rate and one per 8 MFMAs 3 %; it does not carry over.
-        float bq[4][NCB];
-        load_b<NCB, PM>(bq, lb, g);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-          for (int rb = 0; rb < 4; ++rb) {
-            const float4& a4 = ar[gi % RING][rb];
-            const float av = s == 0 ? a4.x : s == 1 ? a4.y : s == 2 ? a4.z : a4.w;
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mfma32x32x2(av, bq[s][cb], acc[rb][cb]);
-          }
-          load_a1_rb(ar[(gi + RING - 1) % RING][s], ap, G + g + RING - 1, s);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#else
         load_a1(ar[(gi + RING - 1) % RING], ap, G + g + RING - 1);
-#ifndef FACPPG_WN_NOSCHEDBAR
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch PD groups ahead (hipcc sinks it otherwise)
-#endif
         float bq[4][NCB];
         load_b<NCB, PM>(bq, lb, g);
         mfma_group<4, NCB>(acc, ar[gi % RING], bq);
-#endif
       }
     }
-#if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 8)
-    asm volatile("" ::"v"(stg[0]));   // ablation: no LDS staging write, no barrier
-#elif defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 32)
-    stage_write((c + 1) & 1);         // ablation: staging write but no barrier (racy: timing only)
-#else
     stage_write((c + 1) & 1);
     __syncthreads();
-#endif
   };
   if constexpr (CPI == 3 && PM) {
     int c0 = 0;
@@ -786,10 +695,6 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-#if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 1)
-        const int ch = w * 64 + rb * 32 + 8 * (r >> 2) + (r & 3) + 4 * kh;
-        const float v = fminf(fmaxf(acc[rb][cb][r], -1.f), 1.f) * fminf(fmaxf(acc[rb + 2][cb][r], 0.f), 1.f);   // ablation: no transcendentals
-#else
         float v;
         const int ch = w * 64 + rb * 32 + 8 * (r >> 2) + (r & 3) + 4 * kh;
         if constexpr (SAVE) {   // training: keep tanh and sigmoid separately for the gate's backward
@@ -804,7 +709,6 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
         } else {
           v = gate_tanh_sigmoid(acc[rb][cb][r], acc[rb + 2][cb][r]);
         }
-#endif
         smem[PM ? k4_index(ch, cb * 32 + li, TNt) : ch * TNt + cb * 32 + li] = v;
       }
   __syncthreads();
@@ -843,28 +747,11 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         const int gi = j * 8 + g;
-#if FACPPG_WN_SPREAD
-        float bq[4][NCB];
-        load_b<NCB, PM>(bq, lb, c * 8 + g);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {   // weight loads one per K-step, see the first GEMM
-#pragma unroll
-          for (int rb = 0; rb < NRB2; ++rb) {
-            const float4& a4 = ar[gi % RING][rb];
-            const float av = s == 0 ? a4.x : s == 1 ? a4.y : s == 2 ? a4.z : a4.w;
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mfma32x32x2(av, bq[s][cb], acc[rb][cb]);
-          }
-          if (s < NRB2) ar[(gi + RING - 1) % RING][s] = ap2[(size_t)s * NG2 * 64 + (c * 8 + g + RING - 1) * 64];
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#else
         load_a<NRB2>(ar[(gi + RING - 1) % RING], ap2, NG2 * 64, c * 8 + g + RING - 1);
         __builtin_amdgcn_sched_barrier(0);
         float bq[4][NCB];
         load_b<NCB, PM>(bq, lb, c * 8 + g);
         mfma_group<NRB2, NCB>(acc, ar[gi % RING], bq);
-#endif
       }
     };
     if constexpr (CPI == 3) {
@@ -941,9 +828,6 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
           for (int r = 0; r < 16; ++r)
             slab[(rbh * 32 + 8 * (r >> 2) + (r & 3) + 4 * kh) * TNt + cb * 32 + li] = acc[half * 2 + rbh][cb][r];
       const int nv = nvalid;   // live columns among this lane's four
-#if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 2)
-      if (acc[0][0][0] != 12345.678f) continue;   // ablation: no epilogue traffic
-#endif
       if (nv <= 0) continue;
       float* gbase = is_res ? p.h_out + (size_t)b * C * p.Lp + in_off : p.skip + (size_t)b * C * p.Lr + sk_off;
       const float* rbase = is_res ? p.h_in + (size_t)b * C * p.Lp + in_off : gbase;
@@ -956,18 +840,10 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
         float4 v = *reinterpret_cast<const float4*>(slab + row * TNt + scol4);
         if (nv >= 4) {
           if (add) {
-#if FACPPG_WN_NT & 4
-            const f32x4 x = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rbase + o));
-#else
             const float4 x = *reinterpret_cast<const float4*>(rbase + o);
-#endif
             v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
           }
-#if FACPPG_WN_NT & 2
-          __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(gbase + o));
-#else
           *reinterpret_cast<float4*>(gbase + o) = v;
-#endif
         } else {
           const float vv[4] = {v.x, v.y, v.z, v.w};
           for (int k = 0; k < nv; ++k) gbase[o + k] = vv[k] + (add ? rbase[o + k] : 0.0f);
@@ -984,11 +860,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
       const int col = cb * 32 + li;
-#if defined(FACPPG_ABLATE) && (FACPPG_ABLATE & 2)
-      if (col < nvalid && acc[rb][cb][0] == 12345.678f) {   // ablation: no epilogue traffic
-#else
       if (col < nvalid) {
-#endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ch = chb + 8 * (r >> 2) + (r & 3);
@@ -1045,12 +917,6 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
     const int lin = blockIdx.x;
     int tile;
     if (p.xcd_map == 1) { const int r = lin >> 3; ph = (r / p.nt) * 8 + (lin & 7); tile = r % p.nt; }
-    else if (p.xcd_map >= 2) {
-      // an XCD walks its phase group (all P/8 phases, or pairs of them) tile by tile: the rows two phases of one XCD share
-      // (taps at +-d for d a multiple of 8) are then re-read while still in that XCD's L2
-      const int r = lin >> 3, npg = p.xcd_map == 2 ? p.P / 8 : 2, per = npg * p.nt, grp = r / per, q = r % per;
-      ph = (grp * npg + q % npg) * 8 + (lin & 7); tile = q / npg;
-    }
     else { ph = lin / p.nt; tile = lin % p.nt; }
     if (ph >= p.P) return;
     int qcol;
@@ -1097,10 +963,6 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
   }
   float4 stg[NSTG4];
   auto stage_load = [&](int c, bool first0 = false) __attribute__((always_inline)) {   // first0: see k_wn_layer
-#if defined(FACPPG_ABLATE8) && (FACPPG_ABLATE8 & 2)
-    for (int jj = 0; jj < NSTG4; ++jj) stg[jj] = make_float4(0.001f * c, 0.f, 0.f, 0.f);   // ablation: no activation loads
-    return;
-#endif
     const bool conv = c < p.nconv;
     const float* base = conv ? hb4 : sb4;
     const int tapc = tap0 + (int)(c >= 4) * (tap1 - tap0) + (int)(c >= 8) * (tap2 - tap1) + lane_q;
@@ -1131,11 +993,7 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
   };
   auto load_a1 = [&](float4 (&a)[2], int gg) __attribute__((always_inline)) {
     const int ngh = 8 * p.nconv;
-#if defined(FACPPG_ABLATE8) && (FACPPG_ABLATE8 & 4)
-    const float4* src = wave_a + (size_t)(gg & 7) * 1024;   // ablation: the weight stream stays in L1/L2
-#else
     const float4* src = gg < ngh ? wave_a + (size_t)gg * 1024 : wave_c + (size_t)(gg - ngh) * 1024;
-#endif
     a[0] = src[0];
     a[1] = src[128];
   };
@@ -1181,9 +1039,7 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
       mfma2(ar[g % RING], bq, 2);
     }
     stage_write((c + 1) & 1);
-#if !(defined(FACPPG_ABLATE8) && (FACPPG_ABLATE8 & 1))
     __syncthreads();   // (ablation bit 1: no barrier per chunk -- racy, timing only)
-#endif
   }
   WN8_STAMP(1);   // K loop
   // gate -> LDS [256][TNt]
@@ -1370,12 +1226,6 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
   {
     const int lin = blockIdx.x;
     if (p.xcd_map == 1) { const int r = lin >> 3; ph = (r / p.nt) * 8 + (lin & 7); tile = r % p.nt; }
-    else if (p.xcd_map >= 2) {
-      // an XCD walks its phase group (all P/8 phases, or pairs of them) tile by tile: the rows two phases of one XCD share
-      // (taps at +-d for d a multiple of 8) are then re-read while still in that XCD's L2
-      const int r = lin >> 3, npg = p.xcd_map == 2 ? p.P / 8 : 2, per = npg * p.nt, grp = r / per, q = r % per;
-      ph = (grp * npg + q % npg) * 8 + (lin & 7); tile = q / npg;
-    }
     else { ph = lin / p.nt; tile = lin % p.nt; }
     if (ph >= p.P) return;
   }
@@ -2109,6 +1959,7 @@ struct facppg_wg {
   int profiling;
   std::vector<hipEvent_t> ev;  // pairs around each k_wn_layer launch
   int ev_used;
+  int last_tile, last_waves, last_tiles;   // shape of the WN layer launches of the most recent infer (facppg_wg_last_launch_shape)
 };
 
 extern "C" int facppg_version(void) { return FACPPG_VERSION; }
@@ -2171,7 +2022,7 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   FACPPG_HIP_CHECK(hipSetDevice(device));
   facppg_wg* h = new (std::nothrow) facppg_wg();
   FACPPG_REQUIRE(h, FACPPG_EINVAL, "out of host memory");
-  h->cfg = *cfg; h->device = device; h->profiling = 0; h->ev_used = 0; h->arena = nullptr;
+  h->cfg = *cfg; h->device = device; h->profiling = 0; h->ev_used = 0; h->last_tile = h->last_waves = h->last_tiles = 0; h->arena = nullptr;
   wg_flow_channels(cfg, h->n_rem, h->n_half, h->early);
 
   // arena layout (bytes, 256-aligned pieces)
@@ -2443,6 +2294,12 @@ extern "C" int facppg_wg_last_layer_ms(facppg_wg* h, float* avg_ms, int* n_launc
   return FACPPG_OK;
 }
 
+extern "C" int facppg_wg_last_launch_shape(const facppg_wg* h, int* tile_frames, int* waves, int* n_tiles) {
+  FACPPG_REQUIRE(h && tile_frames && waves && n_tiles, FACPPG_EINVAL, "NULL argument");
+  *tile_frames = h->last_tile; *waves = h->last_waves; *n_tiles = h->last_tiles;
+  return FACPPG_OK;
+}
+
 template <int H>
 static void launch_flow_end(bool early, bool qs, dim3 grid, hipStream_t s, const EdgeArgs& a) {
   const char* no4 = getenv("FACPPG_FLOW_END_NO4");   // (read per call: the tests flip it)
@@ -2521,10 +2378,12 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
     }
   }
   h->ev_used = 0;
-  // Tile width: 64 frames (4 waves, k_wn_layer) or 32 frames (8 waves, k_wn_layer8).  A launch runs in rounds
-  // of 512 workgroup slots (2 per CU); measured per-round times in microseconds for a full round / a round
-  // that leaves every CU at most one workgroup: 64-frame 331 / 185, 32-frame 181 / 94.  Pick the cheaper.
-  static const char* force_narrow = getenv("FACPPG_WN_FORCE_NARROW");
+  // Tile width.  A launch runs in rounds of 512 workgroup slots (2 per CU); measured per-round times in microseconds for
+  // a full round / a round that leaves every CU at most one workgroup: 64-frame tiles (4 waves, k_wn_layer) 331 / 185,
+  // 32-frame tiles (8 waves, k_wn_layer8) 181 / 94, 16-frame tiles (k_wn_layer16) FACPPG_COST16_*.  Pick the cheapest.
+  // 128-frame tiles (k_wn_layer8<NCB = 4>, one workgroup per CU, half the weight loads per MFMA) measure the same as the
+  // 64-frame tiles on large launches and are never picked by cost.  FACPPG_WN_TILE = 16 | 32 | 64 | 128 forces a width
+  // (tests / tuning; read per call): every width accumulates in the same K order, so a tile gets the same bits from any.
   auto launch_cost = [](long tiles, int full, int half) {
     const long rem = tiles % 512;
     return (tiles / 512) * full + (rem == 0 ? 0 : rem <= 256 ? half : full);
@@ -2533,27 +2392,23 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   const long cols = (long)B * T;
   const long tiles_w = uniform ? (long)w.P * ((cols + 63) / 64) : (long)w.P * B * ((T + 63) / 64);
   const long tiles_n = uniform ? (long)w.P * ((cols + 31) / 32) : (long)w.P * B * ((T + 31) / 32);
-  bool narrow = force_narrow ? atoi(force_narrow) != 0 : launch_cost(tiles_n, 181, 94) < launch_cost(tiles_w, 331, 185);
-  // 16-frame tiles (k_wn_layer16): per-round costs measured the same way
-  static const char* tile16_env = getenv("FACPPG_WN_TILE16");   // 0 never, 1 by cost, 2 always
-  const int tile16_mode = tile16_env ? atoi(tile16_env) : 1;
   const long tiles_16 = (long)w.P * B * ((T + 15) / 16);
+  const long cost_w = launch_cost(tiles_w, 331, 185), cost_n = launch_cost(tiles_n, 181, 94);
   const long cost_16 = launch_cost(tiles_16, FACPPG_COST16_FULL, FACPPG_COST16_HALF);
-  const long cost_best = narrow ? launch_cost(tiles_n, 181, 94) : launch_cost(tiles_w, 331, 185);
-  const bool tile16 = tile16_mode == 2 || (tile16_mode == 1 && !force_narrow && cost_16 < cost_best);
-  if (tile16) narrow = false;
-  // 128-frame tiles on eight waves, one workgroup per CU (k_wn_layer8<NCB = 4>): half the weight loads per MFMA.  For
-  // launches of several rounds of 256 such tiles; FACPPG_WN_W128 = 0 never, 1 by size (default), 2 whenever possible
-  static const char* w128_env = getenv("FACPPG_WN_W128");
-  const int w128_mode = w128_env ? atoi(w128_env) : FACPPG_WN_W128_DEFAULT;
-  const bool wide128 = fold && !narrow && !tile16 && !force_narrow && (w128_mode == 2 || (w128_mode == 1 && tiles_w >= 4 * 512));
-  const int tn = tile16 ? TN16 : narrow ? 32 : wide128 ? 128 : TN;
+  int tn = cost_16 < cost_w && cost_16 < cost_n ? TN16 : cost_n < cost_w ? 32 : TN;
+  if (const char* tile_env = getenv("FACPPG_WN_TILE")) {
+    const int v = atoi(tile_env);
+    FACPPG_REQUIRE(v == 16 || v == 32 || v == 64 || (v == 128 && fold), FACPPG_EINVAL,
+                   "FACPPG_WN_TILE=%s: expected 16, 32, 64 or (with folded flow edges) 128", tile_env);
+    tn = v;
+  }
+  const bool tile16 = tn == TN16, narrow = tn == 32, wide128 = tn == 128;
   WnArgs a;
   memset(&a, 0, sizeof(a));
   a.melp = melp; a.skip = skip; a.t_valid = T_valid_dev; a.T = T; a.hop8 = w.P; a.Lp = w.P * w.Tqp; a.Lr = w.P * w.Tr;
   a.P = w.P; a.Tr = w.Tr; a.Tqp = w.Tqp; a.ntq = (T + tn - 1) / tn; a.nt = a.ntq * B;
   // uniform batch: cut tiles from the B*T frames of a phase laid end to end, so only the very last tile is ragged
-  static const char* no_flat = getenv("FACPPG_WN_NO_FLAT");
+  const char* no_flat = getenv("FACPPG_WN_NO_FLAT");   // tests: per-utterance tiles instead of the flat / group-table cut
   if (!T_valid_dev && T % 4 == 0 && !no_flat && !tile16) { a.flat_cols = B * T; a.nt = (B * T + tn - 1) / tn; }
   if (T_valid_dev && B > 1 && !no_flat && !tile16) {
     // ragged batch: the group table maps every lane's 4 frames to (utterance, frame); tiles past the end exit at once
@@ -2566,20 +2421,14 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   a.ngc = h->kcp / 8; a.kc = h->kc; a.hop = c.hop_length; a.ksize = c.upsample_kernel;
   a.xa = xa;
   // workgroup i lands on XCD i % 8: give every XCD its own phases so a phase's weight image lives in one L2
-  static const char* no_xcd = getenv("FACPPG_WN_NO_XCD_MAP");
-  static const char* tord = getenv("FACPPG_WN_TILE_ORDER");   // 1 phase-slowest (default), 2 tile-slowest, 3 tile-slowest within phase pairs
-  a.xcd_map = ((w.P % 8 == 0) && !no_xcd) ? (tord ? atoi(tord) : 1) : 0;
-  if (a.xcd_map == 3 && (w.P / 8) % 2) a.xcd_map = 1;
+  const char* no_xcd = getenv("FACPPG_WN_NO_XCD_MAP");   // tests: plain phase-major workgroup order
+  a.xcd_map = ((w.P % 8 == 0) && !no_xcd) ? 1 : 0;
   const unsigned lgrid = (unsigned)(w.P * a.nt);
-  {
-    static const char* st_env = getenv("FACPPG_WN_STAGGER");   // experiment: sleeps (of ~3.4 us) for odd-slot first-round tiles
-    a.stagger_sleeps = st_env ? atoi(st_env) : 0;
-    static const char* sm_env = getenv("FACPPG_WN_STAGGER_MODE");
-    a.stagger_first = sm_env ? atoi(sm_env) : 1;
-  }
   // 8 waves per tile for launches that cannot give every SIMD two 4-wave tiles (FACPPG_WN_8W: 0 never, 2 always)
-  static const char* w8env = getenv("FACPPG_WN_8W");
+  const char* w8env = getenv("FACPPG_WN_8W");
   const int w8mode = w8env ? atoi(w8env) : 1;
+  h->last_tile = tn; h->last_tiles = (int)lgrid;
+  h->last_waves = (wide128 || tile16 || (narrow && w8mode != 0) || (!narrow && w8mode == 2)) ? 8 : 4;
   for (int k = nf - 1; k >= 0; --k) {
     for (int i = 0; i < c.wn_layers; ++i) {
       a.h_in = hbuf[hi]; a.h_out = hbuf[hi ^ 1];
@@ -2727,6 +2576,7 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
   // the chip's 512 workgroup slots 1.5 times (single short utterances), halving the per-layer latency
   const bool narrow = (long)(w.Lr / TN) * B < 768;
   const dim3 lgrid(narrow ? w.Lr / 32 : w.Lr / TN, B);
+  h->last_tile = narrow ? 32 : TN; h->last_waves = 4; h->last_tiles = (int)(lgrid.x * lgrid.y);
   for (int k = nf - 1; k >= 0; --k) {
     for (int i = 0; i < c.wn_layers; ++i) {
       WnArgs a;

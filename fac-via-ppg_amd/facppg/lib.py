@@ -91,6 +91,7 @@ def _declare(lib):
         "facppg_affine_backward": (c.c_int, [vp, vp, vp, vp, vp, c.c_int, c.c_int, c.c_int, vp]),
         "facppg_wg_set_profiling": (c.c_int, [vp, c.c_int]),
         "facppg_wg_last_layer_ms": (c.c_int, [vp, c.POINTER(f32), c.POINTER(c.c_int)]),
+        "facppg_wg_last_launch_shape": (c.c_int, [vp, c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)]),
         "facppg_stft_create": (c.c_int, [c.c_int, c.c_int, vp, vp, vp, vp, c.c_int, c.c_int, vp, c.POINTER(vp)]),
         "facppg_stft_destroy": (None, [vp]),
         "facppg_stft_workspace_bytes": (sz, [vp, c.c_int, c.c_int]),

@@ -40,7 +40,24 @@ def parse(argv=None):
                     help='stop each utterance after as many mel frames as it has PPG frames at the latest '
                          '(per-utterance max_decoder_steps; both run at a 10 ms frame shift)')
     ap.add_argument('--dist_backend', default='nccl', help='nccl = RCCL over xGMI (default); gloo for CPU tests')
+    ap.add_argument('--hparams', default='',
+                    help='comma separated "name=value" overrides of create_hparams_stage (train_ppg2mel.py:291-292), '
+                         'e.g. n_symbols=40 for monophone PPGs (data_utils.py:253-258)')
     return ap.parse_args(argv)
+
+
+def parse_hparams(text):
+    """"a=1,b=x" -> create_hparams_stage(a=1, b='x'); values are cast to the type of the default they override."""
+    from common.hparams import create_hparams_stage
+    base = create_hparams_stage()
+    kw = {}
+    for item in filter(None, (t.strip() for t in text.split(','))):
+        name, _, value = item.partition('=')
+        if not hasattr(base, name):
+            raise ValueError("unknown hparam %r" % name)          # same failure as hparams.py:233-237
+        default = getattr(base, name)
+        kw[name] = (value.lower() in ('1', 'true')) if isinstance(default, bool) else type(default)(value)
+    return create_hparams_stage(**kw)
 
 
 def synthesize_shard(synthesizer, ppgs, lengths, rank, world, args):
@@ -97,7 +114,7 @@ def main(argv=None, synthesizer=None):
         lengths = [p.shape[0] for p in ppgs]
         if synthesizer is None:
             from facppg.pipeline import Synthesizer
-            synthesizer = Synthesizer(args.ppg2mel_model, args.waveglow_model)
+            synthesizer = Synthesizer(args.ppg2mel_model, args.waveglow_model, hparams=parse_hparams(args.hparams))
         wavs, ids = synthesize_shard(synthesizer, ppgs, lengths, rank, world, args)
         gathered = collect(wavs, ids, world)
         if rank == 0:

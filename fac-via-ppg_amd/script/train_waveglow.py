@@ -16,7 +16,7 @@ import torch
 from torch.utils.data import DataLoader
 from torch.utils.data.distributed import DistributedSampler
 
-from waveglow.distributed import (init_distributed, apply_gradient_allreduce, allreduce_gradients, broadcast_parameters,
+from waveglow.distributed import (GradientExchange, init_distributed, apply_gradient_allreduce, broadcast_parameters,
                                   reduce_tensor)
 from waveglow.glow import WaveGlow, WaveGlowLoss
 from waveglow.graphed import GraphedTrainStep
@@ -54,11 +54,14 @@ def train_step(model, criterion, optimizer, mel, audio, num_gpus=1):
 
 
 def train(num_gpus, rank, group_name, output_directory, epochs, learning_rate, sigma, iters_per_checkpoint, batch_size, seed,
-          checkpoint_path, data_config, dist_config, waveglow_config, max_iterations=None, train_precision=None, hip_graph=None):
+          checkpoint_path, data_config, dist_config, waveglow_config, max_iterations=None, train_precision=None, hip_graph=None,
+          grad_buckets=3, grad_dtype="fp32"):
     """train_waveglow.py:66-147.  ``train_precision`` (optional key of the config's train section): 'fp32' (default, the
     reference's arithmetic) or 'bf16' (bf16 MFMA operands, fp32 accumulation / master weights / gradients); the
     FACPPG_TRAIN_PRECISION environment variable sets the default.  ``hip_graph`` (optional key): replay the step as one
-    captured HIP graph (waveglow.graphed); default: on for bf16 (FACPPG_TRAIN_GRAPH=0 turns it off), off for fp32."""
+    captured HIP graph (waveglow.graphed); default: on for bf16 (FACPPG_TRAIN_GRAPH=0 turns it off), off for fp32.
+    ``grad_buckets`` / ``grad_dtype`` (optional keys, data parallel only): number of flat gradient buckets reduced
+    asynchronously behind the backward pass, and what the links carry ('fp32', or 'bf16' = half the bytes)."""
     torch.manual_seed(seed)
     torch.cuda.manual_seed(seed)
     if num_gpus > 1:
@@ -69,18 +72,24 @@ def train(num_gpus, rank, group_name, output_directory, epochs, learning_rate, s
         model.train_precision = train_precision
     if hip_graph is None:
         hip_graph = model.train_precision == "bf16" and os.environ.get("FACPPG_TRAIN_GRAPH", "1") != "0"
+    exchange = None
+    comm_dtype = {"fp32": None, "bf16": torch.bfloat16}[grad_dtype]
     if num_gpus > 1:
-        # eager: the exchange hangs off the backward pass; graphed: it follows each replay (no autograd runs then)
+        # eager: buckets are reduced from gradient hooks while the backward pass runs; graphed: the bucket pipeline follows
+        # each replay (no autograd runs then)
         if hip_graph:
             broadcast_parameters(model, 0)
+            exchange = GradientExchange(model, n_buckets=grad_buckets, grad_dtype=comm_dtype)
         else:
-            model = apply_gradient_allreduce(model)
+            model = apply_gradient_allreduce(model, n_buckets=grad_buckets, grad_dtype=comm_dtype)
     # one multi-tensor kernel per Adam state, not 938 x 4; inside the graph when there is no gradient exchange
     optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate, fused=True, capturable=bool(hip_graph and num_gpus == 1))
     stepper = None
     if hip_graph:
-        stepper = GraphedTrainStep(model, criterion, optimizer,
-                                   sync_gradients=(lambda: allreduce_gradients(model)) if num_gpus > 1 else None)
+        seg = data_config["segment_length"]
+        stepper = GraphedTrainStep(model, criterion, optimizer, exchange=exchange,
+                                   expected_shapes=((batch_size, waveglow_config["n_mel_channels"], seg // data_config["hop_length"] + 1),
+                                                    (batch_size, seg)))
     iteration = 0
     if checkpoint_path != "":
         model, optimizer, iteration = load_checkpoint(checkpoint_path, model, optimizer)
@@ -119,6 +128,8 @@ def main(argv=None):
     parser.add_argument('-c', '--config', type=str, default=os.path.join(os.path.dirname(__file__), '..', 'waveglow', 'config.json'))
     parser.add_argument('-r', '--rank', type=int, default=None)
     parser.add_argument('-g', '--group_name', type=str, default=None)
+    parser.add_argument('--num_gpus', type=int, default=None,
+                        help='world size (waveglow.distributed.main passes it, distributed.py:151-152); default: every visible GPU')
     args = parser.parse_args(argv)
     with open(args.config) as f:
         config = json.load(f)
@@ -126,7 +137,7 @@ def main(argv=None):
     dist_config, waveglow_config = dict(config["dist_config"]), config["waveglow_config"]
     rank = dist_config.pop("rank") if args.rank is None else (dist_config.pop("rank"), args.rank)[1]
     group_name = dist_config.pop("group_name") if args.group_name is None else (dist_config.pop("group_name"), args.group_name)[1]
-    num_gpus = torch.cuda.device_count()
+    num_gpus = torch.cuda.device_count() if args.num_gpus is None else args.num_gpus
     if num_gpus > 1 and group_name == '':
         print("WARNING: Multiple GPUs detected but no distributed group set")
         print("Only running 1 GPU.  Use distributed launch (one process per GPU) for multiple GPUs")

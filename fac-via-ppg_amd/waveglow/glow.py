@@ -352,6 +352,21 @@ def reserve_pinned():
     _PINNED["used"] = 0
 
 
+def take_pinned_arenas():
+    """Hand the current arenas to the caller and start afresh.  A captured HIP graph replays uploads FROM these pinned
+    tables, so whoever owns the graph (waveglow.graphed.GraphedTrainStep) must own them too: they then live exactly as long
+    as the graph, and recycling the shared arenas (below) can never pull memory from under a replay."""
+    arenas, _PINNED["arenas"], _PINNED["used"] = _PINNED["arenas"], [], 0
+    return arenas
+
+
+def _recycle_pinned():
+    """Drop every table and the arenas behind them (never called while capturing).  Pinned memory is bounded by this:
+    at most 64 tables (~14 KB each) between two recyclings, whatever addresses the caching allocator hands out."""
+    _WeightNormAllFunction._tables.clear()
+    _PINNED["arenas"], _PINNED["used"] = [], 0
+
+
 class _WeightNormAllFunction(torch.autograd.Function):
     """w_i = g_i * v_i / ||v_i|| (per output row) for EVERY weight-normed conv of the model in one HIP launch, and the
     matching backward in one more (torch's weight_norm recomputes each conv with its own two kernels: 288 convs ->
@@ -374,7 +389,7 @@ class _WeightNormAllFunction(torch.autograd.Function):
                 t[i] = (v, g, w, norm, row0, rows | (ln << 32))
                 row0 += rows
             if len(_WeightNormAllFunction._tables) >= 64 and not torch.cuda.is_current_stream_capturing():
-                _WeightNormAllFunction._tables.clear()
+                _recycle_pinned()
             host = _pinned_like(t)
             hit = _WeightNormAllFunction._tables[key] = (host, host.to(dev, non_blocking=True), row0)
         return hit[1], hit[2]
@@ -631,6 +646,7 @@ class WaveGlow(torch.nn.Module):
         return torch.cat([p.detach().float().reshape(-1) for p in parts])
 
     def _release(self):
+        self.__dict__.pop("_facppg_dicts", None)      # (the module tree may be about to change: re-collected with the next handle)
         h = self.__dict__.pop("_facppg_handle", None)
         if h is not None:
             _lib.load().facppg_wg_destroy(h[0])
@@ -638,11 +654,28 @@ class WaveGlow(torch.nn.Module):
 
     def _fingerprint(self):
         """Identity + in-place version of every tensor the packed handle was built from: optimizer steps and any
-        in-place op on a parameter bump ``_version``, re-assignment changes ``data_ptr``.  Writes through the
+        in-place op on a parameter bump ``_version``, re-assigning a Parameter changes its identity.  Writes through the
         ``.data`` alias bypass autograd's version counter by design and cannot be seen here; the handle is therefore
         also dropped on every ``train()`` / ``eval()`` switch and gradient-enabled forward, and
-        ``invalidate_packed_weights()`` is there for code that pokes ``.data`` within one mode."""
-        return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values() if torch.is_tensor(t))
+        ``invalidate_packed_weights()`` is there for code that pokes ``.data`` within one mode.
+        Reads the submodules' live parameter / buffer dicts (no state_dict, no key strings, no data_ptr calls): this
+        runs on every infer()."""
+        dicts = self.__dict__.get("_facppg_dicts")
+        if dicts is None:       # the live _parameters / _buffers dicts of every submodule, collected once per handle
+            dicts = [d for m in self.modules() for d in (m._parameters, m._buffers)]
+            self.__dict__["_facppg_dicts"] = dicts
+        return tuple((id(t), t._version) for d in dicts for t in d.values() if t is not None)
+
+    def last_launch_shape(self):
+        """(frames per tile, waves per workgroup, workgroups per launch) of the WN-layer kernels of the most recent
+        infer() -- which instantiation of the fused layer kernel ran (facppg_wg_last_launch_shape)."""
+        h = self.__dict__.get("_facppg_handle")
+        if h is None:
+            raise _lib.FacppgError("last_launch_shape: no inference has run on this model yet")
+        c = _lib.ctypes
+        tile, waves, tiles = c.c_int(0), c.c_int(0), c.c_int(0)
+        _lib.check(_lib.load().facppg_wg_last_launch_shape(h[0], c.byref(tile), c.byref(waves), c.byref(tiles)))
+        return tile.value, waves.value, tiles.value
 
     def invalidate_packed_weights(self):
         """Forget the packed MFMA weight images; the next infer()/forward() repacks from the live parameters."""
@@ -681,6 +714,7 @@ class WaveGlow(torch.nn.Module):
     def __getstate__(self):                              # never pickle device handles
         d = dict(self.__dict__)
         d.pop("_facppg_handle", None)
+        d.pop("_facppg_dicts", None)
         d.pop("_facppg_ws", None)
         return d
 
@@ -730,15 +764,23 @@ class WaveGlow(torch.nn.Module):
             spect = spect.contiguous().view(spect.size(0), spect.size(1), -1).permute(0, 2, 1)
             spect_pad = F.pad(spect, (0, -(-Lg // _TN) * _TN - Lg)).contiguous()
         audio = audio.unfold(1, g, g).permute(0, 2, 1)
-        # effective weights of all weight-normed convs in one launch (and one more in the backward)
-        convs = [c for wn in self.WN for c in wn._weight_convs()]
-        if all(hasattr(c, "weight_g") for c in convs):
-            vg = [t for c in convs for t in (c.weight_v, c.weight_g)]
-            eff = list(_WeightNormAllFunction.apply(*vg))
-        else:
-            eff = [_effective_weight(c) for c in convs]
-        per = len(eff) // self.n_flows
-        flow_weights = [self.WN[k]._plain_weights(eff[k * per:(k + 1) * per]) for k in range(self.n_flows)]
+        # effective weights of the weight-normed convs: one launch (and one more in the backward) per GROUP of flows.  The
+        # groups are the gradient buckets of waveglow.distributed.plan_buckets: a group's (v, g) gradients -- 99 % of the
+        # gradient bytes -- leave its backward launch as soon as the backward pass is through with those flows, so the
+        # data-parallel all-reduce of one bucket runs under the backward of the earlier flows
+        ngr = max(1, min(self.n_flows, int(getattr(self, "weight_norm_groups", 3))))
+        flow_weights = [None] * self.n_flows
+        for gi in range(ngr):
+            ks = [k for k in range(self.n_flows) if k * ngr // self.n_flows == gi]
+            convs = [c for k in ks for c in self.WN[k]._weight_convs()]
+            if all(hasattr(c, "weight_g") for c in convs):
+                vg = [t for c in convs for t in (c.weight_v, c.weight_g)]
+                eff = list(_WeightNormAllFunction.apply(*vg))
+            else:
+                eff = [_effective_weight(c) for c in convs]
+            per = len(eff) // len(ks)
+            for j, k in enumerate(ks):
+                flow_weights[k] = self.WN[k]._plain_weights(eff[j * per:(j + 1) * per])
         output_audio, log_s_list, log_det_W_list = [], [], []
         for k in range(self.n_flows):
             if k % self.n_early_every == 0 and k > 0:

@@ -10,19 +10,33 @@ argument, all buffers come from the graph's private pool -- and replayed per bat
 steps), captures on the next call, and replays from then on.  With ``sync_gradients`` (data parallel: the gradient all-reduce
 of waveglow.distributed) the graph holds forward + backward only and the exchange and the optimiser step run after each
 replay; without it the optimiser step is inside the graph (the optimiser must then be built with ``capturable=True``).
-A batch of another shape falls back to an ordinary step on the same gradient buffers.
+With ``exchange`` (a waveglow.distributed.GradientExchange) the replayed graph's gradient tensors are bound as the
+exchange's static sources: each replay is followed by the bucketed, pipelined all-reduce, after which the parameters'
+``.grad`` are views of the flat buckets (no copy back) and the optimiser steps on them.
+A batch of another shape falls back to an ordinary step on the same gradient buffers; a capture that fails (pinned arena
+exhausted, an op that cannot be captured, out of memory in the graph's pool) turns the stepper into plain eager steps for
+good, with a warning.
 """
+import warnings
+
 import torch
 
-from waveglow.glow import reserve_pinned
+from waveglow.glow import reserve_pinned, take_pinned_arenas
 
 
 class GraphedTrainStep:
-    def __init__(self, model, criterion, optimizer, warmup=3, sync_gradients=None):
+    def __init__(self, model, criterion, optimizer, warmup=3, sync_gradients=None, exchange=None, expected_shapes=None):
+        """expected_shapes: optional ((mel shape), (audio shape)) of a regular batch -- the capture then waits for a batch
+        of that shape instead of locking in whatever the first post-warm-up batch happens to be."""
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
-        self.warmup, self.sync_gradients = warmup, sync_gradients
+        self.warmup, self.exchange = warmup, exchange
+        if exchange is not None and sync_gradients is None:
+            sync_gradients = exchange.exchange
+        self.sync_gradients = sync_gradients
+        self.expected_shapes = expected_shapes
         self.calls = 0
         self.graph = None
+        self.capture_failed = False
         self.static_mel = self.static_audio = self.static_loss = None
         self.side = torch.cuda.Stream()
 
@@ -32,45 +46,70 @@ class GraphedTrainStep:
         loss.backward()
         return loss
 
+    def _sync(self, static):
+        if self.exchange is not None:
+            self.exchange.exchange(static=static)
+        elif self.sync_gradients is not None:
+            self.sync_gradients()
+
     def _finish(self):
         """What follows the gradients when it is not part of the graph."""
         if self.sync_gradients is not None:
-            self.sync_gradients()
+            self._sync(static=True)
             self.optimizer.step()
 
     def _eager(self, mel, audio, keep_grad_buffers):
-        # after capture the .grad tensors ARE the graph's outputs: zero them in place instead of dropping them
+        # after capture the .grad tensors ARE the graph's outputs (or, data parallel, the exchange's bucket views): zero
+        # them in place instead of dropping them
         self.optimizer.zero_grad(set_to_none=not keep_grad_buffers)
         loss = self._forward_backward(mel, audio)
-        if self.sync_gradients is not None:
-            self.sync_gradients()
+        self._sync(static=False)
         self.optimizer.step()
         return loss.detach()
 
     def _capture(self, mel, audio):
-        self.static_mel, self.static_audio = mel.clone(), audio.clone()
+        """Capture into locals; the stepper's state changes only once the capture has succeeded."""
+        static_mel, static_audio = mel.clone(), audio.clone()
         reserve_pinned()
         self.optimizer.zero_grad(set_to_none=True)   # the captured backward allocates the gradients in the graph's pool
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        # thread_local: the DataLoader's pin-memory thread may allocate pinned memory while this thread captures
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.static_loss = self._forward_backward(self.static_mel, self.static_audio).detach()
+        graph = torch.cuda.CUDAGraph()
+        # thread_local: other threads (a DataLoader worker pinning memory, a logger) may touch the allocator meanwhile
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            static_loss = self._forward_backward(static_mel, static_audio).detach()
             if self.sync_gradients is None:
                 self.optimizer.step()
+        if self.exchange is not None:
+            self.exchange.bind_static_sources()
+        self.pinned_arenas = take_pinned_arenas()    # the graph replays uploads from these tables: they live with it
+        self.static_mel, self.static_audio, self.static_loss, self.graph = static_mel, static_audio, static_loss, graph
+
+    def _regular(self, mel, audio):
+        if self.expected_shapes is None:
+            return True
+        return tuple(mel.shape) == tuple(self.expected_shapes[0]) and tuple(audio.shape) == tuple(self.expected_shapes[1])
 
     def __call__(self, mel, audio):
         """One optimisation step on (mel, audio); returns the loss (a 0-d tensor)."""
         self.calls += 1
-        if self.graph is None and self.calls <= self.warmup:
+        if self.graph is None and self.calls <= self.warmup and not self.capture_failed:
             # warm-up on a side stream, as torch.cuda.graph asks (lazy initialisations, allocator state, autograd threads)
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
                 loss = self._eager(mel, audio, keep_grad_buffers=False)
             torch.cuda.current_stream().wait_stream(self.side)
             return loss
+        if self.capture_failed or (self.graph is None and not self._regular(mel, audio)):
+            return self._eager(mel, audio, keep_grad_buffers=False)
         if self.graph is None:
-            self._capture(mel, audio)
+            try:
+                self._capture(mel, audio)
+            except Exception as e:   # noqa: BLE001  (any capture failure: the training run goes on, launch by launch)
+                warnings.warn("HIP-graph capture of the training step failed (%r): continuing with eager steps" % (e,))
+                self.capture_failed = True
+                self.graph = None
+                torch.cuda.synchronize()
+                return self._eager(mel, audio, keep_grad_buffers=False)
         if mel.shape != self.static_mel.shape or audio.shape != self.static_audio.shape:
             return self._eager(mel, audio, keep_grad_buffers=True)
         self.static_mel.copy_(mel)

@@ -235,6 +235,12 @@ int facppg_upsample_regroup_backward(const float* mel_dev, const float* dspect_p
 int facppg_wg_set_profiling(facppg_wg* h, int enable);
 int facppg_wg_last_layer_ms(facppg_wg* h, float* avg_ms, int* n_launches);
 
+/* Shape of the fused-WN-layer launches of the most recent facppg_wg_infer on this handle: frames (phase-major
+ * path) or group positions (FACPPG_WG_UNFOLDED=1) per tile, waves per workgroup, workgroups per launch.  The tile
+ * width is picked per call from measured round costs; FACPPG_WN_TILE=16|32|64|128 in the environment forces one.
+ * Lets the parity tests assert WHICH instantiation of k_wn_layer (glow.py:154-175) they compared with the oracle. */
+int facppg_wg_last_launch_shape(const facppg_wg* h, int* tile_frames, int* waves, int* n_tiles);
+
 /* ------------------------------------------------------------------------------------
  * STFT / mel analysis / denoiser (src/common/stft.py, src/common/layers.py,
  * src/waveglow/denoiser.py)

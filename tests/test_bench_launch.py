@@ -34,3 +34,31 @@ def test_bench_refuses_world_size_mismatch():
     must fail loudly, not report a 1-rank number as a 2-GPU one."""
     r = _run(["--gpus", "2", "--launch-check", "--dist-backend", "gloo"], env={"WORLD_SIZE": "1", "RANK": "0", "MASTER_PORT": "29999"})
     assert r.returncode != 0 and "WORLD_SIZE 1 != --gpus 2" in r.stderr
+
+
+def test_bench_corpus_workload_data_path_world2():
+    """--workload corpus (BASELINE config 4) at world 2 on gloo with a CPU stand-in synthesiser: the corpus is sharded by
+    facppg.shard.partition, every rank runs script.synthesize_corpus.synthesize_shard, and rank 0 gets every utterance
+    back through the all_gather + padded gather with N_i = Tin_i * hop."""
+    r = _run(["--gpus", "2", "--launch-check", "--dist-backend", "gloo", "--workload", "corpus", "--utterances", "37"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["workload"] == "corpus" and d["utterances"] == 37 and d["samples"] == d["expected_samples"] and d["lengths_ok"]
+
+
+def test_bench_train_workload_exchange_world2():
+    """--workload train (BASELINE config 5) at world 2 on gloo: flat parameter broadcast + the bucketed GradientExchange
+    leave the mean of the ranks' gradients on every rank."""
+    r = _run(["--gpus", "2", "--launch-check", "--dist-backend", "gloo", "--workload", "train"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["workload"] == "train" and d["exchange_ok"] is True and d["exchange_bytes"] > 0
+
+
+def test_metric_is_baselines_own():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.METRIC == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    assert len(b.kernel_source_id()) == 16

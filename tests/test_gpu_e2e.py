@@ -222,6 +222,53 @@ def test_config4_corpus_script_world1(tmp_path, monkeypatch):
             assert tout == [n] and np.array_equal(single[0], a), i
 
 
+def test_config4_corpus_1024_utterances_monophone(tmp_path, monkeypatch):
+    """BASELINE config 4 at its size on one GPU (world 1): script.synthesize_corpus.main() over 1024 ragged synthetic
+    utterances with the full-length law of SURVEY 8d (Tin_i = 100 + PCG64(11).integers(0, 301) frames, 1-4 s), as 40-dim
+    monophone PPGs (config "1m": hparams n_symbols = 40, data_utils.py:253-258; keeps the fixture files at ~40 MB),
+    batches of 16, per-utterance decoder limits.  Integer facts for every utterance (one wav each, N_i = Tout_i * hop with
+    Tout_i = Tin_i), and 32 utterances spread over the length range equal their own batch-1 synthesis bit for bit."""
+    from common.hparams import create_hparams_stage
+    from facppg.pipeline import Synthesizer
+    from script import synthesize_corpus
+    from waveglow.glow import WaveGlow
+    monkeypatch.setenv("FACPPG_DECODER_MODE", "coop")
+    monkeypatch.setenv("FACPPG_DECODER_COOP_U", "20")
+    monkeypatch.setenv("FACPPG_BILSTM_MODE", "single")
+    n_utt, n_sym = 1024, 40
+    cfg = dict(synth.WAVEGLOW_CONFIG)
+    wg = WaveGlow(**cfg)
+    wg.load_state_dict(weightnorm_state_dict(synth.waveglow_state_dict(cfg)), strict=True)
+    torch.save({"model": wg, "iteration": 0, "optimizer": None, "learning_rate": 1e-4}, tmp_path / "waveglow.pt")
+    hp = create_hparams_stage(n_symbols=n_sym)
+    torch.save({"state_dict": synth.tacotron_state_dict(hp, gate_bias=-10.0), "iteration": 0}, tmp_path / "tacotron.pt")
+    lens = _config3_lengths(n_utt, 11)
+    assert min(lens) >= 100 and max(lens) <= 400 and len(set(lens)) > 250
+    paths = []
+    for i, n in enumerate(lens):
+        paths.append(str(tmp_path / ("utt%04d.npy" % i)))
+        np.save(paths[-1], synth.synthetic_ppg(n, n_sym, seed=5000 + i, alpha=0.1))
+    (tmp_path / "ppgs.txt").write_text("\n".join(paths) + "\n")
+    written = synthesize_corpus.main(["--ppg2mel_model", str(tmp_path / "tacotron.pt"), "--waveglow_model", str(tmp_path / "waveglow.pt"),
+                                      "--ppg_list", str(tmp_path / "ppgs.txt"), "--seed", "123", "--limit_steps_to_input",
+                                      "--hparams", "n_symbols=%d" % n_sym, "--output_dir", str(tmp_path / "out"), "--batch_size", "16"])
+    assert written == ["utt%04d.wav" % i for i in range(n_utt)]
+    assert sorted(os.listdir(tmp_path / "out")) == written                                   # one wav per utterance, nothing else
+    total = 0
+    for i, n in enumerate(lens):
+        sr, a = wavfile.read(tmp_path / "out" / ("utt%04d.wav" % i))
+        assert sr == 16000 and a.dtype == np.float32 and a.shape == (n * 160,), i           # Tout_i = Tin_i, N_i = Tout_i * hop
+        assert np.isfinite(a).all() and float(np.abs(a).max()) > 0.0
+        total += a.shape[0]
+    assert total == 160 * sum(lens)
+    one = Synthesizer(str(tmp_path / "tacotron.pt"), str(tmp_path / "waveglow.pt"), hparams=hp)
+    order = sorted(range(n_utt), key=lambda i: (lens[i], i))
+    for i in order[::n_utt // 32][:32]:                                                      # 32 utterances across the length range
+        single, tout = one([np.load(paths[i])], utterance_seeds=[123 + 2 * i], step_limits=[lens[i]])
+        a = wavfile.read(tmp_path / "out" / ("utt%04d.wav" % i))[1]
+        assert tout == [lens[i]] and np.array_equal(single[0], a), i
+
+
 def test_pipeline_matches_oracle_and_batches_equal_singles(checkpoints):
     from common.hparams import create_hparams_stage
     from common.utils import load_waveglow_model

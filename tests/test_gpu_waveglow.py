@@ -13,6 +13,16 @@ pytestmark = pytest.mark.gpu
 RMS_TOL = 1e-3
 
 
+def _check_expected_launch_shape(m):
+    """test_alternate_kernel_paths_match_golden runs this file in a child interpreter with a launch-shape switch set and
+    FACPPG_TEST_EXPECT_SHAPE = "<frames per tile>x<waves>": the switch must really have selected that kernel."""
+    import os
+    want = os.environ.get("FACPPG_TEST_EXPECT_SHAPE")
+    if want:
+        tile, waves, _ = m.last_launch_shape()
+        assert "%dx%d" % (tile, waves) == want, "expected tile x waves %s, the launch used %dx%d" % (want, tile, waves)
+
+
 def make_model(hop, n_flows=12):
     from waveglow.glow import WaveGlow
     cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=hop, n_flows=n_flows)
@@ -36,6 +46,7 @@ def test_infer_matches_reference_golden(tag, hop, model160):
     zs = synth.synthetic_z(B, T * hop // 8, cfg, seed=int(d["z_seed"]))
     audio = m.infer(mel, sigma=float(d["sigma"]), z=zs).cpu().numpy()
     assert audio.shape == (B, T * hop)
+    _check_expected_launch_shape(m)
     err = audio - d["audio"]
     print("max abs err", np.abs(err).max(), "rms err", rms(err), "rms ref", rms(d["audio"]))
     assert rms(err) <= RMS_TOL
@@ -60,6 +71,8 @@ def test_ragged_batch_equals_independent_runs_and_oracle(model160):
         Lb = Tb * 20
         zb = [z[b:b + 1, :, :Lb].contiguous() for z in zs]
         single = m.infer(mel[b:b + 1, :, :Tb].contiguous().cuda(), sigma=0.6, z=zb).cpu()
+        if b == 0:
+            _check_expected_launch_shape(m)
         assert torch.equal(single[0], out[b, :Tb * 160]), "utterance %d differs from its batch-1 run" % b
         assert torch.count_nonzero(out[b, Tb * 160:]) == 0
         with torch.no_grad():
@@ -80,7 +93,7 @@ def test_device_noise_is_standard_normal_and_seeded(model160):
     assert torch.equal(m.infer(mel, sigma=0.0, seed=5), m.infer(mel, sigma=0.0, z=z0))
 
 
-def test_full_size_properties_hop256_benched_shape():
+def test_full_size_properties_hop256_benched_shape(monkeypatch):
     """The shape bench.py times (BASELINE configs[1] at the metric's rate): B = 8, mel 80 x 1000, hop 256 -> 256 000
     group positions per launch, 32 phases, 4 000 tiles.  Properties only (the oracle would need minutes): determinism,
     finiteness, exact output length, noise linearity (sigma = 0 removes every z term: audio = f(mel) alone), batch
@@ -93,8 +106,17 @@ def test_full_size_properties_hop256_benched_shape():
     assert torch.equal(a, m.infer(mel, sigma=0.6, seed=5)) and not torch.equal(a, m.infer(mel, sigma=0.6, seed=6))
     zs = synth.synthetic_z(B, T * 32, cfg, seed=3)
     full = m.infer(mel, sigma=0.6, z=zs)
+    assert m.last_launch_shape()[:2] == (64, 4)             # the benched instantiation: k_wn_layer<., 2, false, true, true>
     one = m.infer(mel[5:6].contiguous(), sigma=0.6, z=[z[5:6].contiguous() for z in zs])
     assert torch.equal(one[0], full[5])
+    # the same utterance through every OTHER tile width (each anchored to the oracle at this hop by
+    # test_hop256_every_tile_width_matches_oracle): all widths accumulate in the same K order, so bit for bit
+    for tile in (16, 32, 128):
+        monkeypatch.setenv("FACPPG_WN_TILE", str(tile))
+        other = m.infer(mel[5:6].contiguous(), sigma=0.6, z=[z[5:6].contiguous() for z in zs])
+        assert m.last_launch_shape()[0] == tile
+        assert torch.equal(other[0], full[5]), "tile width %d differs from the benched 64-frame kernel" % tile
+    monkeypatch.delenv("FACPPG_WN_TILE")
     a0 = m.infer(mel, sigma=0.0, z=zs)
     assert torch.equal(a0, m.infer(mel, sigma=0.0, seed=123))                    # sigma = 0: the noise cannot matter
     lens = [1000, 1, 999, 64, 65, 512, 777, 1000]
@@ -259,20 +281,66 @@ def test_flow_end_four_frames_per_thread_same_bits(hop, B, T, lengths, monkeypat
         assert one.shape == (1, 3 * hop)
 
 
-@pytest.mark.parametrize("env", ["FACPPG_WG_UNFOLDED=1", "FACPPG_WN_8W=0", "FACPPG_WN_NO_XCD_MAP=1", "FACPPG_WN_NO_FLAT=1", "FACPPG_WN_TILE16=2",
-                                 "FACPPG_WN_TILE16=0", "FACPPG_WG_EDGE_FOLD=0", "FACPPG_WN_W128=2"])
-def test_alternate_kernel_paths_match_golden(env):
-    """The A/B switches select other kernels for the same call (the unfolded K=1408 layer the training
-    direction uses; 4-wave tiles for small launches; no XCD-aware phase mapping; per-utterance tiles; 16-frame
-    tiles always / never; layers without the folded flow edges; 128-frame tiles).  They
-    are read once per process, so each runs the golden comparison in its own interpreter."""
+@pytest.mark.parametrize("env,shape", [("FACPPG_WG_UNFOLDED=1", "32x4"), ("FACPPG_WN_TILE=32 FACPPG_WN_8W=0", "32x4"), ("FACPPG_WN_TILE=32", "32x8"),
+                                       ("FACPPG_WN_NO_XCD_MAP=1", None), ("FACPPG_WN_NO_FLAT=1 FACPPG_WN_TILE=64", "64x4"),
+                                       ("FACPPG_WN_TILE=16", "16x8"), ("FACPPG_WN_TILE=64", "64x4"), ("FACPPG_WN_TILE=64 FACPPG_WN_8W=2", "64x8"),
+                                       ("FACPPG_WN_TILE=128", "128x8"), ("FACPPG_WG_EDGE_FOLD=0", None),
+                                       ("FACPPG_WG_EDGE_FOLD=0 FACPPG_WN_TILE=64", "64x4"), ("FACPPG_WG_EDGE_FOLD=0 FACPPG_WN_TILE=32", "32x8")])
+def test_alternate_kernel_paths_match_golden(env, shape):
+    """The A/B switches select other kernels for the same call (the unfolded K=1408 layer the training direction uses;
+    every tile width -- 16 / 32 / 64 / 128 frames -- forced against the cost model, on 4 or 8 waves; no XCD-aware phase
+    mapping; per-utterance tiles; layers without the folded flow edges).  Each runs the reference-golden comparison at both
+    hops and the ragged batch-vs-oracle test in its own interpreter, which also asserts (facppg_wg_last_launch_shape) that
+    the switch really selected the kernel it names: at the golden sizes the cost model alone would pick 16-frame tiles
+    for every one of them."""
     import os, subprocess, sys
-    k, v = env.split("=")
-    e = dict(os.environ, **{k: v})
+    e = dict(os.environ)
+    for kv in env.split():
+        k, v = kv.split("=")
+        e[k] = v
+    if shape:
+        e["FACPPG_TEST_EXPECT_SHAPE"] = shape
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
                         "test_infer_matches_reference_golden or test_ragged_batch"], env=e, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+_HOP256_ORACLE = {}
+
+
+@pytest.mark.parametrize("tile,waves8", [(64, None), (128, None), (64, "2"), (32, None)])
+@pytest.mark.parametrize("lengths", [None, [152, 37, 149]])
+def test_hop256_every_tile_width_matches_oracle(tile, waves8, lengths, monkeypatch):
+    """The kernel bench.py times (hop 256: 32 phases, kc = 320 folded conditioning rows, 64-frame tiles on 4 waves) and
+    its siblings against the CPU ORACLE at hop 256 -- uniform (flat tile cut) and ragged (group table; lengths that
+    straddle tile edges) -- with the tile width forced and asserted.  B = 3 x 152 frames: 4 864 positions per utterance,
+    so the 255-position receptive field of a flow crosses tile and utterance boundaries many times."""
+    from oracle import waveglow as owg
+    hop = 256
+    m, cfg = make_model(hop)
+    sd = synth.waveglow_state_dict(cfg)
+    B, T = 3, 152            # T % 4 == 0: the uniform batch takes the flat tile cut, as the benched shape does
+    lens = lengths or [T] * B
+    mel = synth.synthetic_mel(B, T, seed=31)
+    zs = synth.synthetic_z(B, T * hop // 8, cfg, seed=32)
+    monkeypatch.setenv("FACPPG_WN_TILE", str(tile))
+    if waves8:
+        monkeypatch.setenv("FACPPG_WN_8W", waves8)
+    out = m.infer(mel.cuda(), sigma=0.6, z=zs, lengths=lengths).cpu()
+    got = m.last_launch_shape()
+    assert got[0] == tile and got[1] == (8 if (tile in (32, 128) or waves8) else 4), got
+    for b, Tb in enumerate(lens):
+        Lb = Tb * hop // 8
+        zb = [z[b:b + 1, :, :Lb].contiguous() for z in zs]
+        if (b, Tb) not in _HOP256_ORACLE:                # the oracle's answer does not depend on the tile width
+            with torch.no_grad():
+                _HOP256_ORACLE[(b, Tb)] = owg.infer(sd, cfg, mel[b:b + 1, :, :Tb], 0.6, zb)
+        ref = _HOP256_ORACLE[(b, Tb)]
+        err = (out[b:b + 1, :Tb * hop] - ref).numpy()
+        print("tile %d utt %d (%d frames): rms err %.2e max %.2e (rms ref %.3f)" % (tile, b, Tb, rms(err), np.abs(err).max(), rms(ref.numpy())))
+        assert rms(err) <= RMS_TOL and np.abs(err).max() <= 5e-3
+        assert torch.count_nonzero(out[b, Tb * hop:]) == 0
 
 
 @pytest.mark.parametrize("hop,B,T,lengths", [(256, 2, 300, None), (256, 3, 90, [90, 41, 7]), (160, 1, 64, None)])

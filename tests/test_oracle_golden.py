@@ -150,3 +150,30 @@ def test_folded_flow_edges_are_the_same_linear_algebra():
     assert torch.allclose(ref, folded, rtol=1e-12, atol=1e-12)
     naive = F.conv1d(x, W_fold[:, :nh], b_in + torch.einsum("oct,c->o", W_in, b_start), dilation=1, padding=1)
     assert not torch.allclose(ref[..., 0], naive[..., 0]) and torch.allclose(ref[..., 1:-1], naive[..., 1:-1])
+
+
+def test_mel_filterbank_matches_an_independent_slaney_implementation():
+    """a11 / f2: the reference takes its mel basis from librosa 0.6.2 (layers.py:82-83), which this image lacks; oracle/dsp.py
+    restates it.  Second, independent derivation: the Slaney filterbank of Hugging Face transformers (audio_utils.mel_filter_bank,
+    norm = mel_scale = "slaney"; shares no code with the oracle; fixture written by tests/golden/make_mel_basis_hf.py).  The
+    two agree to 1e-12 at the reference config, at the 22.05 kHz metric config and on librosa's documentation example, whose
+    printed values (0., 0.016, 0.032 in row 0) both reproduce -- the same non-zero pattern included.  The HIP mel analysis
+    is held to this basis by tests/test_gpu_dsp.py."""
+    from oracle import dsp
+    d = golden("mel_basis_hf.npz")
+    for tag in ("ref16k", "metric22k", "librosa_doc"):
+        sr, n_fft, n_mels, fmin, fmax = d[tag + "_args"]
+        mine = dsp.mel_filterbank(int(sr), int(n_fft), int(n_mels), float(fmin), float(fmax))
+        other = np.zeros(mine.size)
+        other[d[tag + "_idx"]] = d[tag + "_val"]
+        other = other.reshape(mine.shape)
+        assert np.array_equal(mine != 0, other != 0), tag
+        assert np.abs(mine - other).max() <= 1e-12, tag
+    doc = dsp.mel_filterbank(22050, 2048)
+    assert np.allclose(doc[0, :3], [0.0, 0.016, 0.032], atol=5e-4)        # librosa.filters.mel docstring
+    try:                                                                  # where transformers is importable, ask it directly too
+        from transformers.audio_utils import mel_filter_bank
+    except Exception:
+        return
+    live = mel_filter_bank(513, 80, 0.0, 8000.0, 16000, norm="slaney", mel_scale="slaney").T
+    assert np.abs(live - dsp.mel_filterbank(16000, 1024, 80, 0.0, 8000.0)).max() <= 1e-12
