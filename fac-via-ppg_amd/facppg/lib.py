@@ -52,6 +52,11 @@ class WnGrads(ctypes.Structure):
     _fields_ = WnWeights._fields_
 
 
+class TdnnLayer(ctypes.Structure):
+    """facppg_tdnn_layer (include/facppg.h)."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("out_dim", "in_dim", "taps", "dil", "first", "relu")] + [("renorm_target_rms", ctypes.c_float)]
+
+
 def _declare(lib):
     c = ctypes
     vp, i32, u64, f32, sz = c.c_void_p, c.c_int32, c.c_uint64, c.c_float, c.c_size_t
@@ -119,6 +124,12 @@ def _declare(lib):
         "facppg_resample_num_samples": (c.c_int, [c.c_int, c.c_int, c.c_int]),
         "facppg_resample": (c.c_int, [vp, c.c_int, c.c_int, c.c_int, vp, vp]),
         "facppg_reduce_ppg": (c.c_int, [vp, vp, c.c_int, c.c_int, c.c_int, vp, vp]),
+        "facppg_tdnn_weight_count": (sz, [c.POINTER(TdnnLayer), c.c_int]),
+        "facppg_tdnn_create": (c.c_int, [c.POINTER(TdnnLayer), c.c_int, c.c_int, vp, sz, c.c_int, vp, c.POINTER(vp)]),
+        "facppg_tdnn_destroy": (None, [vp]),
+        "facppg_tdnn_context": (c.c_int, [vp, c.POINTER(c.c_int), c.POINTER(c.c_int)]),
+        "facppg_tdnn_workspace_bytes": (sz, [vp, c.c_int]),
+        "facppg_tdnn_forward": (c.c_int, [vp, vp, c.c_int, vp, vp, sz, vp]),
         "facppg_attention_window_mask": (c.c_int, [vp, c.c_int, c.c_int, c.c_int, c.c_int, vp, vp]),
     }
     for name, (res, args) in sigs.items():

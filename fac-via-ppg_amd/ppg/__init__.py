@@ -1,4 +1,3 @@
-"""The reference's ``ppg`` package (src/ppg): see compute_ppg.py for what is built (everything around the acoustic
-model, whose nnet3 blob the reference does not ship)."""
+"""The reference's ``ppg`` package (src/ppg): see compute_ppg.py for what is built."""
 from ppg.compute_ppg import (DependenciesPPG, compute_feat_for_nnet, compute_feat_for_nnet_internal, compute_full_ppg,  # noqa: F401
-                             reduce_ppg_dim)
+                             compute_full_ppg_wrapper, compute_monophone_ppg, reduce_ppg_dim)

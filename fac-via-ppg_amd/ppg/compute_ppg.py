@@ -5,7 +5,10 @@
                            shipped by the reference: ``nnet`` is None when the file is absent
   compute_feat_for_nnet[_internal]   wav -> MFCC -> CMN -> splice -> LDA, the acoustic model's input (compute_ppg.py:97-158)
   reduce_ppg_dim           full (senone) PPG [T, 5816] -> monophone PPG [T, 40] (compute_ppg.py:73-94)
-  compute_full_ppg         raises: it needs a Kaldi nnet3 runtime and the missing blob (compute_ppg.py:42-70)
+  compute_full_ppg         nnet3 TDNN inference on the exact-fp32 MFMA GEMM (csrc/facppg_tdnn.hip): acoustic-model input
+                           features [T, 40] -> senone posteriors [T, K] (compute_ppg.py:42-70).  The model is read by
+                           common.decode.read_nnet3_model / common.nnet3 -- PARITY UNPINNED: the reference ships neither
+                           the model (data/am/final.raw) nor anything Kaldi computed from it
 
 Matrices are float32 GPU tensors; file paths default to ``<repo data dir>/...`` like the reference's module constants and
 can be overridden (FACPPG_DATA_DIR, or the constructor arguments)."""
@@ -13,9 +16,10 @@ import logging
 import os
 import re
 
+import numpy as np
 import torch
 
-from common import feat, kaldi_io
+from common import decode, feat, kaldi_io, nnet3
 from facppg import lib as _lib
 
 DATA_DIR = os.environ.get("FACPPG_DATA_DIR", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "data"))
@@ -25,10 +29,58 @@ REDUCE_DIM_PATH = os.path.join(DATA_DIR, 'feats', 'reduce_dim.mat')
 SPLICE_OPTS_PATH = os.path.join(DATA_DIR, 'feats', 'splice_opts')
 
 
+class _TdnnHandle(object):
+    """The packed HIP form of one nnet3 model on one device (kept on the Nnet object)."""
+
+    def __init__(self, nnet, dev):
+        L = _lib.load()
+        layers, final = nnet3.plan_layers(nnet)
+        table = (_lib.TdnnLayer * len(layers))()
+        blob = []
+        for i, l in enumerate(layers):
+            out_dim, k = l["W"].shape
+            table[i].out_dim, table[i].in_dim, table[i].taps = out_dim, k // l["taps"], l["taps"]
+            table[i].dil, table[i].first, table[i].relu = l["dil"], l["first"], int(l["act"] == "relu")
+            table[i].renorm_target_rms = float(l["renorm"] or 0.0)
+            blob += [l["W"].reshape(-1), l["b"].reshape(-1)]
+        flat = torch.from_numpy(np.concatenate(blob).astype(np.float32)).to(dev)
+        self.handle = _lib.ctypes.c_void_p()
+        self.dev, self.out_dim, self.in_dim = dev, layers[-1]["W"].shape[0], layers[0]["W"].shape[1] // layers[0]["taps"]
+        with torch.cuda.device(dev):
+            _lib.check(L.facppg_tdnn_create(table, len(layers), {"none": 0, "softmax": 1, "log-softmax": 2}[final], _lib.ptr(flat),
+                                            flat.numel(), dev.index, _lib.current_stream(dev), _lib.ctypes.byref(self.handle)))
+
+    def __del__(self):
+        try:
+            _lib.load().facppg_tdnn_destroy(self.handle)
+        except Exception:
+            pass
+
+
 def compute_full_ppg(nnet, feats):
-    raise _lib.FacppgError(
-        "compute_full_ppg needs the Kaldi nnet3 acoustic model (data/am/final.raw), which the reference does not ship, and an nnet3 "
-        "runtime; this build stops at the model's input features (compute_feat_for_nnet) and reads PPGs from precomputed .npy files")
+    """compute_ppg.py:42-70: nnet (common.nnet3.Nnet) x feats [T, D] (GPU tensor or numpy) -> raw PPGs [T, K] on the GPU,
+    K = number of senones.  Batch-norm in test mode, frames beyond the utterance = the edge frames repeated, acoustic
+    scale 1, no priors -- what the reference configures on DecodableNnetSimple."""
+    if nnet is None:
+        raise _lib.FacppgError("compute_full_ppg: no acoustic model -- the reference does not ship data/am/final.raw; pass a model read "
+                               "with common.decode.read_nnet3_model, or use precomputed PPGs (common.data_utils.get_ppg)")
+    L = _lib.load()
+    feats = torch.as_tensor(feats)
+    if not feats.is_cuda:
+        feats = feats.cuda()
+    feats = feats.float().contiguous()
+    dev = feats.device
+    h = getattr(nnet, "_facppg_tdnn", None)
+    if h is None or h.dev != dev:
+        h = nnet._facppg_tdnn = _TdnnHandle(nnet, dev)
+    T, D = feats.shape
+    if D != h.in_dim:
+        raise _lib.FacppgError("compute_full_ppg: features have %d dims, the model's input node has %d" % (D, h.in_dim))
+    out = torch.empty(T, h.out_dim, device=dev)
+    ws = torch.empty(L.facppg_tdnn_workspace_bytes(h.handle, T), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.facppg_tdnn_forward(h.handle, _lib.ptr(feats), T, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)))
+    return out
 
 
 def reduce_ppg_dim(ppgs, transform):
@@ -76,13 +128,26 @@ def compute_feat_for_nnet(wav_path, lda_path):
     return compute_feat_for_nnet_internal(feat.read_wav_kaldi(wav_path), torch.from_numpy(kaldi_io.read_matrix(lda_path)))
 
 
+def compute_monophone_ppg(wav, nnet, lda, transform, shift=10):
+    """compute_ppg.py:161-181: wav -> features -> full PPG -> monophone PPG, as a numpy array."""
+    feats = compute_feat_for_nnet_internal(wav, lda, frame_shift=shift)
+    return reduce_ppg_dim(compute_full_ppg(nnet, feats), transform).cpu().numpy()
+
+
+def compute_full_ppg_wrapper(wav, nnet, lda, shift=10):
+    """compute_ppg.py:184-202"""
+    feats = compute_feat_for_nnet_internal(wav, lda, frame_shift=shift)
+    return compute_full_ppg(nnet, feats).cpu().numpy()
+
+
 class DependenciesPPG(object):
-    """compute_ppg.py:205-256, minus the acoustic model: ``nnet`` is None unless a loader for the blob exists."""
+    """compute_ppg.py:205-256.  The reference does not ship the acoustic model: ``nnet`` is None (and ``precomputed_only``
+    True) when ``nnet_path`` does not exist, else the model read by common.decode.read_nnet3_model."""
 
     def __init__(self, nnet_path=NNET_PATH, lda_path=LDA_PATH, reduce_dim_path=REDUCE_DIM_PATH, splice_opts_path=SPLICE_OPTS_PATH):
         self.nnet_path, self.lda_path, self.reduce_dim_path, self.splice_opts_path = nnet_path, lda_path, reduce_dim_path, splice_opts_path
         self.precomputed_only = not os.path.isfile(nnet_path)
-        self.nnet = None
+        self.nnet = None if self.precomputed_only else decode.read_nnet3_model(nnet_path)
         self.context_parser = re.compile(r"--left-context=(\d+) --right-context=(\d+)")
         self.lda = self.monophone_trans = None
         self.splice_opts, self.left_context, self.right_context = "", None, None

@@ -413,6 +413,36 @@ int facppg_cmn_splice_transform(const float* feats_dev, int T, int D, int do_cmn
 int facppg_reduce_ppg(const float* ppg_dev, const float* transform_t_dev, int T, int K, int M,
                       float* out_dev, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * nnet3 TDNN acoustic model: feature frames -> senone posteriors (the "full PPG")
+ * (src/ppg/compute_ppg.py:42-70 compute_full_ppg = Kaldi nnet3::DecodableNnetSimple through PyKaldi;
+ *  src/common/decode.py:23-38 read_nnet3_model).  The model file (data/am/final.raw) is not shipped by the reference and
+ * no Kaldi runtime exists in this image: PARITY UNPINNED at the Kaldi boundary (see common/nnet3.py, oracle/nnet3.py).
+ * ---------------------------------------------------------------------------------- */
+typedef struct facppg_tdnn facppg_tdnn;
+
+/* One fused layer: y[:, t] = act(W . [x[:, t + first + j*dil], j = 0..taps-1] + b), optionally followed by Kaldi's
+ * NormalizeComponent (renorm_target_rms > 0).  Test-mode BatchNorm / FixedAffine layers are folded into W, b by the
+ * host (common.nnet3.plan_layers, as nnet3::CollapseModel does at compute_ppg.py:57).  first <= 0 <= first + (taps-1)*dil. */
+typedef struct facppg_tdnn_layer {
+  int32_t out_dim, in_dim, taps, dil, first, relu;
+  float renorm_target_rms;
+} facppg_tdnn_layer;
+
+/* Values in the weight blob: per layer W [out_dim][taps*in_dim] (tap-major = Kaldi's Append order) then b [out_dim]. */
+size_t facppg_tdnn_weight_count(const facppg_tdnn_layer* layers, int n_layers);
+/* final_op: 0 = the last layer's output, 1 = softmax (posteriors), 2 = log-softmax.  weights_dev may be freed on return. */
+int facppg_tdnn_create(const facppg_tdnn_layer* layers, int n_layers, int final_op, const float* weights_dev,
+                       size_t n_weights, int device, void* stream, facppg_tdnn** out);
+void facppg_tdnn_destroy(facppg_tdnn* h);
+/* Frames of input context the network needs before / after a frame (nnet3::ComputeSimpleNnetContext). */
+int facppg_tdnn_context(const facppg_tdnn* h, int* left, int* right);
+size_t facppg_tdnn_workspace_bytes(const facppg_tdnn* h, int T);
+/* feats_dev [T][in_dim] row-major (what compute_feat_for_nnet returns) -> out_dev [T][out_dim] row-major; frames beyond
+ * the utterance's ends are the first / last frame repeated (DecodableNnetSimple's edge handling). */
+int facppg_tdnn_forward(facppg_tdnn* h, const float* feats_dev, int T, float* out_dev, void* workspace_dev,
+                        size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
