@@ -250,6 +250,7 @@ def make_train_model(dev, prec="bf16"):
 
 def train_worker():
     from waveglow.graphed import GraphedTrainStep
+    from waveglow.optim import Adam
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     out = {}
@@ -258,7 +259,7 @@ def train_worker():
         m.train_precision = prec
         mel, audio = train_batch(dev, B)
         # graphed: the step replayed as one captured HIP graph, as script.train_waveglow runs it by default under bf16
-        opt = torch.optim.Adam(m.parameters(), lr=1e-5, fused=True, capturable=graphed)
+        opt = Adam(m.parameters(), lr=1e-5)
         stepper = GraphedTrainStep(m, crit, opt, warmup=2) if graphed else None
         ts = []
         for i in range(9 if graphed else 6):
@@ -678,7 +679,8 @@ class TrainWorkload(object):
             broadcast_parameters(self.model, 0)
             self.exchange = GradientExchange(self.model, n_buckets=args.grad_buckets,
                                              grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else None)
-        opt = torch.optim.Adam(self.model.parameters(), lr=1e-5, fused=True, capturable=world == 1)
+        from waveglow.optim import Adam
+        opt = Adam(self.model.parameters(), lr=1e-5)
         self.stepper = GraphedTrainStep(self.model, crit, opt, warmup=2, exchange=self.exchange)
         self.samples = world * self.B * 10000
         self.loss = None

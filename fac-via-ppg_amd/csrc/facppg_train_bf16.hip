@@ -205,19 +205,7 @@ __device__ __forceinline__ void bgemm_store4(const BGemmArgs& p, int b, int n, i
 // order 48 -> 41.6 us; before them deeper staging only made things worse (PD 1 / 2 / 3 / 4: 68 / 82 / 86 / 91 us) -- more
 // streaming lines in flight evicted more weights.  k_wgrad's operands are re-read by neighbouring tiles: non-temporal loads
 // there cost 10 % (230 vs 209 us), so it keeps plain loads.
-#ifndef FACPPG_BG_NT
-#define FACPPG_BG_NT 1
-#endif
-#ifndef FACPPG_WG_NT
-#define FACPPG_WG_NT 0
-#endif
-#ifndef FACPPG_BG_PD
-#define FACPPG_BG_PD 2
-#endif
-#ifndef FACPPG_BG_XCD
-#define FACPPG_BG_XCD 1
-#endif
-constexpr int PD = FACPPG_BG_PD;
+constexpr int PD = 2;   // chunks requested ahead; 3 / 4 / 6 re-measured in round 3: 12.3 / 12.3 / 12.6 ms at batch 3 (12.3 with 2), 25.2 / 25.0 / 26.7 at batch 12 (24.4)
 template <int MODE, int NCB>
 __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs p) {
   constexpr int BNt = 32 * NCB;
@@ -225,14 +213,9 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
   // workgroup lin runs on XCD lin % 8; slot = lin / 8 walks (M tile fastest, then this XCD's column tiles)
   const int nm = (p.M + BM - 1) / BM, ncol = (p.N + BNt - 1) / BNt;
-#if FACPPG_BG_XCD
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int ct = (slot / nm) * 8 + xcd, mt = slot % nm;
   if (ct >= ncol * p.B) return;
-#else
-  const int mt = blockIdx.x % nm, ct = blockIdx.x / nm;
-  if (ct >= ncol * p.B) return;
-#endif
   const int b = ct / ncol, n0 = (ct - b * ncol) * BNt;
   const int mb = mt * 4 + w;
   const bool active = mb * 32 < p.M;
@@ -253,19 +236,8 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs p) {
   auto stage_load = [&](uint4 (&stg)[NCB]) {
     const Seg& sg = p.seg[seg_i];
     const bf16_t* base = sg.x + (size_t)b * sg.bs + (size_t)(sg.row0 + n0 + srow) * sg.ld + seg_c + 8 * sk;
-#if defined(FACPPG_BG_ABLATE) && (FACPPG_BG_ABLATE & 1)
-#pragma unroll
-    for (int j = 0; j < NCB; ++j) stg[j] = make_uint4(0x3c003c00u + seg_c, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);   // ablation: no activation loads
-    (void)base;
-#else
-#if FACPPG_BG_NT & 1
 #pragma unroll
     for (int j = 0; j < NCB; ++j) stg[j] = nt_load16(base + (size_t)(32 * j) * sg.ld);
-#else
-#pragma unroll
-    for (int j = 0; j < NCB; ++j) stg[j] = *reinterpret_cast<const uint4*>(base + (size_t)(32 * j) * sg.ld);
-#endif
-#endif
     // advance to the next chunk; at the very end stay on the last one: the requests of the last iterations are issued
     // UNCONDITIONALLY (they re-read the last chunk, nothing consumes them) -- a branch around a load makes hipcc's waitcnt pass
     // merge the two paths to vmcnt(0) at the next use, which drains every prefetch and exposes a full memory round trip per chunk
@@ -277,18 +249,8 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs p) {
     for (int j = 0; j < NCB; ++j) *reinterpret_cast<uint4*>(&lds[buf][(srow + 32 * j) * LDB + 8 * sk]) = stg[j];
   };
   auto load_a = [&](uint4 (&a)[4], int c) {
-#if defined(FACPPG_BG_ABLATE) && (FACPPG_BG_ABLATE & 2)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) a[s] = make_uint4(0x3c003c00u + c, 0x3c003c00u, 0x3c003c00u + s, 0x3c003c00u);   // ablation: no weight loads
-#else
-#if FACPPG_BG_NT & 2
-#pragma unroll
-    for (int s = 0; s < 4; ++s) a[s] = nt_load16(ap + (size_t)(c * 4 + s) * 64);
-#else
 #pragma unroll
     for (int s = 0; s < 4; ++s) a[s] = ap[(size_t)(min(c, nchunks - 1) * 4 + s) * 64];
-#endif
-#endif
   };
   auto compute = [&](int c, const uint4 (&a)[4]) {
     const bf16_t* lb = &lds[c & 1][li * LDB + 8 * kh];
@@ -325,9 +287,6 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs p) {
     }
   }
   if (!active) return;
-#if defined(FACPPG_BG_ABLATE) && (FACPPG_BG_ABLATE & 4)
-  if (acc[0][0] != 12345.678f) return;   // ablation: no epilogue
-#endif
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) {
     const int n = n0 + cb * 32 + li;
@@ -349,138 +308,13 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs p) {
   }
 }
 
-// k_bgemm2: the large-product shape.  256 rows x 128 columns per workgroup on EIGHT waves (4 along M x 2 along N, 64 x 64 each):
-// both operands go through LDS -- the weight tile is the packed image copied verbatim (it is already in fragment order: a lane
-// reads back its own 16 bytes, lane-linear, conflict-free), so the two column waves of a row block share ONE copy from L2, and
-// the activation tile is shared by the four row waves.  16 MFMAs per wave per 64-deep chunk, 100 KB of LDS (one workgroup per CU,
-// two waves per SIMD), operands of chunk c+2 in flight in registers while chunk c computes.
-constexpr int B2_M = 256, B2_N = 128;
-constexpr size_t B2_LDS_A = (size_t)8 * 4 * 64 * 16, B2_LDS_B = (size_t)B2_N * LDB * 2, B2_LDS = 2 * (B2_LDS_A + B2_LDS_B);
-template <int MODE>
-__global__ __launch_bounds__(512) void k_bgemm2(BGemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
-  uint4* ldsA = reinterpret_cast<uint4*>(lds2);                                     // [2][8 row blocks][4 k16][64 lanes]
-  bf16_t* ldsB = reinterpret_cast<bf16_t*>(lds2 + 2 * B2_LDS_A);                    // [2][128 columns][LDB]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
-  const int wm = w >> 1, wn = w & 1;
-  const int nm = (p.M + B2_M - 1) / B2_M, ncol = (p.N + B2_N - 1) / B2_N;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int ct = (slot / nm) * 8 + xcd, mt = slot % nm;
-  if (ct >= ncol * p.B) return;
-  const int b = ct / ncol, n0 = (ct - b * ncol) * B2_N;
-  const int nrb = p.M / 32;                                                          // row blocks in the image
-  // wave w copies row block mt*8 + w of the weight tile (clamped: blocks past M are never used)
-  const uint4* ap = p.A + (size_t)min(mt * 8 + w, nrb - 1) * p.KG * 64 + lane;
-  const int srow = tid >> 3, sk = tid & 7;                                           // activation staging: rows srow, srow + 64
-  int nchunks = 0;
-  for (int s = 0; s < p.nseg; ++s) nchunks += p.seg[s].nch / KC;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  int seg_i = 0, seg_c = 0;
-  auto stage_load = [&](u32x4 (&sb)[2], u32x4 (&sa)[4], int c) {
-    const Seg& sg = p.seg[seg_i];
-    const bf16_t* base = sg.x + (size_t)b * sg.bs + (size_t)(sg.row0 + n0 + srow) * sg.ld + seg_c + 8 * sk;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) sb[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + (size_t)(64 * j) * sg.ld));
-#pragma unroll
-    for (int s = 0; s < 4; ++s) sa[s] = *reinterpret_cast<const u32x4*>(ap + (size_t)(min(c, nchunks - 1) * 4 + s) * 64);
-    if (seg_c + KC < sg.nch) seg_c += KC;                       // (stays on the last chunk at the end: see k_bgemm)
-    else if (seg_i + 1 < p.nseg) { ++seg_i; seg_c = 0; }
-  };
-  auto stage_write = [&](int buf, const u32x4 (&sb)[2], const u32x4 (&sa)[4]) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x4*>(&ldsB[(size_t)buf * B2_N * LDB + (srow + 64 * j) * LDB + 8 * sk]) = sb[j];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4*>(ldsA + (size_t)buf * (8 * 4 * 64) + (w * 4 + s) * 64 + lane) = sa[s];
-  };
-  auto compute = [&](int buf) {
-    const uint4* la = ldsA + (size_t)buf * (8 * 4 * 64) + (2 * wm) * 4 * 64 + lane;
-    const bf16_t* lb = ldsB + (size_t)buf * B2_N * LDB + (64 * wn + li) * LDB + 8 * kh;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      uint4 av[2], bv[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        av[i] = la[(i * 4 + s) * 64];
-        bv[i] = *reinterpret_cast<const uint4*>(lb + i * 32 * LDB + 16 * s);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(av[i], bv[j], acc[i][j]);
-    }
-  };
-  u32x4 sb0[2], sa0[4], sb1[2], sa1[4];
-  stage_load(sb0, sa0, 0);
-  stage_write(0, sb0, sa0);
-  stage_load(sb0, sa0, 1);
-  __syncthreads();
-  // every request and LDS store is unconditional (see k_bgemm); only the MFMAs of a padding iteration are skipped
-  auto iter = [&](int c, u32x4 (&sb_n)[2], u32x4 (&sa_n)[4], u32x4 (&sb_n2)[2], u32x4 (&sa_n2)[4]) {
-    stage_load(sb_n2, sa_n2, c + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    if (c < nchunks) compute(c & 1);
-    __builtin_amdgcn_sched_barrier(0);
-    stage_write((c + 1) & 1, sb_n, sa_n);
-    __syncthreads();
-  };
-  for (int c = 0; c < nchunks; c += 2) {
-    iter(c, sb0, sa0, sb1, sa1);
-    iter(c + 1, sb1, sa1, sb0, sa0);
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int mb = mt * 8 + 2 * wm + i;
-    if (mb * 32 >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + 64 * wn + 32 * j + li;
-      if (n >= p.N) continue;
-      if constexpr (MODE == EP_GATE) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-          const float v2[4] = {acc[i][j][8 + 4 * q], acc[i][j][8 + 4 * q + 1], acc[i][j][8 + 4 * q + 2], acc[i][j][8 + 4 * q + 3]};
-          bgemm_store4<MODE>(p, b, n, mb, q, kh, v, v2);
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-          bgemm_store4<MODE>(p, b, n, mb, q, kh, v, v);
-        }
-      }
-    }
-  }
-}
-
 template <int MODE>
 void bgemm_dispatch(const BGemmArgs& a, hipStream_t s) {
   const int nm = (a.M + BM - 1) / BM;
   const long wide = (long)((a.N + 127) / 128) * nm * a.B;
-  static const char* wenv = getenv("FACPPG_BG_WIDE");
-  static const long wide_min = wenv ? atol(wenv) : 384;    // 128-column tiles once they give >= 1.5 workgroups per CU
-  static const char* b2env = getenv("FACPPG_BG2_MIN");
-  static const long b2_min = b2env ? atol(b2env) : (1L << 40);   // 256 x 128 / 8-wave tiles: measured slower than k_bgemm in every mode
-                                                                  // (profiles/r02_experiments.txt), so opt-in only
-  const int nm2 = (a.M + B2_M - 1) / B2_M, ct2 = ((a.N + B2_N - 1) / B2_N) * a.B;
-  if ((long)nm2 * ct2 >= b2_min && a.M >= 128) {
-    static bool attr_set[8] = {false, false, false, false, false, false, false, false};
-    if (!attr_set[MODE]) {
-      (void)hipFuncSetAttribute((const void*)k_bgemm2<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B2_LDS);
-      attr_set[MODE] = true;
-    }
-    k_bgemm2<MODE><<<dim3(8 * nm2 * ((ct2 + 7) / 8)), 512, B2_LDS, s>>>(a);
-    return;
-  }
-  if (wide >= wide_min) {
+  // 128-column tiles once they give >= 1.5 workgroups per CU, else 64-column tiles (twice the workgroups).  A 256 x 128 /
+  // 8-wave tile with both operands through LDS was built and measured slower in every mode (profiles/r02_experiments.txt).
+  if (wide >= 384) {
     const int ct = ((a.N + 127) / 128) * a.B;
     k_bgemm<MODE, 4><<<dim3(8 * nm * ((ct + 7) / 8)), 256, 0, s>>>(a);
   } else {
@@ -576,11 +410,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
     const int b = c / nlc, n = (c - b * nlc) * 64 + 8 * pb;
     const bf16_t* s0 = src + (size_t)b * sbs + (size_t)(srow0 + n) * sld + ch0;
 #pragma unroll
-#if FACPPG_WG_NT
-    for (int i = 0; i < 8; ++i) stg[i] = nt_load16(s0 + (size_t)i * sld);
-#else
     for (int i = 0; i < 8; ++i) stg[i] = *reinterpret_cast<const uint4*>(s0 + (size_t)i * sld);   // (M, K multiples of 128: no guard, no branch)
-#endif
   };
   auto stage_write = [&](int buf, const uint4 (&stg)[8]) {
     uint4 t[8];
@@ -674,10 +504,16 @@ int wgrad_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size
   while (ns > 1 && (size_t)nprob * ns * maxM * maxK * 4 > part_bytes) --ns;
   wa.nsplit = ns; wa.part = part; wa.pstride = (size_t)maxM * maxK;
   constexpr size_t kWgradLds = (size_t)2 * 2 * 128 * LDP * sizeof(bf16_t);   // 73 728 B
-  static bool attr_set = false;
-  if (!attr_set) {
-    FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgradLds));
-    attr_set = true;
+  {
+    // > 64 KB of dynamic LDS needs the attribute on EVERY device the kernel runs on (one bit per device; a second thread
+    // setting it again is harmless)
+    static unsigned long long attr_devices = 0;
+    int dev = 0;
+    FACPPG_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 64 || !((attr_devices >> dev) & 1ull)) {
+      FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgradLds));
+      if (dev < 64) attr_devices |= 1ull << dev;
+    }
   }
   k_wgrad<<<dim3((maxK + 127) / 128, (maxM + 127) / 128, nprob * ns), 256, kWgradLds, s>>>(wa);
   if (ns > 1) k_wgrad_reduce<<<dim3((maxM * maxK + 255) / 256, nprob), 256, 0, s>>>(wa);
@@ -725,21 +561,37 @@ __global__ __launch_bounds__(256) void k_colsum_part(ColsumArgs ca) {
   }
   for (int m = threadIdx.x; m < p.M; m += 256) part[m] = red[m];
 }
-// group > 1: out[m / group] also sums `group` adjacent channels (the 8 regrouped samples of one mel channel)
-__global__ void k_colsum_sum(ColsumArgs ca, int group) {
+// group > 1: out[m / group] also sums `group` adjacent channels (the 8 regrouped samples of one mel channel).
+// 32 outputs x 8 slice groups per workgroup: a thread adds its 32 slices on four interleaved chains (the loads overlap),
+// the eight groups meet in LDS in group order -- a fixed order whatever the grid.  (One thread per output walking all 256
+// slices cost 13.7 us per launch, 25 launches per step.)
+__global__ __launch_bounds__(256) void k_colsum_sum(ColsumArgs ca, int group) {
   const ColsumProb& p = ca.prob[blockIdx.y];
-  const int mo = blockIdx.x * blockDim.x + threadIdx.x;
-  if (mo * group >= p.M) return;
-  float v = 0.0f;
-  for (int g = 0; g < group; ++g)
-    for (int sl = 0; sl < CS_SLICES; ++sl) v += ca.part[((size_t)blockIdx.y * CS_SLICES + sl) * 1024 + mo * group + g];
+  __shared__ float red[8][32];
+  const int o = threadIdx.x & 31, q = threadIdx.x >> 5, mo = blockIdx.x * 32 + o;
+  const bool live = mo * group < p.M;
+  float v4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live)
+    for (int g = 0; g < group; ++g) {
+      const float* src = ca.part + ((size_t)blockIdx.y * CS_SLICES + q * (CS_SLICES / 8)) * 1024 + mo * group + g;
+#pragma unroll
+      for (int sl = 0; sl < CS_SLICES / 8; sl += 4)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v4[u] += src[(size_t)(sl + u) * 1024];
+    }
+  red[q][o] = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+  __syncthreads();
+  if (q || !live) return;
+  float v = red[0][o];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) v += red[k][o];
   p.out[mo] = v;
   if (p.out2) p.out2[mo] = v;
 }
 template <bool F32>
 int colsum_launch(ColsumArgs& ca, int nprob, int maxM, int group, hipStream_t s) {
   k_colsum_part<F32><<<dim3(1, CS_SLICES, nprob), 256, 0, s>>>(ca);
-  k_colsum_sum<<<dim3((maxM / group + 255) / 256, nprob), 256, 0, s>>>(ca, group);
+  k_colsum_sum<<<dim3((maxM / group + 31) / 32, nprob), 256, 0, s>>>(ca, group);
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
 }
@@ -830,23 +682,26 @@ __global__ __launch_bounds__(256) void k_small_wgrad_part(const float* __restric
 #pragma unroll
   for (int j = 0; j < 9; ++j) part[((size_t)blockIdx.x * 9 + j) * C + c] = acc[j];
 }
-// out_w[(j, c)] laid out by (o_sj, o_sc); out_wsum[c] = column sums of wide (may be null)
-__global__ __launch_bounds__(1024) void k_small_wgrad_sum(const float* __restrict__ part, int nparts, int nj, float* __restrict__ out_w, int o_sj,
-                                                           int o_sc, float* __restrict__ out_wsum) {
-  // 1024 threads = 256 channels x 4 quarters of the partials; eight interleaved chains per thread so the loads overlap;
-  // chains, then quarters, are combined in a fixed order
-  __shared__ float red[4][C];
-  const int c = threadIdx.x & (C - 1), q = threadIdx.x >> 8, j = blockIdx.x;
-  const int p0 = nparts * q / 4, p1 = nparts * (q + 1) / 4;
-  float v8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int p = p0; p < p1; p += 8)
+// out_w[(j, c)] laid out by (o_sj, o_sc); out_wsum[c] = column sums of wide (may be null).
+// Workgroup (j, 16-channel block): 16 channels x 16 groups of the partials; a thread adds its nparts / 16 partials on four
+// interleaved chains, the groups meet in LDS in group order (fixed order: bit-reproducible).  (Nine workgroups of 1024
+// threads walking 64 partials each cost 21 us per launch, 24 launches per step.)
+__global__ __launch_bounds__(256) void k_small_wgrad_sum(const float* __restrict__ part, int nparts, int nj, float* __restrict__ out_w, int o_sj,
+                                                          int o_sc, float* __restrict__ out_wsum) {
+  __shared__ float red[16][16];
+  const int cl = threadIdx.x & 15, q = threadIdx.x >> 4, c = blockIdx.x * 16 + cl, j = blockIdx.y;
+  const int p0 = nparts * q / 16, p1 = nparts * (q + 1) / 16;
+  float v4[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int p = p0; p < p1; p += 4)
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (p + u < p1) v8[u] += part[((size_t)(p + u) * 9 + j) * C + c];
-  red[q][c] = ((v8[0] + v8[1]) + (v8[2] + v8[3])) + ((v8[4] + v8[5]) + (v8[6] + v8[7]));
+    for (int u = 0; u < 4; ++u)
+      if (p + u < p1) v4[u] += part[((size_t)(p + u) * 9 + j) * C + c];
+  red[q][cl] = (v4[0] + v4[1]) + (v4[2] + v4[3]);
   __syncthreads();
   if (q) return;
-  const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+  float v = red[0][cl];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) v += red[k][cl];
   if (j < nj) out_w[j * o_sj + c * o_sc] = v;
   else if (j == 8 && out_wsum) out_wsum[c] = v;
 }
@@ -1116,21 +971,37 @@ extern "C" int facppg_upsample_regroup_backward(const float* mel_dev, const floa
 // Zero rows [0, r0) and [r1, rows) of every image of a [images][rows][row_bytes] buffer: the conv's zero padding (the
 // 128-row margins) and the rows between L and the 128-padded length, which the GEMM tiles read.  (Zeroing the whole
 // buffers instead cost 0.5 GB of memset per flow and direction at batch 12: 1.5 ms of a 27 ms step.)
-__global__ void k_zero_rows(char* __restrict__ base, long image_bytes, int row_bytes, int r0, int r1, int rows) {
-  const long head = (long)r0 * row_bytes, n16 = (head + (long)(rows - r1) * row_bytes) / 16;
-  char* img = base + (long)blockIdx.y * image_bytes;
+struct ZeroJob { char* base; long images, image_bytes; int row_bytes, r0, r1, rows; };
+struct ZeroBatch { ZeroJob job[3]; int n; };
+// up to three such buffers per launch (blockIdx.z = buffer): the forward zeroes h / ts / acts, the backward dpre / dh / dskip
+__global__ void k_zero_rows(ZeroBatch zb) {
+  const ZeroJob& j = zb.job[blockIdx.z];
+  if ((long)blockIdx.y >= j.images) return;
+  const long head = (long)j.r0 * j.row_bytes, n16 = (head + (long)(j.rows - j.r1) * j.row_bytes) / 16;
+  char* img = j.base + (long)blockIdx.y * j.image_bytes;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
     const long byte = i * 16;
-    *reinterpret_cast<uint4*>(byte < head ? img + byte : img + (long)r1 * row_bytes + (byte - head)) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(byte < head ? img + byte : img + (long)j.r1 * j.row_bytes + (byte - head)) = make_uint4(0, 0, 0, 0);
   }
 }
 
-static void zero_rows(void* base, long images, long image_bytes, int row_bytes, int r0, int r1, int rows, hipStream_t s) {
-  const long n16 = ((long)r0 * row_bytes + (long)(rows - r1) * row_bytes) / 16;
-  if (n16 <= 0 || images <= 0) return;
-  const unsigned gx = (unsigned)((n16 + 255) / 256 > 64 ? 64 : (n16 + 255) / 256);
-  k_zero_rows<<<dim3(gx, (unsigned)images), 256, 0, s>>>((char*)base, image_bytes, row_bytes, r0, r1, rows);
-}
+struct ZeroRows {
+  ZeroBatch zb;
+  long max_images = 0, max_n16 = 0;
+  ZeroRows() { zb.n = 0; }
+  void add(void* base, long images, long image_bytes, int row_bytes, int r0, int r1, int rows) {
+    const long n16 = ((long)r0 * row_bytes + (long)(rows - r1) * row_bytes) / 16;
+    if (n16 <= 0 || images <= 0) return;
+    zb.job[zb.n++] = ZeroJob{(char*)base, images, image_bytes, row_bytes, r0, r1, rows};
+    max_images = std::max(max_images, images);
+    max_n16 = std::max(max_n16, n16);
+  }
+  void launch(hipStream_t s) {
+    if (!zb.n) return;
+    const unsigned gx = (unsigned)((max_n16 + 255) / 256 > 64 ? 64 : (max_n16 + 255) / 256);
+    k_zero_rows<<<dim3(gx, (unsigned)max_images, (unsigned)zb.n), 256, 0, s>>>(zb);
+  }
+};
 
 // WN.forward (glow.py:154-175) with bf16 MFMA operands, keeping what the backward needs in `state`.
 extern "C" int facppg_wn_forward_bf16(const facppg_wn_weights* wts, int n_in, int nl, const float* a0_dev, const void* spect_pm_dev, int B,
@@ -1148,9 +1019,13 @@ extern "C" int facppg_wn_forward_bf16(const facppg_wn_weights* wts, int n_in, in
   char* W = (char*)scratch_dev;
   float* b1 = (float*)(W + sc.total);   // [nl][512] summed biases
   // h: zero margins (the conv padding) and rows >= L; ts, acts: rows >= L meet zero gradients in k_wgrad, but 0 * NaN = NaN
-  zero_rows(S + st.h, (long)(nl + 1) * B, (long)Lp * C * 2, C * 2, HALO, HALO + L, Lp, s);
-  zero_rows(S + st.ts, (long)nl * B, (long)Lr * 2 * C * 2, 2 * C * 2, 0, L, Lr, s);
-  zero_rows(S + st.acts, (long)nl * B, (long)Lr * C * 2, C * 2, 0, L, Lr, s);
+  {
+    ZeroRows z;
+    z.add(S + st.h, (long)(nl + 1) * B, (long)Lp * C * 2, C * 2, HALO, HALO + L, Lp);
+    z.add(S + st.ts, (long)nl * B, (long)Lr * 2 * C * 2, 2 * C * 2, 0, L, Lr);
+    z.add(S + st.acts, (long)nl * B, (long)Lr * C * 2, C * 2, 0, L, Lr);
+    z.launch(s);
+  }
   {
     Packer pk;
     for (int i = 0; i < nl; ++i) {
@@ -1176,12 +1051,6 @@ extern "C" int facppg_wn_forward_bf16(const facppg_wn_weights* wts, int n_in, in
     g.A = (const uint4*)(W + sc.w1 + sc.w1_one * i); g.KG = K1 / 16; g.M = 2 * C; g.N = L; g.B = B; g.nseg = 4;
     for (int t = 0; t < 3; ++t) g.seg[t] = Seg{h_in, (long)Lp * C, C, HALO + (t - 1) * d, C};
     g.seg[3] = Seg{(const bf16_t*)spect_pm_dev, (long)Lr * NCOND, NCOND, 0, NCOND};
-    {
-      static const char* ex = getenv("FACPPG_BG_EXP");   // timing experiment (wrong results): 1 = every segment strided like spect, 2 = like h
-      const int exv = ex ? atoi(ex) : 0;
-      if (exv == 1) for (int t = 0; t < 3; ++t) g.seg[t] = Seg{(const bf16_t*)spect_pm_dev, (long)Lr * NCOND, NCOND, 0, C};
-      if (exv == 2) g.seg[3] = Seg{h_in, (long)Lp * C, C, HALO, NCOND};
-    }
     g.mode = EP_GATE; g.bias = b1 + 2 * C * i; g.Lr = Lr;
     g.acts = (bf16_t*)(S + st.acts + st.acts_one * i); g.ts = (bf16_t*)(S + st.ts + st.ts_one * i);
     if (int rc = bgemm_launch(g, s)) return rc;
@@ -1234,16 +1103,20 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
     }
     if (int rc = pk.launch(s)) return rc;
   }
-  zero_rows(W + sc.dpre, (long)nl * B, (long)Lp * 2 * C * 2, 2 * C * 2, HALO, HALO + L, Lp, s);
-  zero_rows(W + sc.dh, (long)(nl + 1) * B, (long)Lr * C * 2, C * 2, 0, L, Lr, s);
-  zero_rows(W + sc.dskip, B, (long)Lr * C * 2, C * 2, 0, L, Lr, s);
   bf16_t* dskip = (bf16_t*)(W + sc.dskip);
   const dim3 egrid((L + 3) / 4, B);
+  {
+    ZeroRows z;
+    z.add(W + sc.dpre, (long)nl * B, (long)Lp * 2 * C * 2, 2 * C * 2, HALO, HALO + L, Lp);
+    z.add(W + sc.dh, (long)(nl + 1) * B, (long)Lr * C * 2, C * 2, 0, L, Lr);
+    z.add(W + sc.dskip, B, (long)Lr * C * 2, C * 2, 0, L, Lr);
+    z.launch(s);
+  }
   k_t_end_bwd<<<egrid, 256, 0, s>>>(dout_dev, wts->end_w, dskip, nout, L, Lr);
   {  // end conv: weight [nout][256] and bias gradients
     float* part = (float*)(W + sc.part);
     k_small_wgrad_part<false><<<SMALL_PARTS, 256, 0, s>>>(dout_dev, S + st.skip, (long)Lr * C, 0, part, nout, B, L, SMALL_PARTS);
-    k_small_wgrad_sum<<<9, 1024, 0, s>>>(part, SMALL_PARTS, nout, gr->end_w, C, 1, nullptr);
+    k_small_wgrad_sum<<<dim3(C / 16, 9), 256, 0, s>>>(part, SMALL_PARTS, nout, gr->end_w, C, 1, nullptr);
     k_small_rowsum<<<nout, 256, 0, s>>>(dout_dev, gr->end_b, nout, B, L);
   }
   for (int i = nl - 1; i >= 0; --i) {
@@ -1277,7 +1150,7 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
   {  // start conv: weight [256][n_in] and bias [256] gradients
     float* part = (float*)(W + sc.part);
     k_small_wgrad_part<true><<<SMALL_PARTS, 256, 0, s>>>(a0_dev, dh0, (long)Lr * C, 0, part, n_in, B, L, SMALL_PARTS);
-    k_small_wgrad_sum<<<9, 1024, 0, s>>>(part, SMALL_PARTS, n_in, gr->start_w, 1, n_in, gr->start_b);
+    k_small_wgrad_sum<<<dim3(C / 16, 9), 256, 0, s>>>(part, SMALL_PARTS, n_in, gr->start_w, 1, n_in, gr->start_b);
   }
   // weight gradients of the three convs of every layer: NT products over positions, batched over layers (x taps)
   {

@@ -124,6 +124,8 @@ def _declare(lib):
         "facppg_resample_num_samples": (c.c_int, [c.c_int, c.c_int, c.c_int]),
         "facppg_resample": (c.c_int, [vp, c.c_int, c.c_int, c.c_int, vp, vp]),
         "facppg_reduce_ppg": (c.c_int, [vp, vp, c.c_int, c.c_int, c.c_int, vp, vp]),
+        "facppg_adam_chunk_elems": (c.c_int, []),
+        "facppg_adam_step": (c.c_int, [vp, c.c_int, vp, c.c_int, vp, f32, c.c_double, c.c_double, f32, f32, vp]),
         "facppg_tdnn_weight_count": (sz, [c.POINTER(TdnnLayer), c.c_int]),
         "facppg_tdnn_create": (c.c_int, [c.POINTER(TdnnLayer), c.c_int, c.c_int, vp, sz, c.c_int, vp, c.POINTER(vp)]),
         "facppg_tdnn_destroy": (None, [vp]),

@@ -21,6 +21,7 @@ from waveglow.distributed import (GradientExchange, init_distributed, apply_grad
 from waveglow.glow import WaveGlow, WaveGlowLoss
 from waveglow.graphed import GraphedTrainStep
 from waveglow.mel2samp import Mel2Samp
+from waveglow.optim import Adam
 
 
 def load_checkpoint(checkpoint_path, model, optimizer):
@@ -82,8 +83,9 @@ def train(num_gpus, rank, group_name, output_directory, epochs, learning_rate, s
             exchange = GradientExchange(model, n_buckets=grad_buckets, grad_dtype=comm_dtype)
         else:
             model = apply_gradient_allreduce(model, n_buckets=grad_buckets, grad_dtype=comm_dtype)
-    # one multi-tensor kernel per Adam state, not 938 x 4; inside the graph when there is no gradient exchange
-    optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate, fused=True, capturable=bool(hip_graph and num_gpus == 1))
+    # torch.optim.Adam's state and arithmetic, ONE HIP launch over all 938 parameters (waveglow.optim); inside the graph
+    # when there is no gradient exchange
+    optimizer = Adam(model.parameters(), lr=learning_rate)
     stepper = None
     if hip_graph:
         seg = data_config["segment_length"]

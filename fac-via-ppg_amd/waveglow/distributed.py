@@ -135,7 +135,7 @@ class GradientExchange(object):
     eager steps:   ``install_hooks()`` once; every ``backward()`` then leaves rank-averaged gradients behind.
     graphed steps: the captured graph produces the gradients; ``bind_static_sources()`` once after the capture, then
                    ``exchange(static=True)`` after every replay (buckets are packed and reduced in a pipeline: bucket
-                   i+1 is packed on the compute stream while bucket i is on the links)."""
+                   i+1 is packed while bucket i is on the links)."""
 
     def __init__(self, module, n_buckets=3, grad_dtype=None):
         self.module = module
@@ -165,23 +165,29 @@ class GradientExchange(object):
         return [p.grad for p in self.buckets[i]]
 
     def _launch(self, i, static=False):
-        """Pack bucket i into its flat buffer and start its all_reduce."""
+        """Pack bucket i into its flat buffer and start its all_reduce -- both on the communication stream, which waits
+        for the compute stream first: the compute stream itself is never held up."""
         if self.pending[i] is not None:
             return
         grads, views = self._grads(i, static), self.views[i]
         src = [g for g, v in zip(grads, views) if g is not None and g.data_ptr() != v.data_ptr()]
         dst = [v for g, v in zip(grads, views) if g is not None and g.data_ptr() != v.data_ptr()]
-        for g, v in zip(grads, views):
-            if g is None:
-                v.zero_()                                   # a parameter without a gradient adds nothing
-        if src:
-            torch._foreach_copy_(dst, src)                  # one multi-tensor launch; converts when the links carry bf16
         flat = self.flat[i]
+
+        def pack():
+            for g, v in zip(grads, views):
+                if g is None:
+                    v.zero_()                               # a parameter without a gradient adds nothing
+            if src:
+                torch._foreach_copy_(dst, src)              # one multi-tensor launch; converts when the links carry bf16
+
         if self.cuda and dist.get_backend() != "gloo":
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
+                pack()
                 self.pending[i] = dist.all_reduce(flat, async_op=True)
         else:
+            pack()
             _collective(dist.all_reduce, flat)
             self.pending[i] = True
 
@@ -191,6 +197,7 @@ class GradientExchange(object):
             return
         if work is not True:
             work.wait()                                     # orders the current stream behind the collective
+            torch.cuda.current_stream().wait_stream(self.comm_stream)   # (and behind the pack, for the allocator's sake)
         flat = self.flat[i]
         flat.div_(self.world)
         grads = self._grads(i, static)

@@ -157,7 +157,12 @@ def spect_to_posmajor_bf16(spect, Lg):
 
 class _StepShared(object):
     """What the bf16 flows of one training step share: the fp32 position-major conditioning gradient every flow's
-    backward adds to (one buffer instead of 12 tensors summed by autograd), consumed by the upsampler's backward."""
+    backward adds to (one buffer instead of 12 tensors summed by autograd), consumed by the upsampler's backward.
+
+    (Round 3 tried a second stream here: the weight / bias gradients of a flow and the weight-norm backward enqueued
+    behind an event, to run underneath the following flows' data-gradient chains.  Measured slower on one MI355X -- graphed
+    13.3 vs 12.2 ms at batch 3, 24.4 vs 24.0 at batch 12 -- and unsound as soon as autograd copies an incoming gradient
+    instead of adopting it, which it does on the first stream: removed; profiles/r03_experiments.txt.)"""
 
     def __init__(self):
         self.dspect_pm = None

@@ -413,6 +413,16 @@ int facppg_cmn_splice_transform(const float* feats_dev, int T, int D, int do_cmn
 int facppg_reduce_ppg(const float* ppg_dev, const float* transform_t_dev, int T, int K, int M,
                       float* out_dev, void* stream);
 
+/* Replaces torch.optim.Adam(model.parameters(), lr).step() of the training loop (src/script/train_waveglow.py:83,134) for
+ * every parameter in ONE streaming launch.  table_dev: n_tensors entries {float* param, const float* grad, float* exp_avg,
+ * float* exp_avg_sq, int64 numel} (40 bytes each); chunks_dev: n_chunks pairs {tensor index, chunk index} covering every
+ * tensor in chunks of facppg_adam_chunk_elems() elements; step_dev: the step count (a float, as torch's fused Adam keeps
+ * it), incremented on the device BEFORE the update so a captured launch advances it at every replay.  Arithmetic of
+ * torch._fused_adam_ (amsgrad off, maximize off, L2-style weight_decay). */
+int facppg_adam_chunk_elems(void);
+int facppg_adam_step(const void* table_dev, int n_tensors, const int32_t* chunks_dev, int n_chunks, float* step_dev,
+                     float lr, double beta1, double beta2, float eps, float weight_decay, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * nnet3 TDNN acoustic model: feature frames -> senone posteriors (the "full PPG")
  * (src/ppg/compute_ppg.py:42-70 compute_full_ppg = Kaldi nnet3::DecodableNnetSimple through PyKaldi;

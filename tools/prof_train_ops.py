@@ -38,7 +38,8 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     step()
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="count", row_limit=40, max_name_column_width=60))
+print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=90))
+print(prof.key_averages().table(sort_by="count", row_limit=30, max_name_column_width=60))
 # who issues the fills / copies: aggregate by the innermost Python frames of this repo
 from collections import Counter
 for op in ("aten::fill_", "aten::zero_", "aten::copy_", "aten::zeros", "aten::zeros_like"):
