@@ -1,11 +1,11 @@
 #!/bin/bash
-# rocprofv3 kernel-trace summary of the training step (tools/time_train.py <precision> <batch>) -> gpurun_out/prof_txt/
+# rocprofv3 kernel-trace summary of the graphed bf16 training step (tools/time_train_step.py <batch>, 44 steps: 2 eager warm-ups, the
+# capture, 41 replays -- the one-off launches of the warm-ups, e.g. the optimiser-state initialisation, stay in the totals)
+# -> gpurun_out/prof_txt/train_graph_kernel_stats_bf16_B<batch>.txt
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/prof_txt; mkdir -p $O; W=/tmp/facppg_prof_train; rm -rf $W; mkdir -p $W
-for cfg in ${CFGS:-"bf16 3" "bf16 12"}; do
-  tag=$(echo $cfg | tr ' ' '_')
-  timeout 300 rocprofv3 --kernel-trace --stats -d $W/$tag -o r -- python tools/time_train.py $cfg > $W/$tag.log 2>&1; echo "$tag rc=$?"
-  grep seg= $W/$tag.log
-  python tools/rocpd_summary.py stats $W/$tag/r_results.db | cut -c1-200 > $O/train_kernel_stats_$tag.txt
+for B in ${BATCHES:-3 12}; do
+  STEPS=44 timeout 300 rocprofv3 --kernel-trace --stats -d $W/$B -o r -- python tools/time_train_step.py $B > $W/$B.log 2>&1; echo "B=$B rc=$? $(tail -1 $W/$B.log)"
+  python tools/rocpd_summary.py stats $W/$B/r_results.db | cut -c1-200 > $O/train_graph_kernel_stats_bf16_B$B.txt
 done
 ls -la $O

@@ -18,7 +18,8 @@ m = WaveGlow(**cfg)
 m.load_state_dict(weightnorm_state_dict(synth.waveglow_state_dict(cfg)), strict=True)
 m = m.cuda().train()
 m.train_precision = "bf16"
-opt = torch.optim.Adam(m.parameters(), lr=1e-5, fused=True)
+from waveglow.optim import Adam
+opt = Adam(m.parameters(), lr=1e-5)
 crit = WaveGlowLoss(0.7071)
 g = np.random.Generator(np.random.PCG64(1))
 audio = torch.from_numpy(np.clip(g.standard_normal((B, 10000), dtype=np.float32) * 0.1, -1, 1)).cuda()

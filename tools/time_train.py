@@ -20,7 +20,8 @@ def main():
     m = WaveGlow(**cfg)
     m.load_state_dict(weightnorm_state_dict(synth.waveglow_state_dict(cfg)), strict=True)
     m = m.cuda().train()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-5, fused=True)
+    from waveglow.optim import Adam
+    opt = Adam(m.parameters(), lr=1e-5)
     crit = WaveGlowLoss(0.7071)
     from common.layers import TacotronSTFT
     stft = TacotronSTFT(1024, 160, 1024, 80, 16000, 0.0, 8000.0).cuda()

@@ -19,7 +19,7 @@ for B in [int(a) for a in sys.argv[1:]] or [3, 12]:
     opt = Adam(m.parameters(), lr=1e-5)
     st = GraphedTrainStep(m, crit, opt, warmup=2)
     ts = []
-    for i in range(14):
+    for i in range(int(os.environ.get("STEPS", "14"))):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         st(mel, audio)
