@@ -70,3 +70,17 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py") and pat.search(open(os.path.join(d, f)).read()):
                 offenders.append(os.path.join(d, f))
     assert not offenders, offenders
+
+
+def test_committed_pmc_summary_belongs_to_this_kernel_source():
+    """bench.py quotes roofline.traffic from the newest profiles/rNN_pmc.json only if that summary was taken from THIS
+    build of csrc/facppg_wg.hip (tools/make_pmc_json.py records the source identity); a kernel edit without a fresh
+    tools/profile_bench.sh run must not pass silently."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod_pmc", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    traffic, src = b.pmc_traffic()
+    assert traffic is not None and traffic > 0, src
