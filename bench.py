@@ -675,13 +675,14 @@ class TrainWorkload(object):
         self.model, crit = make_train_model(dev, "bf16")
         self.mel, self.audio = train_batch(dev, self.B, seed=1 + rank)
         self.exchange = None
-        if world > 1:
+        if dist is not None:
             broadcast_parameters(self.model, 0)
             self.exchange = GradientExchange(self.model, n_buckets=args.grad_buckets,
                                              grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else None)
         from waveglow.optim import Adam
         opt = Adam(self.model.parameters(), lr=1e-5)
         self.stepper = GraphedTrainStep(self.model, crit, opt, warmup=2, exchange=self.exchange)
+        self.dp = dist is not None
         self.samples = world * self.B * 10000
         self.loss = None
 
@@ -698,7 +699,7 @@ class TrainWorkload(object):
         out["config"] = {"workload": "BASELINE configs[4]: WaveGlow training step (fwd + WaveGlowLoss + bwd + fused Adam), segment 10000 "
                                      "@16 kHz / hop 160, per-GPU batch %d, bf16 MFMA operands, fp32 accumulation / master weights / "
                                      "gradients, one replayed HIP graph per step%s" % (
-                                         self.B, "" if self.world == 1 else ", data parallel: bucketed gradient all-reduce after each replay"),
+                                         self.B, "" if not self.dp else ", data parallel: bucketed gradient all-reduce after each replay"),
                          "per_gpu_batch": self.B, "global_batch": self.B * self.world, "parallelism": "dp%d" % self.world,
                          "graph_captured": self.stepper.graph is not None}
         out["tflops"] = flops / (ms * 1e-3) / 1e12
@@ -753,6 +754,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="N > 1 infer runs: skip the train_dp / corpus_dp entries")
     ap.add_argument("--dist-backend", default="nccl", help=argparse.SUPPRESS)   # "gloo" + --share-gpu: 1-GPU dry run of the N>1 path
     ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)   # a process group even at N = 1: the RCCL code paths on ONE GPU
     ap.add_argument("--cpu-baseline-worker", nargs=2, metavar=("THREADS", "MODE"), help=argparse.SUPPRESS)
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--train-worker", action="store_true", help=argparse.SUPPRESS)
@@ -779,9 +781,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29511")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
         else:
@@ -812,13 +816,13 @@ def main():
         "metric": METRIC if not train else "16 kHz audio samples/sec through the WaveGlow training step (BASELINE configs[4])",
         "value": value, "unit": "samples/s", "n_gpus": world, "world_size": world, "ranks_connected": ranks_connected,
         "rank_devices": rank_devices,
-        "collective_backend": ("RCCL (torch.distributed nccl)" if args.dist_backend == "nccl" else args.dist_backend) if world > 1 else None,
+        "collective_backend": ("RCCL (torch.distributed nccl)" if args.dist_backend == "nccl" else args.dist_backend) if dist is not None else None,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": wl.scaling, "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic", "workload": args.workload,
         "realtime_factor": value / (16000 if train else SR),
     }
     wl.finish(out, elapsed, args.steps)
-    secondary_ok = rank == 0 and world == 1 and args.workload == "infer"
+    secondary_ok = rank == 0 and world == 1 and args.workload == "infer" and not args.force_dist
     if secondary_ok and not args.no_e2e:
         for key, lens in (("end_to_end_batch1", [200]), ("end_to_end_batch16_ragged", config3_lengths())):
             try:
@@ -827,7 +831,7 @@ def main():
                 log("%s failed: %r" % (key, e))
                 out[key] = None
         out["reference_rate_config"] = reference_rate_config(dev, wl.mel, log)
-    if world > 1 and args.workload == "infer" and not args.no_extra:
+    if dist is not None and args.workload == "infer" and not args.no_extra:
         # the two configs whose collectives matter, measured in the same multi-GPU invocation (short runs; a failure
         # is reported as null and never takes the primary figure down)
         del wl
