@@ -615,7 +615,7 @@ class E2EWorkload(object):
 class CorpusWorkload(object):
     """configs[3]: --utterances ragged monophone-PPG utterances (Tin_i = 100 + PCG64(11).integers(0, 301)
     frames, 40 symbols = config "1m") sharded over the ranks by facppg.shard.partition; every rank synthesises its shard
-    in batches of 16 through script.synthesize_corpus.synthesize_shard; the audio comes back to rank 0 through
+    in batches of --corpus-batch (64) through script.synthesize_corpus.synthesize_shard; the audio comes back to rank 0 through
     script.synthesize_corpus.collect (an all_gather of lengths + one padded gather over RCCL).  No files: the PPGs are
     generated in memory and the waveforms stay in memory on rank 0."""
     name, scaling, dtype = "corpus", "strong", "f32"
@@ -626,7 +626,7 @@ class CorpusWorkload(object):
         self.rank, self.world, self.dev = rank, world, dev
         self.lengths = config3_lengths(args.utterances, 11)
         self.samples = sum(self.lengths) * HOP
-        self.args = argparse.Namespace(batch_size=16, sigma=0.6, denoiser_strength=0.005, seed=0, limit_steps_to_input=True)
+        self.args = argparse.Namespace(batch_size=getattr(args, "corpus_batch", 64), sigma=0.6, denoiser_strength=0.005, seed=0, limit_steps_to_input=True)
         from facppg import shard
         mine = set(shard.partition(self.lengths, world)[rank])
         nsym = 40
@@ -657,9 +657,9 @@ class CorpusWorkload(object):
             assert sorted(self.gathered) == list(range(len(self.lengths))), "an utterance was lost or duplicated in the gather"
             assert all(self.gathered[i].numel() == n * HOP for i, n in enumerate(self.lengths))
         out["config"] = {"workload": "BASELINE configs[3]: offline corpus synthesis, %d ragged utterances (100..400 frames, 40-symbol "
-                                     "monophone PPGs) -> wav at hop=%d, sharded length-sorted round-robin over %d rank(s), batches of 16, "
+                                     "monophone PPGs) -> wav at hop=%d, sharded length-sorted round-robin over %d rank(s), batches of %d, "
                                      "per-utterance seeds and decoder limits; one step = the whole corpus incl. the all_gather of lengths "
-                                     "and the padded gather of the audio to rank 0" % (len(self.lengths), HOP, self.world),
+                                     "and the padded gather of the audio to rank 0" % (len(self.lengths), HOP, self.world, self.args.batch_size),
                          "utterances": len(self.lengths), "per_gpu_utterances": -(-len(self.lengths) // self.world),
                          "global_batch": len(self.lengths), "parallelism": "dp%d" % self.world}
 
@@ -743,6 +743,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="infer")
     ap.add_argument("--utterances", type=int, default=1024, help="corpus workload: utterances in the corpus")
+    ap.add_argument("--corpus-batch", type=int, default=64, help="corpus workload: utterances per synthesis batch")
     ap.add_argument("--e2e-batch", type=int, default=16, help="e2e workload: utterances per rank (1 = the metric's batch-1 case)")
     ap.add_argument("--train-batch", type=int, default=3, help="train workload: per-GPU batch (config.json: 3)")
     ap.add_argument("--grad-buckets", type=int, default=3)
