@@ -234,18 +234,25 @@ __global__ __launch_bounds__(NT) void k_bilstm(const float* __restrict__ xproj, 
 // one-workgroup kernel's sums up to fp32 re-association of the K split.
 // Poll an exchange word until its tag shows up.  The producers are co-resident by construction
 // (hipLaunchCooperativeKernel refuses a grid that is not), so the wait is a few microseconds.
-// Run-time bound (device constant, set per handle from FACPPG_POLL_LIMIT; default 4 M polls, 0 = unbounded): a
-// lost producer (a logic error, or a grid that was not co-resident after all) turns into a trapped kernel and a
-// HIP error instead of a hung GPU.
-__constant__ unsigned g_poll_limit = 0x400000u;
+// Run-time bound: a lost producer (a logic error, or a grid that was not co-resident after all) turns into a trapped
+// kernel and a HIP error instead of a hung GPU.  The bound is WALL-CLOCK time on the device's constant-rate counter
+// (wall_clock64), checked every 1024 polls, so a slow but live run -- a debugger, a profiler, a time-sliced or SR-IOV
+// GPU -- is not turned into a fatal one the way a poll count would.  PROCESS-WIDE (one device constant per loaded code
+// object): FACPPG_POLL_LIMIT seconds, read when the first handle is created; default 20 s; 0 = never trap.
+__constant__ unsigned long long g_poll_limit_ticks = 0;   // 0 until the first facppg_taco_create: unbounded
 __device__ __forceinline__ unsigned long long poll_tag(const unsigned long long* w, unsigned tag) {
   unsigned long long v;
-  const unsigned limit = g_poll_limit;
+  const unsigned long long limit = g_poll_limit_ticks;
+  unsigned long long t0 = 0;
   unsigned spins = 0;
 #pragma unroll 1
   do {
     v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (++spins == limit) __builtin_trap();
+    if ((++spins & 1023u) == 0 && limit) {
+      const unsigned long long now = wall_clock64();
+      if (!t0) t0 = now;
+      else if (now - t0 > limit) __builtin_trap();
+    }
   } while ((unsigned)(v >> 32) != tag);
   return v;
 }
@@ -1217,6 +1224,10 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
   FACPPG_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device));
   facppg_taco* h = new (std::nothrow) facppg_taco();
   FACPPG_REQUIRE(h, FACPPG_EINVAL, "out of host memory");
+  struct Guard {   // every early return below frees the handle (and its arena, once allocated)
+    facppg_taco* h;
+    ~Guard() { if (h) { if (h->arena) (void)hipFree(h->arena); delete h; } }
+  } guard{h};
   h->c = *cfg; h->device = device;
   {
     // How many workgroups the cooperative kernels may keep co-resident: what the occupancy calculator says fits
@@ -1236,9 +1247,16 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
     }
     const int resident = n_cu * per_cu;
     h->coop_limit = resident - resident / 16;
-    const char* pl = getenv("FACPPG_POLL_LIMIT");
-    const unsigned limit = pl ? (unsigned)strtoul(pl, nullptr, 0) : 0x400000u;
-    FACPPG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_poll_limit), &limit, sizeof(limit)));
+    static bool poll_limit_set = false;   // process-wide, set once (see poll_tag)
+    if (!poll_limit_set) {
+      const char* pl = getenv("FACPPG_POLL_LIMIT");
+      const double seconds = pl ? strtod(pl, nullptr) : 20.0;
+      int khz = 0;
+      FACPPG_HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device));
+      const unsigned long long ticks = seconds > 0 && khz > 0 ? (unsigned long long)(seconds * 1e3 * khz) : 0ull;
+      FACPPG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_poll_limit_ticks), &ticks, sizeof(ticks)));
+      poll_limit_set = true;
+    }
   }
   const facppg_taco_config& c = *cfg;
   const int S = c.symbols_embedding_dim, E = c.encoder_embedding_dim, H = E / 2, K = c.encoder_kernel_size;
@@ -1282,8 +1300,8 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
     o.post_b[j] = take(co * 4); o.post_sc[j] = take(co * 4); o.post_sh[j] = take(co * 4);
   }
   if (hipMalloc((void**)&h->arena, off) != hipSuccess) {
+    h->arena = nullptr;
     set_error("hipMalloc(%zu) failed", off);
-    delete h;
     return FACPPG_EHIP;
   }
   int rc = FACPPG_OK;
@@ -1383,11 +1401,8 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
   hipok(hipGetLastError());
   hipok(hipStreamSynchronize(s));
   if (!rc && (size_t)(src - wsrc) != n_floats) { set_error("internal: consumed %zu of %zu weights", (size_t)(src - wsrc), n_floats); rc = FACPPG_EINVAL; }
-  if (rc) {
-    (void)hipFree(h->arena);
-    delete h;
-    return rc;
-  }
+  if (rc) return rc;
+  guard.h = nullptr;
   *out = h;
   return FACPPG_OK;
 }
