@@ -2512,7 +2512,7 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
     for (int k = 0; k < c.n_flows; ++k) tot += h->early[k] ? c.n_early_size : 0;
     FACPPG_REQUIRE(tot == 8, FACPPG_EUNSUPPORTED, "noise channel count %d != n_group", tot);
   }
-  static const char* unfolded = getenv("FACPPG_WG_UNFOLDED");
+  const char* unfolded = getenv("FACPPG_WG_UNFOLDED");   // (read per call: the tests flip it)
   if (!unfolded || atoi(unfolded) == 0)
     return wg_infer_pm(h, mel_dev, T_valid_dev, z_dev, seed, sigma, B, T, audio_dev, (char*)ws_, (hipStream_t)stream_);
   hipStream_t s = (hipStream_t)stream_;
