@@ -176,6 +176,7 @@ __device__ __forceinline__ void bgemm_store4(const BGemmArgs& p, int b, int n, i
     bf16_t* d = p.dpre + (size_t)b * p.dpre_bs + (size_t)(HALO + n) * 2 * C + ch;
     *reinterpret_cast<uint2*>(d) = make_uint2(pack2(dt[0], dt[1]), pack2(dt[2], dt[3]));
     *reinterpret_cast<uint2*>(d + C) = make_uint2(pack2(ds[0], ds[1]), pack2(ds[2], ds[3]));
+
   } else if constexpr (MODE == EP_BWD_CONV) {
     const int ch = 32 * mb + 8 * q + 4 * kh;
     const size_t o = ((size_t)b * p.Lr + n) * C + ch;
@@ -561,6 +562,36 @@ __global__ __launch_bounds__(256) void k_colsum_part(ColsumArgs ca) {
   }
   for (int m = threadIdx.x; m < p.M; m += 256) part[m] = red[m];
 }
+// bf16 rows of M = 256 or 512 channels: a thread owns EIGHT adjacent channels (one 16-byte load) of every `lanes`-th row,
+// lanes = 256 / (M / 8) = 8 or 4 -- a quarter / an eighth of the sequential steps of the 4-byte version, which spent 25-32 us
+// per launch at batch 12 on a chain of short loads.  Same slices, same partial layout, row lanes met in lane order.
+__global__ __launch_bounds__(256) void k_colsum_part8(ColsumArgs ca) {
+  const ColsumProb& p = ca.prob[blockIdx.z];
+  const int tpr = p.M / 8, lanes = 256 / tpr;                   // threads per row, row lanes
+  const int c8 = (threadIdx.x % tpr) * 8, rl = threadIdx.x / tpr, sl = blockIdx.y;
+  __shared__ float red[7][512];
+  const long R = (long)ca.B * ca.L, r0 = R * sl / CS_SLICES, r1 = R * (sl + 1) / CS_SLICES;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (long r = r0 + rl; r < r1; r += lanes) {
+    const int b = (int)(r / ca.L), n = (int)(r - (long)b * ca.L);
+    const uint4 x = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.y) + (size_t)b * p.bs + (size_t)(p.row0 + n) * p.ld + c8);
+    v[0] += lo2f(x.x); v[1] += hi2f(x.x); v[2] += lo2f(x.y); v[3] += hi2f(x.y);
+    v[4] += lo2f(x.z); v[5] += hi2f(x.z); v[6] += lo2f(x.w); v[7] += hi2f(x.w);
+  }
+  if (rl) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) red[rl - 1][c8 + t] = v[t];
+  }
+  __syncthreads();
+  if (rl) return;
+  for (int l = 0; l + 1 < lanes; ++l)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] += red[l][c8 + t];
+  float* part = ca.part + ((size_t)blockIdx.z * CS_SLICES + sl) * 1024 + c8;
+  *reinterpret_cast<float4*>(part) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(part + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
 // group > 1: out[m / group] also sums `group` adjacent channels (the 8 regrouped samples of one mel channel).
 // 32 outputs x 8 slice groups per workgroup: a thread adds its 32 slices on four interleaved chains (the loads overlap),
 // the eight groups meet in LDS in group order -- a fixed order whatever the grid.  (One thread per output walking all 256
@@ -590,11 +621,19 @@ __global__ __launch_bounds__(256) void k_colsum_sum(ColsumArgs ca, int group) {
 }
 template <bool F32>
 int colsum_launch(ColsumArgs& ca, int nprob, int maxM, int group, hipStream_t s) {
-  k_colsum_part<F32><<<dim3(1, CS_SLICES, nprob), 256, 0, s>>>(ca);
+  bool wide8 = !F32;    // every problem bf16 with 256 or 512 channels, rows 16-byte aligned: the 16-byte kernel
+  for (int i = 0; i < nprob && wide8; ++i)
+    wide8 = (ca.prob[i].M == 256 || ca.prob[i].M == 512) && ca.prob[i].ld % 8 == 0 && ca.prob[i].bs % 8 == 0 && ((size_t)ca.prob[i].y & 15) == 0;
+  if (wide8) k_colsum_part8<<<dim3(1, CS_SLICES, nprob), 256, 0, s>>>(ca);
+  else k_colsum_part<F32><<<dim3(1, CS_SLICES, nprob), 256, 0, s>>>(ca);
   k_colsum_sum<<<dim3((maxM / group + 31) / 32, nprob), 256, 0, s>>>(ca, group);
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
 }
+
+// the skip half of every layer's res_skip bias gradient is the same vector
+struct SkipBiasCopy { const float* src; float* dst[8]; int n; };
+__global__ void k_copy_skip_bias(SkipBiasCopy cp) { cp.dst[blockIdx.y][threadIdx.x] = cp.src[threadIdx.x]; }
 
 // ---- the <= 8-channel edges of the stack ----------------------------------------------------------------------
 // start conv (glow.py:156): h0[b][HALO + n][c] = sum_j Ws[c][j] a0[b][j][n] + bs[c]
@@ -647,15 +686,20 @@ __global__ void k_t_end_bwd(const float* __restrict__ dout, const float* __restr
 template <bool WIDE_BF16>
 __global__ __launch_bounds__(256) void k_small_wgrad_part(const float* __restrict__ small, const void* __restrict__ wide, long wide_bs,
                                                           int wide_row0, float* __restrict__ part, int nj, int B, int L, int nparts) {
-  // workgroup = a contiguous range of the B*L rows; its slice of `small` (<= 8 x SW values) is staged in LDS first so the
-  // main loop is one coalesced row of `wide` + LDS broadcasts per row
+  // workgroup = a contiguous range of the B*L rows; its slice of `small` (<= 8 x SW values) is staged in LDS first.  A thread
+  // owns FOUR adjacent channels (one 16-byte load of fp32, 8 bytes of bf16) of every fourth row: four row lanes x 64 channel
+  // quads, so a row range is walked in a quarter of the steps with 4x wider loads (one channel per thread walking every row
+  // cost 33-45 us per launch at batch 12: a chain of dependent-latency loads); the row lanes meet in LDS in lane order.
   constexpr int SW = 128;
   __shared__ float ssm[8][SW];
-  const int c = threadIdx.x;
+  __shared__ float red[3][9][C];
+  const int c4 = (threadIdx.x & 63) * 4, rl = threadIdx.x >> 6;
   const long total = (long)B * L, i0 = total * blockIdx.x / nparts, i1 = total * (blockIdx.x + 1) / nparts;
-  float acc[9];
+  float acc[9][4];
 #pragma unroll
-  for (int j = 0; j < 9; ++j) acc[j] = 0.0f;
+  for (int j = 0; j < 9; ++j)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[j][t] = 0.0f;
   for (long base = i0; base < i1; base += SW) {
     const int cnt = (int)((i1 - base) < SW ? (i1 - base) : SW);
     __syncthreads();
@@ -667,20 +711,45 @@ __global__ __launch_bounds__(256) void k_small_wgrad_part(const float* __restric
     }
     __syncthreads();
 #pragma unroll 4
-    for (int r = 0; r < cnt; ++r) {
+    for (int r = rl; r < cnt; r += 4) {
       const long i = base + r;
       const int b = (int)(i / L), n = (int)(i - (long)b * L);
-      float wv;
-      if constexpr (WIDE_BF16) wv = bf2f(reinterpret_cast<const bf16_t*>(wide)[(size_t)b * wide_bs + (size_t)(wide_row0 + n) * C + c]);
-      else wv = reinterpret_cast<const float*>(wide)[(size_t)b * wide_bs + (size_t)(wide_row0 + n) * C + c];
+      const size_t o = (size_t)b * wide_bs + (size_t)(wide_row0 + n) * C + c4;
+      float wv[4];
+      if constexpr (WIDE_BF16) {
+        const uint2 x = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(wide) + o);
+        wv[0] = lo2f(x.x); wv[1] = hi2f(x.x); wv[2] = lo2f(x.y); wv[3] = hi2f(x.y);
+      } else {
+        const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(wide) + o);
+        wv[0] = x.x; wv[1] = x.y; wv[2] = x.z; wv[3] = x.w;
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        if (j < nj) acc[j] = fmaf(ssm[j][r], wv, acc[j]);
-      acc[8] += wv;
+        if (j < nj) {
+          const float sv = ssm[j][r];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[j][t] = fmaf(sv, wv[t], acc[j][t]);
+        }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[8][t] += wv[t];
     }
   }
+  // row lanes 1..3 hand their sums to lane 0, which adds them in lane order
+  if (rl) {
 #pragma unroll
-  for (int j = 0; j < 9; ++j) part[((size_t)blockIdx.x * 9 + j) * C + c] = acc[j];
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) red[rl - 1][j][c4 + t] = acc[j][t];
+  }
+  __syncthreads();
+  if (rl) return;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    float4 v = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+#pragma unroll
+    for (int l = 0; l < 3; ++l) { v.x += red[l][j][c4]; v.y += red[l][j][c4 + 1]; v.z += red[l][j][c4 + 2]; v.w += red[l][j][c4 + 3]; }
+    *reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * 9 + j) * C + c4) = v;
+  }
 }
 // out_w[(j, c)] laid out by (o_sj, o_sc); out_wsum[c] = column sums of wide (may be null).
 // Workgroup (j, 16-channel block): 16 channels x 16 groups of the partials; a thread adds its nparts / 16 partials on four
@@ -774,7 +843,7 @@ __global__ void k_from_posmajor_f32(const float* __restrict__ src, float* __rest
 constexpr int UQ = 16, UMAXJ = 8;
 __global__ __launch_bounds__(256) void k_up_fwd(const float* __restrict__ mel, const float* __restrict__ W, const float* __restrict__ bias,
                                                 bf16_t* __restrict__ spect, int T, int nm, int hop, int ksize, int Lr, int n_limit) {
-  extern __shared__ float smel[];  // [nm][UQ + UMAXJ]
+  extern __shared__ __attribute__((aligned(16))) float smel[];  // [nm][UQ + UMAXJ]
   const int b = blockIdx.z, m = blockIdx.y, q0 = blockIdx.x * UQ;
   const int nj = (ksize + hop - 1) / hop, SW = UQ + UMAXJ;
   for (int i = threadIdx.x; i < nm * SW; i += blockDim.x) {
@@ -790,7 +859,9 @@ __global__ __launch_bounds__(256) void k_up_fwd(const float* __restrict__ mel, c
     for (int j = 0; j < nj; ++j) {
       const int k = pp + j * hop;
       if (k < ksize)
-        for (int mp = 0; mp < nm; ++mp) {
+#pragma unroll 8
+        for (int mp = 0; mp < nm; ++mp) {      // (unrolled: eight weight loads in flight instead of one load -> 16 FMAs -> next load: 530 -> 357 us
+                                               //  at batch 12; holding a channel's 24 staged frames in registers across the taps was slower: 522)
           const float wv = W[((size_t)mp * nm + m) * ksize + k];
           const float* sm = smel + mp * SW + (UMAXJ - 1) - j;
 #pragma unroll
@@ -805,24 +876,36 @@ __global__ __launch_bounds__(256) void k_up_fwd(const float* __restrict__ mel, c
   }
 }
 // backward w.r.t. the kernel: dWu[m'][m][k] = sum_{b,q} mel[b][m'][q] * dup[b][m][q hop + k], dup[b][m][n] = dspect[b][n/8][8m + n%8]
-// (n < n_limit).  One workgroup = (output channel m, 256 taps k); a thread owns one k and all nm input channels m'.
+// (n < n_limit).  One workgroup = (output channel m, 256 taps k); a thread owns one k and all nm input channels m'.  The mel
+// frames are staged UWQ at a time (one barrier pair per UWQ frames instead of per frame: the loop was 756 iterations of
+// barrier -> 80 broadcasts -> barrier, 742 us at batch 12) and the gradient loads of the next frames are in flight under the FMAs.
+constexpr int UWQ = 16;
 template <int NM>
 __global__ __launch_bounds__(256) void k_up_wgrad(const float* __restrict__ mel, const float* __restrict__ dspect, float* __restrict__ dW,
                                                   int B, int T, int hop, int ksize, int Lr, int n_limit) {
-  __shared__ float smel[NM];
+  __shared__ float smel[UWQ][NM];
   const int m = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
   float acc[NM];
 #pragma unroll
   for (int i = 0; i < NM; ++i) acc[i] = 0.0f;
   for (int b = 0; b < B; ++b)
-    for (int q = 0; q < T; ++q) {
+    for (int q0 = 0; q0 < T; q0 += UWQ) {
       __syncthreads();
-      if (threadIdx.x < NM) smel[threadIdx.x] = mel[((size_t)b * NM + threadIdx.x) * T + q];
+      for (int e = threadIdx.x; e < UWQ * NM; e += 256) {
+        const int i = e / UWQ, qq = e - i * UWQ;       // (frames fastest: consecutive threads read consecutive mel values)
+        smel[qq][i] = q0 + qq < T ? mel[((size_t)b * NM + i) * T + q0 + qq] : 0.0f;
+      }
       __syncthreads();
-      const int n = q * hop + k;
-      const float d = (k < ksize && n < n_limit) ? dspect[((size_t)b * Lr + (n >> 3)) * (NM * 8) + m * 8 + (n & 7)] : 0.0f;
+      float d[UWQ];
 #pragma unroll
-      for (int i = 0; i < NM; ++i) acc[i] = fmaf(smel[i], d, acc[i]);
+      for (int qq = 0; qq < UWQ; ++qq) {
+        const int n = (q0 + qq) * hop + k;
+        d[qq] = (k < ksize && q0 + qq < T && n < n_limit) ? dspect[((size_t)b * Lr + (n >> 3)) * (NM * 8) + m * 8 + (n & 7)] : 0.0f;
+      }
+#pragma unroll
+      for (int qq = 0; qq < UWQ; ++qq)
+#pragma unroll
+        for (int i = 0; i < NM; ++i) acc[i] = fmaf(smel[qq][i], d[qq], acc[i]);
     }
   if (k < ksize)
 #pragma unroll
@@ -1186,7 +1269,10 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
     }
     if (int rc = wgrad_launch(wa, nl, 2 * C, C, wgpart, sc.wgpart_bytes, s)) return rc;
   }
-  {  // bias gradients: column sums of dpre_i (in + cond biases share them) and of [dh_{i+1} | dskip]
+  {  // bias gradients: column sums of dpre_i (in + cond biases share them) and of [dh_{i+1} | dskip].  The skip half of every
+     // rs_b[i] is the column sum of the SAME dskip: summed once, copied to the other layers.  (Round 3 also tried leaving
+     // per-tile partial sums behind in the two backward GEMMs' epilogues instead of re-reading dpre / dh: the 32-lane
+     // reductions cost those latency-bound launches 3-4 us each, more than the second pass they saved.)
     ColsumArgs ca;
     memset(&ca, 0, sizeof(ca));
     ca.B = B; ca.L = L; ca.part = (float*)(W + sc.cspart);
@@ -1195,12 +1281,15 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
     if (int rc = colsum_launch<false>(ca, nl, 2 * C, 1, s)) return rc;
     memset(&ca.prob, 0, sizeof(ca.prob));
     int np = 0;
-    for (int i = 0; i < nl; ++i) {
-      const int last = i == nl - 1;
-      if (!last) ca.prob[np++] = ColsumProb{W + sc.dh + sc.dh_one * (i + 1), (long)Lr * C, C, 0, C, gr->rs_b[i]};
-      ca.prob[np++] = ColsumProb{dskip, (long)Lr * C, C, 0, C, gr->rs_b[i] + (last ? 0 : C)};
-    }
+    for (int i = 0; i + 1 < nl; ++i) ca.prob[np++] = ColsumProb{W + sc.dh + sc.dh_one * (i + 1), (long)Lr * C, C, 0, C, gr->rs_b[i], nullptr};
+    ca.prob[np++] = ColsumProb{dskip, (long)Lr * C, C, 0, C, gr->rs_b[nl - 1], nullptr};
     if (int rc = colsum_launch<false>(ca, np, C, 1, s)) return rc;
+    if (nl > 1) {
+      SkipBiasCopy cp;
+      cp.src = gr->rs_b[nl - 1]; cp.n = nl - 1;
+      for (int i = 0; i + 1 < nl; ++i) cp.dst[i] = gr->rs_b[i] + C;
+      k_copy_skip_bias<<<dim3(1, nl - 1), C, 0, s>>>(cp);
+    }
   }
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
