@@ -585,6 +585,18 @@ class WN(torch.nn.Module):
         return _WNFunction.apply(audio.float().contiguous(), spect_pad, *self._plain_weights())
 
 
+_INFER_SIDE_STREAMS = {}
+
+
+def _infer_side_stream(device):
+    """The second HIP stream WaveGlow.infer runs the other half of a ragged batch on (one per device, private to this module:
+    every use starts by waiting for the caller's stream and ends with the caller's stream waiting for it)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _INFER_SIDE_STREAMS:
+        _INFER_SIDE_STREAMS[key] = torch.cuda.Stream(device=torch.device("cuda", key))
+    return _INFER_SIDE_STREAMS[key]
+
+
 class WaveGlow(torch.nn.Module):
     """glow.py:178-303."""
 
@@ -825,10 +837,11 @@ class WaveGlow(torch.nn.Module):
         hop = self.upsample.stride[0]
         h = self._handle(dev)
         nbytes = L.facppg_wg_workspace_bytes(h, B, (N + hop - 1) // hop)
-        ws = self.__dict__.get("_facppg_ws")
+        wss = self.__dict__.setdefault("_facppg_ws", {})
+        ws = wss.get(0)
         if ws is None or ws.numel() < nbytes or ws.device != dev:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            self.__dict__["_facppg_ws"] = ws
+            wss[0] = ws
         Lg = N // self.n_group
         z = torch.empty(B, self.n_group, Lg, device=dev)
         log_s_flat = torch.empty(L.facppg_wg_log_s_count(h, B, N), device=dev)
@@ -859,27 +872,113 @@ class WaveGlow(torch.nn.Module):
             _lib.check(L.facppg_wg_draw_noise(h, _lib.ptr(sd), B, T, _lib.ptr(zt), _lib.current_stream(dev)))
         return zt
 
-    def infer(self, spect, sigma=1.0, z=None, lengths=None, seed=None, utterance_seeds=None):
-        """mel [B, n_mel, T] (GPU, fp32) -> audio [B, T*hop]   (glow.py:252-293)."""
+    # ---- two concurrent half-batches for ragged batches
+    _ROUND_COSTS = ((64, 331, 185), (32, 181, 94), (16, 105, 57))   # frames per tile, us per full / half round (csrc/facppg_wg.hip)
+
+    def _tail_loss(self, lengths, hop):
+        """Fraction of a WN-layer launch of this ragged batch that the chip idles through in its last round of workgroup
+        slots, from the library's measured round costs (512 slots = 2 per CU); 0 for a launch that does not fill the slots
+        once (its problem is not the tail, and splitting it only adds launches)."""
+        P = hop // 8
+        best = None
+        for frames, full, half in self._ROUND_COSTS:
+            cols = sum(-(-int(n) // 4) * 4 for n in lengths)
+            tiles = P * -(-cols // frames)
+            rem = tiles % 512
+            cost = (tiles // 512) * full + (0 if rem == 0 else half if rem <= 256 else full)
+            if best is None or cost < best[0]:
+                best = (cost, tiles / 512.0 * full, tiles)
+        return 1.0 - best[1] / best[0] if best[0] and best[2] > 512 else 0.0
+
+    def _infer_two_groups(self, spect, sigma, zt, lengths, seed, utterance_seeds):
+        """A ragged batch as TWO interleaved half-batches, the second on a side stream.  Utterances are independent and every
+        one is computed exactly as in its own batch-1 call, so the split changes no bit of the result; what it changes is
+        the tail of every layer launch: a launch runs in rounds of 512 workgroup slots and its last, partial round leaves
+        most of the chip idle (16 utterances of 100-400 frames: 4.3 rounds, 6 % of the time) -- with two launch sequences in
+        flight, the free slots of one half's last round are taken by the other half's tiles.  Measured on the 16-utterance
+        batch of BASELINE config 3: 127.1 -> 120.2 ms (profiles/r03_experiments.txt); three or four groups gain nothing.
+        Both halves' inputs are prepared on the caller's stream BEFORE the fork (every host-blocking upload happens there),
+        then the two launch sequences are enqueued back to back without touching the host clock again."""
+        dev, hop, g8 = spect.device, self.upsample.stride[0], self.n_group
+        B, _, T = spect.shape
+        order = sorted(range(B), key=lambda i: (-int(lengths[i]), i))
+        side = _infer_side_stream(dev)
+        cur = torch.cuda.current_stream(dev)
+        out = torch.zeros(B, T * hop, dtype=torch.float32, device=dev)
+        Lfull = T * hop // g8
+        segs = None
+        if zt is not None:          # the injected-z layout: [B, n_remaining, L] ++ [B, n_early_size, L] per early output
+            chans = [self.n_remaining_channels] + [self.n_early_size] * ((g8 - self.n_remaining_channels) // self.n_early_size)
+            segs, off = [], 0
+            for c in chans:
+                segs.append(zt[off:off + B * c * Lfull].view(B, c, Lfull))
+                off += B * c * Lfull
+        sel = torch.tensor(order[0::2] + order[1::2] + [int(lengths[i]) for i in order[0::2] + order[1::2]], device=dev)
+        parts, n0 = [], len(order[0::2])
+        for gi, idx in enumerate((order[0::2], order[1::2])):
+            it = sel[:n0] if gi == 0 else sel[n0:B]
+            lt = (sel[B:B + n0] if gi == 0 else sel[B + n0:]).to(torch.int32)
+            Tg = max(int(lengths[i]) for i in idx)
+            mel_g = spect.index_select(0, it)[:, :, :Tg].contiguous()
+            if utterance_seeds is not None:
+                z_g = self.draw_noise([utterance_seeds[i] for i in idx], Tg, dev)
+            elif segs is not None:
+                z_g = torch.cat([sg.index_select(0, it)[:, :, :Tg * hop // g8].reshape(-1) for sg in segs])
+            else:
+                z_g = None
+            a = torch.zeros(len(idx), Tg * hop, dtype=torch.float32, device=dev)
+            ws = self._infer_workspace(len(idx), Tg, dev, gi)
+            parts.append((it, lt, Tg, mel_g, z_g, a, ws))
+        side.wait_stream(cur)
+        for gi, (it, lt, Tg, mel_g, z_g, a, ws) in enumerate(parts):
+            with torch.cuda.stream(side if gi else cur):
+                self._infer_launch(mel_g, lt, z_g, (seed + 0x9E3779B97F4A7C15 * gi) & 0x7FFFFFFFFFFFFFFF, sigma, a, ws)
+        cur.wait_stream(side)
+        for it, lt, Tg, mel_g, z_g, a, ws in parts:
+            out[:, :Tg * hop].index_copy_(0, it, a)
+        return out
+
+    def _infer_workspace(self, B, T, dev, slot):
+        nbytes = _lib.load().facppg_wg_workspace_bytes(self._handle(dev), B, T)
+        wss = self.__dict__.setdefault("_facppg_ws", {})
+        ws = wss.get(slot)
+        if ws is None or ws.numel() < nbytes or ws.device != dev:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            wss[slot] = ws
+        return ws
+
+    def _infer_launch(self, spect, lt, zt, seed, sigma, audio, ws):
+        """The launch sequence of one batch on the current stream; no host-side waits."""
+        dev = spect.device
+        B, _, T = spect.shape
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().facppg_wg_infer(self._handle(dev), _lib.ptr(spect), _lib.ptr(lt), _lib.ptr(zt),
+                                                   seed & 0xFFFFFFFFFFFFFFFF, float(sigma), B, T, _lib.ptr(audio),
+                                                   _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)))
+
+    def infer(self, spect, sigma=1.0, z=None, lengths=None, seed=None, utterance_seeds=None, groups=None):
+        """mel [B, n_mel, T] (GPU, fp32) -> audio [B, T*hop]   (glow.py:252-293).
+        groups: None = decide from the launch shape (ragged batches whose layer launches would idle through >= 3 % of their
+        time in the last round run as two concurrent half-batches, see _infer_two_groups), 1 = one launch sequence, 2 = force
+        the two half-batches (needs host-side lengths).  With `seed` alone the noise is a function of (seed, batch layout)."""
         _lib.require_cuda(spect, "WaveGlow.infer: spect")
         if spect.dtype != torch.float32:
             raise _lib.FacppgError("WaveGlow.infer: fp32 only (the reference's fp16 branch is not built)")
-        L = _lib.load()
         dev = spect.device
         spect = spect.contiguous()
         B, _, T = spect.shape
         hop = self.upsample.stride[0]
-        h = self._handle(dev)
-        nbytes = L.facppg_wg_workspace_bytes(h, B, T)
-        ws = self.__dict__.get("_facppg_ws")
-        if ws is None or ws.numel() < nbytes or ws.device != dev:
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            self.__dict__["_facppg_ws"] = ws
+        host_lengths = lengths is not None and not torch.is_tensor(lengths)
+        if host_lengths and (len(lengths) != B or max(int(n) for n in lengths) > T or min(int(n) for n in lengths) < 1):
+            raise _lib.FacppgError("lengths must be B values in [1, T]")
+        if groups is None:
+            groups = 2 if (host_lengths and B >= 4 and self._tail_loss(lengths, hop) >= 0.03) else 1
+        if groups == 2 and (not host_lengths or B < 2):
+            raise _lib.FacppgError("WaveGlow.infer: groups=2 needs B >= 2 utterances and their lengths as a host list")
         zt = None
         if utterance_seeds is not None:
             if z is not None or len(utterance_seeds) != B:
                 raise _lib.FacppgError("utterance_seeds: B integers, and not together with z")
-            zt = self.draw_noise(utterance_seeds, T, dev)
         elif z is not None:
             if isinstance(z, (list, tuple)):
                 z = torch.cat([t.to(dev).float().reshape(-1) for t in z])
@@ -887,19 +986,20 @@ class WaveGlow(torch.nn.Module):
             if zt.numel() != B * self.n_group * (T * hop // self.n_group):
                 raise _lib.FacppgError("z has %d values, expected B*n_group*L = %d" % (
                     zt.numel(), B * self.n_group * (T * hop // self.n_group)))
+        if seed is None:
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        if groups == 2:
+            return self._infer_two_groups(spect, sigma, zt, lengths, seed, utterance_seeds)
+        if utterance_seeds is not None:
+            zt = self.draw_noise(utterance_seeds, T, dev)
         lt = None
         if lengths is not None:
             lt = torch.as_tensor(lengths).to(device=dev, dtype=torch.int32).contiguous()
-            if lt.numel() != B or int(lt.max()) > T or int(lt.min()) < 1:
+            if not host_lengths and (lt.numel() != B or int(lt.max()) > T or int(lt.min()) < 1):
                 raise _lib.FacppgError("lengths must be B values in [1, T]")
-        if seed is None:
-            seed = int(torch.empty((), dtype=torch.int64).random_().item())
         audio = torch.zeros(B, T * hop, dtype=torch.float32, device=dev) if lt is not None else \
             torch.empty(B, T * hop, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            _lib.check(L.facppg_wg_infer(h, _lib.ptr(spect), _lib.ptr(lt), _lib.ptr(zt),
-                                         seed & 0xFFFFFFFFFFFFFFFF, float(sigma), B, T, _lib.ptr(audio),
-                                         _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)))
+        self._infer_launch(spect, lt, zt, seed, sigma, audio, self._infer_workspace(B, T, dev, 0))
         return audio
 
     @staticmethod

@@ -95,6 +95,35 @@ def test_ragged_batch_equals_independent_runs_and_oracle(model160):
     _ragged_check(*model160)
 
 
+def test_two_concurrent_half_batches_change_no_bit(model256):
+    """WaveGlow.infer(groups=2) (two interleaved half-batches, the second on a side stream) == groups=1, bit for bit, with
+    injected z and with per-utterance seeds; the 16-utterance ragged batch of BASELINE config 3 is one the launch-shape
+    heuristic splits, a uniform batch and a batch without host-side lengths are not."""
+    m, cfg = model256
+    lens = (100 + np.random.Generator(np.random.PCG64(7)).integers(0, 301, size=16)).tolist()
+    assert m._tail_loss(lens, 256) >= 0.03 and m._tail_loss([1000] * 8, 256) < 0.03 and m._tail_loss([37, 5, 23, 1], 256) == 0.0
+    B, T = len(lens), max(lens)
+    mel = synth.synthetic_mel(B, T, seed=21).cuda()
+    zs = synth.synthetic_z(B, T * 32, cfg, seed=22)
+    one = m.infer(mel, sigma=0.6, z=zs, lengths=lens, groups=1)
+    two = m.infer(mel, sigma=0.6, z=zs, lengths=lens, groups=2)
+    auto = m.infer(mel, sigma=0.6, z=zs, lengths=lens)
+    assert torch.equal(one, two) and torch.equal(one, auto)
+    seeds = list(range(500, 500 + B))
+    one = m.infer(mel, sigma=0.6, lengths=lens, utterance_seeds=seeds, groups=1)
+    two = m.infer(mel, sigma=0.6, lengths=lens, utterance_seeds=seeds, groups=2)
+    assert torch.equal(one, two)
+    for b in (0, 7, 15):                                  # padding stays silent, the valid part is not
+        assert torch.count_nonzero(two[b, lens[b] * 256:]) == 0 and torch.count_nonzero(two[b, :lens[b] * 256]) > 0
+    a = m.infer(mel, sigma=0.6, lengths=lens, seed=9)
+    assert torch.equal(a, m.infer(mel, sigma=0.6, lengths=lens, seed=9)) and torch.isfinite(a).all()
+    with pytest.raises(Exception):
+        m.infer(mel, sigma=0.6, lengths=torch.tensor(lens), groups=2)
+    # back-to-back calls reuse the two workspaces and the side stream: no cross-call interference
+    for _ in range(3):
+        assert torch.equal(m.infer(mel, sigma=0.6, lengths=lens, utterance_seeds=seeds), one)
+
+
 def test_device_noise_is_standard_normal_and_seeded(model160):
     m, cfg = model160
     mel = synth.synthetic_mel(2, 16, seed=3).cuda()
