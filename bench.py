@@ -343,6 +343,27 @@ class EndToEnd(object):
             return pipeline.synthesize(self.ppgs, self.tacotron, self.waveglow, self.denoiser, sigma=0.6, strength=0.005, seed=i,
                                        return_device=True, step_limits=self.lens if len(self.lens) > 1 else None, timer=timer)
 
+    def stream(self, jobs, **kw):
+        """facppg.pipeline.Synthesizer.stream over this object's models (script.synthesize_corpus.synthesize_shard calls it)."""
+        from facppg import pipeline
+        gen = pipeline.synthesize_stream(jobs, self.tacotron, self.waveglow, self.denoiser, **kw)
+        while True:
+            with contextlib.redirect_stdout(sys.stderr):
+                try:
+                    item = next(gen)
+                except StopIteration:
+                    return
+            yield item
+
+    def steady_state(self, overlap=True, **kw):
+        """An endless stream of this batch (seed = step number), software-pipelined unless overlap=False."""
+        def jobs():
+            i = 0
+            while True:
+                yield {"ppgs": self.ppgs, "seed": i, "step_limits": self.lens if len(self.lens) > 1 else None}
+                i += 1
+        return self.stream(jobs(), sigma=0.6, strength=0.005, return_device=True, overlap=overlap, **kw)
+
     def describe(self):
         n = len(self.lens)
         return ("PPG [%s x %d] -> mel -> wav, hop=%d (%d Hz), batch=%d%s (Tacotron2 + WaveGlow + Denoiser), fp32, host PPG in, "
@@ -367,12 +388,29 @@ def time_end_to_end(dev, lens, steps, warmup, log, name, **kw):
     e.step(warmup + steps, timer=timer)
     st = timer.stages_ms()
     assert [int(t) for t in tout] == e.lens and all(torch.isfinite(w).all() for w in wavs)
+    stream_ms = None
+    if len(lens) > 1:           # the same batches back to back, software-pipelined (acoustic model of i+1 under vocoder of i)
+        gen = e.steady_state()
+        for i in range(warmup):
+            next(gen)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            next(gen)
+        torch.cuda.synchronize(dev)
+        stream_ms = (time.perf_counter() - t0) / steps * 1e3
+        gen.close()
+        log("end-to-end %s, back-to-back batches overlapped: %.2f ms/step" % (name, stream_ms))
     ms = el / steps * 1e3
     log("end-to-end %s: %d samples in %.2f ms/step = %.0fx real time" % (name, e.samples, ms, e.samples / (ms * 1e-3) / SR))
     return {"workload": e.describe(), "timing": "host clock around %d steps between device synchronisations, after %d warm-ups; "
             "stage_ms: hipEvents on the launch stream, one further step" % (steps, warmup),
             "steps": steps, "warmup": warmup, "ms_per_step": ms, "ms": ms, "samples": e.samples, "samples_per_s": e.samples / (ms * 1e-3),
             "realtime_factor": e.samples / (ms * 1e-3) / SR, "frames": sum(e.lens), "stage_ms_total": st["total"],
+            **({} if stream_ms is None else {"steady_state_overlapped": {
+                "what": "the same batch back to back through facppg.pipeline.synthesize_stream: step i+1's PPG upload + Tacotron2 on a second "
+                        "HIP stream under step i's WaveGlow + denoiser; host clock around %d steps after %d" % (steps, warmup),
+                "ms_per_step": stream_ms, "samples_per_s": e.samples / (stream_ms * 1e-3), "realtime_factor": e.samples / (stream_ms * 1e-3) / SR}}),
             "stage_ms": {k: v for k, v in st.items() if k != "total"},
             "stage_roofline": stage_rooflines(st, sum(e.lens), sum(e.lens), len(e.lens), HOP)}
 
@@ -587,6 +625,10 @@ class E2EWorkload(object):
         lens = [200] if args.e2e_batch == 1 else config3_lengths(args.e2e_batch, 7 + rank)
         self.e = EndToEnd(dev, lens, seed0=1000 * rank)
         self.world, self.dev = world, dev
+        # back-to-back batches, software-pipelined (facppg.pipeline.synthesize_stream): the acoustic model of step i+1 runs
+        # under the vocoder of step i.  The batch-1 case is the metric's latency figure: one utterance at a time, no overlap.
+        self.overlap = bool(args.e2e_overlap) and len(lens) > 1
+        self.gen = self.e.steady_state() if self.overlap else None
         # every rank has the same number of utterances but its own lengths: count what was really synthesised
         n = torch.tensor([float(self.e.samples)], dtype=torch.float64)
         if dist is not None:
@@ -595,13 +637,16 @@ class E2EWorkload(object):
         self.samples = int(n.item())
 
     def step(self, i):
-        self.out = self.e.step(i)
+        self.out = next(self.gen) if self.overlap else self.e.step(i)
 
     def start_timed(self):
         pass
 
     def finish(self, out, elapsed, steps):
         from facppg import pipeline
+        out["config_overlap"] = ("steady state of back-to-back batches: step i+1's PPG upload + Tacotron2 run on a second HIP stream under "
+                                 "step i's WaveGlow + denoiser; every step's acoustic model and vocoder are inside the timed region "
+                                 "(stage_ms below: one further, un-overlapped step)") if self.overlap else "none: one batch at a time"
         timer = pipeline.StageTimer()
         self.e.step(10 ** 6, timer=timer)
         st = timer.stages_ms()
@@ -635,11 +680,7 @@ class CorpusWorkload(object):
                      for i, n in enumerate(self.lengths)]
         if synthesizer is None:
             e = EndToEnd(dev, [max(self.lengths)], n_symbols=nsym)
-            from facppg import pipeline
-
-            def synthesizer(ppgs, **kw):
-                with contextlib.redirect_stdout(sys.stderr):
-                    return pipeline.synthesize(ppgs, e.tacotron, e.waveglow, e.denoiser, **kw)
+            synthesizer = e
         self.synthesizer = synthesizer
         self.gathered = None
 
@@ -745,6 +786,9 @@ def main():
     ap.add_argument("--utterances", type=int, default=1024, help="corpus workload: utterances in the corpus")
     ap.add_argument("--corpus-batch", type=int, default=64, help="corpus workload: utterances per synthesis batch")
     ap.add_argument("--e2e-batch", type=int, default=16, help="e2e workload: utterances per rank (1 = the metric's batch-1 case)")
+    ap.add_argument("--e2e-overlap", type=int, default=1,
+                    help="e2e workload, batch > 1: 1 = back-to-back steps software-pipelined (Tacotron2 of step i+1 under WaveGlow of step i), "
+                         "0 = strictly one batch after the other")
     ap.add_argument("--train-batch", type=int, default=3, help="train workload: per-GPU batch (config.json: 3)")
     ap.add_argument("--grad-buckets", type=int, default=3)
     ap.add_argument("--grad-dtype", choices=("fp32", "bf16"), default="fp32")

@@ -190,6 +190,10 @@ class Tacotron2(nn.Module):
         self._release()
         return super(Tacotron2, self).train(mode)
 
+    # CUs the decoder may occupy (facppg_taco_set_decoder_workgroups); 0 = the whole device.  facppg.pipeline.synthesize_stream
+    # sets it while the decoder runs under the previous batch's vocoder.
+    decoder_workgroups = 0
+
     def _handle(self, dev):
         h = self.__dict__.get("_facppg_handle")
         if h is not None and h[1] == dev and h[2] == self._fingerprint():
@@ -308,6 +312,7 @@ class Tacotron2(nn.Module):
         gate = torch.zeros(B, steps, device=dev)
         align = torch.zeros(B, steps, Tin, device=dev)
         out_len = torch.zeros(B, dtype=torch.int32, device=dev)
+        _lib.check(L.facppg_taco_set_decoder_workgroups(h, int(self.decoder_workgroups)))
         with torch.cuda.device(dev):
             _lib.check(L.facppg_taco_encode(h, _lib.ptr(x), _lib.ptr(lt), _lib.ptr(enc_m), seed, B, Tin, _lib.ptr(memory),
                                             _lib.ptr(pm), _lib.ptr(ws), ws.numel(), st))

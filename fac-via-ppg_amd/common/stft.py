@@ -103,10 +103,14 @@ class STFT(torch.nn.Module):
     def _lengths(lengths, B, N, dev):
         if lengths is None:
             return None
-        lt = torch.as_tensor(lengths).to(device=dev, dtype=torch.int32).contiguous()
-        if lt.numel() != B or int(lt.max()) > N:
+        if torch.is_tensor(lengths):
+            lt = lengths.to(device=dev, dtype=torch.int32).contiguous()
+            if lt.numel() != B or int(lt.max()) > N:
+                raise _lib.FacppgError("lengths must be B sample counts <= N")
+            return lt
+        if len(lengths) != B or max(int(n) for n in lengths) > N:       # host list: checked here, uploaded without a host stall
             raise _lib.FacppgError("lengths must be B sample counts <= N")
-        return lt
+        return _lib.upload([int(n) for n in lengths], torch.int32, dev)
 
     # ------------------------------------------------------------ reference API
     def transform(self, input_data, lengths=None):

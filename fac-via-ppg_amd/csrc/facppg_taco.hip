@@ -33,6 +33,7 @@ struct facppg_taco {
   facppg_taco_config c;
   int device;
   int coop_limit;   // workgroups the cooperative (co-resident) kernels may use: from the occupancy calculator, see facppg_taco_create
+  int decoder_wg_limit;   // facppg_taco_set_decoder_workgroups: a tighter bound for the decoder alone (0 = none)
   char* arena;
   // encoder
   float4 *pre0, *pre1, *conv[8], *wih;
@@ -1587,15 +1588,18 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
   FACPPG_REQUIRE(smem <= 160 * 1024 - 1024, FACPPG_EUNSUPPORTED, "decoder state (%zu bytes) exceeds LDS", smem);
   // latency mode (few utterances): NWG cooperating workgroups per utterance; throughput mode: one each
   // slice width: the narrowest (most workgroups per utterance) that keeps B * NWG co-resident (coop_limit)
+  // the decoder holds a CU's whole LDS per workgroup: a caller that runs it UNDER another stream's kernels (the vocoder of
+  // the previous batch, facppg.pipeline.synthesize_stream) bounds the CUs it takes away from them
+  const int wg_limit = h->decoder_wg_limit > 0 && h->decoder_wg_limit < h->coop_limit ? h->decoder_wg_limit : h->coop_limit;
   const char* mode = getenv("FACPPG_DECODER_MODE");
   int variant = -1;
   const char* force_u = getenv("FACPPG_DECODER_COOP_U");   // tests / tuning: a specific slice width
   for (int v = 0; v < 5 && variant < 0; ++v)
-    if ((long)B * h->coop_nwg[v] <= h->coop_limit && (!force_u || atoi(force_u) == h->coop_U[v])) variant = v;
+    if ((long)B * h->coop_nwg[v] <= wg_limit && (!force_u || atoi(force_u) == h->coop_U[v])) variant = v;
   // beyond that the widest slices run the batch in chunks of co-resident utterances, one cooperative launch
   // after the other (0.31 ms per utterance at 200 frames; the one-workgroup kernel needs 0.45)
   int chunk = B;
-  if (variant < 0 && !force_u && h->coop_limit / h->coop_nwg[4] >= 1) { variant = 4; chunk = h->coop_limit / h->coop_nwg[4]; }
+  if (variant < 0 && !force_u && wg_limit / h->coop_nwg[4] >= 1) { variant = 4; chunk = wg_limit / h->coop_nwg[4]; }
   bool coop = variant >= 0;
   if (mode && !strcmp(mode, "single")) coop = false;
   if (mode && !strcmp(mode, "coop")) FACPPG_REQUIRE(coop, FACPPG_EUNSUPPORTED, "coop decoder needs B <= 120");
@@ -1611,7 +1615,7 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
   const size_t ustride = (size_t)(a.P + a.E + a.A) + (a.A + a.E + a.D) + (a.D + a.E) + round_up(a.NF, 4) + round_up(a.P, 4);
   int NU = 0;
   for (int nu = 1; nu <= SNU && nu <= max_nu && !NU; ++nu)
-    if ((long)((B + nu - 1) / nu) * (h->split_nwk + nu) <= h->coop_limit && (nu * ustride + 1024) * 4 <= 150 * 1024) NU = nu;
+    if ((long)((B + nu - 1) / nu) * (h->split_nwk + nu) <= wg_limit && (nu * ustride + 1024) * 4 <= 150 * 1024) NU = nu;
   const bool split = coop && !no_split && NU > 0 && a.P + a.E + a.A <= SKP * SKR_LSTM &&
                      a.A + a.E + a.D <= SKP * SKR_LSTM && a.D + a.E <= SKP * SKR_PROJ && a.NF <= SKP * SKR_P1 &&
                      a.P <= SKP * SKR_P2 && a.NF + 1 <= h->split_nwk * SSC && a.P <= h->split_nwk * SSC &&
@@ -1645,7 +1649,7 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
       int cv = variant;   // the last chunk may be small enough for narrower slices
       if (!force_u)
         for (int v = 0; v < variant; ++v)
-          if ((long)nb * h->coop_nwg[v] <= h->coop_limit) { cv = v; break; }
+          if ((long)nb * h->coop_nwg[v] <= wg_limit) { cv = v; break; }
       a.b0 = b0; a.att_coop = h->att_coop[cv]; a.dec_coop = h->dec_coop[cv]; a.U = h->coop_U[cv];
       void* args[] = {(void*)&a};
       FACPPG_HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(h->coop_nwg[cv], nb), dim3(NTC), args, smem, s));
@@ -1703,6 +1707,12 @@ extern "C" size_t facppg_taco_postnet_workspace_bytes(const facppg_taco* h, int 
   if (!h || B <= 0 || T <= 0) return 0;
   const size_t sk = (size_t)16 * B * h->c.postnet_embedding_dim * T * 4;   // split-K partial sums
   return (size_t)2 * B * h->c.postnet_embedding_dim * T * 4 + sk;
+}
+
+extern "C" int facppg_taco_set_decoder_workgroups(facppg_taco* h, int max_workgroups) {
+  FACPPG_REQUIRE(h && max_workgroups >= 0, FACPPG_EINVAL, "NULL handle or negative limit");
+  h->decoder_wg_limit = max_workgroups;
+  return FACPPG_OK;
 }
 
 extern "C" size_t facppg_taco_decode_workspace_bytes(const facppg_taco* h, int B, int max_steps) {

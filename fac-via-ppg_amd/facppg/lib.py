@@ -109,6 +109,7 @@ def _declare(lib):
         "facppg_taco_destroy": (None, [vp]),
         "facppg_taco_workspace_bytes": (sz, [vp, c.c_int, c.c_int]),
         "facppg_taco_decode_workspace_bytes": (sz, [vp, c.c_int, c.c_int]),
+        "facppg_taco_set_decoder_workgroups": (c.c_int, [vp, c.c_int]),
         "facppg_taco_postnet_workspace_bytes": (sz, [vp, c.c_int, c.c_int]),
         "facppg_taco_encode": (c.c_int, [vp, vp, vp, vp, u64, c.c_int, c.c_int, vp, vp, vp, sz, vp]),
         "facppg_taco_decode": (c.c_int, [vp, vp, vp, vp, vp, vp, u64, c.c_int, c.c_int, c.c_int, vp, vp, vp, vp, vp, sz, vp]),
@@ -172,6 +173,13 @@ def require_cuda(t, what):
 
 def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def upload(values, dtype, device):
+    """A small host list -> device tensor WITHOUT stalling the host behind the work already queued on the stream: a copy
+    from pageable memory waits for the stream to reach it (with a WaveGlow.infer in front, > 100 ms during which nothing
+    else gets enqueued); from a pinned staging tensor it is just another queued command."""
+    return torch.tensor(values, dtype=dtype).pin_memory().to(device, non_blocking=True)
 
 
 def current_stream(device):

@@ -32,6 +32,10 @@ class Synthesizer(object):
     def __call__(self, ppgs, sigma=0.6, strength=0.005, **kw):
         return synthesize(ppgs, self.tacotron, self.waveglow, self.denoiser, sigma=sigma, strength=strength, **kw)
 
+    def stream(self, jobs, sigma=0.6, strength=0.005, **kw):
+        """synthesize_stream over this synthesizer's models: batch i+1's acoustic model under batch i's vocoder."""
+        return synthesize_stream(jobs, self.tacotron, self.waveglow, self.denoiser, sigma=sigma, strength=strength, **kw)
+
     @staticmethod
     def has_utterance(utterance_path):
         """The reference checks the teacher wav itself (generate_synthesis.py:89); here a precomputed PPG next to
@@ -88,6 +92,35 @@ def pad_ppgs(ppgs, device=None):
     return x, lens
 
 
+def _acoustic(ppgs, tacotron, seed, dropout_masks, utterance_seeds, step_limits, timer=None):
+    """PPG upload + Tacotron2.inference on the current stream -> (mel_post [B, 80, Tout], [Tout_i]).  Blocks the host once,
+    for the decoder's output lengths."""
+    dev = next(tacotron.parameters()).device
+    x, lens = pad_ppgs(ppgs, device=dev)
+    if timer is not None:
+        timer.mark("ppg_upload")
+    _, mel_post, _, _ = tacotron.inference(x, lengths=lens if len(lens) > 1 else None, dropout_masks=dropout_masks,
+                                           seed=seed, utterance_seeds=utterance_seeds, step_limits=step_limits,
+                                           **({"timer": timer} if timer is not None else {}))
+    return mel_post.contiguous(), [int(v) for v in tacotron.last_output_lengths]
+
+
+def _vocode(mel_post, tout, waveglow, denoiser, sigma, strength, seed, z, utterance_seeds, timer=None):
+    """WaveGlow.infer + Denoiser on the current stream -> audio [B, Tout_max * hop] on the device; no host waits beyond the
+    small uploads (lengths, seeds)."""
+    hop = waveglow.upsample.stride[0]
+    multi = len(tout) > 1
+    wg_seeds = None if utterance_seeds is None else [int(v) + 1 for v in utterance_seeds]
+    audio = waveglow.infer(mel_post, sigma=sigma, z=z, lengths=tout if multi else None, seed=seed, utterance_seeds=wg_seeds)
+    if timer is not None:
+        timer.mark("waveglow")
+    if denoiser is not None:
+        audio = denoiser(audio, strength=strength, lengths=[t * hop for t in tout] if multi else None)[:, 0]
+        if timer is not None:
+            timer.mark("denoiser")
+    return audio
+
+
 def synthesize(ppgs, tacotron, waveglow, denoiser=None, sigma=0.6, strength=0.005, seed=None, dropout_masks=None, z=None,
                return_device=False, utterance_seeds=None, step_limits=None, timer=None):
     """Returns (list of float32 waveforms [N_i], list of mel lengths).  Models must be on the GPU.
@@ -95,29 +128,83 @@ def synthesize(ppgs, tacotron, waveglow, denoiser=None, sigma=0.6, strength=0.00
     utterance_seeds: one integer per utterance -- its dropout and noise streams then depend on that seed alone,
     so the result for an utterance is the same whatever batch, batch size or GPU it is synthesised in.
     step_limits: per-utterance max_decoder_steps (e.g. its PPG length)."""
-    dev = next(tacotron.parameters()).device
     if timer is not None:
         timer.__init__()
-    x, lens = pad_ppgs(ppgs, device=dev)
     hop = waveglow.upsample.stride[0]
-    if timer is not None:
-        timer.mark("ppg_upload")
     with torch.no_grad():
-        _, mel_post, _, _ = tacotron.inference(x, lengths=lens if len(lens) > 1 else None, dropout_masks=dropout_masks,
-                                               seed=seed, utterance_seeds=utterance_seeds, step_limits=step_limits,
-                                               **({"timer": timer} if timer is not None else {}))
-        tout = [int(v) for v in tacotron.last_output_lengths]
-        multi = len(tout) > 1
-        wg_seeds = None if utterance_seeds is None else [int(v) + 1 for v in utterance_seeds]
-        audio = waveglow.infer(mel_post.contiguous(), sigma=sigma, z=z, lengths=tout if multi else None, seed=seed,
-                               utterance_seeds=wg_seeds)
-        if timer is not None:
-            timer.mark("waveglow")
-        if denoiser is not None:
-            audio = denoiser(audio, strength=strength, lengths=[t * hop for t in tout] if multi else None)[:, 0]
-            if timer is not None:
-                timer.mark("denoiser")
+        mel_post, tout = _acoustic(ppgs, tacotron, seed, dropout_masks, utterance_seeds, step_limits, timer)
+        audio = _vocode(mel_post, tout, waveglow, denoiser, sigma, strength, seed, z, utterance_seeds, timer)
     if return_device:
         return [audio[b, :tout[b] * hop] for b in range(len(tout))], tout
     host = audio.cpu().numpy()
     return [host[b, :tout[b] * hop].copy() for b in range(len(tout))], tout
+
+
+_ACOUSTIC_STREAMS = {}
+
+
+def _acoustic_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _ACOUSTIC_STREAMS:
+        _ACOUSTIC_STREAMS[key] = torch.cuda.Stream(device=torch.device("cuda", key))
+    return _ACOUSTIC_STREAMS[key]
+
+
+def synthesize_stream(jobs, tacotron, waveglow, denoiser=None, sigma=0.6, strength=0.005, return_device=True, overlap=True,
+                      acoustic_workgroups=32):
+    """A sequence of batches, software-pipelined: generator of (waveforms, mel lengths), one per job, in order.
+
+    jobs: iterable of dicts with ``ppgs`` and optionally ``seed``, ``utterance_seeds``, ``step_limits`` (as synthesize()).
+    The acoustic model of batch i+1 (PPG upload, encoder, the latency-bound autoregressive decoder, postnet -- a few
+    percent of the chip for ~25 ms) runs on its own HIP stream UNDER the vocoder of batch i (MFMA-bound, ~120 ms for 16
+    utterances) instead of in front of it.  The host enqueues vocoder i first, then walks through acoustic i+1, whose one
+    blocking read (the decoder's output lengths) it would otherwise spend idle.  Every utterance's samples are those of
+    synthesize() on the same job: the stages, their inputs and their random streams are the same, only their placement in
+    time differs (tests/test_gpu_e2e.py).  overlap=False runs the same jobs back to back on the caller's stream.
+
+    acoustic_workgroups: while overlapped, the decoder is held to this many CUs (Tacotron2.decoder_workgroups, unless the model
+    already carries a bound of its own).  A decoder workgroup owns its CU's LDS, so the vocoder loses every CU the decoder
+    sits on; on the whole chip (240 workgroups for 16 utterances) the two stages merely take turns (146.7 -> 140.2 ms per
+    batch), on 32 CUs the decoder takes 60 instead of 18 ms -- still hidden -- and the vocoder keeps 7/8 of the chip
+    (128.3 ms; profiles/r03_experiments.txt).  The slice width that goes with the bound cuts the decoder's LSTM sums
+    differently: samples then equal those of synthesize() with the same Tacotron2.decoder_workgroups bit for bit, and those
+    of the unbounded decoder to rounding."""
+    dev = next(tacotron.parameters()).device
+    hop = waveglow.upsample.stride[0]
+    main = torch.cuda.current_stream(dev)
+    side = _acoustic_stream(dev) if overlap else main
+
+    def acoustic(job):
+        with torch.no_grad(), torch.cuda.stream(side):
+            # (the inputs are host arrays: nothing on the caller's stream to wait for -- in particular not the previous vocoder)
+            bound = tacotron.decoder_workgroups
+            if overlap and not bound and acoustic_workgroups:
+                tacotron.decoder_workgroups = int(acoustic_workgroups)
+            try:
+                mel_post, tout = _acoustic(job["ppgs"], tacotron, job.get("seed"), None, job.get("utterance_seeds"), job.get("step_limits"))
+            finally:
+                tacotron.decoder_workgroups = bound
+            done = torch.cuda.Event()
+            done.record(side)
+        mel_post.record_stream(main)
+        return job, mel_post, tout, done
+
+    def finish(audio, tout):
+        if return_device:
+            return [audio[b, :tout[b] * hop] for b in range(len(tout))], tout
+        host = audio.cpu().numpy()
+        return [host[b, :tout[b] * hop].copy() for b in range(len(tout))], tout
+
+    it = iter(jobs)
+    first = next(it, None)
+    if first is None:
+        return
+    ready = acoustic(first)
+    while ready is not None:
+        job, mel_post, tout, done = ready
+        main.wait_event(done)
+        with torch.no_grad():
+            audio = _vocode(mel_post, tout, waveglow, denoiser, sigma, strength, job.get("seed"), None, job.get("utterance_seeds"))
+        nxt = next(it, None)
+        ready = acoustic(nxt) if nxt is not None else None       # enqueued behind nothing: runs while the vocoder above does
+        yield finish(audio, tout)

@@ -42,6 +42,9 @@ def parse(argv=None):
     ap.add_argument('--limit_steps_to_input', action='store_true',
                     help='stop each utterance after as many mel frames as it has PPG frames at the latest '
                          '(per-utterance max_decoder_steps; both run at a 10 ms frame shift)')
+    ap.add_argument('--no_overlap', action='store_true',
+                    help='run the batches strictly one after the other instead of starting the acoustic model of the next batch '
+                         'under the vocoder of the current one (same waveforms, slower)')
     ap.add_argument('--dist_backend', default='nccl', help='nccl = RCCL over xGMI (default); gloo for CPU tests')
     ap.add_argument('--hparams', default='',
                     help='comma separated "name=value" overrides of create_hparams_stage (train_ppg2mel.py:291-292), '
@@ -66,12 +69,16 @@ def parse_hparams(text):
 def synthesize_shard(synthesizer, ppgs, lengths, rank, world, args):
     """This rank's utterances, longest first, in batches of similar length.  Returns (waveforms, global ids)."""
     mine = shard.partition(lengths, world)[rank]
+    batches = list(shard.batches(mine, lengths, args.batch_size))
+    jobs = ({"ppgs": [np.asarray(ppgs[i]) for i in batch], "utterance_seeds": [args.seed + 2 * i for i in batch],
+             "step_limits": [lengths[i] for i in batch] if args.limit_steps_to_input else None} for batch in batches)
     wavs, ids = [], []
-    for batch in shard.batches(mine, lengths, args.batch_size):
-        out, _ = synthesizer([np.asarray(ppgs[i]) for i in batch], sigma=args.sigma, strength=args.denoiser_strength,
-                             utterance_seeds=[args.seed + 2 * i for i in batch],
-                             step_limits=[lengths[i] for i in batch] if args.limit_steps_to_input else None,
-                             return_device=True)
+    if hasattr(synthesizer, "stream"):      # software-pipelined: batch i+1's acoustic model runs under batch i's vocoder
+        results = synthesizer.stream(jobs, sigma=args.sigma, strength=args.denoiser_strength, return_device=True,
+                                     overlap=not getattr(args, "no_overlap", False))
+    else:
+        results = (synthesizer(return_device=True, sigma=args.sigma, strength=args.denoiser_strength, **job) for job in jobs)
+    for batch, (out, _) in zip(batches, results):
         wavs += out
         ids += batch
     return wavs, ids

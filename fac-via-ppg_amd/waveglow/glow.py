@@ -866,7 +866,7 @@ class WaveGlow(torch.nn.Module):
         L = _lib.load()
         h = self._handle(dev)
         B, hop = len(utterance_seeds), self.upsample.stride[0]
-        sd = torch.tensor([int(v) & 0x7FFFFFFFFFFFFFFF for v in utterance_seeds], dtype=torch.int64, device=dev)
+        sd = _lib.upload([int(v) & 0x7FFFFFFFFFFFFFFF for v in utterance_seeds], torch.int64, dev)
         zt = torch.empty(B * self.n_group * (T * hop // self.n_group), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(L.facppg_wg_draw_noise(h, _lib.ptr(sd), B, T, _lib.ptr(zt), _lib.current_stream(dev)))
@@ -913,7 +913,7 @@ class WaveGlow(torch.nn.Module):
             for c in chans:
                 segs.append(zt[off:off + B * c * Lfull].view(B, c, Lfull))
                 off += B * c * Lfull
-        sel = torch.tensor(order[0::2] + order[1::2] + [int(lengths[i]) for i in order[0::2] + order[1::2]], device=dev)
+        sel = _lib.upload(order[0::2] + order[1::2] + [int(lengths[i]) for i in order[0::2] + order[1::2]], torch.int64, dev)
         parts, n0 = [], len(order[0::2])
         for gi, idx in enumerate((order[0::2], order[1::2])):
             it = sel[:n0] if gi == 0 else sel[n0:B]
@@ -994,9 +994,12 @@ class WaveGlow(torch.nn.Module):
             zt = self.draw_noise(utterance_seeds, T, dev)
         lt = None
         if lengths is not None:
-            lt = torch.as_tensor(lengths).to(device=dev, dtype=torch.int32).contiguous()
-            if not host_lengths and (lt.numel() != B or int(lt.max()) > T or int(lt.min()) < 1):
-                raise _lib.FacppgError("lengths must be B values in [1, T]")
+            if host_lengths:
+                lt = _lib.upload([int(n) for n in lengths], torch.int32, dev)
+            else:
+                lt = lengths.to(device=dev, dtype=torch.int32).contiguous()
+                if lt.numel() != B or int(lt.max()) > T or int(lt.min()) < 1:
+                    raise _lib.FacppgError("lengths must be B values in [1, T]")
         audio = torch.zeros(B, T * hop, dtype=torch.float32, device=dev) if lt is not None else \
             torch.empty(B, T * hop, dtype=torch.float32, device=dev)
         self._infer_launch(spect, lt, zt, seed, sigma, audio, self._infer_workspace(B, T, dev, 0))

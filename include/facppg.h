@@ -328,6 +328,13 @@ void facppg_taco_destroy(facppg_taco* h);
 size_t facppg_taco_workspace_bytes(const facppg_taco* h, int B, int Tin);
 size_t facppg_taco_decode_workspace_bytes(const facppg_taco* h, int B, int max_steps);
 size_t facppg_taco_postnet_workspace_bytes(const facppg_taco* h, int B, int T);
+/* Bounds the workgroups (= CUs: a decoder workgroup holds a CU's whole LDS) later facppg_taco_decode calls on this handle may
+ * occupy; 0 = no bound beyond the device's.  No reference counterpart (the reference decodes one utterance at a time on
+ * the whole device, model.py:489-535): it exists for callers that run the latency-bound decoder of the NEXT batch on a second
+ * stream under the MFMA-bound vocoder of the current one (facppg.pipeline.synthesize_stream) and want it to take few CUs
+ * away from the vocoder.  A tighter bound selects wider weight slices per workgroup, which cuts the LSTM sums differently:
+ * results agree with the unbounded launch to rounding (1e-6 relative on the mel), not bit for bit. */
+int facppg_taco_set_decoder_workgroups(facppg_taco* h, int max_workgroups);
 
 /* Replaces Encoder.inference (model.py:237-249) and the memory_layer projection
  * (model.py:334).  ppg_dev [B][n_symbols][Tin]; lengths_dev NULL or [B] valid frame counts

@@ -160,6 +160,35 @@ def test_config3_batch16_ragged_end_to_end(checkpoints, monkeypatch):
         single, t1 = pipeline.synthesize([ppgs[b]], taco, wg, den, sigma=0.6, strength=0.005, utterance_seeds=[seeds[b]],
                                          step_limits=[lens[b]])
         assert t1 == [lens[b]] and np.array_equal(single[0], wavs[b]), b
+    # the same batch three times, then two smaller ones, through the software-pipelined stream (acoustic model of job i+1 on a
+    # second HIP stream under the vocoder of job i).  With the decoder left on the whole chip (acoustic_workgroups=0) every
+    # job's samples are those of its own synthesize() call ...
+    jobs = [{"ppgs": ppgs, "utterance_seeds": seeds, "step_limits": lens}] * 3 + \
+           [{"ppgs": ppgs[:5], "utterance_seeds": seeds[:5], "step_limits": lens[:5]}, {"ppgs": ppgs[9:10], "seed": 4, "step_limits": [lens[9]]}]
+    got = list(pipeline.synthesize_stream(jobs, taco, wg, den, sigma=0.6, strength=0.005, return_device=False, acoustic_workgroups=0))
+    assert len(got) == 5 and [t for _, t in got] == [lens] * 3 + [lens[:5], lens[9:10]]
+    for k in range(3):
+        assert all(np.array_equal(a, b_) for a, b_ in zip(got[k][0], wavs)), "streamed job %d differs" % k
+    assert all(np.array_equal(a, b_) for a, b_ in zip(got[3][0], wavs[:5]))
+    alone, _ = pipeline.synthesize(ppgs[9:10], taco, wg, den, sigma=0.6, strength=0.005, seed=4, step_limits=[lens[9]])
+    assert np.array_equal(got[4][0][0], alone[0])
+    serial = list(pipeline.synthesize_stream(jobs[2:4], taco, wg, den, sigma=0.6, strength=0.005, return_device=True, overlap=False))
+    assert all(torch.equal(a, torch.from_numpy(b_).cuda()) for a, b_ in zip(serial[1][0], wavs[:5]))
+    assert list(pipeline.synthesize_stream([], taco, wg, den)) == []
+    # ... and with the decoder held to 32 CUs (the default while overlapped: 2 workgroups per utterance instead of 15) they are
+    # those of synthesize() under the same bound, bit for bit, and those of the unbounded decoder to rounding
+    monkeypatch.delenv("FACPPG_DECODER_COOP_U")
+    bounded = list(pipeline.synthesize_stream(jobs[1:3], taco, wg, den, sigma=0.6, strength=0.005, return_device=False))
+    assert taco.decoder_workgroups == 0
+    taco.decoder_workgroups = 32
+    ref32, t32 = pipeline.synthesize(ppgs, taco, wg, den, sigma=0.6, strength=0.005, utterance_seeds=seeds, step_limits=lens)
+    taco.decoder_workgroups = 0
+    assert t32 == lens
+    for k in range(2):
+        assert all(np.array_equal(a, b_) for a, b_ in zip(bounded[k][0], ref32)), "bounded streamed job %d differs" % k
+    worst = max(rms(a - b_) for a, b_ in zip(ref32, wavs))
+    print("decoder on 32 CUs vs whole chip: worst wav rms difference %.2e" % worst)
+    assert worst <= 1e-3
     with torch.no_grad():
         bias = owg.infer(wsd, cfg, torch.zeros(1, 80, 88), 0.0, [torch.zeros(1, 4, 1760), torch.zeros(1, 2, 1760), torch.zeros(1, 2, 1760)])
     oden = dsp.DenoiserOracle(bias)
@@ -192,7 +221,7 @@ def test_config4_corpus_script_world1(tmp_path, monkeypatch):
     from script import synthesize_corpus
     from waveglow.glow import WaveGlow
     monkeypatch.setenv("FACPPG_DECODER_MODE", "coop")
-    monkeypatch.setenv("FACPPG_DECODER_COOP_U", "20")
+    monkeypatch.setenv("FACPPG_DECODER_COOP_U", "150")   # 2 workgroups per utterance: fits the 32-CU bound of the overlapped stream at B = 16 and runs at B = 1
     monkeypatch.setenv("FACPPG_BILSTM_MODE", "single")
     cfg = dict(synth.WAVEGLOW_CONFIG)
     wg = WaveGlow(**cfg)
@@ -211,7 +240,7 @@ def test_config4_corpus_script_world1(tmp_path, monkeypatch):
               "--ppg_list", str(tmp_path / "ppgs.txt"), "--seed", "77", "--limit_steps_to_input"]
     written = synthesize_corpus.main(common + ["--output_dir", str(tmp_path / "out16"), "--batch_size", "16"])
     assert written == ["utt%03d.wav" % i for i in range(64)]
-    synthesize_corpus.main(common + ["--output_dir", str(tmp_path / "out5"), "--batch_size", "5"])
+    synthesize_corpus.main(common + ["--output_dir", str(tmp_path / "out5"), "--batch_size", "5", "--no_overlap"])
     one = Synthesizer(str(tmp_path / "tacotron.pt"), str(tmp_path / "waveglow.pt"))
     for i, n in enumerate(lens):
         sr, a = wavfile.read(tmp_path / "out16" / ("utt%03d.wav" % i))
@@ -233,7 +262,7 @@ def test_config4_corpus_1024_utterances_monophone(tmp_path, monkeypatch):
     from script import synthesize_corpus
     from waveglow.glow import WaveGlow
     monkeypatch.setenv("FACPPG_DECODER_MODE", "coop")
-    monkeypatch.setenv("FACPPG_DECODER_COOP_U", "20")
+    monkeypatch.setenv("FACPPG_DECODER_COOP_U", "150")   # 2 workgroups per utterance: fits the 32-CU bound of the overlapped stream at B = 16 and runs at B = 1
     monkeypatch.setenv("FACPPG_BILSTM_MODE", "single")
     n_utt, n_sym = 1024, 40
     cfg = dict(synth.WAVEGLOW_CONFIG)
