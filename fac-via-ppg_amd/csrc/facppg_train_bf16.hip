@@ -500,7 +500,10 @@ int wgrad_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size
   FACPPG_REQUIRE(maxM % 128 == 0 && maxK % 128 == 0, FACPPG_EINVAL, "k_wgrad: M and K must be multiples of 128 (got %d, %d)", maxM, maxK);
   const int tiles = ((maxK + 127) / 128) * ((maxM + 127) / 128) * nprob;
   const int nall = wa.B * ((wa.L + 63) / 64);
-  int ns = (3 * 256 + tiles - 1) / tiles;       // aim at >= ~3 workgroups per CU
+  // about ONE workgroup per CU (two fit, 73 KB of LDS each): measured at batch 3 / 12, whole step, aiming at 64 / 128 / 256 / 384 /
+  // 512 / 768 / 1536 / 3072 workgroups: 11.48 / 11.23 / 11.09 / 11.18 / 11.31 / 11.53 / 11.99 / 12.93 ms and 24.42 / 23.43 / 22.46 /
+  // 22.55 / 22.66 / 23.06 / 23.12 / 24.26 ms -- every further split adds a 64 KB partial tile per workgroup and a longer reduction
+  int ns = (256 + tiles - 1) / tiles;
   ns = std::max(1, std::min(std::min(ns, WG_MAXSPLIT), nall));
   while (ns > 1 && (size_t)nprob * ns * maxM * maxK * 4 > part_bytes) --ns;
   wa.nsplit = ns; wa.part = part; wa.pstride = (size_t)maxM * maxK;

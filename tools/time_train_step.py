@@ -25,6 +25,6 @@ for B in [int(a) for a in sys.argv[1:]] or [3, 12]:
         st(mel, audio)
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
-    ts = sorted(ts[4:])
+    ts = sorted(ts[4:] or ts)
     out.append("B=%d %.2f ms" % (B, ts[len(ts) // 2] * 1e3))
 print("  ".join(out))
