@@ -191,6 +191,41 @@ __global__ __launch_bounds__(256) void k_affine_bwd(const float* __restrict__ x,
     }
 }
 
+
+// Sums of a handful of strided fp32 segments in ONE launch each stage (WaveGlowLoss, glow.py:43-59: sum(z*z), and the sum of
+// every flow's log_s, which lives in the upper half of that flow's WN output): segment e = `outer` runs of `inner` contiguous
+// floats, `outer_stride` apart; `square` sums v*v.  Stage 1: workgroup (slice, segment) adds its slice in double, threads in a
+// fixed stride pattern, lanes meet in LDS in a fixed tree; stage 2 adds the slices in index order -- bit-reproducible.
+constexpr int SUM_SLICES = 64;
+struct SumSeg { const float* p; long outer_stride; int outer, inner, square, pad; };
+struct SumArgs { SumSeg seg[FACPPG_MAX_SUM_SEGMENTS]; double* part; float* out; };
+__global__ __launch_bounds__(256) void k_seg_sum_part(SumArgs a) {
+  const SumSeg& sg = a.seg[blockIdx.y];
+  const long total = (long)sg.outer * sg.inner;
+  const long i0 = total * blockIdx.x / SUM_SLICES, i1 = total * (blockIdx.x + 1) / SUM_SLICES;
+  double v = 0.0;
+  for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+    const long o = i / sg.inner;
+    const float x = sg.p[o * sg.outer_stride + (i - o * sg.inner)];
+    v += sg.square ? (double)x * x : (double)x;
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.part[blockIdx.y * SUM_SLICES + blockIdx.x] = red[0];
+}
+__global__ void k_seg_sum_final(const double* __restrict__ part, float* __restrict__ out, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  double v = 0.0;
+  for (int s = 0; s < SUM_SLICES; ++s) v += part[e * SUM_SLICES + s];
+  out[e] = (float)v;
+}
+
 }  // namespace
 }  // namespace facppg
 
@@ -310,6 +345,24 @@ extern "C" int facppg_affine_backward(const float* x_dev, const float* wn_out_de
                                       int h, int L, void* stream) {
   FACPPG_REQUIRE(x_dev && wn_out_dev && dy_dev && dx_dev && dwn_out_dev && B > 0 && h > 0 && L > 0 && B <= 65535, FACPPG_EINVAL, "bad argument");
   k_affine_bwd<<<dim3((L + 1023) / 1024, B), 256, 0, (hipStream_t)stream>>>(x_dev, wn_out_dev, dy_dev, dx_dev, dwn_out_dev, h, L);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+extern "C" int facppg_segment_sums(const facppg_sum_segment* segs, int n, void* workspace_dev, size_t workspace_bytes, float* out_dev,
+                                   void* stream) {
+  FACPPG_REQUIRE(segs && out_dev && workspace_dev && n > 0 && n <= FACPPG_MAX_SUM_SEGMENTS, FACPPG_EINVAL, "bad argument (1..%d segments)",
+                 FACPPG_MAX_SUM_SEGMENTS);
+  FACPPG_REQUIRE(workspace_bytes >= (size_t)n * SUM_SLICES * sizeof(double), FACPPG_EINVAL, "workspace of %zu bytes, need %zu", workspace_bytes,
+                 (size_t)n * SUM_SLICES * sizeof(double));
+  SumArgs a;
+  for (int e = 0; e < n; ++e) {
+    FACPPG_REQUIRE(segs[e].data_dev && segs[e].outer > 0 && segs[e].inner > 0, FACPPG_EINVAL, "segment %d is empty", e);
+    a.seg[e] = SumSeg{segs[e].data_dev, segs[e].outer_stride, segs[e].outer, segs[e].inner, segs[e].square, 0};
+  }
+  a.part = (double*)workspace_dev; a.out = out_dev;
+  k_seg_sum_part<<<dim3(SUM_SLICES, n), 256, 0, (hipStream_t)stream>>>(a);
+  k_seg_sum_final<<<1, 64, 0, (hipStream_t)stream>>>(a.part, out_dev, n);
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
 }

@@ -57,6 +57,12 @@ class TdnnLayer(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("out_dim", "in_dim", "taps", "dil", "first", "relu")] + [("renorm_target_rms", ctypes.c_float)]
 
 
+class SumSegment(ctypes.Structure):
+    """facppg_sum_segment (include/facppg.h)."""
+    _fields_ = [("data_dev", ctypes.c_void_p), ("outer_stride", ctypes.c_long), ("outer", ctypes.c_int), ("inner", ctypes.c_int),
+                ("square", ctypes.c_int)]
+
+
 def _declare(lib):
     c = ctypes
     vp, i32, u64, f32, sz = c.c_void_p, c.c_int32, c.c_uint64, c.c_float, c.c_size_t
@@ -93,6 +99,7 @@ def _declare(lib):
         "facppg_weight_norm_forward": (c.c_int, [vp, c.c_int, c.c_long, vp]),
         "facppg_weight_norm_backward": (c.c_int, [vp, vp, c.c_int, c.c_long, vp]),
         "facppg_affine_forward": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, c.c_int, vp]),
+        "facppg_segment_sums": (c.c_int, [c.POINTER(SumSegment), c.c_int, vp, sz, vp, vp]),
         "facppg_affine_backward": (c.c_int, [vp, vp, vp, vp, vp, c.c_int, c.c_int, c.c_int, vp]),
         "facppg_wg_set_profiling": (c.c_int, [vp, c.c_int]),
         "facppg_wg_last_layer_ms": (c.c_int, [vp, c.POINTER(f32), c.POINTER(c.c_int)]),

@@ -29,6 +29,53 @@ def fused_add_tanh_sigmoid_multiply(input_a, input_b, n_channels):
     return torch.tanh(in_act[:, :n, :]) * torch.sigmoid(in_act[:, n:, :])
 
 
+def _sum_segment(t):
+    """(outer, outer_stride, inner) of a float32 CUDA tensor that is `outer` runs of `inner` contiguous elements, or None."""
+    if t.dim() == 0 or t.is_contiguous():
+        return 1, 0, t.numel()
+    if t.dim() == 3 and t.stride(2) == 1 and t.stride(1) == t.size(2):       # a channel slice of a contiguous [B, C, L] tensor
+        return t.size(0), t.stride(0), t.size(1) * t.size(2)
+    return None
+
+
+class _GlowLossFunction(torch.autograd.Function):
+    """WaveGlowLoss.forward (glow.py:43-59) as one autograd node: the 13 reductions of the reference (sum(z*z), one sum(log_s)
+    per flow) are ONE facppg_segment_sums call and the scalar arithmetic around them a handful of 13-element ops, instead of
+    ~50 reduction / add / mul launches forward and as many backward (slice backward + accumulate per flow).  Same value:
+    (sum(z*z) / (2 sigma^2) - sum_k sum(log_s_k) - sum_k log_det_W_k) / numel(z); gradients: z / (sigma^2 numel) for z and the
+    constant -1 / numel for every log_s element and every log_det_W (returned as stride-0 expansions of one scalar)."""
+
+    @staticmethod
+    def forward(ctx, sigma, n_log_s, z, *rest):
+        L = _lib.load()
+        dev = z.device
+        log_s, log_det = rest[:n_log_s], rest[n_log_s:]
+        tensors = [z] + list(log_s)
+        segs = (_lib.SumSegment * len(tensors))()
+        for i, t in enumerate(tensors):
+            outer, stride, inner = _sum_segment(t)
+            segs[i] = _lib.SumSegment(t.data_ptr(), stride, outer, inner, 1 if i == 0 else 0)
+        ws = torch.empty(len(tensors) * 64, dtype=torch.float64, device=dev)
+        sums = torch.empty(len(tensors), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.facppg_segment_sums(segs, len(tensors), _lib.ptr(ws), ws.numel() * 8, _lib.ptr(sums), _lib.current_stream(dev)))
+        n = z.numel()
+        total = sums[0] * (0.5 / (sigma * sigma)) - sums[1:].sum()
+        if log_det:
+            total = total - torch.stack([t.reshape(()) for t in log_det]).sum()
+        ctx.save_for_backward(z)
+        ctx.sigma, ctx.n = float(sigma), n
+        ctx.shapes = [t.shape for t in rest]
+        return total / n
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        c = g / ctx.n
+        neg = -c
+        return (None, None, z * (c * (1.0 / (ctx.sigma * ctx.sigma)))) + tuple(neg.expand(sh) for sh in ctx.shapes)
+
+
 class WaveGlowLoss(torch.nn.Module):
     """glow.py:43-59 (training loss; a scalar reduction of the flow outputs)."""
 
@@ -38,6 +85,10 @@ class WaveGlowLoss(torch.nn.Module):
 
     def forward(self, model_output):
         z, log_s_list, log_det_W_list = model_output
+        fusable = [z] + list(log_s_list) + list(log_det_W_list)
+        if (z.is_cuda and len(log_s_list) < 16 and all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 for t in fusable)
+                and all(_sum_segment(t) is not None for t in [z] + list(log_s_list)) and all(t.numel() == 1 for t in log_det_W_list)):
+            return _GlowLossFunction.apply(self.sigma, len(log_s_list), z, *log_s_list, *log_det_W_list)
         log_s_total = sum(torch.sum(ls) for ls in log_s_list)
         log_det_total = sum(log_det_W_list)
         loss = torch.sum(z * z) / (2 * self.sigma * self.sigma) - log_s_total - log_det_total
@@ -446,7 +497,10 @@ class _WeightNormAllFunction(torch.autograd.Function):
 
 class _AffineFunction(torch.autograd.Function):
     """The affine coupling of one flow in the training direction (glow.py:240-245) as one HIP kernel each way:
-    (x = [x0 | x1], wn_out = [b | log_s]) -> cat(x0, exp(log_s) * x1 + b)."""
+    (x = [x0 | x1], wn_out = [b | log_s]) -> cat(x0, exp(log_s) * x1 + b), log_s.
+    log_s (the upper half of wn_out, which the loss sums) is an OUTPUT of this node rather than a slice the caller takes of
+    wn_out: its gradient arrives here and is added into the kernel's d(wn_out) in place -- instead of a slice backward (a zero
+    fill + a copy of the full tensor) and the engine's add of wn_out's two gradients, per flow."""
 
     @staticmethod
     def forward(ctx, x, wn_out):
@@ -457,10 +511,10 @@ class _AffineFunction(torch.autograd.Function):
         with torch.cuda.device(x.device):
             _lib.check(L.facppg_affine_forward(_lib.ptr(x), _lib.ptr(wn_out), _lib.ptr(y), B, c // 2, Lg, _lib.current_stream(x.device)))
         ctx.save_for_backward(x, wn_out)
-        return y
+        return y, wn_out[:, c // 2:, :]
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dlog_s):
         L = _lib.load()
         x, wn_out = ctx.saved_tensors
         dy = dy.float().contiguous()
@@ -469,6 +523,8 @@ class _AffineFunction(torch.autograd.Function):
         with torch.cuda.device(x.device):
             _lib.check(L.facppg_affine_backward(_lib.ptr(x), _lib.ptr(wn_out), _lib.ptr(dy), _lib.ptr(dx), _lib.ptr(dwn), B, c // 2, Lg,
                                                 _lib.current_stream(x.device)))
+        if dlog_s is not None:
+            dwn[:, c // 2:, :] += dlog_s
         return dx, dwn
 
 
@@ -812,8 +868,8 @@ class WaveGlow(torch.nn.Module):
                 output = _WNFunctionBf16.apply(audio_0.contiguous(), link, shared, spect_pm, *flow_weights[k])
             else:
                 output = _WNFunction.apply(audio_0.contiguous(), spect_pad, *flow_weights[k])
-            log_s_list.append(output[:, n_half:, :])
-            audio = _AffineFunction.apply(audio, output)          # cat(audio_0, exp(log_s) * audio_1 + b), HIP fwd + bwd
+            audio, log_s = _AffineFunction.apply(audio, output)   # cat(audio_0, exp(log_s) * audio_1 + b) and log_s, HIP fwd + bwd
+            log_s_list.append(log_s)
         output_audio.append(audio)
         return torch.cat(output_audio, 1), log_s_list, log_det_W_list
 

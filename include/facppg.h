@@ -152,6 +152,20 @@ int facppg_weight_norm_forward(const void* table_dev, int n_tensors, long total_
 int facppg_weight_norm_backward(const void* table_dev, const void* out_table_dev, int n_tensors,
                                 long total_rows, void* stream);
 
+/* Replaces the reductions of WaveGlowLoss.forward (glow.py:43-59: torch.sum(z*z) and one torch.sum(log_s) per flow, 13 reduction
+ * launches + 12 adds) by two launches: out[e] = sum over segment e, a segment being `outer` runs of `inner` contiguous floats
+ * `outer_stride` elements apart (a flow's log_s is the upper half of every batch item of its WN output), squared first if
+ * `square`.  Double accumulation, fixed summation order (bit-reproducible).  workspace: n * 64 doubles. */
+#define FACPPG_MAX_SUM_SEGMENTS 16
+typedef struct facppg_sum_segment {
+  const float* data_dev;
+  long outer_stride;
+  int outer, inner;
+  int square;
+} facppg_sum_segment;
+int facppg_segment_sums(const facppg_sum_segment* segs, int n, void* workspace_dev, size_t workspace_bytes, float* out_dev,
+                        void* stream);
+
 /* Replaces the affine coupling of WaveGlow.forward (glow.py:240-245): x = [x0 | x1] and wn_out = [b | log_s], all
  * [B][2h][L] fp32 -> y = cat(x0, exp(log_s) * x1 + b); and its backward: dx = [dy0 | dy1 exp(log_s)],
  * dwn_out = [dy1 | dy1 exp(log_s) x1] (the loss's own -sum(log_s) term reaches log_s through autograd separately). */

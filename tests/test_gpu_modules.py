@@ -215,3 +215,40 @@ def test_logdet_kernel_matches_torch():
     assert torch.isnan(_LogDetFunction.apply(N.cuda()))
     S = torch.tensor([[1.0, 2.0], [2.0, 4.0]])
     assert float(_LogDetFunction.apply(S.cuda())) == float("-inf")
+
+
+def test_glow_loss_node_and_segment_sums_match_the_reference_formula():
+    """WaveGlowLoss (glow.py:43-59) on CUDA tensors is one autograd node over facppg_segment_sums; value and every gradient
+    (z, each log_s -- a channel slice of a larger tensor, as the flows hand them over -- and each log_det_W) equal the
+    reference's chain of torch reductions."""
+    from waveglow.glow import WaveGlowLoss, _GlowLossFunction
+    g = torch.Generator().manual_seed(5)
+    B, L = 3, 1250
+    z = torch.randn(B, 8, L, generator=g).cuda().requires_grad_()
+    outs = [torch.randn(B, 2 * h, L, generator=g).cuda().requires_grad_() for h in (4, 4, 3, 3, 2)]
+    dets = [torch.randn((), generator=g).cuda().requires_grad_() for _ in outs]
+    ref_in = [t.detach().clone().requires_grad_() for t in [z] + outs + dets]
+
+    def reference(z_, outs_, dets_, sigma):
+        ls = [o[:, o.shape[1] // 2:, :] for o in outs_]
+        loss = torch.sum(z_ * z_) / (2 * sigma * sigma) - sum(torch.sum(t) for t in ls) - sum(dets_)
+        return loss / z_.numel()
+
+    crit = WaveGlowLoss(sigma=0.8)
+    seen = []
+    orig = _GlowLossFunction.apply
+    _GlowLossFunction.apply = staticmethod(lambda *a: (seen.append(1), orig(*a))[1])
+    try:
+        loss = crit((z, [o[:, o.shape[1] // 2:, :] for o in outs], [d * 7.0 for d in dets]))
+    finally:
+        _GlowLossFunction.apply = orig
+    assert seen, "the fused node did not run"
+    want = reference(ref_in[0], ref_in[1:6], [d * 7.0 for d in ref_in[6:]], 0.8)
+    assert abs(float(loss) - float(want)) <= 1e-6 * max(1.0, abs(float(want)))
+    (loss * 3.0).backward()
+    (want * 3.0).backward()
+    for a, b in zip([z] + outs + dets, ref_in):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-9), (a.shape, (a.grad - b.grad).abs().max())
+    # CPU tensors take the reference's own chain of torch ops
+    zc = torch.randn(2, 8, 10)
+    assert torch.isfinite(crit((zc, [torch.randn(2, 4, 10)], [torch.tensor(0.3)])))
