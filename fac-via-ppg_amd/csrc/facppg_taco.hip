@@ -505,9 +505,14 @@ __device__ __forceinline__ void attn_features(const DecArgs& p, const DecLds& L,
 // Location-sensitive attention (model.py:63-121) evaluated on the index range the reference's
 // window mask keeps (utils.py:64-77).  Reads ah from in_att[P+E:], updates wprev/wcum and writes
 // the context into in_att[P:], in_dec[A:], in_proj[D:].
-template <int NT>
+// QR > 0: the query layer's weights arrive in registers (wq[i] = row k0 + i of this thread's k range of W_q^T, requested by the
+// caller -- the split decoder's main workgroup -- before it started waiting for the hidden state).  Same products in the same
+// order as matvec_part, so the same bits, without the stream's L2 latency between the hidden state and the energies.
+struct NoQueryRegs { float4 w[1]; };
+template <int NT, int QR = 0>
 __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L, const float* mem, const float* pm, int len,
-                                              int t, int b, int tid, bool write_out, bool feat_ready = false) {
+                                              int t, int b, int tid, bool write_out, bool feat_ready = false,
+                                              const float4 (&wq)[QR > 0 ? QR : 1] = NoQueryRegs().w) {
   const int lane = tid & 63, wave = tid >> 6;
   long long atk = clock64();
 #define APROF(slot)                                                     \
@@ -521,7 +526,27 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
   attn_window_range(p.window, t, len, &lo, &hi);
   {
     const int KS = pick_ks<NT>(L.ADp, p.A);
-    matvec_part<(NT <= 512 ? 16 : 4)>(p.q_t, p.A, L.ADp, KS, ah, L.part, tid);
+    if constexpr (QR > 0) {
+      const int ns = L.ADp >> 2, slot = tid % ns, ks = tid / ns;
+      if (ks < KS) {
+        const int k0 = (int)((long)ks * p.A / KS), k1 = (int)((long)(ks + 1) * p.A / KS);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < QR; ++i) {
+          const float vk = k0 + i < k1 ? ah[k0 + i] : 0.0f;
+          acc.x = fmaf(wq[i].x, vk, acc.x); acc.y = fmaf(wq[i].y, vk, acc.y);
+          acc.z = fmaf(wq[i].z, vk, acc.z); acc.w = fmaf(wq[i].w, vk, acc.w);
+        }
+        for (int k = k0 + QR; k < k1; ++k) {      // (layer sizes whose k ranges exceed the prefetched rows: the rest in place)
+          const float4 wv = reinterpret_cast<const float4*>(p.q_t)[(size_t)k * ns + slot];
+          const float vk = ah[k];
+          acc.x = fmaf(wv.x, vk, acc.x); acc.y = fmaf(wv.y, vk, acc.y); acc.z = fmaf(wv.z, vk, acc.z); acc.w = fmaf(wv.w, vk, acc.w);
+        }
+        reinterpret_cast<float4*>(L.part)[ks * ns + slot] = acc;
+      }
+    } else {
+      matvec_part<(NT <= 512 ? 16 : 4)>(p.q_t, p.A, L.ADp, KS, ah, L.part, tid);
+    }
     __syncthreads();
     if (tid < p.AD) L.pq[tid] = part_sum(L.part, L.ADp, KS, tid);
     __syncthreads();
@@ -669,9 +694,9 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
 #pragma unroll
       for (int j = 0; j < QU; ++j) {
         const int q = qb + j * CW;
-        const float wq = q <= hi ? L.en[q] : 0.0f;
+        const float wgt = q <= hi ? L.en[q] : 0.0f;
 #pragma unroll
-        for (int r = 0; r < CR; ++r) accv[r] = fmaf(wq, mv[j][r], accv[r]);
+        for (int r = 0; r < CR; ++r) accv[r] = fmaf(wgt, mv[j][r], accv[r]);
       }
     }
 #pragma unroll
@@ -1110,6 +1135,14 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
   const float* mem = p.memory + (size_t)b * p.Tin * p.E;
   const float* pm = p.pm + (size_t)b * p.Tin * p.AD;
   float* ah = L.in_att + p.P + p.E;
+  // the query layer's weights of this thread's (4-row slot, k range) are REQUESTED every frame before the main workgroup starts
+  // waiting for the workers (gate, then the attention LSTM's hidden state: ~10 us): the 180 KB stream's L2 latency, which was
+  // 2.9 us of the 12.7 us attention, hides in that wait.  (Keeping them in registers for the whole utterance spills: 96 registers
+  // next to the context's 48 and the kernel's 224 for the workers' LSTM slices.)
+  constexpr int QR = 24;
+  const int q_ks = pick_ks<NTC>(L.ADp, p.A);
+  const int q_ns = L.ADp >> 2, q_slot = tid % q_ns, q_part = tid / q_ns;
+  const int q_k0 = (int)((long)q_part * p.A / q_ks), q_k1 = (int)((long)(q_part + 1) * p.A / q_ks);
   long long tk = clock64();
 #define PROF(slot)                                                        \
   if (p.prof && b == 0 && tid == 0) {                                     \
@@ -1122,6 +1155,11 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
     int lo, hi;
     attn_window_range(p.window, t, len, &lo, &hi);
     attn_features<NTC>(p, L, lo, min(64, hi - lo + 1), tid);   // needs only frame t-1's weights
+    float4 wq[QR];
+#pragma unroll
+    for (int i = 0; i < QR; ++i)
+      wq[i] = (q_part < q_ks && q_k0 + i < q_k1) ? reinterpret_cast<const float4*>(p.q_t)[(size_t)(q_k0 + i) * q_ns + q_slot]
+                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
     PROF(2)
     if (t > 0) {
       if (tid == 0) s_stop[0] = sigm(xwait(MEL + p.NF, tag)) > p.gate_thr || t == dec_step_limit(p, b);
@@ -1135,7 +1173,7 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
     for (int i = tid; i < p.A; i += NTC) ah[i] = xwait(AH + i, tag);
     __syncthreads();
     PROF(3)
-    dec_attention<NTC>(p, L, mem, pm, len, t, b, tid, true, true);
+    dec_attention<NTC, QR>(p, L, mem, pm, len, t, b, tid, true, true, wq);
     for (int i = tid; i < p.E; i += NTC) xpub(CTX + i, L.in_proj[p.D + i], tag);
     PROF(5)
   }
