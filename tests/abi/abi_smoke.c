@@ -83,6 +83,31 @@ int main(void) {
   /* error paths */
   if (facppg_wg_infer(h, dmel, NULL, NULL, 1u, 0.6f, B, T, daud, ws, wsb / 2, NULL) != FACPPG_EWORKSPACE) { fprintf(stderr, "expected EWORKSPACE\n"); return 5; }
   if (facppg_wg_infer(h, NULL, NULL, NULL, 1u, 0.6f, B, T, daud, ws, wsb, NULL) != FACPPG_EINVAL) { fprintf(stderr, "expected EINVAL\n"); return 5; }
+  /* a stand-alone entry point with plain structs: sums of strided segments (WaveGlowLoss's reductions) */
+  {
+    const int n = 1000;
+    float* hv = (float*)malloc(2 * n * sizeof(float));
+    double want0 = 0.0, want1 = 0.0;
+    for (int i = 0; i < 2 * n; ++i) hv[i] = (float)((i * 37) % 11) - 5.0f;
+    for (int i = 0; i < n; ++i) { want0 += (double)hv[i] * hv[i]; }
+    for (int o = 0; o < 4; ++o) for (int i = 0; i < 100; ++i) want1 += hv[n + o * 250 + i];
+    float *dv = NULL, *dout = NULL;
+    void* sws = NULL;
+    CHECK_HIP(hipMalloc((void**)&dv, 2 * n * sizeof(float)));
+    CHECK_HIP(hipMalloc((void**)&dout, 2 * sizeof(float)));
+    CHECK_HIP(hipMalloc(&sws, 2 * 64 * sizeof(double)));
+    CHECK_HIP(hipMemcpy(dv, hv, 2 * n * sizeof(float), hipMemcpyHostToDevice));
+    facppg_sum_segment segs[2] = {{dv, 0, 1, n, 1}, {dv + n, 250, 4, 100, 0}};
+    CHECK_RC(facppg_segment_sums(segs, 2, sws, 2 * 64 * sizeof(double), dout, NULL));
+    float got[2];
+    CHECK_HIP(hipMemcpy(got, dout, sizeof(got), hipMemcpyDeviceToHost));
+    if (fabs(got[0] - want0) > 1e-3 * fabs(want0) || fabs(got[1] - want1) > 1e-3 + 1e-5 * fabs(want1)) {
+      fprintf(stderr, "segment sums %g %g, expected %g %g\n", got[0], got[1], want0, want1);
+      return 6;
+    }
+    if (facppg_segment_sums(segs, 2, sws, 8, dout, NULL) != FACPPG_EINVAL) { fprintf(stderr, "expected EINVAL for a short workspace\n"); return 6; }
+    free(hv);
+  }
   facppg_wg_destroy(h);
   printf("abi_smoke ok: version %d, %zu weights, %zu samples, rms %.4f, workspace %zu bytes\n", facppg_version(), nw, n_audio, rms, wsb);
   return 0;

@@ -101,12 +101,24 @@ class _RampSynthesizer(object):
         wavs = [torch.arange(t * 160, dtype=torch.float32) * 1e-3 + float(s) + float(p[0, 0]) for t, s, p in zip(tout, utterance_seeds, ppgs)]
         return wavs, tout
 
+    streamed = 0
+
+    def stream(self, jobs, sigma=0.6, strength=0.005, return_device=True, overlap=True):
+        """facppg.pipeline.Synthesizer.stream: one result per job, in order, pulled lazily (script.synthesize_corpus feeds it a
+        generator of batches and zips the results with them)."""
+        assert return_device and overlap
+        for job in jobs:
+            self.streamed += 1
+            yield self(sigma=sigma, strength=strength, return_device=True, **job)
+
 
 def _corpus_worker(rank, world, port, argv):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from script import synthesize_corpus
-    written = synthesize_corpus.main(argv, synthesizer=_RampSynthesizer())
+    syn = _RampSynthesizer()
+    written = synthesize_corpus.main(argv, synthesizer=syn)
     assert (written is not None) == (rank == 0)
+    assert syn.streamed >= 1, "the corpus script did not go through the synthesizer's pipelined stream"
 
 
 @pytest.mark.parametrize("world", [1, 2])
