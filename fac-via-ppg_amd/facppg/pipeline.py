@@ -200,11 +200,24 @@ def synthesize_stream(jobs, tacotron, waveglow, denoiser=None, sigma=0.6, streng
     if first is None:
         return
     ready = acoustic(first)
+    previous_vocoder = None
     while ready is not None:
         job, mel_post, tout, done = ready
         main.wait_event(done)
         with torch.no_grad():
             audio = _vocode(mel_post, tout, waveglow, denoiser, sigma, strength, job.get("seed"), None, job.get("utterance_seeds"))
+        vocoder_done = torch.cuda.Event()
+        vocoder_done.record(main)
         nxt = next(it, None)
-        ready = acoustic(nxt) if nxt is not None else None       # enqueued behind nothing: runs while the vocoder above does
+        if nxt is not None:
+            # The acoustic model (~25-60 ms) is several times faster than the vocoder it hides under: left alone, the host would run
+            # the acoustic models of ALL remaining jobs under the first vocoders and queue every vocoder call -- each with its output,
+            # noise and workspace buffers -- far ahead of its execution.  One job of look-ahead is all the overlap needs: acoustic
+            # i+1 is enqueued when vocoder i-1 has finished, i.e. as vocoder i starts.
+            if overlap and previous_vocoder is not None:
+                previous_vocoder.synchronize()
+            ready = acoustic(nxt)       # enqueued behind nothing on its own stream: runs while the vocoder above does
+        else:
+            ready = None
+        previous_vocoder = vocoder_done
         yield finish(audio, tout)
