@@ -1,33 +1,39 @@
 #!/usr/bin/env python3
-"""Throughput bench of the PPG->wav hot path on MI355X (driver contract: see the task brief).
+"""Throughput / latency bench of the PPG->wav hot path on MI355X (driver contract: see the task brief).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload infer|e2e|corpus|train]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload e2e|infer|corpus|train]
+
+The metric is BASELINE.json's: 22.05 kHz (hop 256) audio samples per second END TO END (PPG -> wav) and the real-time
+factor at batch = 1.  The DEFAULT run therefore times the metric's own configuration: one 200-frame utterance per step,
+host PPG [200 x 5816] in -> Tacotron2 -> WaveGlow -> Denoiser -> device wav out (SURVEY.md 8d config 1 at hop 256);
+`value` = samples / s of that step, `realtime_factor` = value / 22050, `roofline` = the executed-FLOP fraction of the fp32
+MFMA peak reached by the dominant kernel (the fused WaveNet layer) INSIDE that run, from hipEvents around every one of its
+launches in the timed steps.  The other BASELINE configs are sub-keys of the same JSON line, each with its own steps /
+ms_per_step / roofline: `waveglow_batch8` (configs[1]), `end_to_end_batch16_ragged` (configs[2], one batch at a time and
+software-pipelined), plus `reference_rate_config`, `train_step`, `cpu_baseline`.
 
 --workload (what one "step" is, and what `value` counts; every workload names its BASELINE.json config):
-  infer   (default) WaveGlow.infer over one batch of synthetic mels = configs[1]: batch 8, mel 80x1000, fp32, noise
-          generated on the device, inputs resident in HBM.  Each rank its own batch (weak scaling).
-  e2e     end-to-end PPG -> mel -> wav (Tacotron2 + WaveGlow + Denoiser) on configs[2]: 16 variable-length utterances
-          per rank (--e2e-batch 1: the metric's "batch = 1" case), host PPG in, device wav out.  Weak scaling.
+  e2e     (default) end-to-end PPG -> mel -> wav (Tacotron2 + WaveGlow + Denoiser), host PPG in, device wav out;
+          --e2e-batch 1 (default) = the metric's batch-1 case, --e2e-batch 16 = configs[2] (16 variable-length utterances per
+          rank, back-to-back batches software-pipelined).  Weak scaling.
+  infer   WaveGlow.infer over one batch of synthetic mels = configs[1]: batch 8, mel 80x1000, fp32, noise generated on the
+          device, inputs resident in HBM (--infer-batch / --infer-frames: other shapes, e.g. 1 x 200 for profiling the
+          batch-1 vocoder without the decoder's cooperative launches).  Each rank its own batch (weak scaling).
   corpus  configs[3]: offline synthesis of --utterances (1024) ragged monophone-PPG utterances sharded over the ranks
-          (facppg.shard, script.synthesize_corpus), INCLUDING the all_gather of lengths and the padded gather of the audio to
+          (facppg.shard, script.synthesize_corpus), INCLUDING the all_gather of lengths and the gather of the audio to
           rank 0.  One step = the whole corpus once.  Strong scaling.
-  train   configs[4]: the bf16 WaveGlow training step (fwd + loss + bwd + Adam, segment 10 000) replayed as a HIP graph,
+  train   configs[4]: the bf16 WaveGlow training step (fwd + loss + bwd + Adam, segment 10 000) replayed as HIP graphs,
           data parallel with the bucketed RCCL gradient all-reduce of waveglow.distributed; reports the exchange's share.
-The metric is BASELINE.json's: 22.05 kHz (hop 256) audio samples per second, whole job over all ranks.
 
 With --gpus N > 1 it runs one rank per GPU: either launched under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE /
 MASTER_* in the env), or -- when WORLD_SIZE is not set -- it spawns the N ranks itself (the one-process-per-GPU launcher
 pattern of the reference's distributed.py:145-170).  The world size and the number of ranks RCCL actually sees are asserted
-to equal --gpus.  An N > 1 `infer` run also carries short `train_dp` and `corpus_dp` entries (the two configs whose
-collectives matter), so one 8-GPU invocation measures them too; --no-extra skips them.
+to equal --gpus.  An N > 1 run of the default workload also carries short `train_dp` and `corpus_dp` entries (the two
+configs whose collectives matter), so one 8-GPU invocation measures them too; --no-extra skips them.
 
-Adds to the JSON line:
-  roofline      fp32-MFMA roofline of the dominant kernel (k_wn_layer): algorithmic FLOPs per launch / its average launch
-                duration measured live with hipEvents on the launch stream during the timed steps.
-  end_to_end_*  the metric's own configurations (batch 1 and the 16-utterance ragged batch) timed in THIS process: K steps
-                between synchronisations on the host clock (`steps`, `ms_per_step`) plus a hipEvent stage breakdown.
   cpu_baseline  the CPU oracle (a port of the reference's PyTorch-CPU path) timed on this host's cores on a bounded sample
-                (rank 0, N=1 only): end to end on config 1 and a config-3 subset, median of 3 after a warm-up.
+                (rank 0, N=1 only): end to end on the SAME config-1 input as `value`, pinned to 16 cores, 3 runs after a
+                warm-up (median, min and max stated).
 """
 import argparse
 import contextlib
@@ -109,6 +115,11 @@ def cpu_baseline_worker(threads, mode):
     from common.hparams import create_hparams_stage
     from facppg import synth
     from oracle import dsp, tacotron as otac, waveglow as owg
+    try:        # pin to the first `threads` CPUs this process may use (with OMP_PROC_BIND=close from the parent): round 3's
+        cpus = sorted(os.sched_getaffinity(0))[:threads]      # unpinned runs moved by +-25 % from box to box
+        os.sched_setaffinity(0, set(cpus))
+    except (AttributeError, OSError):
+        pass
     torch.set_num_threads(threads)
     cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=HOP)
     sd = synth.waveglow_state_dict(cfg)
@@ -154,7 +165,7 @@ def cpu_baseline_worker(threads, mode):
             t0 = time.perf_counter()
             samples = run()
             ts.append(time.perf_counter() - t0)
-    print(json.dumps({"threads": threads, "mode": mode, "seconds": sorted(ts)[1], "samples": samples, "runs": 3, "frames": lens}))
+    print(json.dumps({"threads": threads, "mode": mode, "seconds": sorted(ts)[1], "seconds_all": ts, "samples": samples, "runs": 3, "frames": lens}))
 
 
 def cpu_model_name():
@@ -177,7 +188,8 @@ def cpu_baseline(log):
     for mode, limit in (("e2e1", 240), ("e2e3", 240), ("wg600", 120)):
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(threads), mode],
-                               capture_output=True, text=True, timeout=limit)
+                               capture_output=True, text=True, timeout=limit,
+                               env=dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores"))
             d = json.loads(r.stdout.strip().splitlines()[-1])
             d["value"] = d["samples"] / d["seconds"]
             log("cpu baseline %s: %d threads -> %.0f samples/s (%.1f s per run)" % (mode, threads, d["value"], d["seconds"]))
@@ -193,7 +205,10 @@ def cpu_baseline(log):
                      "host threads; value = config 1 end to end: PPG [200 x 5816] -> Tacotron2 -> WaveGlow -> Denoiser at hop %d = "
                      "%d samples, median of 3 runs after a warm-up (%.1f s per run)" % (
                          threads, os.cpu_count() or 0, HOP, head["samples"], head["seconds"]),
-           "realtime_factor": head["value"] / SR}
+           "realtime_factor": head["value"] / SR, "pinned": "sched_setaffinity to the first %d allowed CPUs, OMP_PROC_BIND=close" % threads}
+    if head.get("seconds_all"):
+        out["spread"] = {"runs_s": head["seconds_all"], "value_min": head["samples"] / max(head["seconds_all"]),
+                         "value_max": head["samples"] / min(head["seconds_all"])}
     if "e2e3" in res:
         d = res["e2e3"]
         out["config3_subset"] = {"value": d["value"], "seconds": d["seconds"], "samples": d["samples"],
@@ -439,25 +454,49 @@ def reference_rate_config(dev, mel, log):
             "samples_per_s": n / t, "realtime_factor": n / t / sr}
 
 
-def pmc_traffic():
-    """HBM bytes per k_wn_layer launch, READ FROM the committed rocprofv3 PMC passes of this same command (newest
-    profiles/rNN_pmc.json; FETCH_SIZE doubled per the gfx950 correction, calibrated on k_flow_end) -- PMC counters cannot
-    be collected from inside the timed run.  The summary records the identity of the kernel source it was taken from
-    (tools/make_pmc_json.py); one taken from ANOTHER build of the kernels is refused (traffic = null and the reason in
-    traffic_source) instead of being passed off as this build's.  Returns (bytes or None, provenance)."""
+def pmc_traffic(key="k_wn_layer"):
+    """HBM bytes per launch of the dominant kernel, READ FROM the committed rocprofv3 PMC passes of this same kernel source
+    (newest profiles/rNN_pmc.json; FETCH_SIZE doubled per the gfx950 correction, calibrated on k_flow_end) -- PMC counters
+    cannot be collected from inside the timed run.  `key` names the entry: "k_wn_layer" = the launches of configs[1]
+    (B = 8 x 1000), "k_wn_layer_b1_t200" = those of the metric's batch-1 utterance.  The summary records the identity of the
+    kernel source it was taken from (tools/make_pmc_json.py); one taken from ANOTHER build of the kernels is refused (traffic
+    = null and the reason in traffic_source) instead of being passed off as this build's.  Returns (bytes or None, provenance)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
         try:
             with open(path) as f:
-                d = json.load(f)["k_wn_layer"]
-            have, want = d.get("kernel_source_id"), kernel_source_id()
+                doc = json.load(f)
+            have, want = doc["k_wn_layer"].get("kernel_source_id"), kernel_source_id()
             if have != want:
                 return None, "STALE: %s was taken from kernel source %s, this build is %s -- re-run tools/profile_bench.sh" % (
                     os.path.basename(path), have, want)
-            return d["hbm_bytes_per_launch"], "static: %s (%s)" % (os.path.basename(path), d.get("build", "separate rocprofv3 --pmc passes"))
+            if key not in doc:
+                return None, "%s holds no entry %s" % (os.path.basename(path), key)
+            d = doc[key]
+            return d["hbm_bytes_per_launch"], "static: %s[%s] (%s)" % (os.path.basename(path), key, d.get("build", "separate rocprofv3 --pmc passes"))
         except Exception:   # noqa: BLE001
             continue
     return None, None
+
+
+def wn_layer_roofline(model, layer_ms, layer_n, positions, pmc_key):
+    """`roofline` of the fused WaveNet-layer kernel from the library's own hipEvents (facppg_wg_set_profiling: a pair around
+    every launch on the launch stream): executed FLOPs of one launch (layer_flops_per_position x the group positions one
+    launch processes) / average launch duration.  The same launch is also priced at the reference formulation's FLOPs
+    (2*(3*256+640)*512 + res_skip per position), which can exceed the fp32 MFMA peak because the folded
+    kernels execute a third fewer FLOPs."""
+    flops = layer_flops_per_position() * positions
+    achieved = flops / (layer_ms * 1e-3) / 1e12 if layer_ms > 0 else 0.0
+    flops_ref = layer_flops_per_position(ncond=640, edge_fold=False) * positions
+    achieved_ref = flops_ref / (layer_ms * 1e-3) / 1e12 if layer_ms > 0 else 0.0
+    traffic, traffic_src = pmc_traffic(pmc_key)
+    tile = model.last_launch_shape()
+    return {"bound": "mfma", "kernel": "k_wn_layer", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "avg_launch_ms": layer_ms, "launches_timed": layer_n, "flops_per_launch": flops, "positions_per_launch": positions,
+            "tile_frames": tile[0], "waves_per_workgroup": tile[1], "workgroups_per_launch": tile[2],
+            "kernel_source_id": kernel_source_id(),
+            "reference_formulation": {"flops_per_launch": flops_ref, "achieved": achieved_ref, "frac": achieved_ref / PEAK_F32_MFMA_TFLOPS}}
 
 
 # ---------------------------------------------------------------------------------------------- launch plumbing
@@ -569,16 +608,19 @@ class InferWorkload(object):
     """configs[1]: WaveGlow.infer batch 8 x 80x1000 per rank."""
     name, scaling, dtype = "infer", "weak", "f32"
 
-    def __init__(self, dev, rank, world, args, dist):
+    def __init__(self, dev, rank, world, args, dist, model=None):
         from facppg import lib as flib, synth
         from waveglow.glow import WaveGlow
         self.dev, self.world, self.flib = dev, world, flib
-        cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=HOP)
-        model = WaveGlow.remove_weightnorm(WaveGlow(**cfg))
-        model.load_state_dict(synth.waveglow_state_dict(cfg))
-        self.model = model.to(dev).eval()
-        self.mel = synth.synthetic_mel(BATCH, FRAMES, seed=1234 + rank).to(dev)
-        self.samples = world * BATCH * FRAMES * HOP
+        if model is None:
+            cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=HOP)
+            model = WaveGlow.remove_weightnorm(WaveGlow(**cfg))
+            model.load_state_dict(synth.waveglow_state_dict(cfg))
+            model = model.to(dev).eval()
+        self.model = model
+        self.B, self.T = int(getattr(args, "infer_batch", BATCH)), int(getattr(args, "infer_frames", FRAMES))
+        self.mel = synth.synthetic_mel(self.B, self.T, seed=1234 + rank).to(dev)
+        self.samples = world * self.B * self.T * HOP
         self.audio = None
 
     def step(self, i):
@@ -593,38 +635,26 @@ class InferWorkload(object):
         ms, n = flib.ctypes.c_float(), flib.ctypes.c_int()
         flib.check(L.facppg_wg_last_layer_ms(self.model._handle(self.dev), flib.ctypes.byref(ms), flib.ctypes.byref(n)))
         layer_ms, layer_n = ms.value, n.value
+        flib.check(L.facppg_wg_set_profiling(self.model._handle(self.dev), 0))
         assert os.environ.get("FACPPG_BENCH_NO_CHECK") or torch.isfinite(self.audio).all()
-        positions = BATCH * FRAMES * HOP // 8
-        flops = layer_flops_per_position() * positions
-        achieved = flops / (layer_ms * 1e-3) / 1e12 if layer_ms > 0 else 0.0
-        # the same launch priced at the reference formulation's FLOPs (2*(3*256+640)*512 + res_skip per
-        # position); it can exceed the fp32 MFMA peak because the folded kernels execute a third fewer FLOPs
-        flops_ref = layer_flops_per_position(ncond=640, edge_fold=False) * positions
-        achieved_ref = flops_ref / (layer_ms * 1e-3) / 1e12 if layer_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic()
-        tile = self.model.last_launch_shape()
-        out["config"] = {"workload": "BASELINE configs[1]: WaveGlow.infer batch=%d, mel 80x%d, hop=%d (%d Hz), fp32, sigma=0.6, device "
+        standard = (self.B, self.T) == (BATCH, FRAMES)
+        out["config"] = {"workload": "%sWaveGlow.infer batch=%d, mel 80x%d, hop=%d (%d Hz), fp32, sigma=0.6, device "
                                      "Philox noise; the vocoder stage (98.8 %% of the FLOPs) of the PPG->wav path; seeded synthetic weights "
-                                     "(no checkpoints ship with the reference); the metric's end-to-end configurations are in "
-                                     "end_to_end_batch1 / end_to_end_batch16_ragged" % (BATCH, FRAMES, HOP, SR),
-                         "per_gpu_batch": BATCH, "global_batch": BATCH * self.world, "parallelism": "dp%d" % self.world}
-        out["roofline"] = {"bound": "mfma", "kernel": "k_wn_layer", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                           "avg_launch_ms": layer_ms, "launches_timed": layer_n, "flops_per_launch": flops,
-                           "tile_frames": tile[0], "waves_per_workgroup": tile[1], "workgroups_per_launch": tile[2],
-                           "kernel_source_id": kernel_source_id(),
-                           "reference_formulation": {"flops_per_launch": flops_ref, "achieved": achieved_ref,
-                                                     "frac": achieved_ref / PEAK_F32_MFMA_TFLOPS}}
+                                     "(no checkpoints ship with the reference)" % ("BASELINE configs[1]: " if standard else "", self.B, self.T, HOP, SR),
+                         "per_gpu_batch": self.B, "global_batch": self.B * self.world, "parallelism": "dp%d" % self.world}
+        out["roofline"] = wn_layer_roofline(self.model, layer_ms, layer_n, self.B * self.T * HOP // 8,
+                                            "k_wn_layer" if standard else "k_wn_layer_b%d_t%d" % (self.B, self.T))
 
 
 class E2EWorkload(object):
-    """configs[2] (or, --e2e-batch 1, the metric's batch-1 case): end-to-end PPG -> wav per rank."""
+    """The metric's own configuration (--e2e-batch 1, the default: one 200-frame utterance per step) or configs[2]
+    (--e2e-batch 16: variable-length utterances): end-to-end PPG -> wav per rank, host PPG in, device wav out."""
     name, scaling, dtype = "e2e", "weak", "f32"
 
-    def __init__(self, dev, rank, world, args, dist):
+    def __init__(self, dev, rank, world, args, dist, waveglow=None):
         lens = [200] if args.e2e_batch == 1 else config3_lengths(args.e2e_batch, 7 + rank)
-        self.e = EndToEnd(dev, lens, seed0=1000 * rank)
-        self.world, self.dev = world, dev
+        self.e = EndToEnd(dev, lens, seed0=1000 * rank, waveglow=waveglow)
+        self.world, self.dev, self.steps = world, dev, args.steps
         # back-to-back batches, software-pipelined (facppg.pipeline.synthesize_stream): the acoustic model of step i+1 runs
         # under the vocoder of step i.  The batch-1 case is the metric's latency figure: one utterance at a time, no overlap.
         self.overlap = bool(args.e2e_overlap) and len(lens) > 1
@@ -640,20 +670,34 @@ class E2EWorkload(object):
         self.out = next(self.gen) if self.overlap else self.e.step(i)
 
     def start_timed(self):
-        pass
+        # hipEvent pairs around every fused-WN-layer launch of the timed steps (created here, recorded on the launch stream)
+        from facppg import lib as flib
+        if len(self.e.lens) == 1:
+            flib.check(flib.load().facppg_wg_set_profiling(self.e.waveglow._handle(self.dev), max(2, self.steps)))
 
     def finish(self, out, elapsed, steps):
-        from facppg import pipeline
+        from facppg import lib as flib, pipeline
         out["config_overlap"] = ("steady state of back-to-back batches: step i+1's PPG upload + Tacotron2 run on a second HIP stream under "
                                  "step i's WaveGlow + denoiser; every step's acoustic model and vocoder are inside the timed region "
                                  "(stage_ms below: one further, un-overlapped step)") if self.overlap else "none: one batch at a time"
+        b1 = len(self.e.lens) == 1
+        if b1:
+            L, h = flib.load(), self.e.waveglow._handle(self.dev)
+            ms, n = flib.ctypes.c_float(), flib.ctypes.c_int()
+            flib.check(L.facppg_wg_last_layer_ms(h, flib.ctypes.byref(ms), flib.ctypes.byref(n)))
+            flib.check(L.facppg_wg_set_profiling(h, 0))
+            out["roofline"] = wn_layer_roofline(self.e.waveglow, ms.value, n.value, self.e.lens[0] * HOP // 8, "k_wn_layer_b1_t200")
+            out["roofline"]["measured"] = ("hipEvents around every launch of the fused WN-layer kernel in the %d timed end-to-end steps "
+                                           "(%d launches)" % (steps, n.value))
         timer = pipeline.StageTimer()
         self.e.step(10 ** 6, timer=timer)
         st = timer.stages_ms()
-        out["config"] = {"workload": "BASELINE configs[2]: " + self.e.describe() if len(self.e.lens) > 1 else
-                         "the metric's batch = 1 case (SURVEY.md 8d config 1): " + self.e.describe(),
+        out["config"] = {"workload": "BASELINE configs[2]: " + self.e.describe() if not b1 else
+                         "the metric's own case, real-time factor at batch = 1 (SURVEY.md 8d config 1 at the metric's 22.05 kHz / hop 256): "
+                         + self.e.describe() + "; one utterance per step, nothing overlapped across steps",
                          "per_gpu_batch": len(self.e.lens), "global_batch": len(self.e.lens) * self.world, "parallelism": "dp%d" % self.world}
         out["stage_ms"] = {k: v for k, v in st.items() if k != "total"}
+        out["stage_ms_total"] = st["total"]
         out["stage_roofline"] = stage_rooflines(st, sum(self.e.lens), sum(self.e.lens), len(self.e.lens), HOP)
 
 
@@ -780,12 +824,14 @@ def timed_run(wl, steps, warmup, fence, dist, dev, backend):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="infer")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 20 for e2e batch 1, 5 otherwise)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 3 for e2e batch 1, 2 otherwise)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="e2e")
+    ap.add_argument("--infer-batch", type=int, default=BATCH, help="infer workload: utterances per batch (configs[1]: 8)")
+    ap.add_argument("--infer-frames", type=int, default=FRAMES, help="infer workload: mel frames per utterance (configs[1]: 1000)")
     ap.add_argument("--utterances", type=int, default=1024, help="corpus workload: utterances in the corpus")
     ap.add_argument("--corpus-batch", type=int, default=64, help="corpus workload: utterances per synthesis batch")
-    ap.add_argument("--e2e-batch", type=int, default=16, help="e2e workload: utterances per rank (1 = the metric's batch-1 case)")
+    ap.add_argument("--e2e-batch", type=int, default=1, help="e2e workload: utterances per rank (1 = the metric's batch-1 case, 16 = configs[2])")
     ap.add_argument("--e2e-overlap", type=int, default=1,
                     help="e2e workload, batch > 1: 1 = back-to-back steps software-pipelined (Tacotron2 of step i+1 under WaveGlow of step i), "
                          "0 = strictly one batch after the other")
@@ -804,6 +850,11 @@ def main():
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--train-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    headline = args.workload == "e2e" and args.e2e_batch == 1      # the metric's own configuration
+    if args.steps is None:
+        args.steps = 20 if headline else 5
+    if args.warmup is None:
+        args.warmup = 3 if headline else 2
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(int(args.cpu_baseline_worker[0]), args.cpu_baseline_worker[1])
     if args.train_worker:
@@ -867,16 +918,34 @@ def main():
         "realtime_factor": value / (16000 if train else SR),
     }
     wl.finish(out, elapsed, args.steps)
-    secondary_ok = rank == 0 and world == 1 and args.workload == "infer" and not args.force_dist
+    secondary_ok = rank == 0 and world == 1 and headline and not args.force_dist
     if secondary_ok and not args.no_e2e:
-        for key, lens in (("end_to_end_batch1", [200]), ("end_to_end_batch16_ragged", config3_lengths())):
-            try:
-                out[key] = time_end_to_end(dev, lens, 5, 2, log, key, waveglow=wl.model)
-            except Exception as e:   # noqa: BLE001  (secondary figure: report its absence, never fail the bench)
-                log("%s failed: %r" % (key, e))
-                out[key] = None
-        out["reference_rate_config"] = reference_rate_config(dev, wl.mel, log)
-    if dist is not None and args.workload == "infer" and not args.no_extra:
+        # the other BASELINE configs next to the headline, each timed in this process with its own steps / ms_per_step / roofline
+        try:
+            sub_args = argparse.Namespace(**vars(args))
+            sub_args.infer_batch, sub_args.infer_frames = BATCH, FRAMES
+            sub = InferWorkload(dev, rank, world, sub_args, None, model=wl.e.waveglow)
+            el = timed_run(sub, 5, 2, fence, None, dev, args.dist_backend)
+            entry = {"steps": 5, "warmup": 2, "ms_per_step": el / 5 * 1e3, "value": sub.samples * 5 / el, "unit": "samples/s",
+                     "realtime_factor": sub.samples * 5 / el / SR, "dtype": sub.dtype}
+            sub.finish(entry, el, 5)
+            out["waveglow_batch8"] = entry
+            log("configs[1] WaveGlow.infer batch 8 x 1000: %.1f ms/step = %.2f M samples/s, k_wn_layer at %.3f of fp32 MFMA peak" % (
+                entry["ms_per_step"], entry["value"] / 1e6, entry["roofline"]["frac"]))
+            mel8 = sub.mel
+            del sub
+        except Exception as e:   # noqa: BLE001  (secondary figure: report its absence, never fail the bench)
+            log("waveglow_batch8 failed: %r" % (e,))
+            out["waveglow_batch8"], mel8 = None, None
+        try:
+            out["end_to_end_batch16_ragged"] = time_end_to_end(dev, config3_lengths(), 5, 2, log, "end_to_end_batch16_ragged", waveglow=wl.e.waveglow)
+        except Exception as e:   # noqa: BLE001
+            log("end_to_end_batch16_ragged failed: %r" % (e,))
+            out["end_to_end_batch16_ragged"] = None
+        if mel8 is not None:
+            out["reference_rate_config"] = reference_rate_config(dev, mel8, log)
+            del mel8
+    if dist is not None and (headline or args.workload == "infer") and not args.no_extra:
         # the two configs whose collectives matter, measured in the same multi-GPU invocation (short runs; a failure
         # is reported as null and never takes the primary figure down)
         del wl

@@ -167,21 +167,9 @@ class Tacotron2(nn.Module):
         return torch.cat([sd[k].detach().float().reshape(-1) for k in keys])
 
     def _release(self):
-        self.__dict__.pop("_facppg_dicts", None)      # (the module tree may be about to change: re-collected with the next handle)
         h = self.__dict__.pop("_facppg_handle", None)
         if h is not None:
             _lib.load().facppg_taco_destroy(h[0])
-
-    def _fingerprint(self):
-        """Identity + in-place version of every tensor the packed handle was built from: optimizer steps and in-place
-        ops bump ``_version``, re-assigning a Parameter changes its identity.  Writes through the ``.data`` alias bypass the
-        version counter by design; the handle is also dropped on every ``train()`` / ``eval()`` switch, and
-        ``invalidate_packed_weights()`` covers code that pokes ``.data`` within one mode."""
-        dicts = self.__dict__.get("_facppg_dicts")
-        if dicts is None:       # the live _parameters / _buffers dicts of every submodule, collected once per handle
-            dicts = [d for m in self.modules() for d in (m._parameters, m._buffers)]
-            self.__dict__["_facppg_dicts"] = dicts
-        return tuple((id(t), t._version) for d in dicts for t in d.values() if t is not None)
 
     def invalidate_packed_weights(self):
         self._release()
@@ -196,7 +184,7 @@ class Tacotron2(nn.Module):
 
     def _handle(self, dev):
         h = self.__dict__.get("_facppg_handle")
-        if h is not None and h[1] == dev and h[2] == self._fingerprint():
+        if h is not None and h[1] == dev and h[2].unchanged():
             return h[0]
         self._release()
         L = _lib.load()
@@ -209,7 +197,7 @@ class Tacotron2(nn.Module):
         with torch.cuda.device(dev):
             _lib.check(L.facppg_taco_create(cfg, _lib.ptr(blob), blob.numel(), dev.index, _lib.current_stream(dev),
                                             _lib.ctypes.byref(out)))
-        self.__dict__["_facppg_handle"] = (out, dev, self._fingerprint())
+        self.__dict__["_facppg_handle"] = (out, dev, _lib.WeightIdentity(self))
         return out
 
     def _apply(self, fn, *a, **k):
@@ -223,7 +211,6 @@ class Tacotron2(nn.Module):
     def __getstate__(self):
         d = dict(self.__dict__)
         d.pop("_facppg_handle", None)
-        d.pop("_facppg_dicts", None)
         return d
 
     def __del__(self):

@@ -34,8 +34,10 @@ class Nnet3FormatError(ValueError):
     pass
 
 
-INT_KEYS = {"Dim", "InputDim", "OutputDim", "BlockDim", "RankIn", "RankOut", "UpdatePeriod", "Rank", "NumDimsSelfRepaired",
-            "NumDimsProcessed", "NumComponents"}
+INT_KEYS = {"Dim", "InputDim", "OutputDim", "BlockDim", "RankIn", "RankOut", "UpdatePeriod", "Rank", "NumComponents"}
+# Kaldi keeps these counters as doubles (NonlinearComponent::num_dims_self_repaired_ / num_dims_processed_): 8-byte values in
+# binary mode, possibly "1.2e+06" in text mode
+DOUBLE_KEYS = {"Count", "OderivCount", "NumDimsSelfRepaired", "NumDimsProcessed"}
 BOOL_KEYS = {"IsGradient", "TestMode", "AddLogStddev", "UseNaturalGradient"}
 AFFINE_TYPES = ("NaturalGradientAffineComponent", "AffineComponent", "FixedAffineComponent")
 NONLINEAR_TYPES = ("RectifiedLinearComponent", "SoftmaxComponent", "LogSoftmaxComponent", "NoOpComponent")
@@ -266,6 +268,8 @@ class _Stream(object):
             if b0 in (4, 8) or b0 in (252, 248):   # size byte (negative = unsigned)
                 size = b0 if b0 < 128 else 256 - b0
                 raw = self.buf[self.pos + 1:self.pos + 1 + size]
+                if len(raw) < size:
+                    self.fail("<%s>: the file ends inside a %d-byte value" % (key, size))
                 self.pos += 1 + size
                 if size == 8:
                     return struct.unpack("<d", raw)[0]
@@ -287,7 +291,10 @@ class _Stream(object):
         tok = self.token()
         if key in BOOL_KEYS:
             return tok == "T"
-        return int(tok) if key in INT_KEYS else float(tok)
+        try:
+            return int(tok) if key in INT_KEYS else float(tok)
+        except ValueError:
+            self.fail("<%s>: %r is not a%s" % (key, tok, "n integer" if key in INT_KEYS else " number"))
 
 
 def _read_component(st):
@@ -379,7 +386,7 @@ def _w_value(out, key, v, binary):
     elif v is None:
         pass
     elif binary:
-        if key == "Count" or key == "OderivCount":
+        if key in DOUBLE_KEYS:
             out.append(b"\x08" + struct.pack("<d", float(v)))
         elif key in INT_KEYS:
             out.append(b"\x04" + struct.pack("<i", int(v)))
@@ -525,7 +532,8 @@ def plan_layers(nnet, output="output"):
                 Wg = Wg * pending_scale[None, None, :]
                 pending_scale = pending_shift = None
             prev = layers[-1] if layers else None
-            if prev is not None and prev["act"] == "none" and prev["renorm"] is None and taps == 1:
+            # (an affine reading ONE frame at offset 0: with Offset(prev, k), k != 0, the product would have to shift prev's taps)
+            if prev is not None and prev["act"] == "none" and prev["renorm"] is None and taps == 1 and srt[0] == 0:
                 prev["b"] = Wg[:, 0, :] @ prev["b"] + b            # affine after affine: one matrix
                 prev["W"] = np.einsum("oc,ctk->otk", Wg[:, 0, :], prev["W"].reshape(prev["W"].shape[0], prev["taps"], -1)).reshape(W.shape[0], -1)
             else:

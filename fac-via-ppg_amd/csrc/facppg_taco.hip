@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "facppg_gemm.h"
@@ -1286,15 +1287,23 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
     }
     const int resident = n_cu * per_cu;
     h->coop_limit = resident - resident / 16;
-    static bool poll_limit_set = false;   // process-wide, set once (see poll_tag)
-    if (!poll_limit_set) {
-      const char* pl = getenv("FACPPG_POLL_LIMIT");
-      const double seconds = pl ? strtod(pl, nullptr) : 20.0;
-      int khz = 0;
-      FACPPG_HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device));
-      const unsigned long long ticks = seconds > 0 && khz > 0 ? (unsigned long long)(seconds * 1e3 * khz) : 0ull;
-      FACPPG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_poll_limit_ticks), &ticks, sizeof(ticks)));
-      poll_limit_set = true;
+    // hipMemcpyToSymbol writes the CURRENT device's copy of the constant only, so the bound is uploaded once PER DEVICE (a
+    // process-wide "done" flag left every later GPU of a multi-GPU process at 0 = unbounded); the set is mutex-guarded
+    // because handles may be created from several host threads
+    static std::mutex poll_mu;
+    static unsigned long long poll_devices = 0;   // bit d: device d's copy is set (devices >= 64: uploaded at every create)
+    {
+      std::lock_guard<std::mutex> lock(poll_mu);
+      const bool known = device < 64 && ((poll_devices >> device) & 1ull);
+      if (!known) {
+        const char* pl = getenv("FACPPG_POLL_LIMIT");
+        const double seconds = pl ? strtod(pl, nullptr) : 20.0;
+        int khz = 0;
+        FACPPG_HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device));
+        const unsigned long long ticks = seconds > 0 && khz > 0 ? (unsigned long long)(seconds * 1e3 * khz) : 0ull;
+        FACPPG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_poll_limit_ticks), &ticks, sizeof(ticks)));
+        if (device < 64) poll_devices |= 1ull << device;
+      }
     }
   }
   const facppg_taco_config& c = *cfg;

@@ -517,39 +517,38 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   const float4* wave_a_ptr = PM ? p.w1 + w * 256 + lane : p.w1 + (size_t)(w * 4) * NG1 * 64 + lane;
   const float4* wave_c_ptr = PM ? p.wc + (size_t)ph * p.ngc * 1024 + w * 256 + lane : nullptr;
   const int nch = PM ? pm_chunks(p, ph) : NCH1;
+  // PM: the K order is [conditioning rows | tap -d | tap 0 | tap +d] -- the conditioning chunks, which depend on nothing a
+  // previous layer produced, come FIRST (the persistent small-launch path, facppg_wgp.hip, computes them while it waits for
+  // the taps' operand; every kernel of the inference path sums in this one order, so a tile gets the same bits from any)
+  const int ncc = nch - p.nconv;
   constexpr int F4R = TNt / 4, RPL4 = 64 / F4R, NSTG4 = 16 / RPL4;   // PM staging: float4 per row, rows per wave load, loads
   const int srow4 = lane / F4R, scol4 = (lane % F4R) * 4;
   const bool folded_first = EF && p.nconv == 1;
   const float* hb4 = folded_first ? p.xa + (size_t)b * 8 * p.Lp : p.h_in + (size_t)b * C * p.Lp;   // PM: tapo[] carry the lane's column
   const float* sb4 = PM ? p.melp + (size_t)b * NMEL * p.Tqp + in_off - ph * p.Tqp : nullptr;   // = HQ + qcol
-  // folded first layer: conv row r0 = 8*tap + ch of p.xa (rows >= 24 meet zero weights); computed once, outside the K loop
-  int first_off[NSTG4];
-#pragma unroll
-  for (int jj = 0; jj < NSTG4; ++jj) {
-    const int r0 = w * 16 + NSTG4 * srow4 + jj, tp = min(r0 >> 3, 2);
-    first_off[jj] = (r0 & 7) * p.Lp + (tp == 0 ? tap0 : tp == 1 ? tap1 : tap2) + lane_q;
-  }
   float stg[NSTG];
-  // first0: the prologue's call for chunk 0 of a folded first layer (the only one that needs first_off[]: every chunk the
-  // K loop stages for such a layer is a conditioning chunk, so first_off[] is dead once the loop starts)
-  auto stage_load = [&](int c, bool first0 = false) __attribute__((always_inline)) {
+  auto stage_load = [&](int c) __attribute__((always_inline)) {
     if constexpr (PM) {
       // both kinds of chunk reduce to "base + per-row offset" so the loads themselves are branch-free.
       // Phase rows are contiguous in frames, so a lane fetches 4 columns at once (16-byte loads at
       // 4-byte alignment: tap offsets are arbitrary) -- 4 VMEM instructions per chunk instead of 16.
       // (a lane stages NSTG4 CONSECUTIVE k-rows of its 4 columns: they are neighbours in the K4 image)
-      const bool conv = c < p.nconv;
+      const bool conv = c >= ncc;
+      const int cc = c - ncc;           // conv chunk: channels (cc % 4)*64.. of tap cc / 4
       const float* base = conv ? hb4 : sb4;
-      const int tapc = tap0 + (int)(c >= 4) * (tap1 - tap0) + (int)(c >= 8) * (tap2 - tap1) + lane_q;
+      const int tapc = tap0 + (int)(cc >= 4) * (tap1 - tap0) + (int)(cc >= 8) * (tap2 - tap1) + lane_q;
       int off[NSTG4];
 #pragma unroll
       for (int jj = 0; jj < NSTG4; ++jj) {
         const int r0 = w * 16 + NSTG4 * srow4 + jj;
         // folded conditioning rows r = j*80 + m' <- mel[m'][q - j]; rows past kc (K padding) meet zero weights
-        const int r = min((c - p.nconv) * 64 + r0, p.kc - 1);
+        const int r = min(c * 64 + r0, p.kc - 1);
         const int j = r / NMEL, m = r - j * NMEL;
-        // conv rows: channel (c % 4)*64 + r0 of tap c / 4; the folded first layer's only conv chunk has its offsets in first_off[]
-        const int conv_off = first0 ? first_off[jj] : ((c & 3) * 64 + r0) * p.Lp + tapc;
+        // conv rows: channel (cc % 4)*64 + r0 of tap cc / 4; the folded first layer's only conv chunk: row r0 = 8*tap + ch of
+        // p.xa (rows >= 24 meet zero weights)
+        const int tp = min(r0 >> 3, 2);
+        const int conv_off = folded_first ? (r0 & 7) * p.Lp + (tp == 0 ? tap0 : tp == 1 ? tap1 : tap2) + lane_q
+                                          : ((cc & 3) * 64 + r0) * p.Lp + tapc;
         off[jj] = conv ? conv_off : m * p.Tqp - j;
       }
 #pragma unroll
@@ -574,8 +573,8 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   // A operand of k-group gg (PM: the convolution image, then this phase's conditioning image)
   auto load_a1 = [&](float4 (&a)[4], const float4* ap_, int gg) __attribute__((always_inline)) {
     if constexpr (PM) {
-      const int ngh = 8 * p.nconv;
-      const float4* src = gg < ngh ? ap_ + (size_t)gg * 1024 : wave_c_ptr + (size_t)(gg - ngh) * 1024;
+      const int ngc8 = 8 * ncc;
+      const float4* src = gg < ngc8 ? wave_c_ptr + (size_t)gg * 1024 : ap_ + (size_t)(gg - ngc8) * 1024;
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) a[rb] = src[rb * 64];
     } else {
@@ -608,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
   constexpr int CPI = RING == 3 ? 3 : 1;   // chunks per unrolled iteration
   const float4* ap = wave_a_ptr;
   float4 ar[RING][4];
-  stage_load(0, folded_first);
+  stage_load(0);
 #pragma unroll
   for (int i = 0; i < RING - 1; ++i) load_a1(ar[i], ap, i);
   stage_write(0);
@@ -950,28 +949,26 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
   const float4* wave_a = p.w1 + (wq * 4 + sub) * 64 + lane;
   const float4* wave_c = p.wc + (size_t)ph * p.ngc * 1024 + (wq * 4 + sub) * 64 + lane;
   const int nch = pm_chunks(p, ph);
+  const int ncc = nch - p.nconv;   // the conditioning chunks come first (see k_wn_layer)
   constexpr int F4R = TNt / 4, RPL4 = 64 / F4R, NSTG4 = 8 / RPL4;
   const int srow4 = lane / F4R, scol4 = (lane % F4R) * 4;
   const bool folded_first = EF && p.nconv == 1;
   const float* hb4 = folded_first ? p.xa + (size_t)b * 8 * p.Lp : p.h_in + (size_t)b * C * p.Lp;
   const float* sb4 = p.melp + (size_t)b * NMEL * p.Tqp + in_off - ph * p.Tqp;
-  int first_off[NSTG4];   // folded first layer: conv row r0 = 8*tap + ch of p.xa
-#pragma unroll
-  for (int jj = 0; jj < NSTG4; ++jj) {
-    const int r0 = w8 * 8 + NSTG4 * srow4 + jj, tp = min(r0 >> 3, 2);
-    first_off[jj] = (r0 & 7) * p.Lp + (tp == 0 ? tap0 : tp == 1 ? tap1 : tap2) + lane_q;
-  }
   float4 stg[NSTG4];
-  auto stage_load = [&](int c, bool first0 = false) __attribute__((always_inline)) {   // first0: see k_wn_layer
-    const bool conv = c < p.nconv;
+  auto stage_load = [&](int c) __attribute__((always_inline)) {
+    const bool conv = c >= ncc;
+    const int cc = c - ncc;
     const float* base = conv ? hb4 : sb4;
-    const int tapc = tap0 + (int)(c >= 4) * (tap1 - tap0) + (int)(c >= 8) * (tap2 - tap1) + lane_q;
+    const int tapc = tap0 + (int)(cc >= 4) * (tap1 - tap0) + (int)(cc >= 8) * (tap2 - tap1) + lane_q;
 #pragma unroll
     for (int jj = 0; jj < NSTG4; ++jj) {
       const int r0 = w8 * 8 + NSTG4 * srow4 + jj;   // consecutive k-rows per lane: neighbours in the K4 image (see load_b)
-      const int r = min((c - p.nconv) * 64 + r0, p.kc - 1);
+      const int r = min(c * 64 + r0, p.kc - 1);
       const int j = r / NMEL, m = r - j * NMEL;
-      const int conv_off = first0 ? first_off[jj] : ((c & 3) * 64 + r0) * p.Lp + tapc;
+      const int tp = min(r0 >> 3, 2);               // folded first layer: conv row r0 = 8*tap + ch of p.xa
+      const int conv_off = folded_first ? (r0 & 7) * p.Lp + (tp == 0 ? tap0 : tp == 1 ? tap1 : tap2) + lane_q
+                                        : ((cc & 3) * 64 + r0) * p.Lp + tapc;
       const int off = conv ? conv_off : m * p.Tqp - j;
       const f4u v = *reinterpret_cast<const f4u*>(base + off);
       stg[jj] = make_float4(v.x, v.y, v.z, v.w);
@@ -992,8 +989,8 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
     }
   };
   auto load_a1 = [&](float4 (&a)[2], int gg) __attribute__((always_inline)) {
-    const int ngh = 8 * p.nconv;
-    const float4* src = gg < ngh ? wave_a + (size_t)gg * 1024 : wave_c + (size_t)(gg - ngh) * 1024;
+    const int ngc8 = 8 * ncc;
+    const float4* src = gg < ngc8 ? wave_c + (size_t)gg * 1024 : wave_a + (size_t)(gg - ngc8) * 1024;
     a[0] = src[0];
     a[1] = src[128];
   };
@@ -1010,7 +1007,7 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
   };
   constexpr int RING = 4;
   float4 ar[RING][2];
-  stage_load(0, folded_first);
+  stage_load(0);
 #pragma unroll
   for (int i = 0; i < RING - 1; ++i) load_a1(ar[i], i);
   // accumulators start at the bias; loaded behind the first operand loads so the prologue is one memory round trip, not two
@@ -1243,7 +1240,7 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
   f32x4 acc[4];
   const float4* wave_a = p.w1 + (w8 * 4) * 64 + lane;                                    // + g16 * 2048 + rbl * 64
   const float4* wave_c = p.wc + (size_t)ph * (p.ngc / 2) * 2048 + (w8 * 4) * 64 + lane;   // ngc counts 8-wide groups
-  const int nch = pm_chunks(p, ph), NGH16 = p.nconv * 4;
+  const int nch = pm_chunks(p, ph), ncc = nch - p.nconv, NGC16 = ncc * 4;   // the conditioning chunks come first (see k_wn_layer)
   // staging: a chunk is 64 k-rows x 16 frames = 1024 floats, two per thread
   const int srow = tid >> 3, scol = (tid & 7) * 2;
   const bool folded_first = EF && p.nconv == 1;
@@ -1252,11 +1249,12 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
   typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
   float2 stg;
   auto stage_load = [&](int c) __attribute__((always_inline)) {
-    const bool conv = c < p.nconv;
-    const int r = min((c - p.nconv) * 64 + srow, p.kc - 1);
+    const bool conv = c >= ncc;
+    const int cc = c - ncc;
+    const int r = min(c * 64 + srow, p.kc - 1);
     const int j = r / NMEL, m = r - j * NMEL;
-    const int tp = folded_first ? min(srow >> 3, 2) : c >> 2;
-    const int chn = folded_first ? (srow & 7) : (c & 3) * 64 + srow;
+    const int tp = folded_first ? min(srow >> 3, 2) : cc >> 2;
+    const int chn = folded_first ? (srow & 7) : (cc & 3) * 64 + srow;
     const float* src = conv ? hb + (size_t)chn * p.Lp + (tp == 0 ? tapo[0] : tp == 1 ? tapo[1] : tapo[2])
                             : sb + m * p.Tqp - j;
     const f2u v = *reinterpret_cast<const f2u*>(src);
@@ -1264,7 +1262,7 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
   };
   auto stage_write = [&](int buf) __attribute__((always_inline)) { *reinterpret_cast<float2*>(smem + buf * (KCH * TN16) + srow * TN16 + scol) = stg; };
   auto load_a = [&](float4 (&a)[4], int gg) __attribute__((always_inline)) {   // gg = 16-wide K group over [conv | cond]
-    const float4* src = gg < NGH16 ? wave_a + (size_t)gg * 2048 : wave_c + (size_t)(gg - NGH16) * 2048;
+    const float4* src = gg < NGC16 ? wave_c + (size_t)gg * 2048 : wave_a + (size_t)(gg - NGC16) * 2048;
 #pragma unroll
     for (int rbl = 0; rbl < 4; ++rbl) a[rbl] = src[rbl * 64];
   };
@@ -2037,7 +2035,7 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   h->nj = (cfg->upsample_kernel + cfg->hop_length - 1) / cfg->hop_length;
   h->kc = h->nj * NMEL;
   h->kcp = round_up(h->kc, KCH);
-  const size_t w1pm_bytes = (size_t)NGH * 1024 * sizeof(float4);
+  const size_t w1pm_bytes = (size_t)(NGH + 8) * 1024 * sizeof(float4);   // + the A ring's look-ahead past the last K group
   const size_t wcpm_bytes = ((size_t)h->P * (h->kcp / 8) + 8) * 1024 * sizeof(float4);   // + RING look-ahead past the last phase
   const size_t o_up_w = take(nm * nm * cfg->upsample_kernel * 4), o_up_b = take(nm * 4);
   for (int k = 0; k < cfg->n_flows; ++k) {
@@ -2056,7 +2054,7 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
       fo[k].w2r_16[i] = last ? 0 : take((size_t)(C / 16 + 4) * 16 * 64 * sizeof(float4));
     }
     fo[k].endb = take(8 * 4);
-    fo[k].w1f = take((size_t)8 * 1024 * sizeof(float4)); fo[k].w1f_16 = take((size_t)4 * 2048 * sizeof(float4));
+    fo[k].w1f = take((size_t)(8 + 8) * 1024 * sizeof(float4)); fo[k].w1f_16 = take((size_t)(4 + 4) * 2048 * sizeof(float4));   // + look-ahead
     fo[k].end_w = take(cc * C * 4); fo[k].end_b = take(cc * 4); fo[k].winv = take(cc * cc * 4); fo[k].wfwd = take(cc * cc * 4);
   }
   h->arena_bytes = off;
@@ -2274,9 +2272,21 @@ extern "C" int facppg_debug_wn8_prof(unsigned long long* out8, int reset) {
 }
 #endif
 
+// enable: 0 off, 1 the launches of the most recent infer, n > 1 accumulate over the next n infers (the events of n
+// infers are created HERE, so that none is created inside a timed region)
 extern "C" int facppg_wg_set_profiling(facppg_wg* h, int enable) {
-  FACPPG_REQUIRE(h, FACPPG_EINVAL, "handle is NULL");
-  h->profiling = enable ? 1 : 0;
+  FACPPG_REQUIRE(h && enable >= 0, FACPPG_EINVAL, "handle is NULL or enable < 0");
+  h->profiling = enable;
+  h->ev_used = 0;
+  if (enable > 1) {
+    FACPPG_HIP_CHECK(hipSetDevice(h->device));
+    const size_t need = (size_t)enable * 2 * h->cfg.n_flows * h->cfg.wn_layers;
+    while (h->ev.size() < need) {
+      hipEvent_t ev;
+      FACPPG_HIP_CHECK(hipEventCreate(&ev));
+      h->ev.push_back(ev);
+    }
+  }
   return FACPPG_OK;
 }
 
@@ -2369,15 +2379,15 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
     }
   }
   size_t z_off = (size_t)B * h->n_rem[nf - 1] * w.L;
+  if (h->profiling <= 1) h->ev_used = 0;   // (> 1: the launches of several infers accumulate, facppg_wg_set_profiling)
   if (h->profiling) {
-    const size_t need = (size_t)2 * nf * c.wn_layers;
+    const size_t need = (size_t)h->ev_used + (size_t)2 * nf * c.wn_layers;
     while (h->ev.size() < need) {
       hipEvent_t ev;
       FACPPG_HIP_CHECK(hipEventCreate(&ev));
       h->ev.push_back(ev);
     }
   }
-  h->ev_used = 0;
   // Tile width.  A launch runs in rounds of 512 workgroup slots (2 per CU); measured per-round times in microseconds for
   // a full round / a round that leaves every CU at most one workgroup: 64-frame tiles (4 waves, k_wn_layer) 331 / 185,
   // 32-frame tiles (8 waves, k_wn_layer8) 181 / 94, 16-frame tiles (k_wn_layer16) FACPPG_COST16_*.  Pick the cheapest.
@@ -2563,15 +2573,15 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
     }
   }
   size_t z_off = (size_t)B * h->n_rem[nf - 1] * w.L;
+  if (h->profiling <= 1) h->ev_used = 0;   // (> 1: the launches of several infers accumulate, facppg_wg_set_profiling)
   if (h->profiling) {
-    const size_t need = (size_t)2 * nf * c.wn_layers;
+    const size_t need = (size_t)h->ev_used + (size_t)2 * nf * c.wn_layers;
     while (h->ev.size() < need) {
       hipEvent_t ev;
       FACPPG_HIP_CHECK(hipEventCreate(&ev));
       h->ev.push_back(ev);
     }
   }
-  h->ev_used = 0;
   // tile width: 64 positions per workgroup for throughput; 32 when the launch would not fill
   // the chip's 512 workgroup slots 1.5 times (single short utterances), halving the per-layer latency
   const bool narrow = (long)(w.Lr / TN) * B < 768;

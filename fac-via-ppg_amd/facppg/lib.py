@@ -191,3 +191,27 @@ def upload(values, dtype, device):
 
 def current_stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class WeightIdentity(object):
+    """What a packed-weight handle was built from, cheap to re-check on every call: the identity of every parameter, buffer
+    AND submodule of ``module`` (re-assigning a Parameter, or replacing a submodule -- ``model.WN[k] = ...`` --, changes an
+    id in its parent's dict), and per tensor its in-place version (optimizer steps, any in-place op) and its storage address
+    (``p.data = other`` keeps both the id and the version: EMA swaps and the like).  The module tree is walked once; a check
+    reads the live dicts' values, and the versions / addresses of the cached flat tensor list only while the ids still match."""
+
+    def __init__(self, module):
+        self.dicts = [d for m in module.modules() for d in (m._parameters, m._buffers, m._modules)]
+        self.ids = self._ids()
+        self.tensors = [v for d in self.dicts for v in d.values() if torch.is_tensor(v)]
+        self.state = self._state()
+
+    def _ids(self):
+        return tuple(id(v) for d in self.dicts for v in d.values())
+
+    def _state(self):
+        return tuple(t._version for t in self.tensors), tuple(t.data_ptr() for t in self.tensors)
+
+    def unchanged(self):
+        return self._ids() == self.ids and self._state() == self.state
+

@@ -719,25 +719,10 @@ class WaveGlow(torch.nn.Module):
         return torch.cat([p.detach().float().reshape(-1) for p in parts])
 
     def _release(self):
-        self.__dict__.pop("_facppg_dicts", None)      # (the module tree may be about to change: re-collected with the next handle)
         h = self.__dict__.pop("_facppg_handle", None)
         if h is not None:
             _lib.load().facppg_wg_destroy(h[0])
         self.__dict__.pop("_facppg_ws", None)
-
-    def _fingerprint(self):
-        """Identity + in-place version of every tensor the packed handle was built from: optimizer steps and any
-        in-place op on a parameter bump ``_version``, re-assigning a Parameter changes its identity.  Writes through the
-        ``.data`` alias bypass autograd's version counter by design and cannot be seen here; the handle is therefore
-        also dropped on every ``train()`` / ``eval()`` switch and gradient-enabled forward, and
-        ``invalidate_packed_weights()`` is there for code that pokes ``.data`` within one mode.
-        Reads the submodules' live parameter / buffer dicts (no state_dict, no key strings, no data_ptr calls): this
-        runs on every infer()."""
-        dicts = self.__dict__.get("_facppg_dicts")
-        if dicts is None:       # the live _parameters / _buffers dicts of every submodule, collected once per handle
-            dicts = [d for m in self.modules() for d in (m._parameters, m._buffers)]
-            self.__dict__["_facppg_dicts"] = dicts
-        return tuple((id(t), t._version) for d in dicts for t in d.values() if t is not None)
 
     def last_launch_shape(self):
         """(frames per tile, waves per workgroup, workgroups per launch) of the WN-layer kernels of the most recent
@@ -760,7 +745,7 @@ class WaveGlow(torch.nn.Module):
 
     def _handle(self, device):
         h = self.__dict__.get("_facppg_handle")
-        if h is not None and h[1] == device and h[2] == self._fingerprint():
+        if h is not None and h[1] == device and h[2].unchanged():
             return h[0]
         self._release()
         L = _lib.load()
@@ -773,7 +758,7 @@ class WaveGlow(torch.nn.Module):
         with torch.cuda.device(device):
             _lib.check(L.facppg_wg_create(cfg, _lib.ptr(blob), blob.numel(), device.index,
                                           _lib.current_stream(device), _lib.ctypes.byref(out)))
-        self.__dict__["_facppg_handle"] = (out, device, self._fingerprint())
+        self.__dict__["_facppg_handle"] = (out, device, _lib.WeightIdentity(self))
         return out
 
     def _apply(self, fn, *a, **k):                       # .cuda()/.to()/.float(): weights moved
@@ -787,7 +772,6 @@ class WaveGlow(torch.nn.Module):
     def __getstate__(self):                              # never pickle device handles
         d = dict(self.__dict__)
         d.pop("_facppg_handle", None)
-        d.pop("_facppg_dicts", None)
         d.pop("_facppg_ws", None)
         return d
 
@@ -994,8 +978,8 @@ class WaveGlow(torch.nn.Module):
             out[:, :Tg * hop].index_copy_(0, it, a)
         return out
 
-    def _infer_workspace(self, B, T, dev, slot):
-        nbytes = _lib.load().facppg_wg_workspace_bytes(self._handle(dev), B, T)
+    def _infer_workspace(self, B, T, dev, slot, handle=None):
+        nbytes = _lib.load().facppg_wg_workspace_bytes(handle if handle is not None else self._handle(dev), B, T)
         wss = self.__dict__.setdefault("_facppg_ws", {})
         ws = wss.get(slot)
         if ws is None or ws.numel() < nbytes or ws.device != dev:
@@ -1003,12 +987,12 @@ class WaveGlow(torch.nn.Module):
             wss[slot] = ws
         return ws
 
-    def _infer_launch(self, spect, lt, zt, seed, sigma, audio, ws):
+    def _infer_launch(self, spect, lt, zt, seed, sigma, audio, ws, handle=None):
         """The launch sequence of one batch on the current stream; no host-side waits."""
         dev = spect.device
         B, _, T = spect.shape
         with torch.cuda.device(dev):
-            _lib.check(_lib.load().facppg_wg_infer(self._handle(dev), _lib.ptr(spect), _lib.ptr(lt), _lib.ptr(zt),
+            _lib.check(_lib.load().facppg_wg_infer(handle if handle is not None else self._handle(dev), _lib.ptr(spect), _lib.ptr(lt), _lib.ptr(zt),
                                                    seed & 0xFFFFFFFFFFFFFFFF, float(sigma), B, T, _lib.ptr(audio),
                                                    _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)))
 
@@ -1016,7 +1000,8 @@ class WaveGlow(torch.nn.Module):
         """mel [B, n_mel, T] (GPU, fp32) -> audio [B, T*hop]   (glow.py:252-293).
         groups: None = decide from the launch shape (ragged batches whose layer launches would idle through >= 3 % of their
         time in the last round run as two concurrent half-batches, see _infer_two_groups), 1 = one launch sequence, 2 = force
-        the two half-batches (needs host-side lengths).  With `seed` alone the noise is a function of (seed, batch layout)."""
+        the two half-batches (needs host-side lengths).  With `seed` alone the noise of a uniform batch is a function of (seed, batch
+        layout); a ragged batch with host-side lengths draws per-utterance streams derived from (seed, b), identical in both modes."""
         _lib.require_cuda(spect, "WaveGlow.infer: spect")
         if spect.dtype != torch.float32:
             raise _lib.FacppgError("WaveGlow.infer: fp32 only (the reference's fp16 branch is not built)")
@@ -1044,6 +1029,11 @@ class WaveGlow(torch.nn.Module):
                     zt.numel(), B * self.n_group * (T * hop // self.n_group)))
         if seed is None:
             seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        if utterance_seeds is None and zt is None and host_lengths and B >= 2:
+            # `seed` alone on a ragged batch: give every utterance its own stream derived from (seed, b), so that the noise --
+            # and the audio -- do not depend on whether the launch-shape heuristic above picks one launch sequence or two
+            # half-batches (whose batch layouts differ)
+            utterance_seeds = [(int(seed) * 0x9E3779B97F4A7C15 + (b + 1) * 0xBF58476D1CE4E5B9) & 0x7FFFFFFFFFFFFFFF for b in range(B)]
         if groups == 2:
             return self._infer_two_groups(spect, sigma, zt, lengths, seed, utterance_seeds)
         if utterance_seeds is not None:
@@ -1058,7 +1048,8 @@ class WaveGlow(torch.nn.Module):
                     raise _lib.FacppgError("lengths must be B values in [1, T]")
         audio = torch.zeros(B, T * hop, dtype=torch.float32, device=dev) if lt is not None else \
             torch.empty(B, T * hop, dtype=torch.float32, device=dev)
-        self._infer_launch(spect, lt, zt, seed, sigma, audio, self._infer_workspace(B, T, dev, 0))
+        h = self._handle(dev)           # (ONE validity check of the packed weights per call: it walks ~1000 tensors)
+        self._infer_launch(spect, lt, zt, seed, sigma, audio, self._infer_workspace(B, T, dev, 0, h), h)
         return audio
 
     @staticmethod

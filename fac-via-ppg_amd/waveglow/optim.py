@@ -28,11 +28,13 @@ class Adam(torch.optim.Adam):
     # ---- launch plan of one parameter group
     def _plan(self, gi, group):
         params = group["params"]
-        key = tuple(id(p.grad) for p in params)
+        # keyed on the gradients' ADDRESSES (what the table holds): id(p.grad) can be reused by a new tensor elsewhere
+        key = tuple(p.grad.data_ptr() for p in params)
         plan = self._hip.get(gi)
         if plan is not None and plan["key"] == key:
             return plan
-        if torch.cuda.is_current_stream_capturing() and plan is None:
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing and plan is None:
             raise RuntimeError("waveglow.optim.Adam: take one ordinary step before capturing (the launch plan uploads tables)")
         L = _lib.load()
         dev = params[0].device
@@ -51,15 +53,42 @@ class Adam(torch.optim.Adam):
                 chunks[o:o + c, 0] = i
                 chunks[o:o + c, 1] = np.arange(c)
                 o += c
-            plan = {"step": step, "chunks": torch.from_numpy(chunks).to(dev), "n_chunks": int(chunks.shape[0]),
-                    "host": torch.empty(len(params), 5, dtype=torch.int64).pin_memory(), "table": torch.empty(len(params), 5, dtype=torch.int64, device=dev)}
-            h = plan["host"]
+            base = torch.empty(len(params), 5, dtype=torch.int64)
             for i, (p, st) in enumerate(zip(params, states)):
-                h[i, 0], h[i, 2], h[i, 3], h[i, 4] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+                base[i, 0], base[i, 1], base[i, 2], base[i, 3], base[i, 4] = p.data_ptr(), 0, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+            plan = {"step": step, "chunks": torch.from_numpy(chunks).to(dev), "n_chunks": int(chunks.shape[0]), "base": base,
+                    "slots": [], "next": 0, "table": torch.empty(len(params), 5, dtype=torch.int64, device=dev)}
             self._hip[gi] = plan
-        h = plan["host"]
-        h[:, 1] = torch.tensor([p.grad.data_ptr() for p in params], dtype=torch.int64)
+        # The table is uploaded from PINNED host memory with an asynchronous copy, so a host buffer must not be rewritten
+        # while an earlier upload may still be reading it (a caller that does not synchronise every step: eager steps with
+        # zero_grad(set_to_none=True) change the gradient addresses every step), and never once a captured graph has baked
+        # a copy node that re-reads it at every replay.  Eager steps rotate two staging buffers, each guarded by an event
+        # recorded behind its last upload; a capture takes a buffer of its own (allocated with the plan, i.e. before any
+        # capture: nothing may be synchronised and nothing should be allocated while a stream is capturing), which then
+        # belongs to that graph for good.
+        def staging():
+            return torch.empty(len(params), 5, dtype=torch.int64).pin_memory()
+        if "slots" not in plan or not plan["slots"]:
+            plan["slots"] = [{"host": staging(), "event": None}, {"host": staging(), "event": None}]
+            plan["capture_host"] = staging()
+        if capturing:
+            h = plan["capture_host"] if plan["capture_host"] is not None else staging()
+            plan["capture_host"] = None
+            plan.setdefault("captured_hosts", []).append(h)     # the graph's copy node reads this buffer at every replay
+        else:
+            slot = plan["slots"][plan["next"] % 2]
+            plan["next"] += 1
+            if slot["event"] is not None:
+                slot["event"].synchronize()
+            h = slot["host"]
+        h.copy_(plan["base"])
+        h[:, 1] = torch.tensor(key, dtype=torch.int64)
         plan["table"].copy_(h, non_blocking=True)
+        if not capturing:
+            slot["event"] = torch.cuda.Event()
+            slot["event"].record(torch.cuda.current_stream(dev))
+            if plan["capture_host"] is None:
+                plan["capture_host"] = staging()                # for the next capture
         plan["key"] = key
         return plan
 

@@ -244,7 +244,9 @@ int facppg_upsample_regroup_backward(const float* mel_dev, const float* dspect_p
 
 /* Average device time (ms) of the dominant kernel (the fused WN layer) over the launches of
  * the most recent facppg_wg_infer on this handle, measured with hipEvents on the stream the
- * kernels ran on when profiling was enabled with facppg_wg_set_profiling(h, 1).  Synchronises
+ * kernels ran on when profiling was enabled with facppg_wg_set_profiling(h, 1).  enable = n > 1 accumulates
+ * over the next n facppg_wg_infer calls instead (their events are created by the set_profiling call itself, so
+ * that a timed region creates none); any set_profiling call starts a new accumulation.  Synchronises
  * the recorded events.  *n_launches receives the number of launches averaged. */
 int facppg_wg_set_profiling(facppg_wg* h, int enable);
 int facppg_wg_last_layer_ms(facppg_wg* h, float* avg_ms, int* n_launches);

@@ -182,6 +182,25 @@ def gen_waveglow():
                  out_1=den_out_strong)
 
 
+def gen_denoiser_hop256():
+    """Denoiser at the metric's rate (hop 256 / 22.05 kHz, what bench.py's end-to-end figures build): the bias spectrum
+    of the hop-256 model (denoiser.py:44-61) and the spectral subtraction of a hop-256 utterance (denoiser.py:63-68)."""
+    from waveglow.denoiser import Denoiser
+    hop, B, T = 256, 2, 14
+    cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=hop)
+    m = ref_waveglow(cfg)
+    mel = synth.synthetic_mel(B, T, seed=4242)
+    zs = synth.synthetic_z(B, T * hop // 8, cfg, seed=2424)
+    with torch.no_grad(), InjectNormal(zs):
+        audio = m.infer(mel, sigma=0.6)
+    den = Denoiser(m, filter_length=1024, hop_length=hop, win_length=1024, mode="zeros")
+    with torch.no_grad():
+        out_0005 = den(audio, strength=0.005)
+        out_1 = den(audio, strength=1.0)
+    save("denoiser_hop256.npz", hop=hop, B=B, T=T, mel_seed=4242, z_seed=2424, bias_spec=den.bias_spec, audio_in=audio,
+         out_0005=out_0005, out_1=out_1)
+
+
 def gen_stft():
     from common.stft import STFT
     from common.layers import TacotronSTFT
@@ -376,6 +395,7 @@ def main():
     gen_masks()
     gen_stft()
     gen_waveglow()
+    gen_denoiser_hop256()
     gen_waveglow_old()
     gen_waveglow_train()
     gen_tacotron()
@@ -384,4 +404,11 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:           # python make_golden.py gen_denoiser_hop256 ...: only the named generators
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        install_shims()
+        for name in sys.argv[1:]:
+            globals()[name]()
+    else:
+        main()

@@ -84,6 +84,28 @@ def test_denoiser_golden():
         Denoiser(_wg(), mode="bogus")
 
 
+def test_denoiser_hop256_golden():
+    """Denoiser(hop_length=256) -- what bench.py's end-to-end figures and the 22.05 kHz metric use -- vs the reference's own
+    hop-256 denoiser on the hop-256 model: bias spectrum and both strengths."""
+    from waveglow.denoiser import Denoiser
+    from waveglow.glow import WaveGlow
+    d = golden("denoiser_hop256.npz")
+    hop = int(d["hop"])
+    cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=hop)
+    m = WaveGlow.remove_weightnorm(WaveGlow(**cfg))
+    m.load_state_dict(synth.waveglow_state_dict(cfg))
+    den = Denoiser(m.cuda().eval(), filter_length=1024, hop_length=hop, win_length=1024, mode="zeros")
+    assert den.bias_spec.shape == (1, 513, 1)
+    assert np.abs(den.bias_spec.cpu().numpy() - d["bias_spec"]).max() < 1e-3 * max(1.0, np.abs(d["bias_spec"]).max())
+    x = torch.from_numpy(d["audio_in"]).cuda()
+    for strength, key in ((0.005, "out_0005"), (1.0, "out_1")):
+        out = den(x, strength=strength)
+        assert out.shape == d[key].shape
+        e = out.cpu().numpy() - d[key]
+        print("denoiser hop 256, strength", strength, "rms err", rms(e), "max", np.abs(e).max())
+        assert rms(e) <= 1e-3 and np.abs(e).max() <= 1e-3
+
+
 def test_denoiser_ragged_batch_equals_single_runs():
     from waveglow.denoiser import Denoiser
     den = Denoiser(_wg(), mode="zeros")

@@ -1,6 +1,8 @@
 """GPU: end-to-end PPG -> mel -> wav (BASELINE configs 1 and 3) through the drop-in surface:
 the generate_synthesis CLI on synthetic checkpoints, and the batched pipeline with injected
 dropout masks / z against the CPU oracle of the whole path."""
+import contextlib
+import io
 import os
 
 import numpy as np
@@ -343,6 +345,66 @@ def test_pipeline_matches_oracle_and_batches_equal_singles(checkpoints):
             ref = oden(owg.infer(wsd, cfg, mel_post, 0.6, zb), 0.01)[0, 0].numpy()
         e = wavs[b] - ref
         print("utt %d: Tout %d, wav rms err %.2e (rms ref %.3f)" % (b, tout[b], rms(e), rms(ref)))
+        assert rms(e) <= 1e-3
+
+
+def test_hop256_whole_path_matches_oracle():
+    """The configuration the metric is quoted on -- hop 256 / 22.05 kHz, PPG -> Tacotron2 -> WaveGlow(hop 256) ->
+    Denoiser(hop_length=256), exactly the models bench.py's EndToEnd builds (gate bias -10, max_decoder_steps = Tin_i as in
+    SURVEY.md 8d config 3) -- against the oracle of the WHOLE path (oracle.tacotron + oracle.waveglow +
+    DenoiserOracle(hop_length=256)) on three ragged utterances with injected dropout masks and noise: same number of frames,
+    N = Tout * hop exactly, waveform RMS <= 1e-3; the batch equals its single runs bit for bit."""
+    from common.hparams import create_hparams_stage
+    from facppg import pipeline
+    from oracle import dsp, tacotron as otac, waveglow as owg
+    from script.train_ppg2mel import load_model
+    from waveglow.denoiser import Denoiser
+    from waveglow.glow import WaveGlow
+    hop = 256
+    lens = [31, 18, 26]
+    steps = max(lens)
+    hp = create_hparams_stage(max_decoder_steps=steps)
+    tsd = synth.tacotron_state_dict(hp, gate_bias=-10.0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        taco = load_model(hp)
+    taco.load_state_dict(tsd)
+    taco.eval()
+    cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=hop)
+    wsd = synth.waveglow_state_dict(cfg)
+    wg = WaveGlow.remove_weightnorm(WaveGlow(**cfg))
+    wg.load_state_dict(wsd)
+    wg = wg.cuda().eval()
+    den = Denoiser(wg, hop_length=hop, mode="zeros")          # as bench.py's EndToEnd does
+    ppgs = [synth.synthetic_ppg(n, 5816, seed=160 + i, alpha=0.002) for i, n in enumerate(lens)]
+    B, Tin, P = len(lens), max(lens), hop // 8
+    em = masks_from_seed(15, (2, B, Tin, 600))
+    dm = masks_from_seed(16, (steps, 2, B, 300))
+    zs = synth.synthetic_z(B, steps * P, cfg, seed=177)
+    with contextlib.redirect_stdout(io.StringIO()):          # "Warning! Reached max decoder steps" (model.py:527)
+        wavs, tout = pipeline.synthesize(ppgs, taco, wg, den, sigma=0.6, strength=0.005, dropout_masks=(em, dm), z=zs, step_limits=lens)
+    assert tout == lens and [len(w) for w in wavs] == [t * hop for t in tout]      # N = Tout * hop exactly
+    nb = 88 * P
+    with torch.no_grad():
+        bias = owg.infer(wsd, cfg, torch.zeros(1, 80, 88), 0.0, [torch.zeros(1, 4, nb), torch.zeros(1, 2, nb), torch.zeros(1, 2, nb)])
+    oden = dsp.DenoiserOracle(bias, hop_length=hop)
+    assert np.abs(den.bias_spec.cpu().numpy() - oden.bias_spec.numpy()).max() < 1e-3
+    for b, n in enumerate(lens):
+        emb, dmb = em[:, b:b + 1, :n], dm[:n, :, b:b + 1]
+        zb = [z[b:b + 1, :, :n * P].contiguous() for z in zs]
+        hp_n = create_hparams_stage(max_decoder_steps=n)
+        with contextlib.redirect_stdout(io.StringIO()):
+            taco.decoder.max_decoder_steps = n
+            single, t1 = pipeline.synthesize([ppgs[b]], taco, wg, den, sigma=0.6, strength=0.005, dropout_masks=(emb, dmb), z=zb)
+            taco.decoder.max_decoder_steps = steps
+            x = torch.from_numpy(ppgs[b]).t().unsqueeze(0)
+            mel, mel_post, gate, align = otac.inference(tsd, hp_n, x, torch.from_numpy(emb.astype(np.float32)),
+                                                        torch.from_numpy(dmb.astype(np.float32)))
+        assert t1 == [n] and np.array_equal(single[0], wavs[b])              # batch == independent run, bit-exact
+        assert mel_post.shape[2] == n
+        with torch.no_grad():
+            ref = oden(owg.infer(wsd, cfg, mel_post, 0.6, zb), 0.005)[0, 0].numpy()
+        e = wavs[b] - ref
+        print("hop 256 utt %d: Tout %d, wav rms err %.2e (rms ref %.3f)" % (b, tout[b], rms(e), rms(ref)))
         assert rms(e) <= 1e-3
 
 

@@ -82,6 +82,25 @@ def test_stft_mel_denoiser():
     assert np.abs(den(x, 1.0).numpy() - d["out_1"]).max() < 1e-5
 
 
+def test_denoiser_hop256():
+    """The denoiser at the metric's rate (hop 256 / 22.05 kHz): DenoiserOracle(hop_length=256) vs the reference's
+    Denoiser(hop_length=256) on the hop-256 model (tests/golden/make_golden.py gen_denoiser_hop256)."""
+    d = golden("denoiser_hop256.npz")
+    hop = int(d["hop"])
+    cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=hop)
+    sd = synth.waveglow_state_dict(cfg)
+    L = 88 * hop // 8
+    with torch.no_grad():
+        bias = owg.infer(sd, cfg, torch.zeros(1, 80, 88), 0.0,
+                         [torch.zeros(1, 4, L), torch.zeros(1, 2, L), torch.zeros(1, 2, L)])
+    den = dsp.DenoiserOracle(bias, hop_length=hop)
+    assert np.abs(den.bias_spec.numpy() - d["bias_spec"]).max() < 1e-4
+    x = torch.from_numpy(d["audio_in"])
+    assert x.shape == (int(d["B"]), int(d["T"]) * hop)
+    assert np.abs(den(x, 0.005).numpy() - d["out_0005"]).max() < 1e-5
+    assert np.abs(den(x, 1.0).numpy() - d["out_1"]).max() < 1e-5
+
+
 def test_attention_window_mask_bit_exact():
     d = golden("attn_masks.npz")
     cases = json.loads(bytes(d["cases"]).decode())

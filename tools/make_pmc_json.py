@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """profiles/rNN_pmc.json from the rocprofv3 PMC passes of tools/profile_bench.sh (run on the GPU box).
 
-  python tools/make_pmc_json.py <FETCH_SIZE results.db> <WRITE_SIZE results.db> <out.json> [build note]
+  python tools/make_pmc_json.py <FETCH_SIZE results.db> <WRITE_SIZE results.db> <out.json> [build note
+                                [<FETCH_SIZE results.db> <WRITE_SIZE results.db> of the batch-1 shape, B = 1 x 200 frames]]
 
 Per kernel family (k_wn_layer*, k_flow_end4): launches, average FETCH_SIZE / WRITE_SIZE (KiB, as rocprofv3 reports them)
 and HBM-side bytes per launch = 2 x FETCH (the gfx950 correction of MI355X_MICROARCH.md, HBM section: FETCH_SIZE tallies
@@ -41,13 +42,17 @@ def main():
     fetch, write = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
     positions = bench.BATCH * bench.FRAMES * bench.HOP // 8
     out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_bench.sh) -- "
-                     "python bench.py --no-cpu-baseline --no-e2e --no-train --steps 1 --warmup 0",
+                     "python bench.py --workload infer --no-cpu-baseline --steps 1 --warmup 0 (k_wn_layer_b1_t200: + --infer-batch 1 --infer-frames 200)",
            "correction": "gfx950 FETCH_SIZE reports 1/2 of coalesced reads (MI355X_MICROARCH.md, HBM section) -> fetch doubled; checked in "
                          "this same run on k_flow_end4, whose compulsory traffic is known (see its entry); Infinity-Cache hits are "
                          "included, so this is L2-miss traffic, an upper bound on HBM bytes"}
-    for key, prefix, algo in (("k_wn_layer", "void facppg::(anonymous namespace)::k_wn_layer", positions * 1984.0),
-                              ("k_flow_end4", "void facppg::(anonymous namespace)::k_flow_end4", None)):
-        f, w = family(fetch, prefix), family(write, prefix)
+    b1 = (per_kernel(sys.argv[5], "FETCH_SIZE"), per_kernel(sys.argv[6], "WRITE_SIZE")) if len(sys.argv) > 6 else None
+    wn = "void facppg::(anonymous namespace)::k_wn_layer"
+    entries = [("k_wn_layer", wn, positions * 1984.0, fetch, write), ("k_flow_end4", "void facppg::(anonymous namespace)::k_flow_end4", None, fetch, write)]
+    if b1 is not None:      # the metric's batch-1 utterance: python bench.py --workload infer --infer-batch 1 --infer-frames 200
+        entries.append(("k_wn_layer_b1_t200", wn, 200 * bench.HOP // 8 * 1984.0, b1[0], b1[1]))
+    for key, prefix, algo, ft, wt in entries:
+        f, w = family(ft, prefix), family(wt, prefix)
         if f is None or w is None:
             continue
         hbm = (2.0 * f["avg"] + w["avg"]) * 1024.0
