@@ -58,14 +58,20 @@ METRIC = "22.05 kHz audio samples/sec end-to-end PPG→wav; real-time factor at 
 WG_KERNEL_SOURCE = os.path.join(ROOT, "fac-via-ppg_amd", "csrc", "facppg_wg.hip")
 
 
-def kernel_source_id(path=WG_KERNEL_SOURCE):
-    """Identity of the WaveGlow kernel source a measurement belongs to: sha1 of the file with comments and blank
-    space removed.  profiles/rNN_pmc.json records it (tools/make_pmc_json.py); a PMC summary taken from another
-    build of the kernels is not quoted as this build's traffic."""
-    src = open(path).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    src = re.sub(r"//[^\n]*", "", src)
-    return hashlib.sha1(re.sub(r"\s+", "", src).encode()).hexdigest()[:16]
+def kernel_source_id(path=None):
+    """Identity of the WaveGlow kernel sources a measurement belongs to (csrc/facppg_wg.hip: one launch per layer;
+    csrc/facppg_wgp.hip: the persistent launch; their shared header): sha1 of the files with comments and blank space
+    removed.  profiles/rNN_pmc.json records it (tools/make_pmc_json.py); a PMC summary taken from another build of the
+    kernels is not quoted as this build's traffic."""
+    d = os.path.dirname(WG_KERNEL_SOURCE)
+    paths = [path] if path else [WG_KERNEL_SOURCE, os.path.join(d, "facppg_wgp.hip"), os.path.join(d, "facppg_wg_internal.h")]
+    h = hashlib.sha1()
+    for q in paths:
+        src = open(q).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = re.sub(r"//[^\n]*", "", src)
+        h.update(re.sub(r"\s+", "", src).encode())
+    return h.hexdigest()[:16]
 
 
 def layer_flops_per_position(n_layers=8, C=256, ncond=None, edge_fold=None, n_flows=12, n_early_every=4, n_early_size=2,

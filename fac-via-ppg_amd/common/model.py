@@ -248,10 +248,14 @@ class Tacotron2(nn.Module):
                                                   _lib.current_stream(dev)))
         return enc_m, dec_m
 
-    def inference(self, inputs, lengths=None, dropout_masks=None, seed=None, utterance_seeds=None, step_limits=None, timer=None):
+    def inference(self, inputs, lengths=None, dropout_masks=None, seed=None, utterance_seeds=None, step_limits=None, timer=None,
+                  while_decoding=None):
         """inputs [B, n_symbols, Tin] (GPU fp32) -> [mel, mel_post, gate, alignments]
         = [B,80,Tout], [B,80,Tout], [B,Tout,1], [B,Tout,Tin]  (model.py:597-610).  For B > 1 the
-        outputs are zero beyond each utterance's own Tout, kept in ``self.last_output_lengths``."""
+        outputs are zero beyond each utterance's own Tout, kept in ``self.last_output_lengths``.
+        while_decoding: optional callable run on the host after the decoder has been enqueued and before its output lengths
+        are read back (facppg.pipeline checks the vocoder's packed weights there: ~0.4 ms that would otherwise sit between the
+        acoustic model and the vocoder with the GPU idle)."""
         inputs = self.parse_input(inputs)
         _lib.require_cuda(inputs, "Tacotron2.inference: inputs")
         L = _lib.load()
@@ -308,6 +312,8 @@ class Tacotron2(nn.Module):
             _lib.check(L.facppg_taco_decode(h, _lib.ptr(memory), _lib.ptr(pm), _lib.ptr(lt), _lib.ptr(sl), _lib.ptr(dec_m), seed, B, Tin,
                                             steps, _lib.ptr(mel), _lib.ptr(gate), _lib.ptr(align), _lib.ptr(out_len),
                                             _lib.ptr(ws), ws.numel(), st))
+            if while_decoding is not None:                     # host work that needs no result of the decoder: the GPU is busy for
+                while_decoding()                               # milliseconds, the host would only sit in the read below
             out_len_host = out_len.cpu()                       # the path's single device->host sync
             if timer is not None:
                 timer.mark("decoder")

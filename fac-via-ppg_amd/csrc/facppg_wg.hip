@@ -30,6 +30,7 @@
 //                8-wave, 32-frame shape for launches smaller than the chip.
 //   k_flow_end   end 1x1 conv, affine-coupling inverse, inverse 1x1 conv, early-z concat, then
 //                either the next flow's start conv or the final group->time interleave.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -38,6 +39,7 @@
 #include <vector>
 
 #include "facppg_gemm.h"
+#include "facppg_wg_internal.h"
 
 namespace facppg {
 
@@ -51,16 +53,13 @@ void set_error(const char* fmt, ...) {
 
 namespace {
 
-constexpr int C = 256;        // WN channels (WN_config.n_channels)
 constexpr int TN = 64;        // positions per workgroup tile
 constexpr int HALO = 128;     // zero margin = max dilation 2^7
-constexpr int KCH = 64;       // K rows per LDS chunk
 constexpr int NCOND = 640;    // n_mel * n_group
 constexpr int K1 = 3 * C + NCOND;  // 1408
 constexpr int NG1 = K1 / 8;   // 176 k-groups of 8
 constexpr int NG2 = C / 8;    // 32
 constexpr int NCH1 = K1 / KCH;  // 22 chunks
-constexpr int MAXF = 32;      // max flows
 #ifndef FACPPG_COST16_FULL
 #define FACPPG_COST16_FULL 105   // microseconds per round of 16-frame tiles: full round / at most one workgroup per CU
 #define FACPPG_COST16_HALF 57
@@ -75,8 +74,6 @@ constexpr int MAXF = 32;      // max flows
 #define FACPPG_NARROW_RING 8  // weight prefetch depth (k-groups) of the 32-column tiles, see k_wn_layer
 #endif
 // phase-major ("folded conditioning") inference layout, see k_wn_layer<.., PM = true>
-constexpr int NMEL = 80;      // mel channels (NCOND / n_group)
-constexpr int HQ = 16;        // zero margin in frames on both sides of a phase row (>= 128 / (hop/8) + 1)
 constexpr int NGH = 3 * C / 8;   // 96 k-groups of the dilated convolution
 constexpr int NCHH = 3 * C / KCH;  // its 12 chunks
 
@@ -164,7 +161,6 @@ __global__ void k_pack_cond_pm(const float* __restrict__ F,   // [512][P*kcp] fo
 // meets the K entries in the same sequence as the 32x32x2 kernels do (0,4,1,5,2,6,3,7 within each group of 8):
 // a tile then gets the same bits from either kernel, and a batch equals its single runs whatever tile width
 // each launch picks.
-__device__ __forceinline__ int k16(int s, int kq) { return 8 * (s >> 1) + 2 * (s & 1) + (kq >> 1) + 4 * (kq & 1); }
 __device__ __forceinline__ int row16(int blk, int i) { return ((blk & 3) >> 1) * C + (blk >> 2) * 32 + (blk & 1) * 16 + i; }
 
 __global__ void k_pack_w1_16(const float* __restrict__ in_w, float4* __restrict__ out) {   // [512][256][3] -> K = 768
@@ -399,20 +395,6 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[4][NCB], const float4 (
       for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mfma32x32x2(av, bv[s][cb], acc[rb][cb]);
     }
   }
-}
-
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-// tanh(a) * sigmoid(b) with two hardware exponentials and one reciprocal:
-//   (1 - e^-2a) / ((1 + e^-2a) (1 + e^-b)).  tanh saturates to +-1 in fp32 beyond |a| > 9.02, so
-// clamping a to +-15 keeps e^-2a finite without changing the result; e^-b -> inf gives 0 as it must.
-// Relative error ~1e-6 (v_exp_f32 / v_rcp_f32 are 1-ulp), i.e. fp32-roundoff class for this path;
-// the libm tanhf/expf pair it replaces cost ~150 VALU instructions per element (16 % of the kernel).
-__device__ __forceinline__ float gate_tanh_sigmoid(float a, float b) {
-  const float ea = __expf(-2.0f * fminf(fmaxf(a, -15.0f), 15.0f));
-  const float eb = __expf(-b);
-  // v_rcp_f32 directly: hipcc expands __fdividef to the full IEEE division sequence (v_div_scale x2, v_div_fmas, v_div_fixup)
-  return (1.0f - ea) * __builtin_amdgcn_rcpf((1.0f + ea) * (1.0f + eb));
 }
 
 // PM = true is the phase-major inference variant.  The upsampling ConvTranspose1d (glow.py:253) is
@@ -1924,6 +1906,10 @@ __global__ __launch_bounds__(256) void k_fwd_flow_end(FwdArgs p) {
 }
 
 }  // namespace
+
+void wg_launch_noise(float* z, size_t n, uint64_t seed, hipStream_t s) {
+  k_noise<<<(unsigned)((n / 4 + 255) / 256 + 1), 256, 0, s>>>(z, n, seed);
+}
 }  // namespace facppg
 
 // ==========================================================================================
@@ -1931,34 +1917,6 @@ __global__ __launch_bounds__(256) void k_fwd_flow_end(FwdArgs p) {
 // ==========================================================================================
 using namespace facppg;
 
-struct facppg_wg {
-  facppg_wg_config cfg;
-  int device;
-  int n_rem[MAXF], n_half[MAXF], early[MAXF];
-  char* arena;  // one device allocation holding everything below
-  size_t arena_bytes;
-  float *up_w, *up_b;
-  float *start_w[MAXF], *start_b[MAXF], *end_w[MAXF], *end_b[MAXF], *winv[MAXF], *wfwd[MAXF];
-  float4* w1[MAXF][8];
-  float4* w2[MAXF][8];
-  float *b1[MAXF][8], *b2[MAXF][8];
-  // phase-major inference images (k_wn_layer<PM>): convolution part, folded conditioning per phase, folded bias
-  int P, nj, kc, kcp;
-  float4* w1pm[MAXF][8];
-  float4* wcpm[MAXF][8];
-  float* b1pm[MAXF][8];
-  float4 *w1_16[MAXF][8], *wc_16[MAXF][8], *w2_16[MAXF][8];   // the same weights as k_wn_layer16's 16x16x4 images
-  // folded flow edges (k_fold_end_rows / k_fold_first): end-row image per layer, folded end bias per flow, the first layer's
-  // folded tap image (both lane orders), res-rows-only images of the non-last res_skip convs (both lane orders)
-  float* we[MAXF][8];
-  float* endb[MAXF];
-  float4 *w1f[MAXF], *w1f_16[MAXF];
-  float4 *w2r[MAXF][8], *w2r_16[MAXF][8];
-  int profiling;
-  std::vector<hipEvent_t> ev;  // pairs around each k_wn_layer launch
-  int ev_used;
-  int last_tile, last_waves, last_tiles;   // shape of the WN layer launches of the most recent infer (facppg_wg_last_launch_shape)
-};
 
 extern "C" int facppg_version(void) { return FACPPG_VERSION; }
 extern "C" const char* facppg_last_error(void) { return g_err; }
@@ -2075,7 +2033,9 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
     delete h;
     return FACPPG_EHIP;
   }
-  auto fail = [&](int rc) { hipFree(tmp); hipFree(h->arena); delete h; return rc; };
+  h->wgp = nullptr;
+  auto fail = [&](int rc) { wgp_destroy(h); hipFree(tmp); hipFree(h->arena); delete h; return rc; };
+  if (int rc = wgp_create(h, h->arena, stream)) return fail(rc);   // the persistent small-launch path's own images (facppg_wgp.hip)
 #define WG_TRY(expr)                                                                     \
   do {                                                                                   \
     hipError_t e__ = (expr);                                                             \
@@ -2152,6 +2112,12 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
         k_pack_cond_pm<<<(8 * 1024 + 255) / 256, 256, 0, stream>>>((const float*)(tmp + t_f0), h->w1f[k], 1, 64);
         k_pack_cond_16<<<(4 * 2048 + 255) / 256, 256, 0, stream>>>((const float*)(tmp + t_f0), h->w1f_16[k], 1, 64);
       }
+      {
+        WgpLayerSrc ws;
+        ws.in_w = in_w; ws.folded = (const float*)(tmp + t_f); ws.rs_w = rs_w; ws.b1pm = h->b1pm[k][i]; ws.b2 = h->b2[k][i];
+        ws.f0 = (const float*)(tmp + t_f0);
+        if (int rc = wgp_pack_layer(h, k, i, ws, stream)) return fail(rc);
+      }
     }
     h->end_w[k] = F(fo[k].end_w); h->end_b[k] = F(fo[k].end_b); h->winv[k] = F(fo[k].winv);
     WG_TRY(cpy(h->end_w[k], src, cc * C)); src += cc * C;
@@ -2175,6 +2141,7 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
     WG_TRY(cpy(h->wfwd[k], src, cc * cc)); src += cc * cc;
   }
   WG_TRY(hipGetLastError());
+  if (int rc = wgp_finish_create(h, stream)) return fail(rc);
   WG_TRY(hipStreamSynchronize(stream));
   WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2197,6 +2164,7 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
 extern "C" void facppg_wg_destroy(facppg_wg* h) {
   if (!h) return;
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
+  wgp_destroy(h);
   hipFree(h->arena);
   delete h;
 }
@@ -2257,8 +2225,8 @@ PmLayout pm_layout(const facppg_wg_config& c, int B, int T) {
 
 extern "C" size_t facppg_wg_workspace_bytes(const facppg_wg* h, int B, int T) {
   if (!h || B <= 0 || T <= 0) return 0;
-  const size_t a = ws_layout(h->cfg, B, T).total, b = pm_layout(h->cfg, B, T).total;
-  return a > b ? a : b;
+  const size_t a = ws_layout(h->cfg, B, T).total, b = pm_layout(h->cfg, B, T).total, c = wgp_workspace_bytes(h, B, T);
+  return std::max(a, std::max(b, c));
 }
 
 #ifdef FACPPG_WN8_PROF
@@ -2335,6 +2303,8 @@ static void launch_begin(dim3 grid, hipStream_t s, const EdgeArgs& a) { k_begin<
 static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_valid_dev, const float* z_dev, uint64_t seed,
                        float sigma, int B, int T, float* audio_dev, char* ws, hipStream_t s) {
   const facppg_wg_config& c = h->cfg;
+  // ONE short utterance: the persistent launch (facppg_wgp.hip) -- same bits, no kernel boundary per layer
+  if (wgp_eligible(h, B, T, T_valid_dev)) return wgp_infer(h, mel_dev, z_dev, seed, sigma, T, audio_dev, ws, s);
   const PmLayout w = pm_layout(c, B, T);
   FACPPG_REQUIRE((double)C * w.P * w.Tqp < 2.0e9, FACPPG_EUNSUPPORTED, "T = %d frames is too long for 32-bit row offsets", T);
   float* hbuf[2] = {(float*)(ws + w.h0), (float*)(ws + w.h1)};

@@ -92,7 +92,7 @@ def pad_ppgs(ppgs, device=None):
     return x, lens
 
 
-def _acoustic(ppgs, tacotron, seed, dropout_masks, utterance_seeds, step_limits, timer=None):
+def _acoustic(ppgs, tacotron, seed, dropout_masks, utterance_seeds, step_limits, timer=None, while_decoding=None):
     """PPG upload + Tacotron2.inference on the current stream -> (mel_post [B, 80, Tout], [Tout_i]).  Blocks the host once,
     for the decoder's output lengths."""
     dev = next(tacotron.parameters()).device
@@ -101,7 +101,7 @@ def _acoustic(ppgs, tacotron, seed, dropout_masks, utterance_seeds, step_limits,
         timer.mark("ppg_upload")
     _, mel_post, _, _ = tacotron.inference(x, lengths=lens if len(lens) > 1 else None, dropout_masks=dropout_masks,
                                            seed=seed, utterance_seeds=utterance_seeds, step_limits=step_limits,
-                                           **({"timer": timer} if timer is not None else {}))
+                                           while_decoding=while_decoding, **({"timer": timer} if timer is not None else {}))
     return mel_post.contiguous(), [int(v) for v in tacotron.last_output_lengths]
 
 
@@ -132,7 +132,9 @@ def synthesize(ppgs, tacotron, waveglow, denoiser=None, sigma=0.6, strength=0.00
         timer.__init__()
     hop = waveglow.upsample.stride[0]
     with torch.no_grad():
-        mel_post, tout = _acoustic(ppgs, tacotron, seed, dropout_masks, utterance_seeds, step_limits, timer)
+        dev = next(tacotron.parameters()).device
+        mel_post, tout = _acoustic(ppgs, tacotron, seed, dropout_masks, utterance_seeds, step_limits, timer,
+                                   while_decoding=lambda: waveglow.prepare(dev))     # host work under the decoder's milliseconds
         audio = _vocode(mel_post, tout, waveglow, denoiser, sigma, strength, seed, z, utterance_seeds, timer)
     if return_device:
         return [audio[b, :tout[b] * hop] for b in range(len(tout))], tout

@@ -719,6 +719,7 @@ class WaveGlow(torch.nn.Module):
         return torch.cat([p.detach().float().reshape(-1) for p in parts])
 
     def _release(self):
+        self.__dict__.pop("_facppg_prepared", None)
         h = self.__dict__.pop("_facppg_handle", None)
         if h is not None:
             _lib.load().facppg_wg_destroy(h[0])
@@ -772,6 +773,7 @@ class WaveGlow(torch.nn.Module):
     def __getstate__(self):                              # never pickle device handles
         d = dict(self.__dict__)
         d.pop("_facppg_handle", None)
+        d.pop("_facppg_prepared", None)
         d.pop("_facppg_ws", None)
         return d
 
@@ -996,6 +998,19 @@ class WaveGlow(torch.nn.Module):
                                                    seed & 0xFFFFFFFFFFFFFFFF, float(sigma), B, T, _lib.ptr(audio),
                                                    _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)))
 
+    def prepare(self, device):
+        """Validate (or build) the packed weights for ``device`` NOW and remember that for the next ``infer`` on this thread's
+        next call: the check walks ~1000 tensors (0.4 ms of host time); facppg.pipeline runs it while the acoustic model's
+        decoder keeps the GPU busy instead of between the two models.  Single use: the next infer() consumes it."""
+        self.__dict__["_facppg_prepared"] = (self._handle(device), device)
+
+    def _checked_handle(self, dev):
+        pre = self.__dict__.pop("_facppg_prepared", None)
+        cur = self.__dict__.get("_facppg_handle")
+        if pre is not None and pre[1] == dev and cur is not None and cur[0] is pre[0]:
+            return pre[0]
+        return self._handle(dev)
+
     def infer(self, spect, sigma=1.0, z=None, lengths=None, seed=None, utterance_seeds=None, groups=None):
         """mel [B, n_mel, T] (GPU, fp32) -> audio [B, T*hop]   (glow.py:252-293).
         groups: None = decide from the launch shape (ragged batches whose layer launches would idle through >= 3 % of their
@@ -1048,7 +1063,7 @@ class WaveGlow(torch.nn.Module):
                     raise _lib.FacppgError("lengths must be B values in [1, T]")
         audio = torch.zeros(B, T * hop, dtype=torch.float32, device=dev) if lt is not None else \
             torch.empty(B, T * hop, dtype=torch.float32, device=dev)
-        h = self._handle(dev)           # (ONE validity check of the packed weights per call: it walks ~1000 tensors)
+        h = self._checked_handle(dev)   # (ONE validity check of the packed weights per call -- it walks ~1000 tensors -- or none: prepare())
         self._infer_launch(spect, lt, zt, seed, sigma, audio, self._infer_workspace(B, T, dev, 0, h), h)
         return audio
 

@@ -423,3 +423,53 @@ def test_other_stack_depths_match_oracle(hop, n_flows, n_early_every, n_layers, 
     err = (out - ref).numpy()
     print("rms err", rms(err), "rms ref", rms(ref.numpy()))
     assert rms(err) <= RMS_TOL and np.abs(err).max() <= 5e-3
+
+
+@pytest.mark.parametrize("T", [12, 37, 112, 113, 144, 150, 161, 176, 192, 200, 208, 256])
+def test_persistent_launch_equals_layer_launches_bit_for_bit(T, model256, monkeypatch):
+    """ONE short utterance can run as one persistent launch (csrc/facppg_wgp.hip: work split over output channels, LDS-DMA
+    operand streams, in-launch producer -> consumer hand-offs; picked by a measured rule for 128 < T <= 192 frames,
+    FACPPG_WG_PERSIST=1 forces it); everything else is one launch per WaveNet layer.  Both form every sum in the same
+    order, so the audio must agree BIT FOR BIT -- with injected noise and with the device noise -- at every column-block
+    count the persistent kernel is built for (T = 16 NB boundaries included) and at the metric's T = 200."""
+    m, cfg = model256
+    hop = 256
+    mel = synth.synthetic_mel(1, T, seed=900 + T).cuda()
+    zs = synth.synthetic_z(1, T * hop // 8, cfg, seed=901 + T)
+    monkeypatch.setenv("FACPPG_WG_PERSIST", "1")
+    a = m.infer(mel, sigma=0.6, z=zs)
+    tile, waves, wgs = m.last_launch_shape()
+    assert waves == 8 and wgs == 256 and tile >= T and tile % 16 == 0, "the persistent launch did not run: %s" % ((tile, waves, wgs),)
+    a_seed = m.infer(mel, sigma=0.6, seed=77)
+    monkeypatch.setenv("FACPPG_WG_PERSIST", "0")
+    b = m.infer(mel, sigma=0.6, z=zs)
+    assert m.last_launch_shape()[0] in (16, 32, 64)          # a per-layer tile width
+    b_seed = m.infer(mel, sigma=0.6, seed=77)
+    assert torch.isfinite(a).all() and a.shape == (1, T * hop)
+    d = (a - b).abs().max().item()
+    assert torch.equal(a, b), "persistent vs per-layer launches differ: max abs %.3e" % d
+    assert torch.equal(a_seed, b_seed)
+    monkeypatch.delenv("FACPPG_WG_PERSIST")
+    c = m.infer(mel, sigma=0.6, z=zs)                        # the measured rule picks one of the two: same bits either way
+    assert torch.equal(a, c)
+    assert (m.last_launch_shape()[1:] == (8, 256) and m.last_launch_shape()[0] % 16 == 0 and m.last_launch_shape()[0] > 64) == (128 < T <= 192)
+
+
+def test_persistent_launch_matches_oracle_hop256(model256, monkeypatch):
+    """The persistent launch against the CPU oracle directly (T = 152 frames: 10 column blocks, 4 864 positions), twice in a
+    row on one workspace (the second call finds the first one's flags and arrival counter: they are reset per call)."""
+    from oracle import waveglow as owg
+    m, cfg = model256
+    T, hop = 152, 256
+    mel = synth.synthetic_mel(1, T, seed=31)
+    zs = synth.synthetic_z(1, T * hop // 8, cfg, seed=32)
+    monkeypatch.setenv("FACPPG_WG_PERSIST", "1")
+    got = m.infer(mel.cuda(), sigma=0.6, z=zs).cpu()
+    again = m.infer(mel.cuda(), sigma=0.6, z=zs).cpu()
+    assert m.last_launch_shape() == (160, 8, 256)
+    assert torch.equal(got, again)
+    with torch.no_grad():
+        ref = owg.infer(synth.waveglow_state_dict(cfg), cfg, mel, 0.6, zs)
+    e = (got - ref).numpy()
+    print("persistent launch vs oracle: rms err %.2e (rms ref %.3f)" % (rms(e), rms(ref.numpy())))
+    assert rms(e) <= RMS_TOL
