@@ -766,7 +766,23 @@ class TrainWorkload(object):
         self.model, crit = make_train_model(dev, "bf16")
         self.mel, self.audio = train_batch(dev, self.B, seed=1 + rank)
         self.exchange = None
+        self.baseline_ms = None
         if dist is not None:
+            # what the exchange COSTS a step: the same graphed step without it, timed first on this rank (a throw-away
+            # model of the same shape; 3 steps to capture, then the median of 6)
+            from waveglow.optim import Adam as _Adam
+            bm, bcrit = make_train_model(dev, "bf16")
+            bstep = GraphedTrainStep(bm, bcrit, _Adam(bm.parameters(), lr=1e-5), warmup=2)
+            ts = []
+            for i in range(10):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                bstep(self.mel, self.audio)
+                torch.cuda.synchronize(dev)
+                ts.append(time.perf_counter() - t0)
+            self.baseline_ms = sorted(ts[4:])[3] * 1e3 if bstep.graph is not None else None
+            del bstep, bm, bcrit
+            torch.cuda.empty_cache()
             broadcast_parameters(self.model, 0)
             self.exchange = GradientExchange(self.model, n_buckets=args.grad_buckets,
                                              grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else None)
@@ -790,20 +806,30 @@ class TrainWorkload(object):
         out["config"] = {"workload": "BASELINE configs[4]: WaveGlow training step (fwd + WaveGlowLoss + bwd + fused Adam), segment 10000 "
                                      "@16 kHz / hop 160, per-GPU batch %d, bf16 MFMA operands, fp32 accumulation / master weights / "
                                      "gradients, one replayed HIP graph per step%s" % (
-                                         self.B, "" if not self.dp else ", data parallel: bucketed gradient all-reduce after each replay"),
+                                         self.B, "" if not self.dp else (
+                                             ", data parallel: the bucketed gradient all-reduce is PART of the graph (each bucket on the links "
+                                             "under the backward pass of the earlier flows)" if self.stepper.graph_holds_step else
+                                             ", data parallel: bucketed gradient all-reduce after each replay")),
                          "per_gpu_batch": self.B, "global_batch": self.B * self.world, "parallelism": "dp%d" % self.world,
                          "graph_captured": self.stepper.graph is not None}
         out["tflops"] = flops / (ms * 1e-3) / 1e12
         out["frac_of_mfma_peak"] = out["tflops"] / (PEAK_BF16_MFMA_TFLOPS * self.world)
         if self.exchange is not None:
+            # the exchange on its own, after the timed region (every rank gets here): all buckets launched, then waited for
+            self.exchange.exchange()
             ex_ms = self.exchange.exchange_ms()
             nbytes = self.exchange.bytes_per_exchange()
             out["gradient_exchange"] = {
+                "mode": "captured in the step graph, overlapped with backward" if self.stepper.graph_holds_step else "after each replay",
                 "buckets": len(self.exchange.buckets), "bytes": nbytes, "dtype": str(self.exchange.comm_dtype).replace("torch.", ""),
                 "ms": ex_ms, "fraction_of_step": ex_ms / ms if ex_ms else None,
                 # bus bandwidth in the NCCL-tests convention: algorithm bytes x 2 (N - 1) / N per second
                 "bus_GBps": (nbytes * 2 * (self.world - 1) / self.world / (ex_ms * 1e-3) / 1e9) if ex_ms else None,
-                "timing": "hipEvents on the compute stream around the last step's exchange (pack + all_reduce + scale)"}
+                "step_without_exchange_ms": self.baseline_ms,
+                # what data parallelism adds to a step: (step with the exchange) - (the same graphed step without it, this rank)
+                "exposed_ms": (ms - self.baseline_ms) if self.baseline_ms else None,
+                "timing": "ms: hipEvents on the compute stream around ONE stand-alone exchange after the timed region (all_reduce of every "
+                          "bucket + scale); exposed_ms: ms_per_step minus the median graphed step without any exchange"}
 
 
 WORKLOADS = {"infer": InferWorkload, "e2e": E2EWorkload, "corpus": CorpusWorkload, "train": TrainWorkload}

@@ -76,8 +76,9 @@ def train(num_gpus, rank, group_name, output_directory, epochs, learning_rate, s
     exchange = None
     comm_dtype = {"fp32": None, "bf16": torch.bfloat16}[grad_dtype]
     if num_gpus > 1:
-        # eager: buckets are reduced from gradient hooks while the backward pass runs; graphed: the bucket pipeline follows
-        # each replay (no autograd runs then)
+        # eager: buckets are reduced from gradient hooks while the backward pass runs; graphed: the stepper installs the same
+        # hooks and captures the collectives INTO the graph (waveglow.graphed; if this stack cannot capture them, the bucket
+        # pipeline follows each replay instead)
         if hip_graph:
             broadcast_parameters(model, 0)
             exchange = GradientExchange(model, n_buckets=grad_buckets, grad_dtype=comm_dtype)

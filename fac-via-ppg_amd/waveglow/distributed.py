@@ -133,7 +133,12 @@ class GradientExchange(object):
     """Bucketed, overlapped gradient averaging (see the module docstring).
 
     eager steps:   ``install_hooks()`` once; every ``backward()`` then leaves rank-averaged gradients behind.
-    graphed steps: the captured graph produces the gradients; ``bind_static_sources()`` once after the capture, then
+    graphed steps: (a) OVERLAPPED (waveglow.graphed, the default on RCCL): the hooks stay installed while the step is
+                   captured, so the pack + all_reduce of every bucket become nodes of the replayed graph on a forked
+                   branch -- bucket i is on the links while the backward pass of the earlier flows runs, exactly as in
+                   an eager step, and the optimiser step follows in the same graph;
+                   (b) SERIAL (fallback when the collectives cannot be captured, and the gloo tests): the captured
+                   graph produces the gradients; ``bind_static_sources()`` once after the capture, then
                    ``exchange(static=True)`` after every replay (buckets are packed and reduced in a pipeline: bucket
                    i+1 is packed while bucket i is on the links)."""
 
@@ -157,6 +162,8 @@ class GradientExchange(object):
         self.sources = None
         self.queued = False
         self.last_exchange_ms = None
+        self.hooked = False
+        self._hook_handles = []
 
     # ---- one bucket
     def _grads(self, i, static):
@@ -265,9 +272,19 @@ class GradientExchange(object):
             if self.arrived[i] == len(self.buckets[i]) and all(self.pending[j] is not None for j in range(i)):
                 self._launch(i)
 
-        for p in self.params:
-            p.register_post_accumulate_grad_hook(on_grad)
+        if self.hooked:
+            return self
+        self._hook_handles = [p.register_post_accumulate_grad_hook(on_grad) for p in self.params]
+        self.hooked = True
         return self
+
+    def remove_hooks(self):
+        """Back to explicit ``exchange()`` calls (a graphed step whose capture could not hold the collectives)."""
+        for h in self._hook_handles:
+            h.remove()
+        self._hook_handles, self.hooked, self.queued = [], False, False
+        self.pending = [None] * len(self.buckets)
+        self.arrived = [0] * len(self.buckets)
 
     def bytes_per_exchange(self):
         return sum(f.numel() * f.element_size() for f in self.flat)

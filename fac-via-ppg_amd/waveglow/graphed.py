@@ -10,9 +10,14 @@ argument, all buffers come from the graph's private pool -- and replayed per bat
 steps), captures on the next call, and replays from then on.  With ``sync_gradients`` (data parallel: the gradient all-reduce
 of waveglow.distributed) the graph holds forward + backward only and the exchange and the optimiser step run after each
 replay; without it the optimiser step is inside the graph (the optimiser must then be built with ``capturable=True``).
-With ``exchange`` (a waveglow.distributed.GradientExchange) the replayed graph's gradient tensors are bound as the
-exchange's static sources: each replay is followed by the bucketed, pipelined all-reduce, after which the parameters'
-``.grad`` are views of the flat buckets (no copy back) and the optimiser steps on them.
+With ``exchange`` (a waveglow.distributed.GradientExchange) there are two protocols.  OVERLAPPED (default on RCCL): the
+exchange's autograd hooks stay installed during the capture, so every bucket's pack + all_reduce is captured on a forked
+branch of the graph at the point of the backward pass where its last gradient is complete, joined before the optimiser
+step, which is captured too -- a replay overlaps bucket i's transfer with the backward pass of the earlier flows, as an
+eager step does, without giving up the graph (the round-3 stepper launched all three buckets AFTER the replay: nothing
+overlapped in the mode training actually runs).  SERIAL (fallback if the collectives cannot be captured; gloo): the
+replayed graph's gradient tensors are bound as the exchange's static sources and each replay is followed by the bucketed,
+pipelined all-reduce.  Either way the parameters' ``.grad`` end up views of the flat buckets (no copy back).
 A batch of another shape falls back to an ordinary step on the same gradient buffers; a capture that fails (pinned arena
 exhausted, an op that cannot be captured, out of memory in the graph's pool) turns the stepper into plain eager steps for
 good, with a warning.
@@ -25,17 +30,27 @@ from waveglow.glow import reserve_pinned, take_pinned_arenas
 
 
 class GraphedTrainStep:
-    def __init__(self, model, criterion, optimizer, warmup=3, sync_gradients=None, exchange=None, expected_shapes=None):
+    def __init__(self, model, criterion, optimizer, warmup=3, sync_gradients=None, exchange=None, expected_shapes=None,
+                 overlap_exchange=None):
         """expected_shapes: optional ((mel shape), (audio shape)) of a regular batch -- the capture then waits for a batch
-        of that shape instead of locking in whatever the first post-warm-up batch happens to be."""
+        of that shape instead of locking in whatever the first post-warm-up batch happens to be.
+        overlap_exchange: capture the exchange's collectives INSIDE the graph (None: yes on a GPU backend that can, i.e.
+        not gloo)."""
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
         self.warmup, self.exchange = warmup, exchange
+        if overlap_exchange is None:
+            import torch.distributed as dist
+            overlap_exchange = exchange is not None and exchange.cuda and dist.get_backend() != "gloo"
+        self.overlap_exchange = bool(overlap_exchange and exchange is not None)
+        if self.overlap_exchange:
+            exchange.install_hooks()                 # every backward() -- eager or captured -- now leaves averaged gradients behind
         if exchange is not None and sync_gradients is None:
             sync_gradients = exchange.exchange
         self.sync_gradients = sync_gradients
         self.expected_shapes = expected_shapes
         self.calls = 0
         self.graph = None
+        self.graph_holds_step = False                # the optimiser step (and the exchange, if any) is inside the graph
         self.capture_failed = False
         self.static_mel = self.static_audio = self.static_loss = None
         self.side = torch.cuda.Stream()
@@ -48,13 +63,14 @@ class GraphedTrainStep:
 
     def _sync(self, static):
         if self.exchange is not None:
-            self.exchange.exchange(static=static)
+            if not self.exchange.hooked:             # (hooked: the backward pass has already exchanged)
+                self.exchange.exchange(static=static)
         elif self.sync_gradients is not None:
             self.sync_gradients()
 
     def _finish(self):
         """What follows the gradients when it is not part of the graph."""
-        if self.sync_gradients is not None:
+        if self.sync_gradients is not None and not self.graph_holds_step:
             self._sync(static=True)
             self.optimizer.step()
 
@@ -74,12 +90,16 @@ class GraphedTrainStep:
         self.optimizer.zero_grad(set_to_none=True)   # the captured backward allocates the gradients in the graph's pool
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
+        whole_step = self.sync_gradients is None or (self.exchange is not None and self.exchange.hooked)
         # thread_local: other threads (a DataLoader worker pinning memory, a logger) may touch the allocator meanwhile
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            # (hooked exchange: the backward pass launches every bucket's pack + all_reduce on the communication stream --
+            #  a forked branch of the capture -- and joins them in its final callback)
             static_loss = self._forward_backward(static_mel, static_audio).detach()
-            if self.sync_gradients is None:
+            if whole_step:
                 self.optimizer.step()
-        if self.exchange is not None:
+        self.graph_holds_step = whole_step
+        if self.exchange is not None and not self.exchange.hooked:
             self.exchange.bind_static_sources()
         self.pinned_arenas = take_pinned_arenas()    # the graph replays uploads from these tables: they live with it
         self.static_mel, self.static_audio, self.static_loss, self.graph = static_mel, static_audio, static_loss, graph
@@ -103,7 +123,18 @@ class GraphedTrainStep:
             return self._eager(mel, audio, keep_grad_buffers=False)
         if self.graph is None:
             try:
-                self._capture(mel, audio)
+                try:
+                    self._capture(mel, audio)
+                except Exception as e:   # noqa: BLE001
+                    if not (self.exchange is not None and self.exchange.hooked):
+                        raise
+                    # the collectives could not be captured on this stack: the serial protocol (graph = forward + backward,
+                    # the bucket pipeline after each replay) needs nothing of them inside the capture
+                    warnings.warn("capturing the gradient exchange inside the HIP graph failed (%r): exchanging after each replay" % (e,))
+                    torch.cuda.synchronize()
+                    self.exchange.remove_hooks()
+                    self.overlap_exchange = False
+                    self._capture(mel, audio)
             except Exception as e:   # noqa: BLE001  (any capture failure: the training run goes on, launch by launch)
                 warnings.warn("HIP-graph capture of the training step failed (%r): continuing with eager steps" % (e,))
                 self.capture_failed = True

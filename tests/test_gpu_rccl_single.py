@@ -30,6 +30,8 @@ def test_training_workload_through_rccl_world1(grad_dtype):
     assert d["collective_backend"].startswith("RCCL") and d["ranks_connected"] == 1
     ex = d["gradient_exchange"]
     assert d["config"]["graph_captured"] and ex["buckets"] == 3 and ex["ms"] > 0
+    # the collectives are nodes of the step graph, and what they add to a step is reported (world 1: a local copy per bucket)
+    assert ex["mode"].startswith("captured") and ex["step_without_exchange_ms"] > 0 and ex["exposed_ms"] < 5.0
     assert ex["bytes"] == 87879272 * (4 if grad_dtype == "fp32" else 2)           # 351.5 MB fp32 / 175.8 MB bf16
     assert d["ms_per_step"] < 40.0
 
@@ -39,3 +41,68 @@ def test_corpus_and_infer_extras_through_rccl_world1():
     assert d["collective_backend"].startswith("RCCL") and d["config"]["utterances"] == 48 and d["value"] > 0
     d = _bench(["--steps", "3", "--warmup", "2", "--utterances", "32"], 29524)
     assert d["train_dp"] is not None and d["corpus_dp"] is not None and d["roofline"]["frac"] > 0.3   # the default run is the batch-1 utterance: ~0.5 of the fp32 MFMA peak
+
+
+_CAPTURED_EXCHANGE = r'''
+import os, sys, json, warnings
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(%(root)r, "fac-via-ppg_amd"))
+from facppg import synth
+from waveglow.glow import WaveGlow, WaveGlowLoss
+from waveglow.graphed import GraphedTrainStep
+from waveglow.distributed import GradientExchange
+from waveglow.optim import Adam
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+cfg = dict(synth.WAVEGLOW_CONFIG, n_flows=4)
+g = np.random.Generator(np.random.PCG64(5))
+batches = []
+for i in range(8):
+    n = 2400 if i == 6 else 4000
+    wav = torch.from_numpy((0.1 * g.standard_normal((2, n))).astype(np.float32)).cuda()
+    batches.append((synth.synthetic_mel(2, n // 160 + 1, seed=10 + i).cuda(), wav))
+crit = WaveGlowLoss(0.7071)
+def model():
+    torch.manual_seed(0)
+    m = WaveGlow(**cfg).cuda().train()
+    m.train_precision = "bf16"
+    return m
+m = model()
+opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True)
+eager = []
+for mel, wav in batches:
+    m.zero_grad()
+    loss = crit(m((mel, wav))); loss.backward(); opt.step()
+    eager.append(float(loss))
+m = model()
+ex = GradientExchange(m, n_buckets=3, grad_dtype=%(dtype)s)
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    step = GraphedTrainStep(m, crit, Adam(m.parameters(), lr=1e-4), warmup=2, exchange=ex)
+    graphed = [float(step(mel, wav)) for mel, wav in batches]
+grads_are_views = all(p.grad.data_ptr() == v.data_ptr() for b, vs in zip(ex.buckets, ex.views) for p, v in zip(b, vs))
+print(json.dumps({"eager": eager, "graphed": graphed, "captured": step.graph is not None, "holds_step": step.graph_holds_step,
+                  "hooked": ex.hooked, "views": grads_are_views, "warnings": [str(x.message) for x in w if "graph" in str(x.message).lower()]}))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("grad_dtype", ["fp32", "bf16"])
+def test_exchange_captured_in_the_step_graph_equals_eager_steps(grad_dtype):
+    """The data-parallel stepper's default on RCCL: the gradient hooks stay installed during the capture, so the buckets'
+    pack + all_reduce (RCCL, communication stream) and the optimiser step are nodes of the replayed graph.  At world 1 the
+    average is the identity, so the replayed trajectory must equal plain eager steps -- including the odd-shaped batch
+    that steps eagerly on the graph's buffers in between -- and the capture must not have fallen back."""
+    import numpy as np
+    e = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29526" if grad_dtype == "fp32" else "29527")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        e.pop(k, None)
+    src = _CAPTURED_EXCHANGE % {"root": ROOT, "dtype": "None" if grad_dtype == "fp32" else "torch.bfloat16"}
+    r = subprocess.run([sys.executable, "-c", src], capture_output=True, text=True, env=e, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print(d)
+    assert d["captured"] and d["holds_step"] and d["hooked"] and not d["warnings"], d
+    assert d["views"] == (grad_dtype == "fp32")
+    tol = 2e-4 if grad_dtype == "fp32" else 5e-3          # bf16 links round every gradient to 8 bits of mantissa
+    assert np.allclose(d["eager"], d["graphed"], rtol=0, atol=tol), d
