@@ -22,6 +22,8 @@ A batch of another shape falls back to an ordinary step on the same gradient buf
 exhausted, an op that cannot be captured, out of memory in the graph's pool) turns the stepper into plain eager steps for
 good, with a warning.
 """
+import os
+import time
 import warnings
 
 import torch
@@ -89,6 +91,12 @@ class GraphedTrainStep:
         reserve_pinned()
         self.optimizer.zero_grad(set_to_none=True)   # the captured backward allocates the gradients in the graph's pool
         torch.cuda.synchronize()
+        if self.exchange is not None and self.exchange.hooked:
+            # c10d's watchdog thread polls the end events of the warm-up steps' collectives every 100 ms until it has seen
+            # them complete; HIP refuses an event query on a stream that has meanwhile joined a capture (the process group's
+            # internal stream does, below) and the watchdog then aborts the process.  The collectives are complete (the
+            # synchronize above): give the watchdog a few periods to retire them before the capture begins.
+            time.sleep(float(os.environ.get("FACPPG_CAPTURE_SETTLE_MS", "400")) * 1e-3)
         graph = torch.cuda.CUDAGraph()
         whole_step = self.sync_gradients is None or (self.exchange is not None and self.exchange.hooked)
         # thread_local: other threads (a DataLoader worker pinning memory, a logger) may touch the allocator meanwhile
