@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
 // FACPPG_WN8_PROF: phase stamps of k_wn_layer8 (workgroup 0, thread 0; clock64 ticks summed over launches), read back with
 // facppg_debug_wn8_prof -- where a narrow launch spends its time outside the K loop (tools/prof_wn8.py)
 #ifdef FACPPG_WN8_PROF
-__device__ unsigned long long g_wn8_prof[8];
+__device__ unsigned long long g_wn8_prof[12];   // 0-5 phases, 6 launches, 7 k_wn_flow8's wait, 8 its hand-off
 #define WN8_STAMP_DECL long long wn8_t = clock64()
 #define WN8_STAMP(i)                                                                           \
   do {                                                                                         \
@@ -885,9 +885,59 @@ __device__ unsigned long long g_wn8_prof[8];
 // NCB = 4 (128-frame tiles, ONE workgroup per CU, 256 VGPRs): each weight load then feeds four column blocks -- 2 global
 // loads per 32 MFMAs instead of k_wn_layer's 4.  tools/probes/mfma_probe.hip: with 2 waves per SIMD the fp32 MFMA stream
 // runs at 0.95 of peak next to 2 global_load_dwordx4 per 32 MFMAs and at 0.85 next to 4.
-template <bool LAST, int NCB, bool EF = false>
-__global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// FUSED (k_wn_flow8: all layers of a flow in one launch, see there): what a tile waits for before it touches the previous
+// layer's output, and how long it may wait.  Stores are then write-through (sc1) so that a tile of the next layer, on any CU
+// of any XCD, reads them behind one agent-scope acquire.
+struct FlowWait {
+  const unsigned* ctr;             // completed-tile counter of the previous layer (null: nothing to wait for)
+  unsigned target;                 // its value once every tile of that layer is done
+  unsigned long long poll_limit;   // wall-clock ticks before the wait traps (0: unbounded)
+  int flags;                       // experiments: 1 = wait before the prologue (no overlap), 2 = no acquire behind the wait (racy)
+};
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+// a load that is a global_load whatever hipcc knows about the pointer: pointers that come out of a device table (k_wn_flow8's
+// per-layer operands) or out of integer arithmetic are "generic" to it, and every access through them a flat_load -- which
+// counts on the LDS counter too, so that the K loop's ds_read waits would wait for the weight loads as well
+// (built-in vector types only: a class type such as float4 is copied through a generic reference again)
+#define FACPPG_AS1 __attribute__((address_space(1)))
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gld(const float4* q) {
+  const f32x4s v = *(const FACPPG_AS1 f32x4s*)q;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ f4u gld(const f4u* q) { return *(const FACPPG_AS1 f4u*)q; }
+__device__ __forceinline__ float gld(const float* q) { return *(const FACPPG_AS1 float*)q; }
+template <bool SC1>
+__device__ __forceinline__ void store_f4(float* g, const float4 v) {
+  if constexpr (SC1) {
+    const f32x4s x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(g), "v"(x) : "memory");
+  } else {
+    const f32x4s x = {v.x, v.y, v.z, v.w};
+    *(FACPPG_AS1 f32x4s*)g = x;
+  }
+}
+template <bool SC1>
+__device__ __forceinline__ void store_f1(float* g, const float v) {
+  if constexpr (SC1) __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *(__attribute__((address_space(1))) float*)g = v;
+}
+__device__ __forceinline__ void flow_wait(const FlowWait& fw) {
+  unsigned long long t0 = 0;
+  unsigned spins = 0;
+  while (__hip_atomic_load(fw.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fw.target) {
+    __builtin_amdgcn_s_sleep(4);
+    if ((++spins & 1023u) == 0 && fw.poll_limit) {
+      const unsigned long long now = wall_clock64();
+      if (!t0) t0 = now;
+      else if (now - t0 > fw.poll_limit) __builtin_trap();
+    }
+  }
+  if (!(fw.flags & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU's L1 may hold the buffer's lines of two layers ago
+}
+
+template <bool LAST, int NCB, bool EF, bool FUSED, bool SC1 = FUSED>
+__device__ __forceinline__ void wn_layer8_tile(const WnArgs& p, const int lin, float* __restrict__ smem, const FlowWait fw) {
   constexpr int TNt = 32 * NCB;
   WN8_STAMP_DECL;
   const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, wq = w8 >> 1, sub = w8 & 1;
@@ -895,7 +945,6 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
   const int chb = wq * 64 + sub * 32;   // first channel of this wave's block
   int b, nvalid, ph, in_off, sk_off, tap0, tap1, tap2, lane_q;   // tap0..2 are wave-uniform, the lane's column is lane_q (see k_wn_layer)
   {
-    const int lin = blockIdx.x;
     int tile;
     if (p.xcd_map == 1) { const int r = lin >> 3; ph = (r / p.nt) * 8 + (lin & 7); tile = r % p.nt; }
     else { ph = lin / p.nt; tile = lin % p.nt; }
@@ -937,6 +986,9 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
   const bool folded_first = EF && p.nconv == 1;
   const float* hb4 = folded_first ? p.xa + (size_t)b * 8 * p.Lp : p.h_in + (size_t)b * C * p.Lp;
   const float* sb4 = p.melp + (size_t)b * NMEL * p.Tqp + in_off - ph * p.Tqp;
+  if constexpr (FUSED) {
+    if (fw.ctr && (fw.flags & 1)) flow_wait(fw);
+  }
   float4 stg[NSTG4];
   auto stage_load = [&](int c) __attribute__((always_inline)) {
     const bool conv = c >= ncc;
@@ -952,7 +1004,7 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
       const int conv_off = folded_first ? (r0 & 7) * p.Lp + (tp == 0 ? tap0 : tp == 1 ? tap1 : tap2) + lane_q
                                         : ((cc & 3) * 64 + r0) * p.Lp + tapc;
       const int off = conv ? conv_off : m * p.Tqp - j;
-      const f4u v = *reinterpret_cast<const f4u*>(base + off);
+      const f4u v = gld(reinterpret_cast<const f4u*>(base + off));
       stg[jj] = make_float4(v.x, v.y, v.z, v.w);
     }
   };
@@ -973,8 +1025,8 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
   auto load_a1 = [&](float4 (&a)[2], int gg) __attribute__((always_inline)) {
     const int ngc8 = 8 * ncc;
     const float4* src = gg < ngc8 ? wave_c + (size_t)gg * 1024 : wave_a + (size_t)(gg - ngc8) * 1024;
-    a[0] = src[0];
-    a[1] = src[128];
+    a[0] = gld(src);
+    a[1] = gld(src + 128);
   };
   auto mfma2 = [&](const float4 (&a)[2], const float (&bv)[4][NCB], int nrb) __attribute__((always_inline)) {
 #pragma unroll
@@ -997,7 +1049,7 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
   for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 bv = *reinterpret_cast<const float4*>(p.b1 + rb * C + chb + 4 * kh + 8 * q);
+      const float4 bv = gld(reinterpret_cast<const float4*>(p.b1 + rb * C + chb + 4 * kh + 8 * q));
       acc[rb][0][4 * q + 0] = bv.x; acc[rb][0][4 * q + 1] = bv.y; acc[rb][0][4 * q + 2] = bv.z; acc[rb][0][4 * q + 3] = bv.w;
     }
 #pragma unroll
@@ -1007,6 +1059,18 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
   __syncthreads();
   WN8_STAMP(0);   // prologue
   for (int c = 0; c < nch; ++c) {
+    if constexpr (FUSED) {
+      // the conditioning chunks behind us needed nothing of the previous layer; the first convolution chunk is requested next
+      if (c == ncc - 1 && fw.ctr && !(fw.flags & 1)) {
+#ifdef FACPPG_WN8_PROF
+        const long long w0 = clock64();
+#endif
+        flow_wait(fw);
+#ifdef FACPPG_WN8_PROF
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_wn8_prof[7], (unsigned long long)(clock64() - w0));
+#endif
+      }
+    }
     stage_load(c + 1 < nch ? c + 1 : c);
     const float* lb = smem + (c & 1) * (KCH * TNt) + (kh * TNt + li) * 4;
 #pragma unroll
@@ -1041,7 +1105,7 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
   float4 es0, es1;
   if constexpr (ESPLIT) {
     const float4* wimg = reinterpret_cast<const float4*>(p.we) + w8 * 128 + lane * 2;
-    es0 = wimg[0]; es1 = wimg[1];
+    es0 = gld(wimg); es1 = gld(wimg + 1);
   }
   constexpr bool HPRE = !LAST && NCB == 1;
   float4 hpre[HPRE ? 32 / RPL4 : 1];
@@ -1049,14 +1113,14 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
     if (nvalid >= 4) {
       const float* rb0 = p.h_in + (size_t)b * C * p.Lp + in_off;
 #pragma unroll
-      for (int i = 0; i < 32 / RPL4; ++i) hpre[i] = *reinterpret_cast<const float4*>(rb0 + (size_t)(chb + i * RPL4 + srow4) * p.Lp);
+      for (int i = 0; i < 32 / RPL4; ++i) hpre[i] = gld(reinterpret_cast<const float4*>(rb0 + (size_t)(chb + i * RPL4 + srow4) * p.Lp));
     }
   }
 #pragma unroll
   for (int rb = 0; rb < NRB2; ++rb) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 bv = *reinterpret_cast<const float4*>(p.b2 + (ROWS256 ? 0 : rb * C) + chb + 4 * kh + 8 * q);
+      const float4 bv = gld(reinterpret_cast<const float4*>(p.b2 + (ROWS256 ? 0 : rb * C) + chb + 4 * kh + 8 * q));
       acc[rb][0][4 * q + 0] = bv.x; acc[rb][0][4 * q + 1] = bv.y; acc[rb][0][4 * q + 2] = bv.z; acc[rb][0][4 * q + 3] = bv.w;
     }
 #pragma unroll
@@ -1067,8 +1131,8 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
     const float4* ap2 = p.w2 + (size_t)(ROWS256 ? wq * 2 + sub : wq * 4 + sub) * NG2 * 64 + lane;
     const float* lb = smem + (kh * TNt + li) * 4;
     auto load_a2 = [&](float4 (&a)[2], int g) __attribute__((always_inline)) {
-      a[0] = ap2[g * 64];
-      if constexpr (!ROWS256) a[1] = ap2[(size_t)2 * NG2 * 64 + g * 64];
+      a[0] = gld(ap2 + g * 64);
+      if constexpr (!ROWS256) a[1] = gld(ap2 + (size_t)2 * NG2 * 64 + g * 64);
     };
 #pragma unroll
     for (int i = 0; i < RING - 1; ++i) load_a2(ar[i], i);
@@ -1106,7 +1170,7 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
       const float* gb = smem + (16 * w8 + pl) * 4 + kq;   // K4 image
       float4 a0[8], a1[8];
 #pragma unroll
-      for (int sl = 0; sl < 8; ++sl) { a0[sl] = wimg[sl * 128]; a1[sl] = wimg[sl * 128 + 1]; }
+      for (int sl = 0; sl < 8; ++sl) { a0[sl] = gld(wimg + sl * 128); a1[sl] = gld(wimg + sl * 128 + 1); }
       f32x4 tot = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int sl = 0; sl < 8; ++sl) {
@@ -1144,9 +1208,9 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
       if (nvalid >= 4) {
         float4 x = make_float4(bias, bias, bias, bias);
         if (!p.first) x = *reinterpret_cast<const float4*>(g);
-        *reinterpret_cast<float4*>(g) = make_float4(x.x + vv[0], x.y + vv[1], x.z + vv[2], x.w + vv[3]);
+        store_f4<SC1>(g, make_float4(x.x + vv[0], x.y + vv[1], x.z + vv[2], x.w + vv[3]));
       } else {
-        for (int k = 0; k < nvalid; ++k) g[k] = (p.first ? bias : g[k]) + vv[k];
+        for (int k = 0; k < nvalid; ++k) store_f1<SC1>(g + k, (p.first ? bias : g[k]) + vv[k]);
       }
     }
   }
@@ -1173,17 +1237,94 @@ __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
         if (add) {
           float4 x;
           if (HPRE && is_res) x = hpre[i];
-          else x = *reinterpret_cast<const float4*>(rbase + o);
+          else x = gld(reinterpret_cast<const float4*>(rbase + o));
           v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
         }
-        *reinterpret_cast<float4*>(gbase + o) = v;
+        store_f4<SC1>(gbase + o, v);
       } else {
         const float vv[4] = {v.x, v.y, v.z, v.w};
-        for (int k = 0; k < nv; ++k) gbase[o + k] = vv[k] + (add ? rbase[o + k] : 0.0f);
+        for (int k = 0; k < nv; ++k) store_f1<SC1>(gbase + o + k, vv[k] + (add ? gld(rbase + o + k) : 0.0f));
       }
     }
   }
   WN8_STAMP(5);   // epilogue
+}
+
+template <bool LAST, int NCB, bool EF = false>
+__global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  wn_layer8_tile<LAST, NCB, EF, false>(p, (int)blockIdx.x, smem, FlowWait{nullptr, 0u, 0ull, 0});
+}
+
+// ------------------------------------------------------------------------------------------
+// k_wn_flow8: ALL layers of one flow in ONE launch, for launches that do not fill the chip (one short utterance:
+// 32 phases x 7 tiles of 32 frames = 224 workgroups of k_wn_layer8<NCB = 1>, each bound by its own MFMA stream, 65 us, on
+// 224 of 256 CUs -- and ~13 us of launch ramp, prologue, gate, epilogue and drain around it per layer).
+// Every tile of every layer runs exactly k_wn_layer8's code (same K order, same bits); what changes is who runs it when:
+//   * grid = 2 x tiles: workgroup (w, t) runs tile t of the layers l = w, w + 2, ...  The dispatcher places the first
+//     `tiles` workgroups one per CU and the second `tiles` next to them (VGPRs allow two 8-wave workgroups per CU), so a CU
+//     holds the two workers of (about) one tile: while one is in its prologue / gate / epilogue / hand-off, the other one's
+//     MFMAs run -- the matrix pipe has no kernel boundary to idle through.  Any other placement is correct as well.
+//   * layer l + 1 needs layer l complete (its taps reach into neighbouring tiles' columns and other phases' rows): a tile
+//     of layer l counts itself done on a per-layer counter (write-through stores, s_waitcnt, workgroup barrier, one relaxed
+//     agent atomic); a tile of layer l + 1 runs its CONDITIONING chunks first -- a quarter of its K loop that reads nothing
+//     of layer l -- and only then waits for the counter (one agent-scope acquire behind it).  By then the counter is
+//     usually there.  The h buffers alternate as in the per-layer launches; the same wait covers the write-after-read side
+//     (layer l + 1 writes the buffer layer l read only after every tile of layer l is done).
+// Co-residency of all 2 x tiles workgroups is required (a waiting tile must not keep a producer off the chip): the host
+// uses this launch only while 2 x tiles <= 2 x CUs; a wait that lasts longer than the poll limit traps instead of hanging.
+// ------------------------------------------------------------------------------------------
+struct WnLayerPtrs {   // the per-layer operands of one flow (device table, built once per handle)
+  const float4* w1;
+  const float4* wc;
+  const float* b1;
+  const float4* w2;
+  const float* b2;
+  const float* we;
+};
+struct FlowArgs {
+  WnArgs a;                  // what all layers share; h_in / h_out = layer 0's
+  const WnLayerPtrs* layers;
+  unsigned* done;            // [n_layers] completed-tile counters, zero at launch
+  int n_layers, tiles, workers;
+  int l0;                    // first layer of this launch (0; the timing experiments launch the layers one by one)
+  int flags;                 // FlowWait::flags
+  unsigned long long poll_limit;
+};
+
+__device__ unsigned g_flow_ids[1024];   // FACPPG_WN_FUSED_DEBUG & 16: (XCC_ID << 16 | HW_ID[15:8]) of every workgroup of the last launch
+
+template <bool EF, bool SC1 = true>
+__global__ __launch_bounds__(512, 4) void k_wn_flow8(FlowArgs f) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((f.flags & 4) && threadIdx.x == 0 && blockIdx.x < 1024)
+    g_flow_ids[blockIdx.x] = (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 16) | __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));
+  const int worker = (int)blockIdx.x / f.tiles, lin = (int)blockIdx.x - worker * f.tiles;
+  for (int l = f.l0 + worker; l < f.n_layers; l += f.workers) {
+    WnArgs p = f.a;
+    const WnLayerPtrs lp = f.layers[l];
+    const uintptr_t hx = (uintptr_t)f.a.h_in ^ (uintptr_t)f.a.h_out, odd = (uintptr_t)0 - (uintptr_t)(l & 1);
+    p.h_in = (const float*)((uintptr_t)f.a.h_in ^ (hx & odd));
+    p.h_out = (float*)((uintptr_t)f.a.h_out ^ (hx & odd));
+    p.w1 = lp.w1; p.wc = lp.wc; p.b1 = lp.b1; p.w2 = lp.w2; p.b2 = lp.b2;
+    p.we = lp.we;
+    p.dil = 1 << l; p.first = (l == 0);
+    p.nconv = (EF && l == 0) ? 1 : NCHH;
+    p.nch = p.nconv + f.a.nch;   // (f.a.nch: the conditioning chunks)
+    const FlowWait fw{l > 0 ? f.done + (l - 1) : nullptr, (unsigned)f.tiles, f.poll_limit, f.flags};
+    if (p.dil == 128) wn_layer8_tile<true, 1, EF, true, SC1>(p, lin, smem, fw);   // (the flow's last layer; n_layers = 8 whenever this launch is used)
+    else wn_layer8_tile<false, 1, EF, true, SC1>(p, lin, smem, fw);
+    // this tile of layer l is done once its write-through stores have left the CU
+#ifdef FACPPG_WN8_PROF
+    const long long s0 = clock64();
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // (also: the next layer's prologue rewrites the LDS the epilogue read)
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(f.done + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef FACPPG_WN8_PROF
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_wn8_prof[8], (unsigned long long)(clock64() - s0));
+#endif
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1978,7 +2119,7 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   FACPPG_HIP_CHECK(hipSetDevice(device));
   facppg_wg* h = new (std::nothrow) facppg_wg();
   FACPPG_REQUIRE(h, FACPPG_EINVAL, "out of host memory");
-  h->cfg = *cfg; h->device = device; h->profiling = 0; h->ev_used = 0; h->last_tile = h->last_waves = h->last_tiles = 0; h->arena = nullptr;
+  h->cfg = *cfg; h->device = device; h->profiling = 0; h->ev_used = 0; h->ev_layers = 1; h->poll_limit = 0; h->n_cu = 0; h->last_tile = h->last_waves = h->last_tiles = 0; h->arena = nullptr;
   wg_flow_channels(cfg, h->n_rem, h->n_half, h->early);
 
   // arena layout (bytes, 256-aligned pieces)
@@ -1988,7 +2129,7 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   const size_t w1_bytes = (size_t)(16 * NG1 + 8) * 64 * sizeof(float4);
   auto w2_bytes = [&](int last) { return (size_t)(4 * (last ? 2 : 4) * NG2 + 8) * 64 * sizeof(float4); };
   struct Off { size_t start_w, start_b, end_w, end_b, winv, wfwd, w1[8], w2[8], b1[8], b2[8], w1pm[8], wcpm[8], b1pm[8], w1_16[8], wc_16[8], w2_16[8],
-               we[8], endb, w1f, w1f_16, w2r[8], w2r_16[8]; } fo[MAXF];
+               we[8], endb, w1f, w1f_16, w2r[8], w2r_16[8], ltab; } fo[MAXF];
   h->P = cfg->hop_length / 8;
   h->nj = (cfg->upsample_kernel + cfg->hop_length - 1) / cfg->hop_length;
   h->kc = h->nj * NMEL;
@@ -2012,6 +2153,7 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
       fo[k].w2r_16[i] = last ? 0 : take((size_t)(C / 16 + 4) * 16 * 64 * sizeof(float4));
     }
     fo[k].endb = take(8 * 4);
+    fo[k].ltab = take(8 * sizeof(WnLayerPtrs));
     fo[k].w1f = take((size_t)(8 + 8) * 1024 * sizeof(float4)); fo[k].w1f_16 = take((size_t)(4 + 4) * 2048 * sizeof(float4));   // + look-ahead
     fo[k].end_w = take(cc * C * 4); fo[k].end_b = take(cc * 4); fo[k].winv = take(cc * cc * 4); fo[k].wfwd = take(cc * cc * 4);
   }
@@ -2140,6 +2282,28 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
     h->wfwd[k] = F(fo[k].wfwd);
     WG_TRY(cpy(h->wfwd[k], src, cc * cc)); src += cc * cc;
   }
+  // k_wn_flow8's operand tables (32-frame tiles, folded flow edges), its poll limit, the CUs its workgroups must all fit on
+  for (int k = 0; k < cfg->n_flows; ++k) {
+    WnLayerPtrs t[8];
+    memset(t, 0, sizeof(t));
+    for (int i = 0; i < cfg->wn_layers; ++i) {
+      const bool last = i == cfg->wn_layers - 1;
+      t[i].w1 = i == 0 ? h->w1f[k] : h->w1pm[k][i]; t[i].wc = h->wcpm[k][i]; t[i].b1 = h->b1pm[k][i];
+      t[i].w2 = last ? h->w2[k][i] : h->w2r[k][i]; t[i].b2 = h->b2[k][i]; t[i].we = h->we[k][i];
+    }
+    h->ltab[k] = (WnLayerPtrs*)(h->arena + fo[k].ltab);
+    WG_TRY(hipMemcpyAsync(h->ltab[k], t, sizeof(t), hipMemcpyHostToDevice, stream));
+    WG_TRY(hipStreamSynchronize(stream));   // (t is a stack buffer)
+  }
+  {
+    const char* pl = getenv("FACPPG_POLL_LIMIT");
+    const double seconds = pl ? strtod(pl, nullptr) : 20.0;
+    int khz = 0, ncu = 0;
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+    h->poll_limit = seconds > 0 && khz > 0 ? (unsigned long long)(seconds * 1e3 * khz) : 0ull;
+    h->n_cu = ncu;
+  }
   WG_TRY(hipGetLastError());
   if (int rc = wgp_finish_create(h, stream)) return fail(rc);
   WG_TRY(hipStreamSynchronize(stream));
@@ -2195,7 +2359,7 @@ WsLayout ws_layout(const facppg_wg_config& c, int B, int T) {
 // phase-major layout (k_wn_layer<PM>): frames are the contiguous axis of every phase row
 struct PmLayout {
   int L, La, Tr, Tqp, P;
-  size_t h0, h1, xa, skip, melp, aud0, aud1, z, goff, gtab, total;
+  size_t h0, h1, xa, sync, skip, melp, aud0, aud1, z, goff, gtab, total;
   int ngroups;   // 4-frame groups a ragged batch can have at most (table entries; a multiple of 32 = one 128-frame tile)
 };
 PmLayout pm_layout(const facppg_wg_config& c, int B, int T) {
@@ -2210,6 +2374,7 @@ PmLayout pm_layout(const facppg_wg_config& c, int B, int T) {
   w.h0 = take((size_t)B * C * w.P * w.Tqp);
   w.h1 = take((size_t)B * C * w.P * w.Tqp);
   w.xa = take((size_t)B * 8 * w.P * w.Tqp);     // right behind h0 | h1: one memset zeroes the margins of all three
+  w.sync = take(MAXF * 8);                      // ... and k_wn_flow8's completed-tile counters, one per (flow, layer)
   w.skip = take((size_t)B * C * w.P * w.Tr);
   w.melp = take((size_t)B * NMEL * w.Tqp);
   w.aud0 = take((size_t)B * 8 * w.La);
@@ -2229,11 +2394,16 @@ extern "C" size_t facppg_wg_workspace_bytes(const facppg_wg* h, int B, int T) {
   return std::max(a, std::max(b, c));
 }
 
+extern "C" int facppg_debug_flow_ids(unsigned* out1024) {
+  FACPPG_HIP_CHECK(hipMemcpyFromSymbol(out1024, HIP_SYMBOL(g_flow_ids), 1024 * sizeof(unsigned)));
+  return FACPPG_OK;
+}
+
 #ifdef FACPPG_WN8_PROF
-extern "C" int facppg_debug_wn8_prof(unsigned long long* out8, int reset) {
-  FACPPG_HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_wn8_prof), 8 * sizeof(unsigned long long)));
+extern "C" int facppg_debug_wn8_prof(unsigned long long* out12, int reset) {
+  FACPPG_HIP_CHECK(hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_wn8_prof), 12 * sizeof(unsigned long long)));
   if (reset) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     FACPPG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_wn8_prof), z, sizeof(z)));
   }
   return FACPPG_OK;
@@ -2267,7 +2437,8 @@ extern "C" int facppg_wg_last_layer_ms(facppg_wg* h, float* avg_ms, int* n_launc
     FACPPG_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
     tot += ms;
   }
-  *n_launches = h->ev_used / 2;
+  // (k_wn_flow8: a pair brackets a whole flow; reported per layer all the same)
+  *n_launches = h->ev_used / 2 * std::max(1, h->ev_layers);
   *avg_ms = *n_launches ? (float)(tot / *n_launches) : 0.0f;
   return FACPPG_OK;
 }
@@ -2409,8 +2580,39 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   const int w8mode = w8env ? atoi(w8env) : 1;
   h->last_tile = tn; h->last_tiles = (int)lgrid;
   h->last_waves = (wide128 || tile16 || (narrow && w8mode != 0) || (!narrow && w8mode == 2)) ? 8 : 4;
+  // A launch that leaves CUs empty can run all layers of a flow in ONE launch (k_wn_flow8): FACPPG_WN_FUSED = 1 one worker per
+  // tile, 2 two workers per tile taking turns on the layers.  Same bits, but MEASURED SLOWER than one launch per layer (T = 200:
+  // 7.69 ms per layer launches, 9.07 / 10.74 ms fused with 1 / 2 workers -- profiles/r04_experiments.txt section 2), so it is
+  // off unless asked for.
+  const char* fenv = getenv("FACPPG_WN_FUSED");
+  const int fworkers = fenv ? atoi(fenv) : 0;
+  FACPPG_REQUIRE(fworkers >= 0 && fworkers <= 2, FACPPG_EINVAL, "FACPPG_WN_FUSED=%s: expected 0, 1 or 2", fenv);
+  const bool fused = fold && narrow && w8mode != 0 && fworkers > 0 && h->n_cu > 0 && (long)lgrid <= h->n_cu && c.wn_layers == 8;
+  h->ev_layers = fused ? c.wn_layers : 1;
   for (int k = nf - 1; k >= 0; --k) {
-    for (int i = 0; i < c.wn_layers; ++i) {
+    if (fused) {
+      FlowArgs f;
+      a.h_in = hbuf[hi]; a.h_out = hbuf[hi ^ 1];
+      a.endb = h->endb[k]; a.nch = h->kcp / KCH;
+      f.a = a; f.layers = (const WnLayerPtrs*)h->ltab[k]; f.done = (unsigned*)(ws + w.sync) + (size_t)k * 8;
+      f.n_layers = c.wn_layers; f.tiles = (int)lgrid; f.workers = fworkers; f.poll_limit = h->poll_limit;
+      if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
+      f.l0 = 0;
+      const char* fdbg = getenv("FACPPG_WN_FUSED_DEBUG");   // timing experiments: 1 = plain stores (racy), 2 = one launch per layer
+      const int dbg = fdbg ? atoi(fdbg) : 0;
+      f.flags = (dbg >> 2) & 7;   // 4 = wait before the prologue, 8 = no acquire behind the wait
+      if (dbg & 2) {
+        for (int l = 0; l < c.wn_layers; ++l) {
+          f.l0 = l; f.n_layers = l + 1; f.workers = 1;
+          if (dbg & 1) k_wn_flow8<true, false><<<lgrid, 512, 32768 + 8 * 1024, s>>>(f);
+          else k_wn_flow8<true, true><<<lgrid, 512, 32768 + 8 * 1024, s>>>(f);
+        }
+      } else if (dbg & 1) k_wn_flow8<true, false><<<lgrid * fworkers, 512, 32768 + 8 * 1024, s>>>(f);
+      else k_wn_flow8<true><<<lgrid * fworkers, 512, 32768 + 8 * 1024, s>>>(f);
+      if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
+      if ((c.wn_layers - 1) & 1) hi ^= 1;
+    }
+    for (int i = 0; i < (fused ? 0 : c.wn_layers); ++i) {
       a.h_in = hbuf[hi]; a.h_out = hbuf[hi ^ 1];
       a.w1 = h->w1pm[k][i]; a.wc = h->wcpm[k][i]; a.b1 = h->b1pm[k][i]; a.w2 = h->w2[k][i]; a.b2 = h->b2[k][i];
       if (tile16) { a.w1 = h->w1_16[k][i]; a.wc = h->wc_16[k][i]; a.w2 = h->w2_16[k][i]; }

@@ -64,6 +64,10 @@ struct facppg_wg {
   int profiling;
   std::vector<hipEvent_t> ev;  // pairs around each k_wn_layer launch
   int ev_used;
+  int ev_layers;               // layers one pair brackets (k_wn_flow8: a whole flow)
+  void* ltab[facppg::MAXF];    // device tables of k_wn_flow8's per-layer operands (WnLayerPtrs[8] per flow)
+  unsigned long long poll_limit;   // wall-clock ticks an in-launch wait may last before it traps
+  int n_cu;
   facppg::WgpState* wgp;   // persistent small-launch path (facppg_wgp.hip), or null
   int last_tile, last_waves, last_tiles;   // shape of the WN layer launches of the most recent infer (facppg_wg_last_launch_shape)
 };
