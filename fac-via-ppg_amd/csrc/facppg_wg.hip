@@ -923,16 +923,22 @@ __device__ __forceinline__ void store_f1(float* g, const float v) {
   else *(__attribute__((address_space(1))) float*)g = v;
 }
 __device__ __forceinline__ void flow_wait(const FlowWait& fw) {
-  unsigned long long t0 = 0;
-  unsigned spins = 0;
-  while (__hip_atomic_load(fw.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fw.target) {
-    __builtin_amdgcn_s_sleep(4);
-    if ((++spins & 1023u) == 0 && fw.poll_limit) {
-      const unsigned long long now = wall_clock64();
-      if (!t0) t0 = now;
-      else if (now - t0 > fw.poll_limit) __builtin_trap();
+  // ONE wave polls (1 800 waves would hammer one address; a scalar s_load glc poll, which would leave the vector memory pipeline
+  // alone, sees the counter ~300 us late on this stack); the others meet it at the barrier
+  if (threadIdx.x < 64) {
+    unsigned long long t0 = 0;
+    unsigned spins = 0;
+    for (;;) {
+      if (__hip_atomic_load(fw.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= fw.target) break;
+      __builtin_amdgcn_s_sleep(16);
+      if ((++spins & 1023u) == 0 && fw.poll_limit) {
+        const unsigned long long now = wall_clock64();
+        if (!t0) t0 = now;
+        else if (now - t0 > fw.poll_limit) __builtin_trap();
+      }
     }
   }
+  __syncthreads();
   if (!(fw.flags & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU's L1 may hold the buffer's lines of two layers ago
 }
 
