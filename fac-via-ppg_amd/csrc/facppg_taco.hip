@@ -503,6 +503,77 @@ __device__ __forceinline__ void attn_features(const DecArgs& p, const DecLds& L,
     }
 }
 
+// The part of the energies that does not need the query (model.py:101-104: e = v . tanh(W_q q + W_loc f + processed_memory)):
+// this wave's block of pa = ldense . feat (MFMA) and its processed-memory values, for the FIRST 64-position pass of the window.
+// The split decoder's main workgroup forms them while the attention LSTM's hidden state is still in flight; dec_attention<PRE>
+// then only adds the processed query, takes the tanh and reduces -- the same values through the same expression, so the same bits.
+// Waves < NRB: acc / pm of the 16 rows of row block `wave` (column block 0); with a short tail (see dec_attention) the other
+// waves hold up to four 16x16 tail tiles (4 values each).  A wave whose share does not fit (second loop iteration, more than
+// four tiles) computes the rest in dec_attention as before.
+constexpr int PRE_TAIL_TILES = 4;
+template <int NT>
+__device__ __forceinline__ void attn_energy_pre(const DecArgs& p, const DecLds& L, const float* pm, int c0, int nc, int tid,
+                                                float4* __restrict__ stash) {   // LDS, [8][NT] float4: slots 0-3 acc, 4-7 pm
+  // (opaque thread index: otherwise hipcc hoists the ~50 per-lane row offsets below out of the frame loop, where they cost
+  //  ~100 registers for the whole utterance and spill)
+  asm volatile("" : "+v"(tid));
+  float pacc[16], ppm[16];
+  const int lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
+  constexpr int NW = NT / 64;
+  const int NRB = L.AD32 / 32;
+  const int ntail = nc - 32;
+  const bool tail_valu = ntail > 0 && ntail <= 16 && NW > NRB;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { pacc[r] = 0.0f; ppm[r] = 0.0f; }
+  if (wave < (tail_valu ? NRB : 2 * NRB) && 32 * (tail_valu ? 0 : wave & 1) < nc) {
+    const int rb = tail_valu ? wave : wave >> 1, cb = tail_valu ? 0 : wave & 1;
+    const int pos = 32 * cb + li;
+    const float* pmp = pm + (size_t)(32 * rb + 4 * kh) * p.Tin + c0 + pos;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int a = 32 * rb + 8 * (r >> 2) + (r & 3) + 4 * kh;
+      ppm[r] = (pos < nc && a < p.AD) ? pmp[(size_t)(8 * (r >> 2) + (r & 3)) * p.Tin] : 0.0f;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const int f = 2 * s2 + kh;
+      acc = mfma32x32x2(L.ldense[f * L.AD32 + 32 * rb + li], L.feat[f * 64 + pos], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pacc[r] = acc[r];
+  } else if (tail_valu) {
+    const int pl = lane & 15, kq = lane >> 4, pos = 32 + pl;
+#pragma unroll
+    for (int j = 0; j < PRE_TAIL_TILES; ++j) {
+      const int tile = wave - NRB + j * (NW - NRB);
+      if (tile * 16 >= p.AD) break;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = 16 * tile + 4 * kq + r;
+        ppm[4 * j + r] = (pl < ntail && a < p.AD) ? pm[(size_t)a * p.Tin + c0 + pos] : 0.0f;
+      }
+      f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) {
+        const int f = 4 * s2 + kq;
+        acc = mfma16x16x4(L.ldense[f * L.AD32 + 16 * tile + pl], L.feat[f * 64 + pos], acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pacc[4 * j + r] = acc[r];
+    }
+  }
+  // (kept in LDS, not in registers, across the wait for the workers: the main workgroup already holds the query layer's 96
+  //  weight registers there; each thread reads back only what it wrote, so no barrier is involved)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    stash[j * NT + tid] = make_float4(pacc[4 * j], pacc[4 * j + 1], pacc[4 * j + 2], pacc[4 * j + 3]);
+    stash[(4 + j) * NT + tid] = make_float4(ppm[4 * j], ppm[4 * j + 1], ppm[4 * j + 2], ppm[4 * j + 3]);
+  }
+}
+
 // Location-sensitive attention (model.py:63-121) evaluated on the index range the reference's
 // window mask keeps (utils.py:64-77).  Reads ah from in_att[P+E:], updates wprev/wcum and writes
 // the context into in_att[P:], in_dec[A:], in_proj[D:].
@@ -510,10 +581,12 @@ __device__ __forceinline__ void attn_features(const DecArgs& p, const DecLds& L,
 // caller -- the split decoder's main workgroup -- before it started waiting for the hidden state).  Same products in the same
 // order as matvec_part, so the same bits, without the stream's L2 latency between the hidden state and the energies.
 struct NoQueryRegs { float4 w[1]; };
-template <int NT, int QR = 0>
+template <int NT, int QR = 0, bool PRE = false>
 __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L, const float* mem, const float* pm, int len,
                                               int t, int b, int tid, bool write_out, bool feat_ready = false,
-                                              const float4 (&wq)[QR > 0 ? QR : 1] = NoQueryRegs().w) {
+                                              const float4 (&wq)[QR > 0 ? QR : 1] = NoQueryRegs().w,
+                                              const float4* __restrict__ stash = nullptr) {   // PRE: attn_energy_pre's [8][NT] float4
+  if constexpr (PRE) asm volatile("" : "+v"(tid));   // (see attn_energy_pre: no per-lane offsets hoisted out of the frame loop)
   const int lane = tid & 63, wave = tid >> 6;
   long long atk = clock64();
 #define APROF(slot)                                                     \
@@ -581,19 +654,28 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
       const int pos = 32 * cb + li;
       // processed-memory values of this lane's 16 rows, fetched up front (L2 latency under the MFMAs)
       float pmv[16];
-      const float* pmp = pm + (size_t)(32 * rb + 4 * kh) * p.Tin + c0 + pos;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int a = 32 * rb + 8 * (r >> 2) + (r & 3) + 4 * kh;
-        pmv[r] = (pos < nc && a < p.AD) ? pmp[(size_t)(8 * (r >> 2) + (r & 3)) * p.Tin] : 0.0f;
-      }
       f32x16 acc;
+      if (PRE && c0 == lo && pr == wave) {   // formed by attn_energy_pre before the hidden state arrived
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int j = 0; j < 4; ++j) {
+          const float4 av = stash[j * NT + tid], pv = stash[(4 + j) * NT + tid];
+          acc[4 * j] = av.x; acc[4 * j + 1] = av.y; acc[4 * j + 2] = av.z; acc[4 * j + 3] = av.w;
+          pmv[4 * j] = pv.x; pmv[4 * j + 1] = pv.y; pmv[4 * j + 2] = pv.z; pmv[4 * j + 3] = pv.w;
+        }
+      } else {
+        const float* pmp = pm + (size_t)(32 * rb + 4 * kh) * p.Tin + c0 + pos;
 #pragma unroll
-      for (int s2 = 0; s2 < 16; ++s2) {
-        const int f = 2 * s2 + kh;
-        acc = mfma32x32x2(L.ldense[f * L.AD32 + 32 * rb + li], L.feat[f * 64 + pos], acc);
+        for (int r = 0; r < 16; ++r) {
+          const int a = 32 * rb + 8 * (r >> 2) + (r & 3) + 4 * kh;
+          pmv[r] = (pos < nc && a < p.AD) ? pmp[(size_t)(8 * (r >> 2) + (r & 3)) * p.Tin] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+          const int f = 2 * s2 + kh;
+          acc = mfma32x32x2(L.ldense[f * L.AD32 + 32 * rb + li], L.feat[f * 64 + pos], acc);
+        }
       }
       float e = 0.0f;
 #pragma unroll
@@ -608,7 +690,22 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
       // tail positions 32 .. 32+ntail-1 as (16 attention dims x 16 positions) tiles of the 16x16x4 MFMA
       const int pl = lane & 15, kq = lane >> 4, pos = 32 + pl;
       float et = 0.0f;
-      for (int tile = wave - NRB; tile * 16 < p.AD; tile += NW - NRB) {
+      int tile = wave - NRB;
+      if (PRE && c0 == lo) {   // the first PRE_TAIL_TILES tiles were formed by attn_energy_pre
+#pragma unroll
+        for (int j = 0; j < PRE_TAIL_TILES; ++j) {
+          if (tile * 16 >= p.AD) break;
+          const float4 av = stash[j * NT + tid], pv = stash[(4 + j) * NT + tid];
+          const float a4[4] = {av.x, av.y, av.z, av.w}, p4[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int a = 16 * tile + 4 * kq + r;   // a < AD32: vv is zero past AD
+            et = fmaf(L.vv[a], tanh_fast(L.pq[a] + a4[r] + p4[r]), et);
+          }
+          tile += NW - NRB;
+        }
+      }
+      for (; tile * 16 < p.AD; tile += NW - NRB) {
         float pmv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -643,6 +740,27 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
     __syncthreads();
     APROF(10)
   }
+  // The context's memory rows (2 rounds of 3 positions per wave cover the reference's 41-wide window) depend on the window only:
+  // with PRE they are requested in front of the softmax, and their L2 latency passes under it and the weight update.  (Requested
+  // earlier -- behind the query -- one or both rounds spill next to the energies' registers and the frame gets slower: measured.)
+  constexpr int CW = 8;    // position groups (with 16 waves, waves w and w+8 share a group and split the channels)
+  constexpr int QU = 3;    // positions per wave issued together (2 rounds cover the 41-wide window)
+  constexpr int CR = 12 / (NT / 64 / CW);   // 64-channel rounds per wave (E <= 768)
+  constexpr int PRE_ROUNDS = PRE ? 2 : 0;
+  const int grp = wave & (CW - 1), halfsel = wave / CW;
+  float mvp[PRE_ROUNDS > 0 ? PRE_ROUNDS : 1][QU][CR];
+  auto request_rows = [&](int rd) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < QU; ++j) {
+      const int q = lo + grp + rd * CW * QU + j * CW;
+#pragma unroll
+      for (int r = 0; r < CR; ++r) {
+        const int c = lane + 64 * (halfsel * CR + r);
+        mvp[rd][j][r] = (q <= hi && c < p.E) ? mem[(size_t)q * p.E + c] : 0.0f;
+      }
+    }
+  };
+  if constexpr (PRE) { request_rows(0); request_rows(1); }
   if (wave == 0) {   // softmax over [lo, hi]; everything else is masked to -inf => weight 0
     float mx = -INFINITY;
     for (int q = lo + lane; q <= hi; q += 64) mx = fmaxf(mx, L.en[q]);
@@ -672,16 +790,23 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
   // free here) and are summed in a FIXED order: the result must be bitwise reproducible, because
   // in coop mode every workgroup recomputes it and must reach the same stop decision.
   {
-    constexpr int CW = 8;    // position groups (with 16 waves, waves w and w+8 share a group and split the channels)
-    constexpr int QU = 3;    // positions per wave issued together (2 rounds cover the 41-wide window)
-    constexpr int CR = 12 / (NT / 64 / CW);   // 64-channel rounds per wave (E <= 768)
     float* cpart = L.part;   // [CW][E]  (part + feat = 6144 floats >= 8 * E for E <= 768)
     static_assert(NT / 64 == 2 * CW || NT / 64 == CW, "context code deals positions to 8 waves or wave pairs");
-    const int grp = wave & (CW - 1), halfsel = wave / CW;
     float accv[CR];
 #pragma unroll
     for (int r = 0; r < CR; ++r) accv[r] = 0.0f;
-    for (int qb = lo + grp; qb <= hi; qb += CW * QU) {
+    if constexpr (PRE) {
+#pragma unroll
+      for (int rd = 0; rd < PRE_ROUNDS; ++rd)
+#pragma unroll
+        for (int j = 0; j < QU; ++j) {
+          const int q = lo + grp + rd * CW * QU + j * CW;
+          const float wgt = q <= hi ? L.en[q] : 0.0f;
+#pragma unroll
+          for (int r = 0; r < CR; ++r) accv[r] = fmaf(wgt, mvp[rd][j][r], accv[r]);
+        }
+    }
+    for (int qb = lo + grp + PRE_ROUNDS * CW * QU; qb <= hi; qb += CW * QU) {
       float mv[QU][CR];
 #pragma unroll
       for (int j = 0; j < QU; ++j) {
@@ -1136,6 +1261,8 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
   const float* mem = p.memory + (size_t)b * p.Tin * p.E;
   const float* pm = p.pm + (size_t)b * p.Tin * p.AD;
   float* ah = L.in_att + p.P + p.E;
+  // attn_energy_pre's results, behind everything dec_carve laid out
+  float4* stash = reinterpret_cast<float4*>(sm + round_up((int)dec_lds_floats(p.P, p.E, p.A, p.D, p.NF, p.AD, p.NFIL, p.KSZ, p.Tin), 4));
   // the query layer's weights of this thread's (4-row slot, k range) are REQUESTED every frame before the main workgroup starts
   // waiting for the workers (gate, then the attention LSTM's hidden state: ~10 us): the 180 KB stream's L2 latency, which was
   // 2.9 us of the 12.7 us attention, hides in that wait.  (Keeping them in registers for the whole utterance spills: 96 registers
@@ -1156,6 +1283,9 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
     int lo, hi;
     attn_window_range(p.window, t, len, &lo, &hi);
     attn_features<NTC>(p, L, lo, min(64, hi - lo + 1), tid);   // needs only frame t-1's weights
+    __syncthreads();
+    attn_energy_pre<NTC>(p, L, pm, lo, min(64, hi - lo + 1), tid, stash);   // ... and so does this part of the energies
+    asm volatile("" ::: "memory");   // (the 96 registers of query weights requested next must not be hoisted over it: spills)
     float4 wq[QR];
 #pragma unroll
     for (int i = 0; i < QR; ++i)
@@ -1174,7 +1304,7 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
     for (int i = tid; i < p.A; i += NTC) ah[i] = xwait(AH + i, tag);
     __syncthreads();
     PROF(3)
-    dec_attention<NTC, QR>(p, L, mem, pm, len, t, b, tid, true, true, wq);
+    dec_attention<NTC, QR, true>(p, L, mem, pm, len, t, b, tid, true, true, wq, stash);
     for (int i = tid; i < p.E; i += NTC) xpub(CTX + i, L.in_proj[p.D + i], tag);
     PROF(5)
   }
@@ -1673,7 +1803,8 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
     a.w1p_t = h->w1p_t; a.b1p = h->b1p;
     FACPPG_HIP_CHECK(hipMemsetAsync(ws + w.xchg, 0, w.total - w.xchg, s));
     size_t ssm = (NU * ustride + 1024) * 4;
-    if (ssm < smem) ssm = smem;
+    const size_t main_smem = (round_up((int)(smem / 4), 4) + (size_t)8 * NTC * 4) * 4;   // + attn_energy_pre's stash
+    if (ssm < main_smem) ssm = main_smem;
     const void* fn = NU == 1 ? (const void*)k_decoder_split<1> : NU == 2 ? (const void*)k_decoder_split<2>
                    : NU == 3 ? (const void*)k_decoder_split<3> : (const void*)k_decoder_split<4>;
     FACPPG_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ssm));
