@@ -4,6 +4,7 @@
 // c strided 4-byte-per-lane rows, a lane owns 4 consecutive positions (16-byte accesses), the c x c matrix
 // sits in SGPRs/registers.
 #include <algorithm>
+#include <vector>
 
 #include "facppg_common.h"
 
@@ -444,6 +445,228 @@ extern "C" int facppg_adam_step(const void* table_dev, int n_tensors, const int3
   hipStream_t s = (hipStream_t)stream;
   k_adam_tick<<<1, 1, 0, s>>>(step_dev);
   k_adam<<<(unsigned)n_chunks, 256, 0, s>>>((const AdamTensor*)table_dev, (const int2*)chunks_dev, step_dev, lr, beta1, beta2, eps, weight_decay);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+namespace facppg {
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Weight and bias gradients of one flow's WN stack in fp32 (the autograd backward of glow.py:154-175 with respect to the
+// parameters; until round 4 these were torch.bmm(...).sum(0) calls, i.e. rocBLAS): every weight gradient is an NT product
+// over the positions of two channel-major saved tensors,
+//     out[m][k] = sum_b sum_{n < L} A[b][m][n] * X[b][k][n]      (X optionally the product of two tensors: the gate output)
+// k_wgrad_f32 forms a 128 x 64 tile of one such product per workgroup on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32;
+// wave w: rows 32w .. 32w+31, two 32-column blocks), all products of a flow in ONE launch (blockIdx.z = problem).  The
+// reduction runs over 32 positions per stage: both operand tiles are read along their contiguous position axis (16 B per
+// lane), written to LDS as [n/4][row][4] with the four positions of a group in the order (0, 2, 1, 3), so that a lane's two
+// MFMA K-steps of a group (n = 4g + kh and 4g + 2 + kh) are ONE 8-byte LDS read; two LDS buffers, loads of the next stage in
+// registers under the MFMAs of this one.  The sum over the batch runs inside the workgroup (fixed order: deterministic, no
+// partial buffers).  k_rowsum_f32 forms the bias gradients (row sums over batch and positions) in a fixed order.
+// ------------------------------------------------------------------------------------------
+struct WgradF32Prob {
+  const float* A;    // [B][>= M][lda]   (row m at A + b * a_bs + m * lda)
+  const float* X;    // [B][>= K][ldx]
+  const float* X2;   // optional: X is taken as X[k][n] * X2[k][n]
+  float* out;        // element (m, k) at out[m * so_m + k * so_k]
+  long a_bs, x_bs;
+  int lda, ldx, M, K, so_m, so_k;
+};
+struct RowSumF32 {
+  const float* src;  // [B][rows][ld]
+  float* out;        // [rows]
+  float* out2;       // optional second copy (the in and cond biases share their gradient)
+  long bs;
+  int ld, rows, first;   // first: index of this group's first row in the launch
+};
+
+typedef float f4ua __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
+
+constexpr int WG_TM = 128, WG_TK = 64, WG_TN = 32;
+
+__global__ __launch_bounds__(256) void k_wgrad_f32(const WgradF32Prob* __restrict__ probs, int B, int L) {
+  __shared__ __attribute__((aligned(16))) float As[2][WG_TN / 4][WG_TM][4];
+  __shared__ __attribute__((aligned(16))) float Xs[2][WG_TN / 4][WG_TK][4];
+  const WgradF32Prob pr = probs[blockIdx.z];
+  const int m0 = blockIdx.y * WG_TM, k0 = blockIdx.x * WG_TK;
+  if (m0 >= pr.M || k0 >= pr.K) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
+  const int g = tid & 7, r0 = tid >> 3;   // staging: 8 threads cover 32 positions of a row, 32 rows per pass
+  f32x16 acc[2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+  float4 ra[4], rx[2];
+  const int nchunk = (L + WG_TN - 1) / WG_TN, nst = B * nchunk;
+  auto load = [&](int st) __attribute__((always_inline)) {
+    const int b = st / nchunk, n = (st - b * nchunk) * WG_TN + 4 * g;
+    // positions >= L add nothing (and may never have been written: 0 * NaN = NaN, so BOTH operands are zeroed there);
+    // the last group of a row is read element by element -- a row of a0 / dout ends where the tensor ends
+    auto row4 = [&](const float* p) __attribute__((always_inline)) {
+      if (n + 4 <= L) {
+        const f4ua q = *reinterpret_cast<const f4ua*>(p + n);
+        return make_float4(q.x, q.y, q.z, q.w);
+      }
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < L) v.x = p[n];
+      if (n + 1 < L) v.y = p[n + 1];
+      if (n + 2 < L) v.z = p[n + 2];
+      return v;
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + r0 + 32 * j;
+      ra[j] = m < pr.M ? row4(pr.A + (size_t)b * pr.a_bs + (size_t)m * pr.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + r0 + 32 * j;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < pr.K) {
+        const size_t o = (size_t)b * pr.x_bs + (size_t)k * pr.ldx;
+        v = row4(pr.X + o);
+        if (pr.X2) {
+          const float4 q2 = row4(pr.X2 + o);
+          v.x *= q2.x; v.y *= q2.y; v.z *= q2.z; v.w *= q2.w;
+        }
+      }
+      rx[j] = v;
+    }
+  };
+  auto stash = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&As[buf][g][r0 + 32 * j][0]) = make_float4(ra[j].x, ra[j].z, ra[j].y, ra[j].w);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(&Xs[buf][g][r0 + 32 * j][0]) = make_float4(rx[j].x, rx[j].z, rx[j].y, rx[j].w);
+  };
+  load(0);
+  stash(0);
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nst) load(st + 1);
+#pragma unroll
+    for (int gg = 0; gg < WG_TN / 4; ++gg) {
+      const float2 a = *reinterpret_cast<const float2*>(&As[buf][gg][32 * w + li][2 * kh]);
+      const float2 x0 = *reinterpret_cast<const float2*>(&Xs[buf][gg][li][2 * kh]);
+      const float2 x1 = *reinterpret_cast<const float2*>(&Xs[buf][gg][32 + li][2 * kh]);
+      acc[0] = mfma32x32x2(a.x, x0.x, acc[0]);
+      acc[1] = mfma32x32x2(a.x, x1.x, acc[1]);
+      acc[0] = mfma32x32x2(a.y, x0.y, acc[0]);
+      acc[1] = mfma32x32x2(a.y, x1.y, acc[1]);
+    }
+    if (st + 1 < nst) stash(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int k = k0 + 32 * cb + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + 32 * w + 8 * (r >> 2) + (r & 3) + 4 * kh;
+      if (m < pr.M && k < pr.K) pr.out[(size_t)m * pr.so_m + (size_t)k * pr.so_k] = acc[cb][r];
+    }
+  }
+}
+
+// one workgroup per row: sum over batch and positions, each thread a strided share in index order, then the wave's
+// shuffle tree and the four waves in LDS order
+__global__ __launch_bounds__(256) void k_rowsum_f32(const RowSumF32* __restrict__ groups, int n_groups, int B, int L) {
+  __shared__ float part[4];
+  int gi = 0;
+  while (gi + 1 < n_groups && (int)blockIdx.x >= groups[gi + 1].first) ++gi;
+  const RowSumF32 gr = groups[gi];
+  const int row = blockIdx.x - gr.first;
+  float s = 0.0f;
+  for (int b = 0; b < B; ++b) {
+    const float* p = gr.src + (size_t)b * gr.bs + (size_t)row * gr.ld;
+    for (int n = threadIdx.x; n < L; n += 256) s += p[n];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = ((part[0] + part[1]) + part[2]) + part[3];
+    gr.out[row] = t;
+    if (gr.out2) gr.out2[row] = t;
+  }
+}
+
+}  // namespace
+}  // namespace facppg
+
+extern "C" size_t facppg_wn_weight_grads_workspace_bytes(int n_layers) {
+  return (size_t)(6 * n_layers + 2) * sizeof(facppg::WgradF32Prob) + (size_t)(3 * n_layers + 2) * sizeof(facppg::RowSumF32) + 512;
+}
+
+// Lr = round_up(L, 64), Lp = 128 + Lr + 128 as in facppg_wn_forward_save / facppg_wn_backward_data, whose tensors these are.
+extern "C" int facppg_wn_weight_grads(int n_in, int n_layers, const float* a0_dev, const float* spect_pad_dev, const float* h_all_dev,
+                                      const float* ts_all_dev, const float* skip_dev, const float* dout_dev,
+                                      const float* dpre_all_dev, const float* dh_all_dev, const float* dskip_dev, int B, int L,
+                                      const facppg_wn_grads* g, void* ws_, size_t ws_bytes, void* stream_) {
+  using namespace facppg;
+  FACPPG_REQUIRE(a0_dev && spect_pad_dev && h_all_dev && ts_all_dev && skip_dev && dout_dev && dpre_all_dev && dh_all_dev && dskip_dev &&
+                     g && ws_, FACPPG_EINVAL, "NULL argument");
+  FACPPG_REQUIRE(n_in >= 1 && n_in <= 4 && n_layers >= 1 && n_layers <= 8 && B > 0 && L > 0, FACPPG_EINVAL,
+                 "n_in %d, n_layers %d, B %d, L %d out of range", n_in, n_layers, B, L);
+  FACPPG_REQUIRE(ws_bytes >= facppg_wn_weight_grads_workspace_bytes(n_layers), FACPPG_EWORKSPACE, "workspace has %zu bytes, need %zu",
+                 ws_bytes, facppg_wn_weight_grads_workspace_bytes(n_layers));
+  hipStream_t s = (hipStream_t)stream_;
+  constexpr int CH = 256, NC = 640, HALO_ = 128;
+  const int Lr = round_up(L, 64), Lp = HALO_ + Lr + HALO_;
+  const size_t dh_sz = (size_t)B * CH * Lr, dp_sz = (size_t)B * 2 * CH * Lr, h_sz = (size_t)B * CH * Lp;
+  std::vector<WgradF32Prob> probs;
+  std::vector<RowSumF32> rows;
+  int first = 0;
+  auto prob = [&](const float* A, long a_bs, int lda, int M, const float* X, const float* X2, long x_bs, int ldx, int K, float* out,
+                  int so_m, int so_k) {
+    WgradF32Prob q;
+    q.A = A; q.X = X; q.X2 = X2; q.out = out; q.a_bs = a_bs; q.x_bs = x_bs; q.lda = lda; q.ldx = ldx; q.M = M; q.K = K; q.so_m = so_m; q.so_k = so_k;
+    probs.push_back(q);
+  };
+  auto rowsum = [&](const float* src, long bs, int ld, int n, float* out, float* out2) {
+    RowSumF32 r;
+    r.src = src; r.out = out; r.out2 = out2; r.bs = bs; r.ld = ld; r.rows = n; r.first = first;
+    first += n;
+    rows.push_back(r);
+  };
+  // start conv (glow.py:130-131): d start.w[m][c] = sum dh_0[m][n] a0[c][n]
+  prob(dh_all_dev, (long)CH * Lr, Lr, CH, a0_dev, nullptr, (long)n_in * L, L, n_in, g->start_w, n_in, 1);
+  rowsum(dh_all_dev, (long)CH * Lr, Lr, CH, g->start_b, nullptr);
+  for (int i = 0; i < n_layers; ++i) {
+    const bool last = i == n_layers - 1;
+    const float* dpre = dpre_all_dev + (size_t)i * dp_sz;
+    const float* ts = ts_all_dev + (size_t)i * dp_sz;
+    const float* h = h_all_dev + (size_t)i * h_sz;
+    const int d = 1 << i;
+    for (int tap = 0; tap < 3; ++tap)   // dilated conv (glow.py:137-143): d in.w[m][c][tap] = sum dpre[m][n] h_i[c][n + (tap-1) d]
+      prob(dpre, (long)2 * CH * Lr, Lr, 2 * CH, h + HALO_ + (tap - 1) * d, nullptr, (long)CH * Lp, Lp, CH, g->in_w[i] + tap, 3 * CH, 3);
+    // conditioning conv (glow.py:145-147)
+    prob(dpre, (long)2 * CH * Lr, Lr, 2 * CH, spect_pad_dev, nullptr, (long)NC * Lr, Lr, NC, g->cond_w[i], NC, 1);
+    rowsum(dpre, (long)2 * CH * Lr, Lr, 2 * CH, g->in_b[i], g->cond_b[i]);
+    // res_skip conv on the gate output tanh * sigmoid (glow.py:150-158, 166-173): res rows take dh_{i+1}, skip rows dskip
+    const float* dres = dh_all_dev + (size_t)(i + 1) * dh_sz;
+    if (!last) {
+      prob(dres, (long)CH * Lr, Lr, CH, ts, ts + (size_t)CH * Lr, (long)2 * CH * Lr, Lr, CH, g->rs_w[i], CH, 1);
+      rowsum(dres, (long)CH * Lr, Lr, CH, g->rs_b[i], nullptr);
+    }
+    float* skw = g->rs_w[i] + (last ? 0 : (size_t)CH * CH);
+    prob(dskip_dev, (long)CH * Lr, Lr, CH, ts, ts + (size_t)CH * Lr, (long)2 * CH * Lr, Lr, CH, skw, CH, 1);
+    rowsum(dskip_dev, (long)CH * Lr, Lr, CH, g->rs_b[i] + (last ? 0 : CH), nullptr);
+  }
+  // end conv (glow.py:160-164): d end.w[m][c] = sum dout[m][n] skip[c][n]
+  prob(dout_dev, (long)2 * n_in * L, L, 2 * n_in, skip_dev, nullptr, (long)CH * Lr, Lr, CH, g->end_w, CH, 1);
+  rowsum(dout_dev, (long)2 * n_in * L, L, 2 * n_in, g->end_b, nullptr);
+  char* ws = (char*)ws_;
+  WgradF32Prob* probs_dev = (WgradF32Prob*)ws;
+  RowSumF32* rows_dev = (RowSumF32*)(ws + round_up((int)(probs.size() * sizeof(WgradF32Prob)), 256));
+  FACPPG_HIP_CHECK(hipMemcpyAsync(probs_dev, probs.data(), probs.size() * sizeof(WgradF32Prob), hipMemcpyHostToDevice, s));
+  FACPPG_HIP_CHECK(hipMemcpyAsync(rows_dev, rows.data(), rows.size() * sizeof(RowSumF32), hipMemcpyHostToDevice, s));
+  k_wgrad_f32<<<dim3((NC + WG_TK - 1) / WG_TK, (2 * CH + WG_TM - 1) / WG_TM, (unsigned)probs.size()), 256, 0, s>>>(probs_dev, B, L);
+  k_rowsum_f32<<<first, 256, 0, s>>>(rows_dev, (int)rows.size(), B, L);
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
 }

@@ -81,6 +81,9 @@ def _declare(lib):
                                              vp, sz, vp]),
         "facppg_wn_backward_data": (c.c_int, [c.POINTER(WnWeights), c.c_int, c.c_int, vp, vp, c.c_int, c.c_int, vp, vp, vp, vp,
                                               vp, vp, sz, vp]),
+        "facppg_wn_weight_grads_workspace_bytes": (sz, [c.c_int]),
+        "facppg_wn_weight_grads": (c.c_int, [c.c_int, c.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, c.c_int, c.c_int, c.POINTER(WnGrads),
+                                             vp, sz, vp]),
         "facppg_conv1x1": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, c.c_int, c.c_int, vp]),
         "facppg_logdet": (c.c_int, [vp, c.c_int, vp, vp, vp]),
         "facppg_conv1x1_wgrad_workspace_bytes": (sz, [c.c_int]),

@@ -113,8 +113,8 @@ class _WNFunction(torch.autograd.Function):
                tanh/sigmoid halves of each gate;
     backward = facppg_wn_backward_data for everything that flows through the data (transposed
                dilated convs, gate derivative, conditioning gradient: exact-fp32 MFMA GEMMs) plus
-               the weight gradients, which are plain [M x N].[N x K] products over the saved tensors
-               and go to rocBLAS through torch.
+               facppg_wn_weight_grads for the weight / bias gradients (NT products over batch and positions
+               of the saved tensors, exact-fp32 MFMA as well): nothing of the stack runs in torch or rocBLAS.
     Inputs: a0 [B, n_in, L], spect_pad [B, 640, Lr], then start.w, start.b, per layer
     (in.w, in.b, cond.w, cond.b, res_skip.w, res_skip.b), end.w, end.b -- plain effective weights."""
 
@@ -171,25 +171,17 @@ class _WNFunction(torch.autograd.Function):
                                                  _lib.ptr(dh_all), _lib.ptr(dskip), _lib.ptr(dspect), _lib.ptr(da0),
                                                  _lib.ptr(work), work.numel(), _lib.current_stream(dev)))
 
-        def outer(a, b):                      # sum over batch and positions of a[:, m, n] * b[:, k, n]
-            # batched NT product on the strided views, then a B-term sum: einsum would first copy both
-            # operands into [M, B*N] / [K, B*N] matrices (a tenth of the step in elementwise kernels)
-            return torch.bmm(a, b.transpose(1, 2)).sum(0)
-
-        sp = spect_pad[:, :, :Lg]
-        grads = [outer(dh_all[0][:, :, :Lg], a0).unsqueeze(-1), dh_all[0][:, :, :Lg].sum((0, 2))]
-        dsk = dskip[:, :, :Lg]
-        for i in range(n_layers):
-            acts = ts_all[i][:, :256, :Lg] * ts_all[i][:, 256:, :Lg]
-            dpre = dpre_all[i][:, :, :Lg]
-            d = 2 ** i
-            d_in = torch.stack([outer(dpre, h_all[i][:, :, _HALO + (tap - 1) * d:_HALO + (tap - 1) * d + Lg])
-                                for tap in range(3)], dim=2)
-            db = dpre.sum((0, 2))
-            drs = torch.cat((dh_all[i + 1][:, :, :Lg], dsk), 1) if i < n_layers - 1 else dsk
-            grads += [d_in, db, outer(dpre, sp).unsqueeze(-1), db, outer(drs, acts).unsqueeze(-1), drs.sum((0, 2))]
-        grads += [outer(dout, skip[:, :, :Lg]).unsqueeze(-1), dout.sum((0, 2))]
-        grads = [g.reshape(w.shape) for g, w in zip(grads, ws_t)]
+            # the parameter half: every weight gradient is an NT product over batch and positions of two saved tensors (the
+            # dilated conv's three taps against shifted views of the layer input, the conditioning conv against the
+            # spectrogram, res_skip against tanh * sigmoid, start / end against a0 / skip), every bias gradient a row sum:
+            # two launches of the library's fp32 MFMA kernels for the whole stack (torch.bmm(...).sum(0) per product until
+            # round 4).  dout has L columns per row, everything else Lr (the kernels mask positions >= L).
+            grads = [torch.empty_like(w) for w in ws_t]
+            gs, _ = _WNFunction._weights_struct(grads, _lib.WnGrads)
+            gwork = torch.empty(L.facppg_wn_weight_grads_workspace_bytes(n_layers), dtype=torch.uint8, device=dev)
+            _lib.check(L.facppg_wn_weight_grads(n_in, n_layers, _lib.ptr(a0), _lib.ptr(spect_pad), _lib.ptr(h_all), _lib.ptr(ts_all),
+                                                _lib.ptr(skip), _lib.ptr(dout), _lib.ptr(dpre_all), _lib.ptr(dh_all), _lib.ptr(dskip),
+                                                B, Lg, gs, _lib.ptr(gwork), gwork.numel(), _lib.current_stream(dev)))
         return (da0, dspect, *grads)
 
 

@@ -201,6 +201,17 @@ int facppg_wn_backward_data(const facppg_wn_weights* w, int n_in, int n_layers, 
                             float* dh_all_dev, float* dskip_dev, float* dspect_dev, float* da0_dev,
                             void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* Weight and bias gradients of the stack from what facppg_wn_forward_save and facppg_wn_backward_data kept (the parameter half of
+ * the autograd backward of src/waveglow/glow.py:154-175; reference: torch autograd over nn.Conv1d): every weight gradient
+ * is an NT product over batch and positions on the exact-fp32 MFMA, every bias gradient a row sum, all in two launches,
+ * deterministic.  g: fp32 outputs with the shapes of facppg_wn_weights. */
+struct facppg_wn_grads;
+size_t facppg_wn_weight_grads_workspace_bytes(int n_layers);
+int facppg_wn_weight_grads(int n_in, int n_layers, const float* a0_dev, const float* spect_pad_dev, const float* h_all_dev,
+                           const float* ts_all_dev, const float* skip_dev, const float* dout_dev, const float* dpre_all_dev,
+                           const float* dh_all_dev, const float* dskip_dev, int B, int L, const struct facppg_wn_grads* g,
+                           void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* ---- the same stack with bf16 MFMA operands (BASELINE config 5: bf16 training, fp32 accumulation, fp32 master
  * weights and fp32 gradients).  Activations are kept POSITION-major ([B][Lr][channels] bf16, Lr =
  * facppg_wn_bf16_padded_len(L)) because the bf16 MFMA takes 8 consecutive reduction entries per lane; everything --
