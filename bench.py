@@ -7,7 +7,7 @@ The metric is BASELINE.json's: 22.05 kHz (hop 256) audio samples per second END 
 factor at batch = 1.  The DEFAULT run therefore times the metric's own configuration: one 200-frame utterance per step,
 host PPG [200 x 5816] in -> Tacotron2 -> WaveGlow -> Denoiser -> device wav out (SURVEY.md 8d config 1 at hop 256);
 `value` = samples / s of that step, `realtime_factor` = value / 22050, `roofline` = the executed-FLOP fraction of the fp32
-MFMA peak reached by the dominant kernel (the fused WaveNet layer) INSIDE that run, from hipEvents around every one of its
+MFMA peak reached by the dominant kernel (the fused WaveNet layer) INSIDE that run, from hipEvents around each flow's run of its
 launches in the timed steps.  The other BASELINE configs are sub-keys of the same JSON line, each with its own steps /
 ms_per_step / roofline: `waveglow_batch8` (configs[1]), `end_to_end_batch16_ragged` (configs[2], one batch at a time and
 software-pipelined), plus `reference_rate_config`, `train_step`, `cpu_baseline`.
@@ -487,7 +487,8 @@ def pmc_traffic(key="k_wn_layer"):
 
 def wn_layer_roofline(model, layer_ms, layer_n, positions, pmc_key):
     """`roofline` of the fused WaveNet-layer kernel from the library's own hipEvents (facppg_wg_set_profiling: a pair around
-    every launch on the launch stream): executed FLOPs of one launch (layer_flops_per_position x the group positions one
+    each flow's eight back-to-back launches on the launch stream, divided by eight -- a pair per launch costs a 78 us launch
+    ~9 us of its own, and rocprofv3's per-kernel average would not agree): executed FLOPs of one launch (layer_flops_per_position x the group positions one
     launch processes) / average launch duration.  The same launch is also priced at the reference formulation's FLOPs
     (2*(3*256+640)*512 + res_skip per position), which can exceed the fp32 MFMA peak because the folded
     kernels execute a third fewer FLOPs."""
@@ -676,7 +677,7 @@ class E2EWorkload(object):
         self.out = next(self.gen) if self.overlap else self.e.step(i)
 
     def start_timed(self):
-        # hipEvent pairs around every fused-WN-layer launch of the timed steps (created here, recorded on the launch stream)
+        # hipEvent pairs around every flow's fused-WN-layer launches of the timed steps (created here, recorded on the launch stream)
         from facppg import lib as flib
         if len(self.e.lens) == 1:
             flib.check(flib.load().facppg_wg_set_profiling(self.e.waveglow._handle(self.dev), max(2, self.steps)))
@@ -693,7 +694,7 @@ class E2EWorkload(object):
             flib.check(L.facppg_wg_last_layer_ms(h, flib.ctypes.byref(ms), flib.ctypes.byref(n)))
             flib.check(L.facppg_wg_set_profiling(h, 0))
             out["roofline"] = wn_layer_roofline(self.e.waveglow, ms.value, n.value, self.e.lens[0] * HOP // 8, "k_wn_layer_b1_t200")
-            out["roofline"]["measured"] = ("hipEvents around every launch of the fused WN-layer kernel in the %d timed end-to-end steps "
+            out["roofline"]["measured"] = ("hipEvents around each flow's 8 launches of the fused WN-layer kernel in the %d timed end-to-end steps "
                                            "(%d launches)" % (steps, n.value))
         timer = pipeline.StageTimer()
         self.e.step(10 ** 6, timer=timer)

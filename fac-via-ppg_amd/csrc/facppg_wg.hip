@@ -2594,7 +2594,7 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   const int fworkers = fenv ? atoi(fenv) : 0;
   FACPPG_REQUIRE(fworkers >= 0 && fworkers <= 2, FACPPG_EINVAL, "FACPPG_WN_FUSED=%s: expected 0, 1 or 2", fenv);
   const bool fused = fold && narrow && w8mode != 0 && fworkers > 0 && h->n_cu > 0 && (long)lgrid <= h->n_cu && c.wn_layers == 8;
-  h->ev_layers = fused ? c.wn_layers : 1;
+  h->ev_layers = c.wn_layers;
   for (int k = nf - 1; k >= 0; --k) {
     if (fused) {
       FlowArgs f;
@@ -2631,7 +2631,7 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
         if (i == 0) { a.nconv = 1; a.w1 = tile16 ? h->w1f_16[k] : h->w1f[k]; }
       }
       a.nch = a.nconv + h->kcp / KCH;
-      if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
+      if (h->profiling && i == 0) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));   // one pair per flow, see facppg_wg_last_layer_ms
       // folded flow edges need 8 more LDS rows per tile (the end rows; 16-frame tiles: their 8 K-slice partials)
 #define WN_LAUNCH(KERNEL_LAST, KERNEL_MID, THREADS, LDS)              \
   do {                                                                 \
@@ -2656,7 +2656,7 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
       }
 #undef WN_LAUNCH
       if (!last) hi ^= 1;
-      if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
+      if (h->profiling && last) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
     }
     e.aud_in = aud[ai]; e.aud_out = aud[ai ^ 1]; e.h_out = hbuf[hi];
     e.end_w = h->end_w[k]; e.end_b = h->end_b[k]; e.winv = h->winv[k];
@@ -2765,6 +2765,7 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
   const bool narrow = (long)(w.Lr / TN) * B < 768;
   const dim3 lgrid(narrow ? w.Lr / 32 : w.Lr / TN, B);
   h->last_tile = narrow ? 32 : TN; h->last_waves = 4; h->last_tiles = (int)(lgrid.x * lgrid.y);
+  h->ev_layers = c.wn_layers;
   for (int k = nf - 1; k >= 0; --k) {
     for (int i = 0; i < c.wn_layers; ++i) {
       WnArgs a;
@@ -2773,7 +2774,7 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
       a.t_valid = T_valid_dev; a.T = T; a.hop8 = hop8; a.Lp = w.Lp; a.Lr = w.Lr; a.dil = 1 << i; a.first = (i == 0);
       a.save_ts = nullptr;
       const bool last = i == c.wn_layers - 1;
-      if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
+      if (h->profiling && i == 0) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
       if (narrow) {
         if (last) k_wn_layer<true, 1><<<lgrid, 256, 32768, s>>>(a);
         else k_wn_layer<false, 1><<<lgrid, 256, 32768, s>>>(a);
@@ -2783,7 +2784,7 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
         else k_wn_layer<false, 2><<<lgrid, 256, lds_bytes, s>>>(a);
       }
       if (!last) hi ^= 1;
-      if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
+      if (h->profiling && last) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
     }
     e.aud_in = aud[ai]; e.aud_out = aud[ai ^ 1]; e.h_out = hbuf[hi];
     e.end_w = h->end_w[k]; e.end_b = h->end_b[k]; e.winv = h->winv[k];

@@ -255,7 +255,9 @@ int facppg_upsample_regroup_backward(const float* mel_dev, const float* dspect_p
 
 /* Average device time (ms) of the dominant kernel (the fused WN layer) over the launches of
  * the most recent facppg_wg_infer on this handle, measured with hipEvents on the stream the
- * kernels ran on when profiling was enabled with facppg_wg_set_profiling(h, 1).  enable = n > 1 accumulates
+ * kernels ran on when profiling was enabled with facppg_wg_set_profiling(h, 1).  One event pair brackets the
+ * back-to-back layer launches of a flow (nothing else runs between them) and the figure is that time / the layers:
+ * a pair per launch costs a 78 us launch ~9 us of its own, and the summary of rocprofv3 --kernel-trace would not agree.  enable = n > 1 accumulates
  * over the next n facppg_wg_infer calls instead (their events are created by the set_profiling call itself, so
  * that a timed region creates none); any set_profiling call starts a new accumulation.  Synchronises
  * the recorded events.  *n_launches receives the number of launches averaged. */

@@ -21,15 +21,18 @@ with contextlib.redirect_stdout(sys.stderr):
 torch.cuda.synchronize()
 
 
-def t(label, fn, n=20):
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+def t(label, fn, n=10):
+    """every call starts on a drained GPU: host = until the call returns, total = until the GPU is done as well"""
+    host = tot = 0.0
     for _ in range(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         r = fn()
-    host = (time.perf_counter() - t0) / n
-    torch.cuda.synchronize()
-    tot = (time.perf_counter() - t0) / n
-    print("%-52s host %.3f ms   (+ drain: %.3f ms)" % (label, host * 1e3, tot * 1e3))
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        host += t1 - t0
+        tot += time.perf_counter() - t0
+    print("%-52s host %.3f ms   total %.3f ms" % (label, host / n * 1e3, tot / n * 1e3), flush=True)
     return r
 
 
