@@ -95,8 +95,8 @@ class GraphedTrainStep:
             # c10d's watchdog thread polls the end events of the warm-up steps' collectives every 100 ms until it has seen
             # them complete; HIP refuses an event query on a stream that has meanwhile joined a capture (the process group's
             # internal stream does, below) and the watchdog then aborts the process.  The collectives are complete (the
-            # synchronize above): give the watchdog a few periods to retire them before the capture begins.
-            time.sleep(float(os.environ.get("FACPPG_CAPTURE_SETTLE_MS", "400")) * 1e-3)
+            # synchronize above): give the watchdog ten periods to retire them before the capture begins (once per training run).
+            time.sleep(float(os.environ.get("FACPPG_CAPTURE_SETTLE_MS", "1000")) * 1e-3)
         graph = torch.cuda.CUDAGraph()
         whole_step = self.sync_gradients is None or (self.exchange is not None and self.exchange.hooked)
         # thread_local: other threads (a DataLoader worker pinning memory, a logger) may touch the allocator meanwhile
