@@ -42,7 +42,9 @@ class GraphedTrainStep:
         self.warmup, self.exchange = warmup, exchange
         if overlap_exchange is None:
             import torch.distributed as dist
-            overlap_exchange = exchange is not None and exchange.cuda and dist.get_backend() != "gloo"
+            # (FACPPG_TRAIN_CAPTURE_EXCHANGE=0: exchange after each replay instead, should a stack not hold collectives in a graph)
+            overlap_exchange = (exchange is not None and exchange.cuda and dist.get_backend() != "gloo"
+                                and os.environ.get("FACPPG_TRAIN_CAPTURE_EXCHANGE", "1") != "0")
         self.overlap_exchange = bool(overlap_exchange and exchange is not None)
         if self.overlap_exchange:
             exchange.install_hooks()                 # every backward() -- eager or captured -- now leaves averaged gradients behind
