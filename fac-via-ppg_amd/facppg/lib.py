@@ -120,6 +120,7 @@ def _declare(lib):
         "facppg_taco_workspace_bytes": (sz, [vp, c.c_int, c.c_int]),
         "facppg_taco_decode_workspace_bytes": (sz, [vp, c.c_int, c.c_int]),
         "facppg_taco_set_decoder_workgroups": (c.c_int, [vp, c.c_int]),
+        "facppg_taco_set_decoder_heaters": (c.c_int, [vp, c.c_int]),
         "facppg_taco_postnet_workspace_bytes": (sz, [vp, c.c_int, c.c_int]),
         "facppg_taco_encode": (c.c_int, [vp, vp, vp, vp, u64, c.c_int, c.c_int, vp, vp, vp, sz, vp]),
         "facppg_taco_decode": (c.c_int, [vp, vp, vp, vp, vp, vp, u64, c.c_int, c.c_int, c.c_int, vp, vp, vp, vp, vp, sz, vp]),

@@ -364,6 +364,14 @@ size_t facppg_taco_postnet_workspace_bytes(const facppg_taco* h, int B, int T);
  * away from the vocoder.  A tighter bound selects wider weight slices per workgroup, which cuts the LSTM sums differently:
  * results agree with the unbounded launch to rounding (1e-6 relative on the mel), not bit for bit. */
 int facppg_taco_set_decoder_workgroups(facppg_taco* h, int max_workgroups);
+/* Heater workgroups for the small-batch (split) decoder launch; 0 = none (default), n > 0 = that many, -1 = as many as stay
+ * co-resident.  No reference counterpart: one short utterance occupies ~76 of 256 CUs for milliseconds, the chip's clock governor
+ * answers the mostly idle chip by lowering the clock, and the vocoder that follows runs its first milliseconds ~10 % slower
+ * (tools/idle_gap_probe.py).  Heaters are extra workgroups of the same cooperative launch that run matrix instructions on
+ * registers -- no memory traffic, CUs of their own (every workgroup of that launch holds a CU's LDS) -- until the utterances'
+ * attention workgroups are done.  Results are unchanged bit for bit; the launch then holds the whole chip, so a caller that runs
+ * something else next to the decoder (facppg_taco_set_decoder_workgroups > 0) gets none.  FACPPG_DECODER_HEATERS overrides. */
+int facppg_taco_set_decoder_heaters(facppg_taco* h, int heaters);
 
 /* Replaces Encoder.inference (model.py:237-249) and the memory_layer projection
  * (model.py:334).  ppg_dev [B][n_symbols][Tin]; lengths_dev NULL or [B] valid frame counts
