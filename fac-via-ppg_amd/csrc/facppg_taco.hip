@@ -356,7 +356,7 @@ struct DecArgs {
   int b0;                // k_decoder_coop: first utterance of this launch (large batches run in chunks)
   float gate_thr;
   // k_decoder_split: worker workgroups per group, and HEATER workgroups behind them (see there)
-  int nwk, heaters, heat_sleep;
+  int nwk, heaters, heat_sleep, heat_lead;
   unsigned* heat_done;   // [groups] main workgroups of the group that have finished
 };
 
@@ -1137,6 +1137,15 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
     // empty therefore run matrix instructions on registers -- no memory traffic, own CUs (every workgroup of this launch
     // holds a CU's LDS) -- until the group's main workgroups are done.
     const int need = min(NU, p.B - grp * NU);
+    if (p.heat_lead > 0) {
+      // heat only the last heat_lead frames before the group's first utterance reaches its step limit (the frame count is the
+      // tag of its gate word); until then the heaters sleep
+      const unsigned long long* gatew = p.xsplit + (size_t)(grp * NU) * xstride + p.NF;
+      const int start = dec_step_limit(p, grp * NU) - p.heat_lead;
+      while ((int)(__hip_atomic_load(gatew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) < start &&
+             __hip_atomic_load(p.heat_done + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)need)
+        __builtin_amdgcn_s_sleep(64);
+    }
     const float a = 1.0f + 1e-3f * (float)(tid & 63), bq = 0.5f - 1e-3f * (float)(tid >> 6);
     f32x16 acc;
     float sink = 0.0f;
@@ -1851,6 +1860,10 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
     if (h->decoder_wg_limit > 0) heaters = 0;
     a.nwk = h->split_nwk; a.heaters = heaters; a.heat_done = (unsigned*)(ws + w.heat);
     a.heat_sleep = getenv("FACPPG_DECODER_HEAT_SLEEP") ? atoi(getenv("FACPPG_DECODER_HEAT_SLEEP")) : 0;
+    // heat only the last frames before the step limit (1.7 ms at 21 us per frame): as good as heating the whole decode
+    // (tools/heater_sweep.sh: 13.91 vs 13.95-13.99 ms per end-to-end step, 14.22-14.32 without) at a third of the energy, and the
+    // decoder itself stays undisturbed until then; an utterance whose gate stops it earlier simply gets none.  0 = from the start.
+    a.heat_lead = getenv("FACPPG_DECODER_HEAT_LEAD") ? atoi(getenv("FACPPG_DECODER_HEAT_LEAD")) : 80;
     FACPPG_HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(h->split_nwk + NU + heaters, groups), dim3(NTC), args, ssm, s));
     if (a.prof) {
       long long pr[16];

@@ -368,8 +368,8 @@ int facppg_taco_set_decoder_workgroups(facppg_taco* h, int max_workgroups);
  * co-resident.  No reference counterpart: one short utterance occupies ~76 of 256 CUs for milliseconds, the chip's clock governor
  * answers the mostly idle chip by lowering the clock, and the vocoder that follows runs its first milliseconds ~10 % slower
  * (tools/idle_gap_probe.py).  Heaters are extra workgroups of the same cooperative launch that run matrix instructions on
- * registers -- no memory traffic, CUs of their own (every workgroup of that launch holds a CU's LDS) -- until the utterances'
- * attention workgroups are done.  Results are unchanged bit for bit; the launch then holds the whole chip, so a caller that runs
+ * registers -- no memory traffic, CUs of their own (every workgroup of that launch holds a CU's LDS) -- during the last
+ * FACPPG_DECODER_HEAT_LEAD (80) frames before the step limit, until the utterances' attention workgroups are done.  Results are unchanged bit for bit; the launch then holds the whole chip, so a caller that runs
  * something else next to the decoder (facppg_taco_set_decoder_workgroups > 0) gets none.  FACPPG_DECODER_HEATERS overrides. */
 int facppg_taco_set_decoder_heaters(facppg_taco* h, int heaters);
 

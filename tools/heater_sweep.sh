@@ -1,7 +1,8 @@
 #!/bin/bash
-# decoder heaters: how many, how hard?  whole end-to-end batch-1 step (tools/host_overhead_probe.py) per setting
-for hh in 0 -1 96; do for sl in 0 16 64 200; do
-  [ "$hh" = "0" ] && [ "$sl" != "0" ] && continue
-  r=$(FACPPG_DECODER_HEATERS=$hh FACPPG_DECODER_HEAT_SLEEP=$sl python tools/host_overhead_probe.py 2>&1 | grep "tacotron.inference\|whole step" | sed 's/  */ /g' | tr '\n' '|')
-  echo "heaters $hh sleep $sl: $r"
-done; done
+# decoder heaters: how many, how hard, from when?  whole end-to-end batch-1 step (tools/host_overhead_probe.py) per setting
+run() { r=$(env "$@" python tools/host_overhead_probe.py 2>&1 | grep "tacotron.inference\|whole step" | sed 's/  */ /g; s/(.*)//' | tr '\n' '|'); echo "$*: $r"; }
+run FACPPG_DECODER_HEATERS=0
+run FACPPG_DECODER_HEATERS=-1
+for lead in 30 60 100 150; do run FACPPG_DECODER_HEATERS=-1 FACPPG_DECODER_HEAT_LEAD=$lead; done
+run FACPPG_DECODER_HEATERS=0
+run FACPPG_DECODER_HEATERS=-1
