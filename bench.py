@@ -853,39 +853,40 @@ class TrainWorkload(object):
 WORKLOADS = {"infer": InferWorkload, "e2e": E2EWorkload, "corpus": CorpusWorkload, "train": TrainWorkload}
 
 
-def isolated_train_dp(args, rank, world, dist, log, steps=10, warmup=4, timeout=600):
-    """The data-parallel training step of an N > 1 headline run, measured by a second set of N ranks that rank 0 spawns (this
-    script with --workload train) while the ranks of this run wait, host-side, on the process group's store.  Returns the entry
-    for `train_dp` (rank 0) or None."""
+def isolated_extra(args, rank, world, dist, log, name, steps, warmup, timeout=600):
+    """A secondary workload (`train` / `corpus`) of an N > 1 headline run, measured by a second set of N ranks that rank 0
+    spawns (this script with --workload <name>) while the ranks of this run wait, host-side, on the process group's store.
+    Returns the entry for `<name>_dp` (rank 0) or None."""
     import datetime
     import subprocess
     store = dist.distributed_c10d._get_default_store()
-    key = "facppg_train_dp_done"
+    key = "facppg_%s_dp_done" % name
     entry = None
     if rank == 0:
         try:
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GROUP_RANK",
                                                                      "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
-            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--workload", "train", "--steps", str(steps),
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--workload", name, "--steps", str(steps),
                    "--warmup", str(warmup), "--no-extra", "--train-batch", str(args.train_batch), "--grad-buckets", str(args.grad_buckets),
-                   "--grad-dtype", args.grad_dtype, "--dist-backend", args.dist_backend]
+                   "--grad-dtype", args.grad_dtype, "--dist-backend", args.dist_backend, "--utterances", str(args.utterances),
+                   "--corpus-batch", str(args.corpus_batch)]
             if args.share_gpu:
                 cmd.append("--share-gpu")
             if world == 1:
                 cmd.append("--force-dist")
-                env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29511")) + 17)
+                env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29511")) + (17 if name == "train" else 18))
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
             lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode == 0 and lines:
                 child = json.loads(lines[-1])
                 entry = {k: child[k] for k in ("steps", "warmup", "ms_per_step", "value", "unit", "scaling", "dtype", "config", "tflops",
                                                "frac_of_mfma_peak", "gradient_exchange", "ranks_connected", "rank_devices") if k in child}
-                entry["measured_by"] = "a second set of %d ranks spawned by rank 0 (bench.py --workload train) while this run's ranks waited" % world
-                log("train_dp: %.1f ms/step" % entry["ms_per_step"])
+                entry["measured_by"] = "a second set of %d ranks spawned by rank 0 (bench.py --workload %s) while this run's ranks waited" % (world, name)
+                log("%s_dp: %.1f ms/step" % (name, entry["ms_per_step"]))
             else:
-                log("train_dp: the spawned run failed (rc %s): %s" % (r.returncode, r.stderr[-600:]))
+                log("%s_dp: the spawned run failed (rc %s): %s" % (name, r.returncode, r.stderr[-600:]))
         except Exception as e:   # noqa: BLE001
-            log("train_dp: %r" % (e,))
+            log("%s_dp: %r" % (name, e))
         store.set(key, "1")
     else:
         store.wait([key], datetime.timedelta(seconds=timeout + 120))
@@ -1039,39 +1040,17 @@ def main():
         # is reported as null and never takes the primary figure down)
         del wl
         torch.cuda.empty_cache()
-        # train_dp runs in processes of its own (rank 0 starts `bench.py --gpus N --workload train`, the other ranks wait on the
-        # store, GPUs idle): its step graph holds RCCL collectives, and what can go wrong there -- c10d's watchdog thread meeting
-        # a capturing stream -- ABORTS a process instead of raising; the headline of this run must survive that
-        try:
-            out["train_dp"] = isolated_train_dp(args, rank, world, dist, log)
-        except Exception as e:   # noqa: BLE001
-            log("train_dp failed: %r" % (e,))
-            out["train_dp"] = None
-        for key, name, steps, warm in (("corpus_dp", "corpus", 1, 1),):
-            sub, err = None, None
+        # train_dp and corpus_dp run in processes of their own (rank 0 starts `bench.py --gpus N --workload train|corpus`, the
+        # other ranks wait on the store, GPUs idle): the training step's graph holds RCCL collectives, the corpus gather is
+        # point-to-point RCCL traffic, and what can go wrong there on a stack that has never run them across GPUs -- c10d's
+        # watchdog meeting a capturing stream, a collective timing out -- ABORTS a process instead of raising; the headline of
+        # this run must survive that
+        for key, name, steps, warm in (("train_dp", "train", 10, 4), ("corpus_dp", "corpus", 1, 1)):
             try:
-                sub = WORKLOADS[name](dev, rank, world, argparse.Namespace(**vars(args)), dist)
-            except Exception as e:   # noqa: BLE001
-                err = e
-            # every rank must enter the sub-workload's collectives or none: agree on whether all of them got this far
-            ready = torch.tensor([0 if sub is None else 1], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.int32)
-            dist.all_reduce(ready, op=dist.ReduceOp.MIN)
-            if int(ready.item()) == 0:
-                log("%s skipped: a rank could not set it up (%r)" % (key, err))
-                out[key] = None
-                continue
-            try:
-                el = timed_run(sub, steps, warm, fence, dist, dev, args.dist_backend)
-                entry = {"steps": steps, "warmup": warm, "ms_per_step": el / steps * 1e3, "value": sub.samples * steps / el,
-                         "unit": "samples/s", "scaling": sub.scaling, "dtype": sub.dtype}
-                sub.finish(entry, el, steps)
-                out[key] = entry
-                log("%s: %.1f ms/step" % (key, entry["ms_per_step"]))
+                out[key] = isolated_extra(args, rank, world, dist, log, name, steps, warm)
             except Exception as e:   # noqa: BLE001
                 log("%s failed: %r" % (key, e))
                 out[key] = None
-            del sub
-            torch.cuda.empty_cache()
     if secondary_ok and not args.no_train:
         wl = None
         torch.cuda.empty_cache()
