@@ -12,17 +12,26 @@ from waveglow.mel2samp import MAX_WAV_VALUE, files_to_list
 
 
 def main(mel_files, waveglow_path, sigma, output_dir, sampling_rate, is_fp16, batch_size=16):
-    if is_fp16:
-        raise NotImplementedError("the reference's fp16 branch is not built; libfacppg_hip runs fp32")
     mel_files = files_to_list(mel_files)
     waveglow = torch.load(waveglow_path, weights_only=False)['model']
     waveglow = waveglow.remove_weightnorm(waveglow)
     waveglow.cuda().eval()
+    if is_fp16:
+        # The reference casts the module and every mel to half here (inference.py:38-48, through apex) and runs cuDNN's half
+        # kernels.  This library computes on the fp32 MFMA path only, so the half branch is run as "the reference's VALUES, this
+        # library's arithmetic": parameters, buffers and mels are rounded to fp16 and every product is then formed and
+        # accumulated in fp32 -- at least the precision of the reference's run, and within fp16 round-off of it.
+        with torch.no_grad():
+            for t in list(waveglow.parameters()) + list(waveglow.buffers()):
+                if t.is_floating_point():
+                    t.copy_(t.half().float())
     hop = waveglow.upsample.stride[0]
     os.makedirs(output_dir, exist_ok=True)
     for i0 in range(0, len(mel_files), batch_size):
         paths = mel_files[i0:i0 + batch_size]
         mels = [torch.load(p, weights_only=False).float() for p in paths]
+        if is_fp16:
+            mels = [m.half().float() for m in mels]
         lens = [m.shape[1] for m in mels]
         batch = torch.zeros(len(mels), mels[0].shape[0], max(lens))
         for b, m in enumerate(mels):
