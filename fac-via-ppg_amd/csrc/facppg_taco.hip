@@ -356,7 +356,7 @@ struct DecArgs {
   int b0;                // k_decoder_coop: first utterance of this launch (large batches run in chunks)
   float gate_thr;
   // k_decoder_split: worker workgroups per group, and HEATER workgroups behind them (see there)
-  int nwk, heaters, heat_sleep, heat_lead;
+  int nwk, heaters, heat_sleep, heat_lead, dbg_flags;
   unsigned* heat_done;   // [groups] main workgroups of the group that have finished
 };
 
@@ -578,6 +578,54 @@ __device__ __forceinline__ void attn_energy_pre(const DecArgs& p, const DecLds& 
   }
 }
 
+// The context's operand, the encoder memory rows of the attention window, RESIDENT IN REGISTERS across frames (split decoder's
+// main workgroup).  The window [lo, hi] slides by at most one position per frame, so of its <= 41 rows (600 floats each: 98 KB
+// re-read from L2 every frame, with the weights they are multiplied by known only after the softmax) at most one is new.  Wave g
+// of the eight keeps the rows q = g (mod 8) -- the same sets, summed in the same ascending order, as the per-frame code's
+// "offset (q - lo) mod 8" groups, which it then meets in the same fixed order: the context keeps its bits -- in CTX_SLOTS
+// register slots, slot (q / 8) mod CTX_SLOTS: a row is overwritten by row q + 48, when the window (<= 41 wide) has long left
+// it.  The entering row is requested at the top of the frame, before the main workgroup waits for the workers.
+constexpr int CTX_SLOTS = 6, CTX_CR = 10;   // 6 x 8 = 48 >= 41 + 7 positions; 10 x 64 channels (encoder_embedding_dim <= 640)
+struct CtxRows { float v[CTX_SLOTS][CTX_CR]; };
+__device__ __forceinline__ bool ctx_rows_usable(const DecArgs& p) {
+  return p.window >= 0 && 2 * p.window + 1 <= 8 * CTX_SLOTS - 7 && p.E <= 64 * CTX_CR;
+}
+template <int S>
+__device__ __forceinline__ void ctx_row_load(CtxRows& R, const float* __restrict__ row, int lane, int E) {
+#pragma unroll
+  for (int r = 0; r < CTX_CR; ++r) {
+    const int c = lane + 64 * r;
+    R.v[S][r] = c < E ? row[c] : 0.0f;
+  }
+}
+__device__ __forceinline__ void ctx_rows_update(const DecArgs& p, const float* __restrict__ mem, int hi_prev, int hi, int tid, CtxRows& R) {
+  asm volatile("" : "+v"(tid));   // (no per-lane offsets hoisted out of the frame loop, see attn_energy_pre)
+  const int lane = tid & 63, g = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;
+  for (int q = hi_prev + 1; q <= hi; ++q) {   // one row per frame once the window is full; hi + 1 rows in frame 0
+    if ((q & 7) != g) continue;
+    const float* row = mem + (size_t)q * p.E;
+    switch ((q >> 3) % CTX_SLOTS) {
+      case 0: ctx_row_load<0>(R, row, lane, p.E); break;
+      case 1: ctx_row_load<1>(R, row, lane, p.E); break;
+      case 2: ctx_row_load<2>(R, row, lane, p.E); break;
+      case 3: ctx_row_load<3>(R, row, lane, p.E); break;
+      case 4: ctx_row_load<4>(R, row, lane, p.E); break;
+      default: ctx_row_load<5>(R, row, lane, p.E); break;
+    }
+  }
+}
+// accv[r] += sum over this wave's rows first, first + 8, ... <= hi (ascending), slot of `first` = S0
+template <int S0>
+__device__ __forceinline__ void ctx_rows_fma(const CtxRows& R, const float* __restrict__ en, int first, int hi, float (&accv)[CTX_CR]) {
+#pragma unroll
+  for (int k = 0; k < CTX_SLOTS; ++k) {
+    const int q = first + 8 * k;
+    const float wgt = q <= hi ? en[q] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < CTX_CR; ++r) accv[r] = fmaf(wgt, R.v[(S0 + k) % CTX_SLOTS][r], accv[r]);
+  }
+}
+
 // Location-sensitive attention (model.py:63-121) evaluated on the index range the reference's
 // window mask keeps (utils.py:64-77).  Reads ah from in_att[P+E:], updates wprev/wcum and writes
 // the context into in_att[P:], in_dec[A:], in_proj[D:].
@@ -585,11 +633,12 @@ __device__ __forceinline__ void attn_energy_pre(const DecArgs& p, const DecLds& 
 // caller -- the split decoder's main workgroup -- before it started waiting for the hidden state).  Same products in the same
 // order as matvec_part, so the same bits, without the stream's L2 latency between the hidden state and the energies.
 struct NoQueryRegs { float4 w[1]; };
-template <int NT, int QR = 0, bool PRE = false>
+template <int NT, int QR = 0, bool PRE = false, bool ROWS = false>
 __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L, const float* mem, const float* pm, int len,
                                               int t, int b, int tid, bool write_out, bool feat_ready = false,
                                               const float4 (&wq)[QR > 0 ? QR : 1] = NoQueryRegs().w,
-                                              const float4* __restrict__ stash = nullptr) {   // PRE: attn_energy_pre's [8][NT] float4
+                                              const float4* __restrict__ stash = nullptr,   // PRE: attn_energy_pre's [8][NT] float4
+                                              const CtxRows& rows = CtxRows(), bool rows_ok = false) {   // ROWS: the window's memory rows
   if constexpr (PRE) asm volatile("" : "+v"(tid));   // (see attn_energy_pre: no per-lane offsets hoisted out of the frame loop)
   const int lane = tid & 63, wave = tid >> 6;
   long long atk = clock64();
@@ -750,7 +799,7 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
   constexpr int CW = 8;    // position groups (with 16 waves, waves w and w+8 share a group and split the channels)
   constexpr int QU = 3;    // positions per wave issued together (2 rounds cover the 41-wide window)
   constexpr int CR = 12 / (NT / 64 / CW);   // 64-channel rounds per wave (E <= 768)
-  constexpr int PRE_ROUNDS = PRE ? 2 : 0;
+  constexpr int PRE_ROUNDS = PRE && !ROWS ? 2 : 0;   // (ROWS: the rows are in registers already; its fallback loads them in place)
   const int grp = wave & (CW - 1), halfsel = wave / CW;
   float mvp[PRE_ROUNDS > 0 ? PRE_ROUNDS : 1][QU][CR];
   auto request_rows = [&](int rd) __attribute__((always_inline)) {
@@ -764,7 +813,7 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
       }
     }
   };
-  if constexpr (PRE) { request_rows(0); request_rows(1); }
+  if constexpr (PRE_ROUNDS > 0) { request_rows(0); request_rows(1); }
   if (wave == 0) {   // softmax over [lo, hi]; everything else is masked to -inf => weight 0
     float mx = -INFINITY;
     for (int q = lo + lane; q <= hi; q += 64) mx = fmaxf(mx, L.en[q]);
@@ -796,10 +845,36 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
   {
     float* cpart = L.part;   // [CW][E]  (part + feat = 6144 floats >= 8 * E for E <= 768)
     static_assert(NT / 64 == 2 * CW || NT / 64 == CW, "context code deals positions to 8 waves or wave pairs");
+    bool rows_done = false;
+    if constexpr (ROWS) {
+      if (rows_ok) {   // (workgroup-uniform)
+        static_assert(!ROWS || NT / 64 == CW, "resident rows: one wave per residue");
+        float ra[CTX_CR];
+#pragma unroll
+        for (int r = 0; r < CTX_CR; ++r) ra[r] = 0.0f;
+        const int g = __builtin_amdgcn_readfirstlane(wave) & 7;
+        const int first = lo + ((g - lo) & 7);   // this wave's first row of the window: the group "offset (first - lo)" of the code below
+        switch ((first >> 3) % CTX_SLOTS) {
+          case 0: ctx_rows_fma<0>(rows, L.en, first, hi, ra); break;
+          case 1: ctx_rows_fma<1>(rows, L.en, first, hi, ra); break;
+          case 2: ctx_rows_fma<2>(rows, L.en, first, hi, ra); break;
+          case 3: ctx_rows_fma<3>(rows, L.en, first, hi, ra); break;
+          case 4: ctx_rows_fma<4>(rows, L.en, first, hi, ra); break;
+          default: ctx_rows_fma<5>(rows, L.en, first, hi, ra); break;
+        }
+        const int off = (first - lo) & 7;
+#pragma unroll
+        for (int r = 0; r < CTX_CR; ++r) {
+          const int c = lane + 64 * r;
+          if (c < p.E) cpart[off * p.E + c] = ra[r];
+        }
+        rows_done = true;
+      }
+    }
     float accv[CR];
 #pragma unroll
     for (int r = 0; r < CR; ++r) accv[r] = 0.0f;
-    if constexpr (PRE) {
+    if constexpr (PRE_ROUNDS > 0) {
 #pragma unroll
       for (int rd = 0; rd < PRE_ROUNDS; ++rd)
 #pragma unroll
@@ -810,7 +885,7 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
           for (int r = 0; r < CR; ++r) accv[r] = fmaf(wgt, mvp[rd][j][r], accv[r]);
         }
     }
-    for (int qb = lo + grp + PRE_ROUNDS * CW * QU; qb <= hi; qb += CW * QU) {
+    for (int qb = lo + grp + PRE_ROUNDS * CW * QU; qb <= hi && !rows_done; qb += CW * QU) {
       float mv[QU][CR];
 #pragma unroll
       for (int j = 0; j < QU; ++j) {
@@ -829,10 +904,12 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
         for (int r = 0; r < CR; ++r) accv[r] = fmaf(wgt, mv[j][r], accv[r]);
       }
     }
+    if (!rows_done) {
 #pragma unroll
-    for (int r = 0; r < CR; ++r) {
-      const int c = lane + 64 * (halfsel * CR + r);
-      if (c < p.E) cpart[grp * p.E + c] = accv[r];
+      for (int r = 0; r < CR; ++r) {
+        const int c = lane + 64 * (halfsel * CR + r);
+        if (c < p.E) cpart[grp * p.E + c] = accv[r];
+      }
     }
     __syncthreads();
     for (int i = tid; i < p.E; i += NT) {
@@ -1308,6 +1385,13 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
   const int q_ks = pick_ks<NTC>(L.ADp, p.A);
   const int q_ns = L.ADp >> 2, q_slot = tid % q_ns, q_part = tid / q_ns;
   const int q_k0 = (int)((long)q_part * p.A / q_ks), q_k1 = (int)((long)(q_part + 1) * p.A / q_ks);
+  CtxRows crows;
+#pragma unroll
+  for (int i = 0; i < CTX_SLOTS; ++i)
+#pragma unroll
+    for (int r = 0; r < CTX_CR; ++r) crows.v[i][r] = 0.0f;
+  const bool rows_on = ctx_rows_usable(p) && !(p.dbg_flags & 1);   // (dbg_flags bit 0: FACPPG_DECODER_NO_ROWS, A/B runs)
+  int hi_prev = -1;
   long long tk = clock64();
 #define PROF(slot)                                                        \
   if (p.prof && b == 0 && tid == 0) {                                     \
@@ -1322,6 +1406,7 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
     attn_features<NTC>(p, L, lo, min(64, hi - lo + 1), tid);   // needs only frame t-1's weights
     __syncthreads();
     attn_energy_pre<NTC>(p, L, pm, lo, min(64, hi - lo + 1), tid, stash);   // ... and so does this part of the energies
+    if (rows_on) { ctx_rows_update(p, mem, hi_prev, hi, tid, crows); hi_prev = hi; }   // ... and the window's entering memory row
     asm volatile("" ::: "memory");   // (the 96 registers of query weights requested next must not be hoisted over it: spills)
     float4 wq[QR];
 #pragma unroll
@@ -1344,7 +1429,7 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
     for (int i = tid; i < p.A; i += NTC) ah[i] = xwait(AH + i, tag);
     __syncthreads();
     PROF(3)
-    dec_attention<NTC, QR, true>(p, L, mem, pm, len, t, b, tid, true, true, wq, stash);
+    dec_attention<NTC, QR, true, true>(p, L, mem, pm, len, t, b, tid, true, true, wq, stash, crows, rows_on);
     for (int i = tid; i < p.E; i += NTC) xpub(CTX + i, L.in_proj[p.D + i], tag);
     PROF(5)
   }
@@ -1859,6 +1944,7 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
     if (heaters < 0 || heaters > room) heaters = room > 0 ? room : 0;
     if (h->decoder_wg_limit > 0) heaters = 0;
     a.nwk = h->split_nwk; a.heaters = heaters; a.heat_done = (unsigned*)(ws + w.heat);
+    a.dbg_flags = getenv("FACPPG_DECODER_NO_ROWS") ? 1 : 0;
     a.heat_sleep = getenv("FACPPG_DECODER_HEAT_SLEEP") ? atoi(getenv("FACPPG_DECODER_HEAT_SLEEP")) : 0;
     // heat only the last frames before the step limit (1.7 ms at 21 us per frame): as good as heating the whole decode
     // (tools/heater_sweep.sh: 13.91 vs 13.95-13.99 ms per end-to-end step, 14.22-14.32 without) at a third of the energy, and the
