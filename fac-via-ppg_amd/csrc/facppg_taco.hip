@@ -1253,10 +1253,17 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
     float w_att[SKR_LSTM], w_dec[SKR_LSTM], w_proj[SKR_PROJ], w_p1[SKR_PROJ], w_p2[SKR_P2];
     stat_load(w_att, p.att_w4 + (size_t)wg * KA * SSC, SSC, 0, SSC, KA, tid);
     stat_load(w_dec, p.dec_w4 + (size_t)wg * KD * SSC, SSC, 0, SSC, KD, tid);
-    stat_load(w_proj, p.proj_t, round_up(p.NF + 1, 4), row0, p.NF + 1, KP, tid);
+    // The projection + gate rows go to the workers BEHIND those that hold prenet rows (workers 19..24 with the reference's widths)
+    // when there are enough of them: both matvecs start from the same [dh | ctx] and then run side by side instead of one after
+    // the other in workers 0..5, the slowest link of every frame (worker 0: 2.3 us of its 11 us outside the attention).  Same rows,
+    // same sums: same bits.
+    const int pre_wk = (p.P + SSC - 1) / SSC, proj_wk = (p.NF + 1 + SSC - 1) / SSC;
+    const int proj_w0 = pre_wk + proj_wk <= p.nwk ? pre_wk : 0;
+    const int prow0 = (wg - proj_w0) * SSC;   // (negative: none)
+    stat_load(w_proj, p.proj_t, round_up(p.NF + 1, 4), prow0 < 0 ? p.NF + 1 : prow0, p.NF + 1, KP, tid);
     stat_load(w_p1, p.w1p_t, round_up(p.P, 4), row0, p.P, KP, tid);
     stat_load(w_p2, p.dp1_t, round_up(p.P, 4), row0, p.P, p.P, tid);
-    const bool has_proj = row0 < p.NF + 1, has_pre = row0 < p.P;
+    const bool has_proj = prow0 >= 0 && prow0 < p.NF + 1, has_pre = row0 < p.P;
     unsigned alive = 0;   // bit u: utterance u of the group is still decoding (identical in every workgroup)
     for (int u = 0; u < NU; ++u)
       if (grp * NU + u < p.B) alive |= 1u << u;
@@ -1269,6 +1276,13 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
   float* in_att = sm + (size_t)u * ustride; float* in_dec = in_att + KA; float* in_proj = in_dec + KD;  \
   float* xin = in_proj + KP; float* p1 = xin + round_up(p.NF, 4);                                       \
   (void)MEL; (void)X1; (void)X2; (void)AH; (void)CTX; (void)DH; (void)in_att; (void)in_dec; (void)in_proj; (void)xin; (void)p1
+    long long wtk = clock64();
+#define WPROF(slot)                                                       \
+  if (p.prof && wg == 0 && grp == 0 && tid == 0) {                        \
+    const long long now = clock64();                                      \
+    p.prof[16 + slot] += now - wtk;                                       \
+    wtk = now;                                                            \
+  }
     for (int t = 0;; ++t) {
       const unsigned tag = t + 1;
       if (t > 0) {
@@ -1276,8 +1290,8 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
         if (has_proj) stat_mv16n<SKR_PROJ, NU>(w_proj, KP, sm + KA + KD, ustride, alive, part, tid);
         if (has_proj) FOR_ALIVE(u) {
           UTT(u);
-          if (tid < SSC && row0 + tid <= p.NF) {
-            const int row = row0 + tid;
+          if (tid < SSC && prow0 + tid <= p.NF) {
+            const int row = prow0 + tid;
             const float v = part[512 + u * SSC + tid] + p.proj_b[row];
             if (row < p.NF) p.mel[((size_t)b * p.NF + row) * p.max_steps + t - 1] = v;
             else { p.gate[(size_t)b * p.max_steps + t - 1] = v; xpub(MEL + row, v, tag); }   // only the gate crosses workgroups
@@ -1291,6 +1305,7 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
           if (tid < SSC && row0 + tid < p.P)
             xpub(X1 + row0 + tid, fmaxf(part[512 + u * SSC + tid] + p.b1p[row0 + tid], 0.0f) * (float)mk[row0 + tid] * 2.0f, tag);
         }
+        WPROF(0)   // projection + prenet-1 rows
         FOR_ALIVE(u) {
           UTT(u);
           if (tid == 0) s_stop[u] = sigm(xwait(MEL + p.NF, tag)) > p.gate_thr || t == dec_step_limit(p, b);
@@ -1304,6 +1319,7 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
           for (int i = tid; i < p.P; i += NTC) p1[i] = xwait(X1 + i, tag);
         }
         __syncthreads();
+        WPROF(1)   // gather gate + X1
       }
       // (frame 0: the go frame is zero and the prenet has no bias, so p1 = 0 as initialised)
       if (has_pre) stat_mv16n<SKR_P2, NU>(w_p2, p.P, sm + KA + KD + KP + round_up(p.NF, 4), ustride, alive, part, tid);
@@ -1313,11 +1329,13 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
         if (tid < SSC && row0 + tid < p.P)
           xpub(X2 + row0 + tid, fmaxf(part[512 + u * SSC + tid], 0.0f) * (float)mk[(size_t)p.B * p.P + row0 + tid] * 2.0f, tag);
       }
+      WPROF(2)   // prenet-2 rows
       FOR_ALIVE(u) {
         UTT(u);
         for (int i = tid; i < p.P; i += NTC) in_att[i] = xwait(X2 + i, tag);
       }
       __syncthreads();
+      WPROF(3)   // gather X2
       // attention LSTMCell slice on [prenet | ctx | ah]  (model.py:400-403)
       stat_mv16n<SKR_LSTM, NU>(w_att, KA, sm, ustride, alive, part, tid);
       FOR_ALIVE(u) {
@@ -1329,10 +1347,12 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
                                    gs[3 * SU + tid] + p.att_b[3 * p.A + un], &c_att[u][tid]), tag);
         }
       }
+      WPROF(4)   // attention LSTM slice
       FOR_ALIVE(u) {
         UTT(u);
         for (int i = tid; i < p.A; i += NTC) { const float h = xwait(AH + i, tag); in_att[p.P + p.E + i] = h; in_dec[i] = h; }
       }
+      WPROF(5)   // gather AH
       FOR_ALIVE(u) {
         UTT(u);
         for (int i = tid; i < p.E; i += NTC) {
@@ -1341,6 +1361,7 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
         }
       }
       __syncthreads();
+      WPROF(6)   // gather CTX (= the main workgroup's attention)
       // decoder LSTMCell slice on [ah | ctx | dh]  (model.py:425-428)
       stat_mv16n<SKR_LSTM, NU>(w_dec, KD, sm + KA, ustride, alive, part, tid);
       FOR_ALIVE(u) {
@@ -1356,8 +1377,11 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
         UTT(u);
         for (int i = tid; i < p.D; i += NTC) { const float h = xwait(DH + i, tag); in_dec[p.A + p.E + i] = h; in_proj[i] = h; }
       }
+      WPROF(7)   // decoder LSTM slice + gather DH
       __syncthreads();
+      WPROF(8)
     }
+#undef WPROF
 #undef FOR_ALIVE
 #undef UTT
     return;
@@ -1809,7 +1833,7 @@ DecWs dec_ws(const facppg_taco_config& c, int B, int max_steps) {
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   w.mask = take((size_t)max_steps * 2 * B * c.prenet_dim);
   w.xchg = take((size_t)B * 2 * c.attention_rnn_dim * 8);
-  w.prof = take(16 * 8);
+  w.prof = take(32 * 8);
   w.xsplit = take((size_t)B * (c.n_acoustic_feat_dims + 1 + 2 * c.prenet_dim + c.attention_rnn_dim + c.encoder_embedding_dim + c.decoder_rnn_dim + 8) * 8);
   w.heat = take((size_t)B * 4);
   w.total = off;
@@ -1952,11 +1976,14 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
     a.heat_lead = getenv("FACPPG_DECODER_HEAT_LEAD") ? atoi(getenv("FACPPG_DECODER_HEAT_LEAD")) : 80;
     FACPPG_HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(h->split_nwk + NU + heaters, groups), dim3(NTC), args, ssm, s));
     if (a.prof) {
-      long long pr[16];
+      long long pr[32];
       FACPPG_HIP_CHECK(hipMemcpyAsync(pr, a.prof, sizeof(pr), hipMemcpyDeviceToHost, s));
       FACPPG_HIP_CHECK(hipStreamSynchronize(s));
       fprintf(stderr, "[facppg split decoder prof (main), shader cycles] features %lld wait_gate %lld wait_ah %lld attention %lld | att: query %lld energy %lld softmax %lld update %lld context %lld\n",
               pr[2], pr[0], pr[3], pr[5], pr[8], pr[10], pr[11], pr[12], pr[13]);
+      fprintf(stderr, "[facppg split decoder prof (worker 0), shader cycles] proj+prenet1 %lld | gather gate,X1 %lld | prenet2 %lld | gather X2 %lld | "
+              "att LSTM %lld | gather AH %lld | gather CTX %lld | dec LSTM + gather DH %lld | barrier %lld\n",
+              pr[16], pr[17], pr[18], pr[19], pr[20], pr[21], pr[22], pr[23], pr[24]);
     }
   } else
   if (coop) {

@@ -94,10 +94,13 @@ class GraphedTrainStep:
         self.optimizer.zero_grad(set_to_none=True)   # the captured backward allocates the gradients in the graph's pool
         torch.cuda.synchronize()
         if self.exchange is not None and self.exchange.hooked:
-            # c10d's watchdog thread polls the end events of the warm-up steps' collectives every 100 ms until it has seen
-            # them complete; HIP refuses an event query on a stream that has meanwhile joined a capture (the process group's
-            # internal stream does, below) and the watchdog then aborts the process.  The collectives are complete (the
-            # synchronize above): give the watchdog ten periods to retire them before the capture begins (once per training run).
+            # OBSERVED once (world 1, RCCL): the process aborted from c10d's watchdog thread with "HIP error: operation not
+            # permitted on an event last recorded in a capturing stream" while this capture was in progress.  INFERRED, not
+            # verified: the watchdog was still polling the end events of the warm-up steps' (completed) collectives, and HIP
+            # rejects an event query once the event's stream (the process group's internal one) has joined a capture.  Evidence
+            # for the pause below is one stress probe only (tools/capture_race_probe.py, repeated captures in one process: abort
+            # after 13 without it, 60 clean with 400 ms -- and one unexplained segfault at capture 28 with it); 12 ordinary bench
+            # runs did not reproduce the abort with or without it.  A mitigation, then, not a fix of an understood cause.
             time.sleep(float(os.environ.get("FACPPG_CAPTURE_SETTLE_MS", "1000")) * 1e-3)
         graph = torch.cuda.CUDAGraph()
         whole_step = self.sync_gradients is None or (self.exchange is not None and self.exchange.hooked)
