@@ -714,7 +714,7 @@ class E2EWorkload(object):
                 "ms_per_step": (time.perf_counter() - t0) / 10 * 1e3, "steps": 10, "warmup": 2,
                 "what": "the timed steps run facppg.pipeline.synthesize as it is called by default: the batch-1 decoder launch carries "
                         "heater workgroups (matrix instructions on registers, no memory traffic) on the ~180 CUs it leaves empty, so that "
-                        "the clock governor does not lower the clock ahead of the vocoder; this is the same step with decoder_heaters=0 "
+                        "the vocoder does not start ~10 % slow behind milliseconds of low activity (measured; cause not identified); same step with decoder_heaters=0 "
                         "(FACPPG_DECODER_HEATERS=0 switches them off everywhere)"}
         out["config"] = {"workload": "BASELINE configs[2]: " + self.e.describe() if not b1 else
                          "the metric's own case, real-time factor at batch = 1 (SURVEY.md 8d config 1 at the metric's 22.05 kHz / hop 256): "

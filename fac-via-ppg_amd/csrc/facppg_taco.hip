@@ -1208,11 +1208,13 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
   const int KA = p.P + p.E + p.A, KD = p.A + p.E + p.D, KP = p.D + p.E;
   if (tid < SNU) s_stop[tid] = 0;
   if (blk >= NU + p.nwk) {   // ------------------------------------------ heater
-    // One short utterance keeps 76 of 256 CUs busy for ~4 ms, and the chip's clock governor answers a mostly idle chip by
-    // lowering the clock: the vocoder that follows then runs its first milliseconds ~10 % slower (tools/idle_gap_probe.py:
-    // WaveGlow.infer 7.9 ms on a busy chip, 8.7 ms behind 6 ms of idle or behind this decoder).  The CUs the decoder leaves
-    // empty therefore run matrix instructions on registers -- no memory traffic, own CUs (every workgroup of this launch
-    // holds a CU's LDS) -- until the group's main workgroups are done.
+    // MEASURED (tools/idle_gap_probe.py): WaveGlow.infer takes 7.9 ms on a chip that was busy just before, 8.7 ms behind 6 ms
+    // of idle or behind this decoder (76 of 256 CUs busy for ~4 ms), and keeping the other CUs busy during the decoder's last
+    // milliseconds recovers ~0.4 ms of that.  WHY is not established: the obvious guess, a lowered shader clock, is NOT what the
+    // GPU's sysfs reports (tools/clock_probe.py: sclk ~2400 MHz, mclk and fclk constant, idle or busy, at 20 ms sampling) --
+    // some faster power-management effect, or something else.  The CUs the decoder leaves empty therefore run matrix
+    // instructions on registers -- no memory traffic, own CUs (every workgroup of this launch holds a CU's LDS) -- until the
+    // group's main workgroups are done: an empirical remedy.
     const int need = min(NU, p.B - grp * NU);
     if (p.heat_lead > 0) {
       // heat only the last heat_lead frames before the group's first utterance reaches its step limit (the frame count is the

@@ -127,8 +127,8 @@ def synthesize(ppgs, tacotron, waveglow, denoiser=None, sigma=0.6, strength=0.00
 
     decoder_heaters: this is the latency path -- one batch, the vocoder right behind the acoustic model -- so the small-batch
     decoder launch carries heater workgroups on the CUs it leaves empty (Tacotron2.decoder_heaters; -1 = all that fit, 0 = none;
-    same samples either way): the chip's clock governor otherwise lowers the clock during the decoder's milliseconds and the
-    vocoder starts ~10 % slower (0.6 ms of a 14 ms utterance).  A model that already carries its own setting keeps it.
+    same samples either way): measured, the vocoder otherwise starts ~10 % slower behind the decoder's milliseconds of low
+    activity (0.4-0.6 ms of a 14 ms utterance; cause not identified -- the GPU's reported clocks do not move).  A model that already carries its own setting keeps it.
 
     utterance_seeds: one integer per utterance -- its dropout and noise streams then depend on that seed alone,
     so the result for an utterance is the same whatever batch, batch size or GPU it is synthesised in.

@@ -365,9 +365,9 @@ size_t facppg_taco_postnet_workspace_bytes(const facppg_taco* h, int B, int T);
  * results agree with the unbounded launch to rounding (1e-6 relative on the mel), not bit for bit. */
 int facppg_taco_set_decoder_workgroups(facppg_taco* h, int max_workgroups);
 /* Heater workgroups for the small-batch (split) decoder launch; 0 = none (default), n > 0 = that many, -1 = as many as stay
- * co-resident.  No reference counterpart: one short utterance occupies ~76 of 256 CUs for milliseconds, the chip's clock governor
- * answers the mostly idle chip by lowering the clock, and the vocoder that follows runs its first milliseconds ~10 % slower
- * (tools/idle_gap_probe.py).  Heaters are extra workgroups of the same cooperative launch that run matrix instructions on
+ * co-resident.  No reference counterpart: MEASURED, the vocoder runs ~10 % slower for its first milliseconds behind a batch-1
+ * decoder (~76 of 256 CUs busy for milliseconds) or behind idle time than on a chip that was busy just before
+ * (tools/idle_gap_probe.py); the cause is not identified (the GPU's reported clocks do not change, tools/clock_probe.py).  Heaters are extra workgroups of the same cooperative launch that run matrix instructions on
  * registers -- no memory traffic, CUs of their own (every workgroup of that launch holds a CU's LDS) -- during the last
  * FACPPG_DECODER_HEAT_LEAD (80) frames before the step limit, until the utterances' attention workgroups are done.  Results are unchanged bit for bit; the launch then holds the whole chip, so a caller that runs
  * something else next to the decoder (facppg_taco_set_decoder_workgroups > 0) gets none.  FACPPG_DECODER_HEATERS overrides. */

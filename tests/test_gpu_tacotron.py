@@ -196,7 +196,7 @@ def test_large_batch_runs_in_chunks_and_matches_single_runs():
 def test_decoder_heater_workgroups_change_nothing_but_the_launch(lens, monkeypatch):
     """Tacotron2.decoder_heaters (facppg_taco_set_decoder_heaters; facppg.pipeline.synthesize switches it on): extra workgroups
     of the small-batch decoder launch that run matrix instructions on registers on the CUs the decoder leaves empty, so that the
-    clock governor does not lower the clock ahead of the vocoder.  They own no data: every output must be bit for bit what the
+    vocoder behind it does not start slow (a measured effect of low activity whose cause is not identified).  They own no data: every output must be bit for bit what the
     launch without them gives -- all that fit (-1), a handful (5), and with the environment override switching them off."""
     monkeypatch.setenv("FACPPG_DECODER_MODE", "split")
     d, hp, sd, ppg, em, dm = tacotron_case("stop")
