@@ -41,10 +41,10 @@ def test_corpus_and_infer_extras_through_rccl_world1():
     assert d["collective_backend"].startswith("RCCL") and d["config"]["utterances"] == 48 and d["value"] > 0
     d = _bench(["--steps", "3", "--warmup", "2", "--utterances", "32"], 29524)
     assert d["train_dp"] is not None and d["corpus_dp"] is not None
-    # the default run is the batch-1 utterance: ~0.55 of the fp32 MFMA peak when bench.py has the GPU to itself.  Inside the
-    # whole GPU suite this subprocess shares the device with the pytest process, which by now owns a dozen idle HIP streams:
-    # its 3 timed steps have been seen at 0.23 (launch gaps inside the per-flow event pairs, stages of the following step at
-    # full speed) -- only the plumbing is asserted here, the figure itself is the driver's bench run
+    # the default run is the batch-1 utterance: ~0.55 of the fp32 MFMA peak when bench.py runs on its own.  As a subprocess of
+    # the whole GPU suite its 3 timed steps have been measured at 0.23 (avg launch 0.20 ms instead of 0.08; the stages of the
+    # following step at full speed); in isolation the same test gives ~0.5 every time.  The cause was not established -- only
+    # the plumbing is asserted here, the figure itself is the driver's bench run
     assert 0.05 < d["roofline"]["frac"] < 1.0, (d["roofline"], d["ms_per_step"], d.get("stage_ms"))
 
 
