@@ -32,3 +32,17 @@ r = []
 for _ in range(10):
     a = torch.randn(4096, 4096, device=dev); b = a @ a; torch.cuda.synchronize(); r.append(infer_ms())
 print("after a 4096^3 fp32 matmul ", stat(r))
+
+# what kind of activity in front of the vocoder removes the slow start?  (after 20 ms of idle each time)
+arena = torch.empty(400 * 1024 * 1024 // 4, device=dev)           # stands in for "touch a few hundred MB" (not the weights themselves)
+big = torch.randn(8192, 8192, device=dev)
+def after(label, fn, n=10):
+    r = []
+    for _ in range(n):
+        torch.cuda.synchronize(); time.sleep(0.02); fn(); torch.cuda.synchronize(); r.append(infer_ms())
+    print("%-46s" % label, stat(r))
+after("20 ms idle, then nothing", lambda: None)
+after("20 ms idle, then read 400 MB (sum)", lambda: arena.sum())
+after("20 ms idle, then 1 fp32 matmul 8192^3 (~8 ms)", lambda: big @ big)
+after("20 ms idle, then 1 fp32 matmul 2048^3 (~0.2 ms)", lambda: big[:2048, :2048] @ big[:2048, :2048])
+after("20 ms idle, then WaveGlow.infer itself", lambda: wg.infer(mel, sigma=0.6, seed=1))
