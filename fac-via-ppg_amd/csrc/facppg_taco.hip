@@ -638,7 +638,8 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
                                               int t, int b, int tid, bool write_out, bool feat_ready = false,
                                               const float4 (&wq)[QR > 0 ? QR : 1] = NoQueryRegs().w,
                                               const float4* __restrict__ stash = nullptr,   // PRE: attn_energy_pre's [8][NT] float4
-                                              const CtxRows& rows = CtxRows(), bool rows_ok = false) {   // ROWS: the window's memory rows
+                                              const CtxRows& rows = CtxRows(), bool rows_ok = false,      // ROWS: the window's memory rows
+                                              unsigned long long* ctx_words = nullptr, unsigned ctx_tag = 0) {   // ROWS: publish the context
   if constexpr (PRE) asm volatile("" : "+v"(tid));   // (see attn_energy_pre: no per-lane offsets hoisted out of the frame loop)
   const int lane = tid & 63, wave = tid >> 6;
   long long atk = clock64();
@@ -689,6 +690,8 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
   const int NRB = L.AD32 / 32;
   const int li = lane & 31, kh = lane >> 5;
   float* epart = L.part;   // [NRB][64]
+  bool fused_softmax = false;
+  float e_reg = 0.0f;
   for (int c0 = lo; c0 <= hi; c0 += 64) {
     const int nc = min(64, hi - c0 + 1);
     if (!(feat_ready && c0 == lo)) attn_features<NT>(p, L, c0, nc, tid);
@@ -782,15 +785,20 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
       if (lane < 16) epart[NRB * 64 + (wave - NRB) * 16 + lane] = et;   // one partial per free wave
     }
     __syncthreads();
+    // ROWS (split decoder's main workgroup; the window is one pass): wave 0 forms the energies in registers and goes straight
+    // on to the softmax below -- the same sums, maximum, exponentials and quotients, without the round trip through L.en and
+    // its barrier
+    fused_softmax = ROWS && c0 == lo && hi - lo + 1 <= 64;
     if (tid < nc) {
       float e = 0.0f;
       if (tail_valu && tid >= 32)
         for (int j = 0; j < NW - NRB; ++j) e += epart[NRB * 64 + j * 16 + tid - 32];
       else
         for (int j = 0; j < NRB; ++j) e += epart[j * 64 + tid];
-      L.en[c0 + tid] = e;
+      if (fused_softmax) e_reg = e;
+      else L.en[c0 + tid] = e;
     }
-    __syncthreads();
+    if (!fused_softmax) __syncthreads();
     APROF(10)
   }
   // The context's memory rows (2 rounds of 3 positions per wave cover the reference's 41-wide window) depend on the window only:
@@ -814,7 +822,19 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
     }
   };
   if constexpr (PRE_ROUNDS > 0) { request_rows(0); request_rows(1); }
-  if (wave == 0) {   // softmax over [lo, hi]; everything else is masked to -inf => weight 0
+  if (fused_softmax) {
+    if (wave == 0) {   // lane = position lo + lane (the loops below with one element per lane)
+      const bool in = lo + lane <= hi;
+      float mx = in ? e_reg : -INFINITY;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      const float ex = in ? expf(e_reg - mx) : 0.0f;
+      float sum = ex;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      if (in) L.en[lo + lane] = ex / sum;
+    }
+  } else if (wave == 0) {   // softmax over [lo, hi]; everything else is masked to -inf => weight 0
     float mx = -INFINITY;
     for (int q = lo + lane; q <= hi; q += 64) mx = fmaxf(mx, L.en[q]);
 #pragma unroll
@@ -917,6 +937,10 @@ __device__ __forceinline__ void dec_attention(const DecArgs& p, const DecLds& L,
 #pragma unroll
       for (int j = 0; j < CW; ++j) s += cpart[j * p.E + i];
       L.in_att[p.P + i] = s; L.in_dec[p.A + i] = s; L.in_proj[p.D + i] = s;
+      if constexpr (ROWS) {   // the split decoder's main workgroup: the workers wait for exactly this value -- publish it from here
+        if (ctx_words) __hip_atomic_store(ctx_words + i, ((unsigned long long)ctx_tag << 32) | __float_as_uint(s), __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     __syncthreads();
   }
@@ -1455,8 +1479,7 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
     for (int i = tid; i < p.A; i += NTC) ah[i] = xwait(AH + i, tag);
     __syncthreads();
     PROF(3)
-    dec_attention<NTC, QR, true, true>(p, L, mem, pm, len, t, b, tid, true, true, wq, stash, crows, rows_on);
-    for (int i = tid; i < p.E; i += NTC) xpub(CTX + i, L.in_proj[p.D + i], tag);
+    dec_attention<NTC, QR, true, true>(p, L, mem, pm, len, t, b, tid, true, true, wq, stash, crows, rows_on, CTX, tag);   // (publishes CTX)
     PROF(5)
   }
 #undef PROF
