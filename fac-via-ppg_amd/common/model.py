@@ -203,6 +203,17 @@ class Tacotron2(nn.Module):
         self.__dict__["_facppg_handle"] = (out, dev, _lib.WeightIdentity(self))
         return out
 
+    def last_decoder_launch(self):
+        """(mode, workgroups) of the most recent decoder launch (facppg_taco_last_decoder_launch): mode is 'single', 'coop' or
+        'split'."""
+        h = self.__dict__.get("_facppg_handle")
+        if h is None:
+            raise _lib.FacppgError("last_decoder_launch: no inference has run on this model yet")
+        c = _lib.ctypes
+        mode, wgs = c.c_int(), c.c_int()
+        _lib.check(_lib.load().facppg_taco_last_decoder_launch(h[0], c.byref(mode), c.byref(wgs)))
+        return ("single", "coop", "split")[mode.value], wgs.value
+
     def _apply(self, fn, *a, **k):
         self._release()
         return super(Tacotron2, self)._apply(fn, *a, **k)

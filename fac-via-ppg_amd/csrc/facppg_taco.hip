@@ -36,6 +36,7 @@ struct facppg_taco {
   int coop_limit;   // workgroups the cooperative (co-resident) kernels may use: from the occupancy calculator, see facppg_taco_create
   int decoder_wg_limit;   // facppg_taco_set_decoder_workgroups: a tighter bound for the decoder alone (0 = none)
   int decoder_heaters;    // facppg_taco_set_decoder_heaters: heater workgroups of the split decoder (0 none, -1 all that fit)
+  int last_mode, last_wgs;   // facppg_taco_last_decoder_launch: 0 one workgroup per utterance, 1 cooperative, 2 split; workgroups launched
   char* arena;
   // encoder
   float4 *pre0, *pre1, *conv[8], *wih;
@@ -2000,6 +2001,7 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
     // decoder itself stays undisturbed until then; an utterance whose gate stops it earlier simply gets none.  0 = from the start.
     a.heat_lead = getenv("FACPPG_DECODER_HEAT_LEAD") ? atoi(getenv("FACPPG_DECODER_HEAT_LEAD")) : 80;
     FACPPG_HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(h->split_nwk + NU + heaters, groups), dim3(NTC), args, ssm, s));
+    h->last_mode = 2; h->last_wgs = (h->split_nwk + NU + heaters) * groups;
     if (a.prof) {
       long long pr[32];
       FACPPG_HIP_CHECK(hipMemcpyAsync(pr, a.prof, sizeof(pr), hipMemcpyDeviceToHost, s));
@@ -2024,6 +2026,7 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
       a.b0 = b0; a.att_coop = h->att_coop[cv]; a.dec_coop = h->dec_coop[cv]; a.U = h->coop_U[cv];
       void* args[] = {(void*)&a};
       FACPPG_HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(h->coop_nwg[cv], nb), dim3(NTC), args, smem, s));
+      h->last_mode = 1; h->last_wgs = h->coop_nwg[cv] * nb;
     }
     if (a.prof) {
       long long pr[16];
@@ -2035,6 +2038,7 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
   } else {
     FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_decoder, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     k_decoder<<<B, NT, smem, s>>>(a);
+    h->last_mode = 0; h->last_wgs = B;
   }
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
@@ -2089,6 +2093,12 @@ extern "C" int facppg_taco_set_decoder_workgroups(facppg_taco* h, int max_workgr
 extern "C" int facppg_taco_set_decoder_heaters(facppg_taco* h, int heaters) {
   FACPPG_REQUIRE(h && heaters >= -1, FACPPG_EINVAL, "NULL handle or heaters < -1");
   h->decoder_heaters = heaters;
+  return FACPPG_OK;
+}
+
+extern "C" int facppg_taco_last_decoder_launch(const facppg_taco* h, int* mode, int* workgroups) {
+  FACPPG_REQUIRE(h && mode && workgroups, FACPPG_EINVAL, "NULL argument");
+  *mode = h->last_mode; *workgroups = h->last_wgs;
   return FACPPG_OK;
 }
 

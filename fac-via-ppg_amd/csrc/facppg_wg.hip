@@ -349,6 +349,10 @@ struct WnArgs {
   const float* we;     // end-row image of this layer (k_fold_end_rows)
   const float* endb;   // [8] folded end bias (seeds the accumulator in the first layer)
   int nconv;           // K chunks before the conditioning rows: 12 (three taps of 256 channels) or 1 (folded first layer)
+  // seeded tiles (k_wn_layer8<..., SEED>): the gate accumulators start from bias + conditioning sums formed ahead of time by
+  // k_cond_seed (this layer's slice of its buffer), and the K loop is the convolution chunks alone
+  const float4* seed;  // [P][seed_nt][8 waves][2 row blocks][4][64 lanes]
+  int seed_nt;         // 32-frame tiles per phase in that buffer
 };
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
@@ -942,16 +946,17 @@ __device__ __forceinline__ void flow_wait(const FlowWait& fw) {
   if (!(fw.flags & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU's L1 may hold the buffer's lines of two layers ago
 }
 
-template <bool LAST, int NCB, bool EF, bool FUSED, bool SC1 = FUSED>
+template <bool LAST, int NCB, bool EF, bool FUSED, bool SC1 = FUSED, bool SEED = false>
 __device__ __forceinline__ void wn_layer8_tile(const WnArgs& p, const int lin, float* __restrict__ smem, const FlowWait fw) {
+  static_assert(!SEED || (NCB == 1 && !FUSED), "seeded tiles: 32 frames, one launch per layer");
   constexpr int TNt = 32 * NCB;
   WN8_STAMP_DECL;
   const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, wq = w8 >> 1, sub = w8 & 1;
   const int li = lane & 31, kh = lane >> 5;
   const int chb = wq * 64 + sub * 32;   // first channel of this wave's block
   int b, nvalid, ph, in_off, sk_off, tap0, tap1, tap2, lane_q;   // tap0..2 are wave-uniform, the lane's column is lane_q (see k_wn_layer)
+  int tile;
   {
-    int tile;
     if (p.xcd_map == 1) { const int r = lin >> 3; ph = (r / p.nt) * 8 + (lin & 7); tile = r % p.nt; }
     else { ph = lin / p.nt; tile = lin % p.nt; }
     if (ph >= p.P) return;
@@ -985,8 +990,9 @@ __device__ __forceinline__ void wn_layer8_tile(const WnArgs& p, const int lin, f
   // images are [k-group][16 row blocks][64 lanes]; row block index = wq*4 + sub (+2 for the second half)
   const float4* wave_a = p.w1 + (wq * 4 + sub) * 64 + lane;
   const float4* wave_c = p.wc + (size_t)ph * p.ngc * 1024 + (wq * 4 + sub) * 64 + lane;
-  const int nch = pm_chunks(p, ph);
-  const int ncc = nch - p.nconv;   // the conditioning chunks come first (see k_wn_layer)
+  // SEED: the conditioning chunks (and the bias) are already in the accumulators' seed
+  const int nch = SEED ? p.nconv : pm_chunks(p, ph);
+  const int ncc = SEED ? 0 : nch - p.nconv;   // the conditioning chunks come first (see k_wn_layer)
   constexpr int F4R = TNt / 4, RPL4 = 64 / F4R, NSTG4 = 8 / RPL4;
   const int srow4 = lane / F4R, scol4 = (lane % F4R) * 4;
   const bool folded_first = EF && p.nconv == 1;
@@ -1050,12 +1056,14 @@ __device__ __forceinline__ void wn_layer8_tile(const WnArgs& p, const int lin, f
   stage_load(0);
 #pragma unroll
   for (int i = 0; i < RING - 1; ++i) load_a1(ar[i], i);
-  // accumulators start at the bias; loaded behind the first operand loads so the prologue is one memory round trip, not two
+  // accumulators start at the bias (SEED: at bias + conditioning sums, k_cond_seed's registers as it left them); loaded behind
+  // the first operand loads so the prologue is one memory round trip, not two
+  const float4* seedp = SEED ? p.seed + ((((size_t)ph * p.seed_nt + tile) * 8 + w8) * 8) * 64 + lane : nullptr;
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 bv = gld(reinterpret_cast<const float4*>(p.b1 + rb * C + chb + 4 * kh + 8 * q));
+      const float4 bv = SEED ? gld(seedp + (rb * 4 + q) * 64) : gld(reinterpret_cast<const float4*>(p.b1 + rb * C + chb + 4 * kh + 8 * q));
       acc[rb][0][4 * q + 0] = bv.x; acc[rb][0][4 * q + 1] = bv.y; acc[rb][0][4 * q + 2] = bv.z; acc[rb][0][4 * q + 3] = bv.w;
     }
 #pragma unroll
@@ -1256,11 +1264,12 @@ __device__ __forceinline__ void wn_layer8_tile(const WnArgs& p, const int lin, f
   WN8_STAMP(5);   // epilogue
 }
 
-template <bool LAST, int NCB, bool EF = false>
+template <bool LAST, int NCB, bool EF = false, bool SEED = false>
 __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  wn_layer8_tile<LAST, NCB, EF, false>(p, (int)blockIdx.x, smem, FlowWait{nullptr, 0u, 0ull, 0});
+  wn_layer8_tile<LAST, NCB, EF, false, false, SEED>(p, (int)blockIdx.x, smem, FlowWait{nullptr, 0u, 0ull, 0});
 }
+
 
 // ------------------------------------------------------------------------------------------
 // k_wn_flow8: ALL layers of one flow in ONE launch, for launches that do not fill the chip (one short utterance:
@@ -1330,6 +1339,157 @@ __global__ __launch_bounds__(512, 4) void k_wn_flow8(FlowArgs f) {
 #ifdef FACPPG_WN8_PROF
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_wn8_prof[8], (unsigned long long)(clock64() - s0));
 #endif
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_cond_seed: the conditioning part of every WN layer's gate GEMM, ahead of the layers themselves.
+// A layer's accumulators are bias + sum over the conditioning chunks BEFORE any tap (the K order of k_wn_layer8 is
+// conditioning first), and that part depends on the mel frames alone -- not on the flow variable.  For one utterance the
+// decoder leaves most of the chip idle for milliseconds while the mel frames trickle out; this kernel forms, for a block of
+// frames that are final, exactly the MFMA sequence k_wn_layer8 would run for its conditioning chunks (same operands, same
+// order: same bits) for EVERY (flow, layer, phase), and parks the accumulator registers in HBM in the lane order the seeded
+// layer kernel reads them back in (k_wn_layer8<..., SEED>: 12 K chunks instead of 17, first layers 1 instead of 6).
+// Workgroup = (group of `lpw` layers, phase, block of NCB 32-frame tiles): the mel window of the block is staged into LDS
+// once (all conditioning chunks: ncc * 8 KiB per 32 frames) and every layer streams its folded per-phase weight image past
+// it -- no barrier inside the K loop.  One pass over a frame block reads every (layer, phase) image once (2 GB at hop 256):
+// 16 * NCB FLOP per weight byte, so narrow blocks are HBM-bound and wide ones MFMA-bound.
+// ------------------------------------------------------------------------------------------
+struct SeedArgs {
+  const float* melp;        // [80][Tqp] zero-margined mel frames of the ONE utterance
+  float4* seeds;            // [layers_total][P][seed_nt][8][2][4][64]
+  const void* ltab[MAXF];   // per flow: WnLayerPtrs[wn_layers] (device)
+  int layers_total, wn_layers, lpw;
+  int P, Tqp, seed_nt;
+  int tile0, nblk;          // first 32-frame tile of this launch, NCB-tile blocks from there
+  int ncmax, kc, ngc, hop, ksize;   // conditioning chunks at most (kcp / 64), rows, k-groups per phase image, upsampler stride / size
+};
+
+template <int NCB>
+__global__ __launch_bounds__(512, NCB <= 2 ? 4 : 2) void k_cond_seed(SeedArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [ncc][64 k][TNt] K4 images of the block's mel window
+  constexpr int TNt = 32 * NCB;
+  const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, wq = w8 >> 1, sub = w8 & 1;
+  const int li = lane & 31, kh = lane >> 5;
+  const int chb = wq * 64 + sub * 32;
+  // workgroup i lands on XCD i % 8: the blocks that share a (layer, phase) image run back to back on one XCD
+  int lg, ph, blk;
+  {
+    const int lin = (int)blockIdx.x;
+    if (p.P % 8 == 0) {
+      const int r = lin >> 3, rest = r / p.nblk;
+      blk = r - rest * p.nblk; ph = (rest % (p.P / 8)) * 8 + (lin & 7); lg = rest / (p.P / 8);
+    } else {
+      blk = lin % p.nblk; const int rest = lin / p.nblk;
+      ph = rest % p.P; lg = rest / p.P;
+    }
+  }
+  const int l0 = lg * p.lpw, l1 = min(l0 + p.lpw, p.layers_total);
+  if (l0 >= l1) return;
+  // conditioning chunks of this phase (pm_chunks): late phases reach one mel frame less
+  const int nj = (p.ksize - 1 - 8 * ph) / p.hop + 1;
+  const int ncc = min(p.ncmax, (nj * NMEL + KCH - 1) / KCH);
+  const int q0 = (p.tile0 + blk * NCB) * 32;   // first frame of the block
+  constexpr int F4R = TNt / 4, RPL4 = 64 / F4R, NSTG4 = 8 / RPL4;
+  const int srow4 = lane / F4R, scol4 = (lane % F4R) * 4;
+  // stage every conditioning chunk, exactly as k_wn_layer8's stage_load / stage_write do for c < ncc
+  {
+    const float* sb4 = p.melp + HQ + q0 + scol4;
+    for (int c = 0; c < ncc; ++c) {
+      float4 stg[NSTG4];
+#pragma unroll
+      for (int jj = 0; jj < NSTG4; ++jj) {
+        const int r0 = w8 * 8 + NSTG4 * srow4 + jj;
+        const int r = min(c * 64 + r0, p.kc - 1);
+        const int j = r / NMEL, m = r - j * NMEL;
+        const f4u v = gld(reinterpret_cast<const f4u*>(sb4 + m * p.Tqp - j));
+        stg[jj] = make_float4(v.x, v.y, v.z, v.w);
+      }
+      float* dst = smem + c * (KCH * TNt) + k4_index(w8 * 8 + NSTG4 * srow4, scol4, TNt);
+      if constexpr (NSTG4 == 4) {
+        *reinterpret_cast<float4*>(dst) = make_float4(stg[0].x, stg[1].x, stg[2].x, stg[3].x);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(stg[0].y, stg[1].y, stg[2].y, stg[3].y);
+        *reinterpret_cast<float4*>(dst + 8) = make_float4(stg[0].z, stg[1].z, stg[2].z, stg[3].z);
+        *reinterpret_cast<float4*>(dst + 12) = make_float4(stg[0].w, stg[1].w, stg[2].w, stg[3].w);
+      } else if constexpr (NSTG4 == 2) {
+        dst[0] = stg[0].x; dst[1] = stg[1].x; dst[4] = stg[0].y; dst[5] = stg[1].y;
+        dst[8] = stg[0].z; dst[9] = stg[1].z; dst[12] = stg[0].w; dst[13] = stg[1].w;
+      } else {
+        dst[0] = stg[0].x; dst[4] = stg[0].y; dst[8] = stg[0].z; dst[12] = stg[0].w;
+      }
+    }
+  }
+  // the weight stream: k-group G of the workgroup = group G % ng of layer l0 + G / ng; ring of 4, as in k_wn_layer8
+  const int ng = 8 * ncc, ngt = ng * (l1 - l0);
+  const size_t wave_off = (size_t)ph * p.ngc * 1024 + (wq * 4 + sub) * 64 + lane;
+  auto layer_ptrs = [&](int l) __attribute__((always_inline)) {
+    const WnLayerPtrs* t = reinterpret_cast<const WnLayerPtrs*>(p.ltab[l / p.wn_layers]) + (l % p.wn_layers);
+    return t;
+  };
+  constexpr int RING = 4;
+  float4 ar[RING][2];
+  const float4* wc_cur = layer_ptrs(l0)->wc + wave_off;   // image of the layer the prefetch is in
+  int g_in = 0, l_pre = l0;                             // its k-group inside that layer
+  auto load_next = [&](float4 (&a)[2]) __attribute__((always_inline)) {
+    const float4* src = wc_cur + (size_t)g_in * 1024;
+    a[0] = gld(src);
+    a[1] = gld(src + 128);
+    if (++g_in == ng) {                                  // (wave-uniform) on to the next layer's image; past the last one: stay
+      g_in = 0;
+      if (l_pre + 1 < l1) { ++l_pre; wc_cur = layer_ptrs(l_pre)->wc + wave_off; }
+      else g_in = ng - 1;
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < RING - 1; ++i) load_next(ar[i]);
+  __syncthreads();
+  const float* lb0 = smem + (kh * TNt + li) * 4;
+  (void)ngt;
+  for (int l = l0; l < l1; ++l) {
+    const float* b1 = layer_ptrs(l)->b1;
+    f32x16 acc[2][NCB];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 bv = gld(reinterpret_cast<const float4*>(b1 + rb * C + chb + 4 * kh + 8 * q));
+        acc[rb][0][4 * q + 0] = bv.x; acc[rb][0][4 * q + 1] = bv.y; acc[rb][0][4 * q + 2] = bv.z; acc[rb][0][4 * q + 3] = bv.w;
+      }
+#pragma unroll
+      for (int cb = 1; cb < NCB; ++cb) acc[rb][cb] = acc[rb][0];
+    }
+    for (int c = 0; c < ncc; ++c) {
+      const float* lb = lb0 + c * (KCH * TNt);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        load_next(ar[(g + RING - 1) % RING]);
+        __builtin_amdgcn_sched_barrier(0);
+        float bq[4][NCB];
+        load_b<NCB, true>(bq, lb, g);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) {
+            const float4& a4 = ar[g % RING][rb];
+            const float av = s4 == 0 ? a4.x : s4 == 1 ? a4.y : s4 == 2 ? a4.z : a4.w;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mfma32x32x2(av, bq[s4][cb], acc[rb][cb]);
+          }
+      }
+    }
+    // park the accumulators: one 32-frame tile per column block, in the seeded kernel's own register order
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const int tile = p.tile0 + blk * NCB + cb;
+      if (tile >= p.seed_nt) continue;
+      float4* dst = p.seeds + (((((size_t)l * p.P + ph) * p.seed_nt + tile) * 8 + w8) * 8) * 64 + lane;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          store_f4<false>(reinterpret_cast<float*>(dst + (rb * 4 + q) * 64),
+                          make_float4(acc[rb][cb][4 * q + 0], acc[rb][cb][4 * q + 1], acc[rb][cb][4 * q + 2], acc[rb][cb][4 * q + 3]));
+    }
   }
 }
 
@@ -2325,6 +2485,10 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer8<true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer8<false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer8<true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_cond_seed<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_cond_seed<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_cond_seed<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_cond_seed<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipFree(tmp);
 #undef WG_TRY
   *out = h;
@@ -2477,16 +2641,19 @@ template <int HN>
 static void launch_begin(dim3 grid, hipStream_t s, const EdgeArgs& a) { k_begin<HN><<<grid, 256, 0, s>>>(a); }
 
 // WaveGlow.infer on the phase-major layout (folded conditioning): no spect tensor, no upsample kernel.
+// seeds (B = 1): the gate accumulators of every layer start from k_cond_seed's buffer (facppg_wg_cond_seed) for the first
+// `seeded_frames` frames; melp_ext is then the caller's zero-margined mel buffer the seeds were formed from
 static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_valid_dev, const float* z_dev, uint64_t seed,
-                       float sigma, int B, int T, float* audio_dev, char* ws, hipStream_t s) {
+                       float sigma, int B, int T, float* audio_dev, char* ws, hipStream_t s, const float* melp_ext = nullptr,
+                       const float4* seeds = nullptr, int seeded_frames = 0) {
   const facppg_wg_config& c = h->cfg;
   // ONE short utterance: the persistent launch (facppg_wgp.hip) -- same bits, no kernel boundary per layer
-  if (wgp_eligible(h, B, T, T_valid_dev)) return wgp_infer(h, mel_dev, z_dev, seed, sigma, T, audio_dev, ws, s);
+  if (!seeds && wgp_eligible(h, B, T, T_valid_dev)) return wgp_infer(h, mel_dev, z_dev, seed, sigma, T, audio_dev, ws, s);
   const PmLayout w = pm_layout(c, B, T);
   FACPPG_REQUIRE((double)C * w.P * w.Tqp < 2.0e9, FACPPG_EUNSUPPORTED, "T = %d frames is too long for 32-bit row offsets", T);
   float* hbuf[2] = {(float*)(ws + w.h0), (float*)(ws + w.h1)};
   float* skip = (float*)(ws + w.skip);
-  float* melp = (float*)(ws + w.melp);
+  const float* melp = melp_ext ? melp_ext : (const float*)(ws + w.melp);
   float* aud[2] = {(float*)(ws + w.aud0), (float*)(ws + w.aud1)};
   float* zbuf = (float*)(ws + w.z);
   const int nf = c.n_flows;
@@ -2496,7 +2663,7 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   float* xa = (float*)(ws + w.xa);
   // zero margins of h and xa (the convolution's zero padding) and the frames past each utterance's end
   FACPPG_HIP_CHECK(hipMemsetAsync(ws + w.h0, 0, w.skip - w.h0, s));
-  k_mel_pad<<<dim3((w.Tqp + 255) / 256, B * NMEL), 256, 0, s>>>(mel_dev, melp, T_valid_dev, T, w.Tqp);
+  if (!melp_ext) k_mel_pad<<<dim3((w.Tqp + 255) / 256, B * NMEL), 256, 0, s>>>(mel_dev, (float*)(ws + w.melp), T_valid_dev, T, w.Tqp);
   const float* z = z_dev;
   const size_t zn = (size_t)B * 8 * w.L;
   if (!z) {
@@ -2559,6 +2726,12 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
                    "FACPPG_WN_TILE=%s: expected 16, 32, 64 or (with folded flow edges) 128", tile_env);
     tn = v;
   }
+  if (seeds) {
+    FACPPG_REQUIRE(B == 1 && !T_valid_dev && fold, FACPPG_EUNSUPPORTED, "seeded inference: one utterance, folded flow edges");
+    FACPPG_REQUIRE(seeded_frames % 32 == 0 && seeded_frames >= T, FACPPG_EUNSUPPORTED,
+                   "seeded inference: %d seeded frames do not cover the %d frames", seeded_frames, T);
+    tn = 32;   // the seeds are 32-frame tiles of k_wn_layer8's accumulators
+  }
   const bool tile16 = tn == TN16, narrow = tn == 32, wide128 = tn == 128;
   WnArgs a;
   memset(&a, 0, sizeof(a));
@@ -2583,7 +2756,8 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   const unsigned lgrid = (unsigned)(w.P * a.nt);
   // 8 waves per tile for launches that cannot give every SIMD two 4-wave tiles (FACPPG_WN_8W: 0 never, 2 always)
   const char* w8env = getenv("FACPPG_WN_8W");
-  const int w8mode = w8env ? atoi(w8env) : 1;
+  const int w8mode = seeds ? 1 : w8env ? atoi(w8env) : 1;
+  a.seed_nt = w.Tr / 32;
   h->last_tile = tn; h->last_tiles = (int)lgrid;
   h->last_waves = (wide128 || tile16 || (narrow && w8mode != 0) || (!narrow && w8mode == 2)) ? 8 : 4;
   // A launch that leaves CUs empty can run all layers of a flow in ONE launch (k_wn_flow8): FACPPG_WN_FUSED = 1 one worker per
@@ -2593,7 +2767,7 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   const char* fenv = getenv("FACPPG_WN_FUSED");
   const int fworkers = fenv ? atoi(fenv) : 0;
   FACPPG_REQUIRE(fworkers >= 0 && fworkers <= 2, FACPPG_EINVAL, "FACPPG_WN_FUSED=%s: expected 0, 1 or 2", fenv);
-  const bool fused = fold && narrow && w8mode != 0 && fworkers > 0 && h->n_cu > 0 && (long)lgrid <= h->n_cu && c.wn_layers == 8;
+  const bool fused = !seeds && fold && narrow && w8mode != 0 && fworkers > 0 && h->n_cu > 0 && (long)lgrid <= h->n_cu && c.wn_layers == 8;
   h->ev_layers = c.wn_layers;
   for (int k = nf - 1; k >= 0; --k) {
     if (fused) {
@@ -2642,7 +2816,10 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
         if (wide128) WN_LAUNCH((k_wn_layer8<true, 4, true>), (k_wn_layer8<false, 4, true>), 512, 131072 + 4096);
         else if (tile16) WN_LAUNCH((k_wn_layer16<true, true>), (k_wn_layer16<false, true>), 512, 16384 + 4096);
         else if (narrow) {
-          if (w8mode == 0) WN_LAUNCH((k_wn_layer<true, 1, false, true, true>), (k_wn_layer<false, 1, false, true, true>), 256, 32768 + 1024);
+          if (seeds) {
+            a.seed = seeds + (size_t)(k * c.wn_layers + i) * w.P * a.seed_nt * 8 * 8 * 64;
+            WN_LAUNCH((k_wn_layer8<true, 1, true, true>), (k_wn_layer8<false, 1, true, true>), 512, 32768 + 8 * 1024);
+          } else if (w8mode == 0) WN_LAUNCH((k_wn_layer<true, 1, false, true, true>), (k_wn_layer<false, 1, false, true, true>), 256, 32768 + 1024);
           else WN_LAUNCH((k_wn_layer8<true, 1, true>), (k_wn_layer8<false, 1, true>), 512, 32768 + 8 * 1024);   // + the end rows' 8 K-slice partials
         } else if (w8mode == 2) WN_LAUNCH((k_wn_layer8<true, 2, true>), (k_wn_layer8<false, 2, true>), 512, 65536 + 2048);
         else WN_LAUNCH((k_wn_layer<true, 2, false, true, true>), (k_wn_layer<false, 2, false, true, true>), 256, 65536 + 2048);
@@ -2808,6 +2985,69 @@ extern "C" int facppg_wg_infer(facppg_wg* h, const float* mel_dev, const int32_t
   }
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
+}
+
+extern "C" int facppg_wg_seed_layout(const facppg_wg* h, int T, int* Tqp, int* margin, size_t* seed_bytes) {
+  FACPPG_REQUIRE(h && T > 0 && Tqp && margin && seed_bytes, FACPPG_EINVAL, "NULL argument or T <= 0");
+  const PmLayout w = pm_layout(h->cfg, 1, T);
+  *Tqp = w.Tqp; *margin = HQ;
+  *seed_bytes = (size_t)h->cfg.n_flows * h->cfg.wn_layers * w.P * (w.Tr / 32) * 8 * 8 * 64 * sizeof(float4);
+  return FACPPG_OK;
+}
+
+extern "C" int facppg_wg_cond_seed(facppg_wg* h, const float* melp_dev, int T, int frame0, int nframes, int block_tiles,
+                                   int layers_per_workgroup, float* seeds_dev, size_t seed_bytes, void* stream_) {
+  FACPPG_REQUIRE(h && melp_dev && seeds_dev, FACPPG_EINVAL, "NULL argument");
+  const facppg_wg_config& c = h->cfg;
+  const PmLayout w = pm_layout(c, 1, T);
+  size_t need = 0; int tqp = 0, mg = 0;
+  facppg_wg_seed_layout(h, T, &tqp, &mg, &need);
+  FACPPG_REQUIRE(seed_bytes >= need, FACPPG_EWORKSPACE, "seed buffer has %zu bytes, need %zu", seed_bytes, need);
+  FACPPG_REQUIRE(frame0 >= 0 && frame0 % 32 == 0 && nframes > 0 && frame0 + nframes <= w.Tr, FACPPG_EINVAL,
+                 "frames [%d, %d): the first must be a multiple of 32 and the range inside the %d padded frames", frame0, frame0 + nframes, w.Tr);
+  FACPPG_REQUIRE(block_tiles >= 1 && block_tiles <= 4 && layers_per_workgroup >= 1, FACPPG_EINVAL, "block_tiles in 1..4, layers_per_workgroup >= 1");
+  SeedArgs a;
+  memset(&a, 0, sizeof(a));
+  a.melp = melp_dev; a.seeds = (float4*)seeds_dev;
+  for (int k = 0; k < c.n_flows; ++k) a.ltab[k] = h->ltab[k];
+  a.layers_total = c.n_flows * c.wn_layers; a.wn_layers = c.wn_layers; a.lpw = layers_per_workgroup;
+  a.P = w.P; a.Tqp = w.Tqp; a.seed_nt = w.Tr / 32;
+  const int ntiles = (nframes + 31) / 32;
+  a.tile0 = frame0 / 32; a.nblk = (ntiles + block_tiles - 1) / block_tiles;
+  a.ncmax = h->kcp / KCH; a.kc = h->kc; a.ngc = h->kcp / 8; a.hop = c.hop_length; a.ksize = c.upsample_kernel;
+  const size_t lds = (size_t)a.ncmax * KCH * 32 * block_tiles * sizeof(float);
+  FACPPG_REQUIRE(lds <= 160 * 1024, FACPPG_EUNSUPPORTED, "block_tiles = %d needs %zu bytes of LDS", block_tiles, lds);
+  const int lgroups = (a.layers_total + a.lpw - 1) / a.lpw;
+  const unsigned grid = (unsigned)(lgroups * w.P * a.nblk);
+  hipStream_t s = (hipStream_t)stream_;
+  switch (block_tiles) {
+    case 1: k_cond_seed<1><<<grid, 512, lds, s>>>(a); break;
+    case 2: k_cond_seed<2><<<grid, 512, lds, s>>>(a); break;
+    case 3: k_cond_seed<3><<<grid, 512, lds, s>>>(a); break;
+    default: k_cond_seed<4><<<grid, 512, lds, s>>>(a); break;
+  }
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+extern "C" int facppg_wg_mel_pad(const facppg_wg* h, const float* mel_dev, int T, int ld, float* melp_dev, void* stream_) {
+  FACPPG_REQUIRE(h && mel_dev && melp_dev && T > 0 && ld >= T, FACPPG_EINVAL, "NULL argument or bad T / ld");
+  const PmLayout w = pm_layout(h->cfg, 1, T);
+  FACPPG_HIP_CHECK(hipMemsetAsync(melp_dev, 0, (size_t)NMEL * w.Tqp * 4, (hipStream_t)stream_));
+  FACPPG_HIP_CHECK(hipMemcpy2DAsync(melp_dev + HQ, (size_t)w.Tqp * 4, mel_dev, (size_t)ld * 4, (size_t)T * 4, NMEL, hipMemcpyDeviceToDevice,
+                                    (hipStream_t)stream_));
+  return FACPPG_OK;
+}
+
+extern "C" int facppg_wg_infer_seeded(facppg_wg* h, const float* melp_dev, int T, const float* seeds_dev, int seeded_frames,
+                                      const float* z_dev, uint64_t seed, float sigma, float* audio_dev, void* ws_, size_t ws_bytes,
+                                      void* stream_) {
+  FACPPG_REQUIRE(h && melp_dev && seeds_dev && audio_dev && ws_, FACPPG_EINVAL, "NULL argument");
+  FACPPG_REQUIRE(T > 0, FACPPG_EINVAL, "T must be positive (got %d)", T);
+  const size_t need = facppg_wg_workspace_bytes(h, 1, T);
+  FACPPG_REQUIRE(ws_bytes >= need, FACPPG_EWORKSPACE, "workspace has %zu bytes, need %zu", ws_bytes, need);
+  return wg_infer_pm(h, nullptr, nullptr, z_dev, seed, sigma, 1, T, audio_dev, (char*)ws_, (hipStream_t)stream_, melp_dev,
+                     (const float4*)seeds_dev, seeded_frames);
 }
 
 extern "C" int facppg_wg_draw_noise(const facppg_wg* h, const uint64_t* seeds_dev, int B, int T, float* z_dev, void* stream_) {

@@ -990,6 +990,58 @@ class WaveGlow(torch.nn.Module):
                                                    seed & 0xFFFFFFFFFFFFFFFF, float(sigma), B, T, _lib.ptr(audio),
                                                    _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)))
 
+    # ---- seeded inference of ONE utterance: the conditioning part of every layer's gate GEMM formed ahead of time
+    def seed_layout(self, T, device):
+        """(Tqp, margin, seed_bytes) for an utterance of T frames: the zero-margined mel buffer is [n_mel, Tqp] with frame q at
+        column margin + q; the seed buffer has seed_bytes bytes (facppg_wg_seed_layout)."""
+        c = _lib.ctypes
+        tqp, mg, nb = c.c_int(), c.c_int(), c.c_size_t()
+        _lib.check(_lib.load().facppg_wg_seed_layout(self._handle(device), int(T), c.byref(tqp), c.byref(mg), c.byref(nb)))
+        return tqp.value, mg.value, nb.value
+
+    def mel_pad(self, mel, handle=None):
+        """mel [1, n_mel, T] -> the zero-margined [n_mel, Tqp] buffer cond_seed / infer_seeded read."""
+        dev = mel.device
+        T = mel.shape[2]
+        tqp, _, _ = self.seed_layout(T, dev)
+        out = torch.empty(mel.shape[1], tqp, dtype=torch.float32, device=dev)
+        m = mel[0]
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().facppg_wg_mel_pad(self._handle(dev), _lib.ptr(m), T, m.stride(0), _lib.ptr(out), _lib.current_stream(dev)))
+        return out
+
+    def cond_seed(self, melp, T, frame0, nframes, seeds, block_tiles=1, layers_per_workgroup=4):
+        """Form the gate accumulators' seeds (bias + conditioning sums, k_cond_seed) of frames [frame0, frame0 + nframes) of the
+        utterance whose zero-margined mel frames are ``melp``, for every flow, layer and phase, on the current stream."""
+        dev = melp.device
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().facppg_wg_cond_seed(self._handle(dev), _lib.ptr(melp), int(T), int(frame0), int(nframes), int(block_tiles),
+                                                       int(layers_per_workgroup), _lib.ptr(seeds), seeds.numel() * seeds.element_size(),
+                                                       _lib.current_stream(dev)))
+
+    def infer_seeded(self, melp, T, seeds, seeded_frames, sigma=1.0, z=None, seed=None, handle=None):
+        """WaveGlow.infer of ONE utterance (glow.py:252-293) whose layers start from ``seeds``: audio [1, T*hop].  Same samples
+        as infer() on the same mel frames, bit for bit."""
+        dev = melp.device
+        hop = self.upsample.stride[0]
+        zt = None
+        if z is not None:
+            if isinstance(z, (list, tuple)):
+                z = torch.cat([t.to(dev).float().reshape(-1) for t in z])
+            zt = z.to(dev).float().contiguous()
+            if zt.numel() != self.n_group * (T * hop // self.n_group):
+                raise _lib.FacppgError("z has %d values, expected n_group*L = %d" % (zt.numel(), self.n_group * (T * hop // self.n_group)))
+        if seed is None:
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        h = handle if handle is not None else self._handle(dev)
+        ws = self._infer_workspace(1, T, dev, 0, h)
+        audio = torch.empty(1, T * hop, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().facppg_wg_infer_seeded(h, _lib.ptr(melp), int(T), _lib.ptr(seeds), int(seeded_frames), _lib.ptr(zt),
+                                                          seed & 0xFFFFFFFFFFFFFFFF, float(sigma), _lib.ptr(audio), _lib.ptr(ws), ws.numel(),
+                                                          _lib.current_stream(dev)))
+        return audio
+
     def prepare(self, device):
         """Validate (or build) the packed weights for ``device`` NOW and remember that for the next ``infer`` on this thread's
         next call: the check walks ~1000 tensors (0.4 ms of host time); facppg.pipeline runs it while the acoustic model's

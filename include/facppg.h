@@ -372,6 +372,11 @@ int facppg_taco_set_decoder_workgroups(facppg_taco* h, int max_workgroups);
  * FACPPG_DECODER_HEAT_LEAD (80) frames before the step limit, until the utterances' attention workgroups are done.  Results are unchanged bit for bit; the launch then holds the whole chip, so a caller that runs
  * something else next to the decoder (facppg_taco_set_decoder_workgroups > 0) gets none.  FACPPG_DECODER_HEATERS overrides. */
 int facppg_taco_set_decoder_heaters(facppg_taco* h, int heaters);
+/* Which decoder kernel the most recent facppg_taco_decode launched (tests assert the shape they mean to cover, as
+ * facppg_wg_last_launch_shape does for the vocoder): *mode = 0 one workgroup per utterance (k_decoder), 1 cooperative
+ * slices (k_decoder_coop), 2 split (k_decoder_split: one attention workgroup per utterance + register-resident dense-layer
+ * workers); *workgroups = workgroups of that launch.  The reference has one code path (model.py:489-535). */
+int facppg_taco_last_decoder_launch(const facppg_taco* h, int* mode, int* workgroups);
 
 /* Replaces Encoder.inference (model.py:237-249) and the memory_layer projection
  * (model.py:334).  ppg_dev [B][n_symbols][Tin]; lengths_dev NULL or [B] valid frame counts

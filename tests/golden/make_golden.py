@@ -375,6 +375,44 @@ def gen_e2e():
          audio=ac_wav, ac_wav=out)
 
 
+def gen_e2e_metric():
+    """The metric's own case at the shape bench.py times (BASELINE.json `metric`, SURVEY.md 8d config 1 at 22.05 kHz / hop 256):
+    PPG [200 x 5816] seed 0 -> get_inference (gate bias -10: the decoder runs its 200 steps) -> waveglow_audio(sigma 0.6) at
+    hop 256 -> Denoiser(hop_length=256, 'zeros')(strength 0.005), on the imported reference (generate_synthesis.py:74-98,
+    glow.py:252-293) with the models bench.py's EndToEnd builds; dropout masks and z injected.  ~3 s of CPU."""
+    from common import hparams as rh
+    from common import model as rmodel
+    from common.utils import get_inference, waveglow_audio
+    from waveglow.denoiser import Denoiser
+    Tin, hop, n_sym = 200, 256, 5816
+    hp = rh.create_hparams_stage(max_decoder_steps=Tin, n_symbols=n_sym)
+    taco = rmodel.Tacotron2(hp)
+    taco.load_state_dict(synth.tacotron_state_dict(hp, seed=16807, gate_bias=-10.0), strict=True)
+    taco.eval()
+    cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=hop)
+    wg = ref_waveglow(cfg)
+    denoiser = Denoiser(wg, filter_length=1024, hop_length=hop, win_length=1024, mode="zeros")
+    ppg = synth.synthetic_ppg(Tin, n_sym, seed=0, alpha=0.002)
+    enc_masks = masks_from_seed(991, (2, 1, Tin, hp.symbols_embedding_dim))
+    dec_masks = masks_from_seed(992, (Tin, 2, 1, hp.prenet_dim))
+    queue = [enc_masks[0], enc_masks[1]] + [dec_masks[t, j] for t in range(Tin) for j in range(2)]
+    with torch.no_grad(), InjectDropout(rmodel, queue):
+        ac_mel = get_inference(ppg, taco, False)
+    Tout = ac_mel.shape[2]
+    assert Tout == Tin, Tout
+    zs = synth.synthetic_z(1, Tout * hop // 8, cfg, seed=993)
+    with InjectNormal(zs) as inj:
+        ac_wav = waveglow_audio(ac_mel, wg, 0.6, True)
+        assert inj.i == 3
+    with torch.no_grad():
+        out = denoiser(ac_wav, strength=0.005)[:, 0]
+    assert ac_wav.shape == out.shape == (1, Tout * hop)
+    print("e2e_metric: Tout", Tout, "samples", out.shape[1], "rms", float(out.double().pow(2).mean().sqrt()))
+    save("e2e_metric.npz", Tin=Tin, hop=hop, gate_bias=-10.0, n_symbols=n_sym, ppg_seed=0, ppg_alpha=0.002, enc_mask_seed=991,
+         dec_mask_seed=992, z_seed=993, sigma=0.6, strength=0.005, Tout=Tout, ppg_sha=sha(ppg), mel_post=ac_mel, audio=ac_wav,
+         audio_denoised=out)
+
+
 def gen_kaldi_data():
     """The front-end's DATA files as the reference ships them (data/feats: LDA matrix, pdf -> monophone reduction, splice
     options; its own tests read the same files through test/data symlinks, test_feat.py:74-87, test_ppg.py:25-27)."""
@@ -400,6 +438,7 @@ def main():
     gen_waveglow_train()
     gen_tacotron()
     gen_e2e()
+    gen_e2e_metric()
     gen_kaldi_data()
 
 

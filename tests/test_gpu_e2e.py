@@ -408,6 +408,51 @@ def test_hop256_whole_path_matches_oracle():
         assert rms(e) <= 1e-3
 
 
+def test_metric_shape_matches_reference_golden():
+    """The headline's own shape against what the REFERENCE produced for it (tests/golden/e2e_metric.npz, written by
+    make_golden.py gen_e2e_metric from the imported reference: generate_synthesis.py:74-98 on PPG [200 x 5816], 200 decoder steps,
+    hop 256, sigma 0.6, Denoiser(hop_length=256)) -- the models and the call bench.py's EndToEnd times, default launch selection
+    (asserted: the split decoder and 32-frame / 8-wave vocoder tiles), injected dropout masks and z: mel <= 1e-4, N = 51 200
+    exactly, waveform RMS <= 1e-3 before and after the denoiser."""
+    from test_oracle_golden import metric_case
+    from facppg import pipeline
+    from script.train_ppg2mel import load_model
+    from waveglow.denoiser import Denoiser
+    from waveglow.glow import WaveGlow
+    d, hp, tsd, ppg, em, dm, cfg, zs = metric_case()
+    hop, Tout = int(d["hop"]), int(d["Tout"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        taco = load_model(hp)
+    taco.load_state_dict(tsd)
+    taco.eval()
+    wg = WaveGlow.remove_weightnorm(WaveGlow(**cfg))
+    wg.load_state_dict(synth.waveglow_state_dict(cfg))
+    wg = wg.cuda().eval()
+    den = Denoiser(wg, hop_length=hop, mode="zeros")
+    seen = {}
+    infer = wg.infer
+
+    def spy(spect, **kw):
+        seen["mel_post"] = spect.detach().cpu().numpy()
+        seen["audio"] = infer(spect, **kw)
+        return seen["audio"]
+    wg.infer = spy
+    with contextlib.redirect_stdout(io.StringIO()):
+        wavs, tout = pipeline.synthesize([ppg], taco, wg, den, sigma=float(d["sigma"]), strength=float(d["strength"]),
+                                         dropout_masks=(em, dm), z=zs)
+    del wg.infer
+    assert taco.last_decoder_launch()[0] == "split"
+    assert wg.last_launch_shape()[:2] == (32, 8)
+    assert tout == [Tout] and wavs[0].shape == (Tout * hop,) == (51200,)                      # integer: N = Tout * hop
+    assert seen["mel_post"].shape == d["mel_post"].shape
+    e_mel = np.abs(seen["mel_post"] - d["mel_post"]).max()
+    e_pre = rms(seen["audio"].cpu().numpy() - d["audio"])
+    e_post = rms(wavs[0] - d["audio_denoised"][0])
+    print("metric shape vs reference golden: mel_post %.2e, audio rms err %.2e, denoised rms err %.2e (rms %.3f)" % (
+        e_mel, e_pre, e_post, rms(d["audio_denoised"])))
+    assert e_mel <= 1e-4 and e_pre <= 1e-3 and e_post <= 1e-3
+
+
 def test_waveglow_inference_cli_and_mel2samp(checkpoints, tmp_path):
     """waveglow.inference (mel .pt list -> int16 wavs) fed by waveglow.mel2samp's GPU mel analysis."""
     from waveglow import inference

@@ -127,6 +127,43 @@ def test_tacotron_inference(tag):
     assert np.abs(align.numpy() - d["align"]).max() < 1e-6
 
 
+def metric_case():
+    """Inputs of tests/golden/e2e_metric.npz (make_golden.py gen_e2e_metric): the metric's own case at the shape bench.py times."""
+    from common.hparams import create_hparams_stage
+    from helpers import masks_from_seed
+    d = golden("e2e_metric.npz")
+    Tin, hop, ns = int(d["Tin"]), int(d["hop"]), int(d["n_symbols"])
+    hp = create_hparams_stage(max_decoder_steps=Tin, n_symbols=ns)
+    tsd = synth.tacotron_state_dict(hp, seed=16807, gate_bias=float(d["gate_bias"]))
+    ppg = synth.synthetic_ppg(Tin, ns, seed=int(d["ppg_seed"]), alpha=float(d["ppg_alpha"]))
+    em = masks_from_seed(int(d["enc_mask_seed"]), (2, 1, Tin, hp.symbols_embedding_dim))
+    dm = masks_from_seed(int(d["dec_mask_seed"]), (Tin, 2, 1, hp.prenet_dim))
+    cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=hop)
+    zs = synth.synthetic_z(1, Tin * hop // 8, cfg, seed=int(d["z_seed"]))
+    return d, hp, tsd, ppg, em, dm, cfg, zs
+
+
+def test_end_to_end_at_the_metric_shape():
+    """The oracle of the WHOLE path at the headline's shape -- PPG [200 x 5816] -> Tacotron2 (200 steps) -> WaveGlow at hop 256
+    -> Denoiser(hop_length=256) -- against the imported reference's output for exactly that run (e2e_metric.npz;
+    generate_synthesis.py:74-98)."""
+    d, hp, tsd, ppg, em, dm, cfg, zs = metric_case()
+    hop, Tout = int(d["hop"]), int(d["Tout"])
+    x = torch.from_numpy(ppg).t().unsqueeze(0)
+    with torch.no_grad():
+        _, mel_post, _, _ = otac.inference(tsd, hp, x, torch.from_numpy(em.astype(np.float32)), torch.from_numpy(dm.astype(np.float32)))
+        assert mel_post.shape == d["mel_post"].shape == (1, 80, Tout)
+        assert np.abs(mel_post.numpy() - d["mel_post"]).max() < 1e-5
+        wsd = synth.waveglow_state_dict(cfg)
+        audio = owg.infer(wsd, cfg, mel_post, float(d["sigma"]), zs)
+        assert audio.shape == d["audio"].shape == (1, Tout * hop)                   # N = Tout * hop exactly
+        assert np.sqrt(np.mean((audio.numpy().astype(np.float64) - d["audio"]) ** 2)) < 1e-5
+        nb = 88 * hop // 8
+        bias = owg.infer(wsd, cfg, torch.zeros(1, 80, 88), 0.0, [torch.zeros(1, 4, nb), torch.zeros(1, 2, nb), torch.zeros(1, 2, nb)])
+        out = dsp.DenoiserOracle(bias, hop_length=hop)(audio, float(d["strength"]))[:, 0]
+    assert np.sqrt(np.mean((out.numpy().astype(np.float64) - d["audio_denoised"]) ** 2)) < 1e-5
+
+
 def test_hparams_surface():
     from common import hparams
     with open(os.path.join(GOLDEN, "hparams.json")) as f:
