@@ -263,13 +263,16 @@ class Tacotron2(nn.Module):
         return enc_m, dec_m
 
     def inference(self, inputs, lengths=None, dropout_masks=None, seed=None, utterance_seeds=None, step_limits=None, timer=None,
-                  while_decoding=None):
+                  while_decoding=None, frame_consumer=None):
         """inputs [B, n_symbols, Tin] (GPU fp32) -> [mel, mel_post, gate, alignments]
         = [B,80,Tout], [B,80,Tout], [B,Tout,1], [B,Tout,Tin]  (model.py:597-610).  For B > 1 the
         outputs are zero beyond each utterance's own Tout, kept in ``self.last_output_lengths``.
         while_decoding: optional callable run on the host after the decoder has been enqueued and before its output lengths
         are read back (facppg.pipeline checks the vocoder's packed weights there: ~0.4 ms that would otherwise sit between the
-        acoustic model and the vocoder with the GPU idle)."""
+        acoustic model and the vocoder with the GPU idle).
+        frame_consumer: optional (B = 1; facppg.pipeline.ConditioningStream): the split decoder publishes every mel frame the
+        moment it exists and the consumer runs the postnet -- and whatever else it wants of the frames -- on a second stream
+        WHILE the decoder is still running; mel_post is then the consumer's (the same values bit for bit)."""
         inputs = self.parse_input(inputs)
         _lib.require_cuda(inputs, "Tacotron2.inference: inputs")
         L = _lib.load()
@@ -319,6 +322,10 @@ class Tacotron2(nn.Module):
         out_len = torch.zeros(B, dtype=torch.int32, device=dev)
         _lib.check(L.facppg_taco_set_decoder_workgroups(h, int(self.decoder_workgroups)))
         _lib.check(L.facppg_taco_set_decoder_heaters(h, int(self.decoder_heaters)))
+        streaming = False
+        if frame_consumer is not None and B == 1:
+            words = frame_consumer.begin(self, h, dev, steps, Tin)          # (zeroed on this stream, ahead of the decoder launch)
+            _lib.check(L.facppg_taco_set_frame_stream(h, _lib.ptr(words), steps if words is not None else 0))
         with torch.cuda.device(dev):
             _lib.check(L.facppg_taco_encode(h, _lib.ptr(x), _lib.ptr(lt), _lib.ptr(enc_m), seed, B, Tin, _lib.ptr(memory),
                                             _lib.ptr(pm), _lib.ptr(ws), ws.numel(), st))
@@ -327,6 +334,15 @@ class Tacotron2(nn.Module):
             _lib.check(L.facppg_taco_decode(h, _lib.ptr(memory), _lib.ptr(pm), _lib.ptr(lt), _lib.ptr(sl), _lib.ptr(dec_m), seed, B, Tin,
                                             steps, _lib.ptr(mel), _lib.ptr(gate), _lib.ptr(align), _lib.ptr(out_len),
                                             _lib.ptr(ws), ws.numel(), st))
+            if frame_consumer is not None and B == 1:
+                _lib.check(L.facppg_taco_set_frame_stream(h, None, 0))
+                flag = _lib.ctypes.c_int()
+                _lib.check(L.facppg_taco_last_decode_streamed(h, _lib.ctypes.byref(flag)))
+                streaming = bool(flag.value)
+                if streaming:
+                    frame_consumer.enqueue(out_len)            # its launches, gated on the frames, on its own stream
+                else:
+                    frame_consumer.cancel()
             if while_decoding is not None:                     # host work that needs no result of the decoder: the GPU is busy for
                 while_decoding()                               # milliseconds, the host would only sit in the read below
             out_len_host = out_len.cpu()                       # the path's single device->host sync
@@ -335,10 +351,13 @@ class Tacotron2(nn.Module):
             Tout = int(out_len_host.max())
             if Tout == int(self.decoder.max_decoder_steps):
                 print("Warning! Reached max decoder steps")     # model.py:527
-            mel_post = torch.zeros_like(mel)
-            ws2 = torch.empty(L.facppg_taco_postnet_workspace_bytes(h, B, Tout), dtype=torch.uint8, device=dev)
-            _lib.check(L.facppg_taco_postnet(h, _lib.ptr(mel), _lib.ptr(out_len), B, Tout, steps, _lib.ptr(mel_post),
-                                             _lib.ptr(ws2), ws2.numel(), st))
+            if streaming:
+                mel_post = frame_consumer.finish(Tout, out_len)       # [1, NF, >= Tout] view: what is left of the postnet, on this stream
+            else:
+                mel_post = torch.zeros_like(mel)
+                ws2 = torch.empty(L.facppg_taco_postnet_workspace_bytes(h, B, Tout), dtype=torch.uint8, device=dev)
+                _lib.check(L.facppg_taco_postnet(h, _lib.ptr(mel), _lib.ptr(out_len), B, Tout, steps, _lib.ptr(mel_post),
+                                                 _lib.ptr(ws2), ws2.numel(), st))
             if timer is not None:
                 timer.mark("postnet")
         self.last_output_lengths = out_len_host.to(torch.long)

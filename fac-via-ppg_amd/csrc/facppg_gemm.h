@@ -35,6 +35,12 @@ struct GemmArgs {
   long x_bs = 0;
   int ldx = 0;
   int N = 0;                  // columns (max over the batch)
+  // column window (streaming convolutions: a layer is extended by the columns whose inputs have become final): output
+  // columns [col0, N) only; source columns are valid in [0, src_hi) (src_hi = 0: up to the output bound, i.e. the
+  // convolution's zero padding starts where the outputs end); *skip != 0 (device): the launch does nothing
+  int col0 = 0;
+  int src_hi = 0;
+  const int* skip = nullptr;
   const int* n_valid = nullptr;  // optional per-batch column count (device)
   int n_valid_mul = 1;           // valid columns = n_valid[b] * n_valid_mul + n_valid_add
   int n_valid_add = 0;

@@ -54,9 +54,11 @@ __global__ __launch_bounds__(256) void k_gemm(KArgs ka) {
   const GemmArgs& p = ka.g;
   __shared__ __attribute__((aligned(16))) float smem[2 * KCH * TN];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
-  const int b = blockIdx.z / ka.sk, ks = blockIdx.z % ka.sk, n0 = blockIdx.x * TN;
+  const int b = blockIdx.z / ka.sk, ks = blockIdx.z % ka.sk, n0 = p.col0 + blockIdx.x * TN;
   const int Nb = p.n_valid ? min(p.N, p.n_valid[b] * p.n_valid_mul + p.n_valid_add) : p.N;
   if (n0 >= Nb) return;
+  if (p.skip && *p.skip) return;
+  const int Ns = p.src_hi > 0 ? (p.n_valid ? min(p.src_hi, p.n_valid[b] * p.n_valid_mul + p.n_valid_add) : p.src_hi) : Nb;
   const int mb = blockIdx.y * 4 + w;
   const int MB = (p.M + 31) / 32;
   const bool active = mb < MB;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void k_gemm(KArgs ka) {
       const int kk = c * KCH + w * 16 + j;
       const int tap = kk / p.Cin, ch = kk - tap * p.Cin;
       const int sc = col + (tap - p.pad) * p.dil;
-      stg[j] = (kk < K && sc >= 0 && sc < Nb) ? xb[(size_t)ch * p.ldx + sc] : 0.0f;
+      stg[j] = (kk < K && sc >= 0 && sc < Ns) ? xb[(size_t)ch * p.ldx + sc] : 0.0f;
     }
   };
   auto stage_write = [&](int buf) {
@@ -138,9 +140,10 @@ __global__ __launch_bounds__(256) void k_gemm(KArgs ka) {
 // second pass of a split-K product: fixed-order sum of the partials, then the epilogue
 __global__ void k_gemm_reduce(KArgs ka) {
   const GemmArgs& p = ka.g;
-  const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y, b = blockIdx.z;
+  const int n = p.col0 + blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y, b = blockIdx.z;
   const int Nb = p.n_valid ? min(p.N, p.n_valid[b] * p.n_valid_mul + p.n_valid_add) : p.N;
   if (n >= Nb) return;
+  if (p.skip && *p.skip) return;
   float v = 0.0f;
   for (int ks = 0; ks < ka.sk; ++ks) v += p.splitk_ws[(((size_t)ks * p.B + b) * p.M + m) * p.N + n];
   gemm_epilogue(p, b, m, n, v);
@@ -161,13 +164,13 @@ int pack_a(const float* src, int M, int Cin, int taps, float4* dst, hipStream_t 
 }
 
 int gemm_launch(const GemmArgs& a, hipStream_t s) {
-  FACPPG_REQUIRE(a.A && a.X && a.C && a.M > 0 && a.N > 0 && a.Cin > 0 && a.taps > 0 && a.B > 0, FACPPG_EINVAL,
+  FACPPG_REQUIRE(a.A && a.X && a.C && a.M > 0 && a.N > 0 && a.Cin > 0 && a.taps > 0 && a.B > 0 && a.col0 >= 0 && a.col0 < a.N, FACPPG_EINVAL,
                  "gemm_launch: bad arguments");
   KArgs ka;
   ka.g = a;
   ka.KG = gemm_kpad(a.Cin * a.taps) / 8;
   ka.sk = 1;
-  dim3 grid((a.N + TN - 1) / TN, (round_up(a.M, 32) / 32 + 3) / 4, a.B);
+  dim3 grid((a.N - a.col0 + TN - 1) / TN, (round_up(a.M, 32) / 32 + 3) / 4, a.B);
   // Long reductions are split over K when the caller lent a partial-sum buffer: a product with few columns
   // (one short utterance through the encoder / postnet) otherwise launches a few dozen workgroups with a
   // long serial K loop each.  The split factor depends on K ALONE -- not on the batch or the padded
@@ -183,7 +186,7 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
   }
   grid.z = a.B * ka.sk;
   k_gemm<<<grid, 256, 0, s>>>(ka);
-  if (ka.sk > 1) k_gemm_reduce<<<dim3((a.N + 255) / 256, a.M, a.B), 256, 0, s>>>(ka);
+  if (ka.sk > 1) k_gemm_reduce<<<dim3((a.N - a.col0 + 255) / 256, a.M, a.B), 256, 0, s>>>(ka);
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
 }

@@ -36,6 +36,9 @@ struct facppg_taco {
   int coop_limit;   // workgroups the cooperative (co-resident) kernels may use: from the occupancy calculator, see facppg_taco_create
   int decoder_wg_limit;   // facppg_taco_set_decoder_workgroups: a tighter bound for the decoder alone (0 = none)
   int decoder_heaters;    // facppg_taco_set_decoder_heaters: heater workgroups of the split decoder (0 none, -1 all that fit)
+  unsigned long long* frame_stream;   // facppg_taco_set_frame_stream: tagged mel frames as the split decoder emits them (B = 1), or null
+  int frame_stream_frames;
+  int last_streamed;         // the most recent decode published its frames there
   int last_mode, last_wgs;   // facppg_taco_last_decoder_launch: 0 one workgroup per utterance, 1 cooperative, 2 split; workgroups launched
   char* arena;
   // encoder
@@ -59,6 +62,17 @@ struct facppg_taco {
 };
 
 namespace {
+
+// The cooperating kernels (decoder, BiLSTM) need all their workgroups co-resident; hipLaunchCooperativeKernel checks that the grid
+// fits and the launches below size their grids from the occupancy calculator.  FACPPG_COOP_PLAIN=1 launches the SAME kernels with
+// the same grids as ordinary launches (read per call): rocprofv3 on this stack dies on cooperative launches, and an ordinary
+// launch of a grid that fits an otherwise idle GPU is co-resident all the same (every poll is bounded in wall-clock time:
+// a launch that did not fit traps instead of hanging) -- the profiling mode of tools/profile_coop.sh, not a production setting.
+hipError_t launch_coop(const void* fn, dim3 grid, dim3 block, void** args, size_t smem, hipStream_t s) {
+  const char* plain = getenv("FACPPG_COOP_PLAIN");
+  if (plain && atoi(plain) != 0) return hipLaunchKernel(fn, grid, block, args, smem, s);
+  return hipLaunchCooperativeKernel(fn, grid, block, args, smem, s);
+}
 
 constexpr int NT = 1024;  // threads of the one-workgroup-per-utterance persistent kernels (16 waves, <= 128 VGPRs)
 constexpr int NTC = 512;  // threads of a cooperative decoder workgroup (8 waves, <= 256 VGPRs: no spills, deeper loads in flight)
@@ -359,6 +373,10 @@ struct DecArgs {
   // k_decoder_split: worker workgroups per group, and HEATER workgroups behind them (see there)
   int nwk, heaters, heat_sleep, heat_lead, dbg_flags;
   unsigned* heat_done;   // [groups] main workgroups of the group that have finished
+  // k_decoder_split, B = 1: every mel value of frame t is ALSO published as a {value, t + 1} word at melx[t * NF + row] the moment
+  // its projection row is formed (agent-scope store: visible to kernels on other streams while this launch is still running --
+  // the plain stores to `mel` are only guaranteed visible once it has ended); facppg_taco_collect_frames reads them
+  unsigned long long* melx;
 };
 
 // The frame count at which utterance b stops if its gate never fires (model.py:524-528's max_decoder_steps,
@@ -1320,8 +1338,10 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
           if (tid < SSC && prow0 + tid <= p.NF) {
             const int row = prow0 + tid;
             const float v = part[512 + u * SSC + tid] + p.proj_b[row];
-            if (row < p.NF) p.mel[((size_t)b * p.NF + row) * p.max_steps + t - 1] = v;
-            else { p.gate[(size_t)b * p.max_steps + t - 1] = v; xpub(MEL + row, v, tag); }   // only the gate crosses workgroups
+            if (row < p.NF) {
+              p.mel[((size_t)b * p.NF + row) * p.max_steps + t - 1] = v;
+              if (p.melx) xpub(p.melx + (size_t)(t - 1) * p.NF + row, v, tag - 1);
+            } else { p.gate[(size_t)b * p.max_steps + t - 1] = v; xpub(MEL + row, v, tag); }   // only the gate crosses workgroups
           }
         }
         // prenet layer 1 of frame t from the same [dh | ctx]: relu((W1 Wp) v + W1 bp), dropout  (model.py:132-135)
@@ -1470,7 +1490,7 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
       __syncthreads();
       if (s_stop[0]) {
         if (tid == 0) {
-          p.out_len[b] = t;
+          __hip_atomic_store(p.out_len + b, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (a frame collector on another stream watches it)
           if (p.heaters) __hip_atomic_fetch_add(p.heat_done + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         break;
@@ -1834,8 +1854,8 @@ extern "C" int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const in
     int Tin_ = Tin, H_ = H;
     void* args[] = {(void*)&xp, (void*)&w0, (void*)&w1, (void*)&lengths_dev, (void*)&Tin_, (void*)&H_, (void*)&xchg,
                     (void*)&memory_dev, (void*)&mem_cm};
-    if (fit32) FACPPG_HIP_CHECK(hipLaunchCooperativeKernel((const void*)k_bilstm_coop<32, 96>, dim3((H + 31) / 32, 2, B), dim3(NTC), args, 0, s));
-    else FACPPG_HIP_CHECK(hipLaunchCooperativeKernel((const void*)k_bilstm_coop<64, 152>, dim3((H + 63) / 64, 2, B), dim3(NTC), args, 0, s));
+    if (fit32) FACPPG_HIP_CHECK(launch_coop((const void*)k_bilstm_coop<32, 96>, dim3((H + 31) / 32, 2, B), dim3(NTC), args, 0, s));
+    else FACPPG_HIP_CHECK(launch_coop((const void*)k_bilstm_coop<64, 152>, dim3((H + 63) / 64, 2, B), dim3(NTC), args, 0, s));
   } else {
     const int KS = NT / H < H ? NT / H : H;
     const size_t smem = (size_t)(2 * H + (KS > 0 ? KS : 1) * 4 * H) * 4;
@@ -1927,6 +1947,7 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
     masks = (const uint8_t*)(ws + w.mask);
   }
   DecArgs a;
+  a.melx = nullptr; h->last_streamed = 0;
   a.dp0_t = h->dp0_t; a.dp1_t = h->dp1_t; a.att_t = h->att_t; a.att_b = h->att_b; a.dec_t = h->dec_t; a.dec_b = h->dec_b;
   a.q_t = h->q_t; a.proj_t = h->proj_t; a.proj_b = h->proj_b; a.loc_conv = h->loc_conv; a.loc_dense = h->loc_dense; a.v = h->v;
   a.xchg = (unsigned long long*)(ws + w.xchg);
@@ -1994,13 +2015,15 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
     if (heaters < 0 || heaters > room) heaters = room > 0 ? room : 0;
     if (h->decoder_wg_limit > 0) heaters = 0;
     a.nwk = h->split_nwk; a.heaters = heaters; a.heat_done = (unsigned*)(ws + w.heat);
+    a.melx = (B == 1 && h->frame_stream && h->frame_stream_frames >= max_steps) ? h->frame_stream : nullptr;
+    h->last_streamed = a.melx != nullptr;
     a.dbg_flags = getenv("FACPPG_DECODER_NO_ROWS") ? 1 : 0;
     a.heat_sleep = getenv("FACPPG_DECODER_HEAT_SLEEP") ? atoi(getenv("FACPPG_DECODER_HEAT_SLEEP")) : 0;
     // heat only the last frames before the step limit (1.7 ms at 21 us per frame): as good as heating the whole decode
     // (tools/heater_sweep.sh: 13.91 vs 13.95-13.99 ms per end-to-end step, 14.22-14.32 without) at a third of the energy, and the
     // decoder itself stays undisturbed until then; an utterance whose gate stops it earlier simply gets none.  0 = from the start.
     a.heat_lead = getenv("FACPPG_DECODER_HEAT_LEAD") ? atoi(getenv("FACPPG_DECODER_HEAT_LEAD")) : 80;
-    FACPPG_HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(h->split_nwk + NU + heaters, groups), dim3(NTC), args, ssm, s));
+    FACPPG_HIP_CHECK(launch_coop(fn, dim3(h->split_nwk + NU + heaters, groups), dim3(NTC), args, ssm, s));
     h->last_mode = 2; h->last_wgs = (h->split_nwk + NU + heaters) * groups;
     if (a.prof) {
       long long pr[32];
@@ -2025,7 +2048,7 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
           if ((long)nb * h->coop_nwg[v] <= wg_limit) { cv = v; break; }
       a.b0 = b0; a.att_coop = h->att_coop[cv]; a.dec_coop = h->dec_coop[cv]; a.U = h->coop_U[cv];
       void* args[] = {(void*)&a};
-      FACPPG_HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(h->coop_nwg[cv], nb), dim3(NTC), args, smem, s));
+      FACPPG_HIP_CHECK(launch_coop(fn, dim3(h->coop_nwg[cv], nb), dim3(NTC), args, smem, s));
       h->last_mode = 1; h->last_wgs = h->coop_nwg[cv] * nb;
     }
     if (a.prof) {
@@ -2093,6 +2116,123 @@ extern "C" int facppg_taco_set_decoder_workgroups(facppg_taco* h, int max_workgr
 extern "C" int facppg_taco_set_decoder_heaters(facppg_taco* h, int heaters) {
   FACPPG_REQUIRE(h && heaters >= -1, FACPPG_EINVAL, "NULL handle or heaters < -1");
   h->decoder_heaters = heaters;
+  return FACPPG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Streaming the decoder's frames into the postnet while the decoder is still running (B = 1, split decoder).
+// ------------------------------------------------------------------------------------------
+namespace {
+// frames [fa, fb) of the tagged stream -> dst[row][f] (channel-major, ld).  A word is waited for (bounded in wall-clock time like
+// every poll of this file); if the decoder has stopped short of a frame (out_len set, frame >= out_len) the whole block is void:
+// *void_flag = 1 -- every launch of THIS block that is handed the flag does nothing, and the caller handles those frames once it
+// knows the length.  A block behind a void block is void as well (prev_flag).  One flag per block: blocks overlap in time (the
+// seed pass of block k runs while block k + 1 is being collected), a shared flag would cut a valid block's launches short.
+__global__ __launch_bounds__(256) void k_collect_frames(const unsigned long long* __restrict__ melx, const int* __restrict__ out_len,
+                                                        int NF, int fa, int fb, float* __restrict__ dst, int ld, int* void_flag,
+                                                        const int* prev_flag) {
+  if (prev_flag && __hip_atomic_load(prev_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+    if (void_flag) __hip_atomic_store(void_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  const int n = (fb - fa) * NF;
+  const unsigned long long limit = g_poll_limit_ticks;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int f = fa + i / NF, row = i - (f - fa) * NF;
+    const unsigned long long* w = melx + (size_t)f * NF + row;
+    unsigned long long v, t0 = 0;
+    unsigned spins = 0;
+    for (;;) {
+      v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)(v >> 32) == (unsigned)(f + 1)) break;
+      const int ol = __hip_atomic_load(out_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ol > 0 && f >= ol) {   // the decoder stopped before this frame
+        if (void_flag) __hip_atomic_store(void_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(32);
+      if ((++spins & 1023u) == 0 && limit) {
+        const unsigned long long now = wall_clock64();
+        if (!t0) t0 = now;
+        else if (now - t0 > limit) __builtin_trap();
+      }
+    }
+    dst[(size_t)row * ld + f] = __uint_as_float((unsigned)v);
+  }
+}
+}  // namespace
+
+extern "C" int facppg_taco_set_frame_stream(facppg_taco* h, void* words_dev, int frames) {
+  FACPPG_REQUIRE(h && frames >= 0 && (words_dev || frames == 0), FACPPG_EINVAL, "NULL handle, or a NULL buffer with frames > 0");
+  h->frame_stream = (unsigned long long*)words_dev; h->frame_stream_frames = words_dev ? frames : 0;
+  return FACPPG_OK;
+}
+
+extern "C" int facppg_taco_last_decode_streamed(const facppg_taco* h, int* streamed) {
+  FACPPG_REQUIRE(h && streamed, FACPPG_EINVAL, "NULL argument");
+  *streamed = h->last_streamed;
+  return FACPPG_OK;
+}
+
+extern "C" int facppg_taco_collect_frames(const facppg_taco* h, const void* words_dev, const int32_t* out_length_dev, int frame_a,
+                                          int frame_b, float* mel_dev, int ld, int32_t* void_flag_dev, const int32_t* prev_flag_dev,
+                                          void* stream_) {
+  FACPPG_REQUIRE(h && words_dev && out_length_dev && mel_dev, FACPPG_EINVAL, "NULL argument");
+  FACPPG_REQUIRE(frame_a >= 0 && frame_b > frame_a && frame_b <= ld, FACPPG_EINVAL, "frames [%d, %d) with ld %d", frame_a, frame_b, ld);
+  const int n = (frame_b - frame_a) * h->c.n_acoustic_feat_dims;
+  k_collect_frames<<<(n + 255) / 256 < 8 ? (n + 255) / 256 : 8, 256, 0, (hipStream_t)stream_>>>(
+      (const unsigned long long*)words_dev, out_length_dev, h->c.n_acoustic_feat_dims, frame_a, frame_b, mel_dev, ld, void_flag_dev,
+      prev_flag_dev);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+// Postnet + residual (model.py:178-184, 604-605) as a STREAMING convolution stack: every layer is extended by the columns
+// whose inputs have become final.  With f frames of mel known, layer j (1-based, kernel 2*pad + 1) is final up to f - j*pad;
+// a call advances the frontier from f_prev to f_new frames (final_T > 0: the utterance has ended at final_T frames, every
+// layer runs up to it and the convolutions' zero padding starts there).  Every output column is the same sum, in the same
+// order, as in facppg_taco_postnet's one-shot launch (the split-K factor depends on K alone): same bits.
+extern "C" size_t facppg_taco_postnet_stream_workspace_bytes(const facppg_taco* h, int max_frames) {
+  if (!h || max_frames <= 0) return 0;
+  const size_t PE = h->c.postnet_embedding_dim, n = h->c.postnet_n_convolutions;
+  return (n - 1) * PE * max_frames * 4 + (size_t)16 * PE * max_frames * 4;
+}
+
+extern "C" int facppg_taco_postnet_range(facppg_taco* h, const float* mel_dev, int ld, int f_prev, int f_new, int final_T,
+                                         float* mel_post_dev, int ld_post, void* ws_, size_t ws_bytes, int max_frames,
+                                         const int32_t* skip_dev, void* stream_) {
+  FACPPG_REQUIRE(h && mel_dev && mel_post_dev && ws_, FACPPG_EINVAL, "NULL argument");
+  const facppg_taco_config& c = h->c;
+  const int PE = c.postnet_embedding_dim, NF = c.n_acoustic_feat_dims, n = c.postnet_n_convolutions, pad = (c.postnet_kernel_size - 1) / 2;
+  FACPPG_REQUIRE(f_prev >= 0 && f_new >= f_prev && f_new <= max_frames && max_frames <= ld && final_T <= max_frames, FACPPG_EINVAL,
+                 "bad frame range [%d, %d) / final %d / max %d", f_prev, f_new, final_T, max_frames);
+  FACPPG_REQUIRE(final_T == 0 || final_T == f_new, FACPPG_EINVAL, "a final call covers exactly the utterance's frames");
+  const size_t need = facppg_taco_postnet_stream_workspace_bytes(h, max_frames);
+  FACPPG_REQUIRE(ws_bytes >= need, FACPPG_EWORKSPACE, "workspace has %zu bytes, need %zu", ws_bytes, need);
+  hipStream_t s = (hipStream_t)stream_;
+  float* bufs = (float*)ws_;
+  float* skws = bufs + (size_t)(n - 1) * PE * max_frames;
+  const size_t skws_bytes = (size_t)16 * PE * max_frames * 4;
+  int src_hi = f_new;
+  for (int j = 0; j < n; ++j) {
+    const int lag = pad * (j + 1);
+    const int lo = f_prev - lag > 0 ? f_prev - lag : 0;
+    const int hi = final_T > 0 ? final_T : f_new - lag;
+    if (hi > lo) {
+      const int ci = j == 0 ? NF : PE, co = j == n - 1 ? NF : PE;
+      GemmArgs g;
+      g.splitk_ws = skws; g.splitk_ws_bytes = skws_bytes;
+      g.B = 1; g.N = hi; g.col0 = lo; g.src_hi = src_hi; g.skip = skip_dev;
+      g.A = h->post[j]; g.M = co; g.Cin = ci; g.taps = c.postnet_kernel_size; g.pad = pad;
+      g.X = j == 0 ? mel_dev : bufs + (size_t)(j - 1) * PE * max_frames; g.ldx = j == 0 ? ld : max_frames;
+      g.bias = h->post_b[j]; g.scale = h->post_scale[j]; g.shift = h->post_shift[j];
+      if (j < n - 1) { g.act = ACT_TANH; g.C = bufs + (size_t)j * PE * max_frames; g.ldc = max_frames; }
+      else { g.res = mel_dev; g.ldres = ld; g.C = mel_post_dev; g.ldc = ld_post; }
+      if (int rc = gemm_launch(g, s)) return rc;
+    }
+    src_hi = hi > 0 ? hi : 0;   // the next layer reads this one's final columns only
+    if (src_hi == 0) break;
+  }
   return FACPPG_OK;
 }
 

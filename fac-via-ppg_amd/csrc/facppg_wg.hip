@@ -1363,19 +1363,33 @@ struct SeedArgs {
   int P, Tqp, seed_nt;
   int tile0, nblk;          // first 32-frame tile of this launch, NCB-tile blocks from there
   int ncmax, kc, ngc, hop, ksize;   // conditioning chunks at most (kcp / 64), rows, k-groups per phase image, upsampler stride / size
+  const int* skip;          // optional (device): *skip != 0 -> the launch does nothing (the frames never became final)
+  int items;                // work items = layer groups x phases x blocks (a bounded launch has fewer workgroups than that)
+  int layer0, layer1;       // the layers of this launch: [layer0, layer1) of layers_total (flow-major: layer = flow * wn_layers + i)
 };
 
-template <int NCB>
+template <bool NT>
+__device__ __forceinline__ float4 gld_w(const float4* q) {   // NT: a stream that is read once -- do not keep it in the L2
+  if constexpr (NT) {
+    const f32x4s v = __builtin_nontemporal_load((const FACPPG_AS1 f32x4s*)q);
+    return make_float4(v.x, v.y, v.z, v.w);
+  } else return gld(q);
+}
+
+template <int NCB, bool NT>
 __global__ __launch_bounds__(512, NCB <= 2 ? 4 : 2) void k_cond_seed(SeedArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [ncc][64 k][TNt] K4 images of the block's mel window
   constexpr int TNt = 32 * NCB;
   const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, wq = w8 >> 1, sub = w8 & 1;
   const int li = lane & 31, kh = lane >> 5;
   const int chb = wq * 64 + sub * 32;
+  if (p.skip && *p.skip) return;
+  // a launch may be bounded to fewer workgroups than it has work items (p.items): each then walks items blockIdx, + gridDim, ...
+  // (gridDim a multiple of 8: an item stays on the XCD its index names)
+  for (int lin = (int)blockIdx.x; lin < p.items; lin += (int)gridDim.x) {
   // workgroup i lands on XCD i % 8: the blocks that share a (layer, phase) image run back to back on one XCD
   int lg, ph, blk;
   {
-    const int lin = (int)blockIdx.x;
     if (p.P % 8 == 0) {
       const int r = lin >> 3, rest = r / p.nblk;
       blk = r - rest * p.nblk; ph = (rest % (p.P / 8)) * 8 + (lin & 7); lg = rest / (p.P / 8);
@@ -1384,8 +1398,8 @@ __global__ __launch_bounds__(512, NCB <= 2 ? 4 : 2) void k_cond_seed(SeedArgs p)
       ph = rest % p.P; lg = rest / p.P;
     }
   }
-  const int l0 = lg * p.lpw, l1 = min(l0 + p.lpw, p.layers_total);
-  if (l0 >= l1) return;
+  const int l0 = p.layer0 + lg * p.lpw, l1 = min(l0 + p.lpw, p.layer1);
+  if (l0 >= l1) continue;
   // conditioning chunks of this phase (pm_chunks): late phases reach one mel frame less
   const int nj = (p.ksize - 1 - 8 * ph) / p.hop + 1;
   const int ncc = min(p.ncmax, (nj * NMEL + KCH - 1) / KCH);
@@ -1420,7 +1434,7 @@ __global__ __launch_bounds__(512, NCB <= 2 ? 4 : 2) void k_cond_seed(SeedArgs p)
     }
   }
   // the weight stream: k-group G of the workgroup = group G % ng of layer l0 + G / ng; ring of 4, as in k_wn_layer8
-  const int ng = 8 * ncc, ngt = ng * (l1 - l0);
+  const int ng = 8 * ncc;
   const size_t wave_off = (size_t)ph * p.ngc * 1024 + (wq * 4 + sub) * 64 + lane;
   auto layer_ptrs = [&](int l) __attribute__((always_inline)) {
     const WnLayerPtrs* t = reinterpret_cast<const WnLayerPtrs*>(p.ltab[l / p.wn_layers]) + (l % p.wn_layers);
@@ -1432,8 +1446,8 @@ __global__ __launch_bounds__(512, NCB <= 2 ? 4 : 2) void k_cond_seed(SeedArgs p)
   int g_in = 0, l_pre = l0;                             // its k-group inside that layer
   auto load_next = [&](float4 (&a)[2]) __attribute__((always_inline)) {
     const float4* src = wc_cur + (size_t)g_in * 1024;
-    a[0] = gld(src);
-    a[1] = gld(src + 128);
+    a[0] = gld_w<NT>(src);
+    a[1] = gld_w<NT>(src + 128);
     if (++g_in == ng) {                                  // (wave-uniform) on to the next layer's image; past the last one: stay
       g_in = 0;
       if (l_pre + 1 < l1) { ++l_pre; wc_cur = layer_ptrs(l_pre)->wc + wave_off; }
@@ -1444,7 +1458,6 @@ __global__ __launch_bounds__(512, NCB <= 2 ? 4 : 2) void k_cond_seed(SeedArgs p)
   for (int i = 0; i < RING - 1; ++i) load_next(ar[i]);
   __syncthreads();
   const float* lb0 = smem + (kh * TNt + li) * 4;
-  (void)ngt;
   for (int l = l0; l < l1; ++l) {
     const float* b1 = layer_ptrs(l)->b1;
     f32x16 acc[2][NCB];
@@ -1486,10 +1499,14 @@ __global__ __launch_bounds__(512, NCB <= 2 ? 4 : 2) void k_cond_seed(SeedArgs p)
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          store_f4<false>(reinterpret_cast<float*>(dst + (rb * 4 + q) * 64),
-                          make_float4(acc[rb][cb][4 * q + 0], acc[rb][cb][4 * q + 1], acc[rb][cb][4 * q + 2], acc[rb][cb][4 * q + 3]));
+        for (int q = 0; q < 4; ++q) {
+          const f32x4s x = {acc[rb][cb][4 * q + 0], acc[rb][cb][4 * q + 1], acc[rb][cb][4 * q + 2], acc[rb][cb][4 * q + 3]};
+          if constexpr (NT) __builtin_nontemporal_store(x, (FACPPG_AS1 f32x4s*)(dst + (rb * 4 + q) * 64));
+          else *(FACPPG_AS1 f32x4s*)(dst + (rb * 4 + q) * 64) = x;
+        }
     }
+  }
+  __syncthreads();   // (the next item restages the LDS image)
   }
 }
 
@@ -1502,20 +1519,12 @@ __global__ __launch_bounds__(512, NCB <= 2 ? 4 : 2) void k_cond_seed(SeedArgs p)
 // ------------------------------------------------------------------------------------------
 constexpr int TN16 = 16;
 
-template <bool LAST, bool EF = false>
-__global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// one 16-frame tile: phase ph, frames q0 .. q0 + 15 of utterance b
+template <bool LAST, bool EF>
+__device__ __forceinline__ void wn_layer16_tile(const WnArgs& p, const int ph, const int b, const int q0, float* __restrict__ smem) {
   const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6;
   const int pl = lane & 15, kq = lane >> 4;
   const int chb = w8 * 32;
-  int ph, tile;
-  {
-    const int lin = blockIdx.x;
-    if (p.xcd_map == 1) { const int r = lin >> 3; ph = (r / p.nt) * 8 + (lin & 7); tile = r % p.nt; }
-    else { ph = lin / p.nt; tile = lin % p.nt; }
-    if (ph >= p.P) return;
-  }
-  const int b = tile / p.ntq, q0 = (tile % p.ntq) * TN16;
   const int nvalid = (p.t_valid ? p.t_valid[b] : p.T) - q0;
   if (nvalid <= 0) return;
   const int in_off = ph * p.Tqp + HQ + q0, sk_off = ph * p.Tr + q0;
@@ -1714,6 +1723,39 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
       }
     }
   }
+}
+
+template <bool LAST, bool EF = false>
+__global__ __launch_bounds__(512, 4) void k_wn_layer16(WnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int ph, tile;
+  {
+    const int lin = blockIdx.x;
+    if (p.xcd_map == 1) { const int r = lin >> 3; ph = (r / p.nt) * 8 + (lin & 7); tile = r % p.nt; }
+    else { ph = lin / p.nt; tile = lin % p.nt; }
+    if (ph >= p.P) return;
+  }
+  wn_layer16_tile<LAST, EF>(p, ph, tile / p.ntq, (tile % p.ntq) * TN16, smem);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_wn_layer_mixed (one streamed utterance): the frames whose seeds k_cond_seed formed under the decoder run as seeded
+// 32-frame tiles (12 K chunks), the frames behind them -- the ones that became final only when the decoder ended -- as
+// UNSEEDED 16-frame tiles of the same launch (17 K chunks on half the columns: 57 us against the seeded tile's 56 with one
+// workgroup per CU), instead of waiting for a seed pass over them (2 GB of weight images for a handful of frames) in front of
+// the vocoder.  Per phase: n32 seeded tiles, then the 16-frame tiles from frame 32 * n32 on.  Both kinds of tile are the code of
+// the single-kind launches (wn_layer8_tile<SEED>, wn_layer16_tile): same sums in the same order, same bits.
+// ------------------------------------------------------------------------------------------
+template <bool LAST>
+__global__ __launch_bounds__(512, 4) void k_wn_layer_mixed(WnArgs p32, WnArgs p16, int n32) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lin = (int)blockIdx.x, nt = p32.nt;   // tiles per phase of this launch: n32 + the 16-frame tiles
+  int ph, tile;
+  if (p32.xcd_map == 1) { const int r = lin >> 3; ph = (r / nt) * 8 + (lin & 7); tile = r % nt; }
+  else { ph = lin / nt; tile = lin % nt; }
+  if (ph >= p32.P) return;
+  if (tile < n32) wn_layer8_tile<LAST, 1, true, false, false, true>(p32, lin, smem, FlowWait{nullptr, 0u, 0ull, 0});
+  else wn_layer16_tile<LAST, true>(p16, ph, 0, 32 * n32 + (tile - n32) * TN16, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2485,10 +2527,14 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
   WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer8<true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer8<false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   WG_TRY(hipFuncSetAttribute((const void*)k_wn_layer8<true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  WG_TRY(hipFuncSetAttribute((const void*)k_cond_seed<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  WG_TRY(hipFuncSetAttribute((const void*)k_cond_seed<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  WG_TRY(hipFuncSetAttribute((const void*)k_cond_seed<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  WG_TRY(hipFuncSetAttribute((const void*)k_cond_seed<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_cond_seed<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_cond_seed<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_cond_seed<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_cond_seed<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_cond_seed<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_cond_seed<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_cond_seed<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  WG_TRY(hipFuncSetAttribute((const void*)k_cond_seed<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipFree(tmp);
 #undef WG_TRY
   *out = h;
@@ -2645,11 +2691,14 @@ static void launch_begin(dim3 grid, hipStream_t s, const EdgeArgs& a) { k_begin<
 // `seeded_frames` frames; melp_ext is then the caller's zero-margined mel buffer the seeds were formed from
 static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_valid_dev, const float* z_dev, uint64_t seed,
                        float sigma, int B, int T, float* audio_dev, char* ws, hipStream_t s, const float* melp_ext = nullptr,
-                       const float4* seeds = nullptr, int seeded_frames = 0) {
+                       const float4* seeds = nullptr, int seeded_frames = 0, int T_layout = 0, void* const* flow_events = nullptr) {
   const facppg_wg_config& c = h->cfg;
   // ONE short utterance: the persistent launch (facppg_wgp.hip) -- same bits, no kernel boundary per layer
   if (!seeds && wgp_eligible(h, B, T, T_valid_dev)) return wgp_infer(h, mel_dev, z_dev, seed, sigma, T, audio_dev, ws, s);
-  const PmLayout w = pm_layout(c, B, T);
+  // T_layout >= T: the strides (frames per phase row) of buffers that were laid out before T was known -- the mel buffer and
+  // the seeds of a streamed utterance -- while everything that is counted (positions, tiles, noise, samples) follows T itself
+  PmLayout w = pm_layout(c, B, T_layout > T ? T_layout : T);
+  w.L = T * w.P; w.La = round_up(w.L, TN);
   FACPPG_REQUIRE((double)C * w.P * w.Tqp < 2.0e9, FACPPG_EUNSUPPORTED, "T = %d frames is too long for 32-bit row offsets", T);
   float* hbuf[2] = {(float*)(ws + w.h0), (float*)(ws + w.h1)};
   float* skip = (float*)(ws + w.skip);
@@ -2728,10 +2777,13 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   }
   if (seeds) {
     FACPPG_REQUIRE(B == 1 && !T_valid_dev && fold, FACPPG_EUNSUPPORTED, "seeded inference: one utterance, folded flow edges");
-    FACPPG_REQUIRE(seeded_frames % 32 == 0 && seeded_frames >= T, FACPPG_EUNSUPPORTED,
-                   "seeded inference: %d seeded frames do not cover the %d frames", seeded_frames, T);
+    FACPPG_REQUIRE(seeded_frames % 32 == 0 && seeded_frames > 0, FACPPG_EUNSUPPORTED,
+                   "seeded inference: %d seeded frames, expected a positive multiple of 32", seeded_frames);
     tn = 32;   // the seeds are 32-frame tiles of k_wn_layer8's accumulators
   }
+  // frames behind the seeded ones run as unseeded 16-frame tiles of the same launches (k_wn_layer_mixed)
+  const int n32 = seeds && seeded_frames < T ? seeded_frames / 32 : 0;
+  const int n16 = n32 ? (T - seeded_frames + TN16 - 1) / TN16 : 0;
   const bool tile16 = tn == TN16, narrow = tn == 32, wide128 = tn == 128;
   WnArgs a;
   memset(&a, 0, sizeof(a));
@@ -2753,6 +2805,7 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   // workgroup i lands on XCD i % 8: give every XCD its own phases so a phase's weight image lives in one L2
   const char* no_xcd = getenv("FACPPG_WN_NO_XCD_MAP");   // tests: plain phase-major workgroup order
   a.xcd_map = ((w.P % 8 == 0) && !no_xcd) ? 1 : 0;
+  if (n32) a.nt = n32 + n16;
   const unsigned lgrid = (unsigned)(w.P * a.nt);
   // 8 waves per tile for launches that cannot give every SIMD two 4-wave tiles (FACPPG_WN_8W: 0 never, 2 always)
   const char* w8env = getenv("FACPPG_WN_8W");
@@ -2792,6 +2845,8 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
       if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
       if ((c.wn_layers - 1) & 1) hi ^= 1;
     }
+    // (streamed utterance: the seeds of this flow come from a pass that may still be running on another stream)
+    if (flow_events && flow_events[k]) FACPPG_HIP_CHECK(hipStreamWaitEvent(s, (hipEvent_t)flow_events[k], 0));
     for (int i = 0; i < (fused ? 0 : c.wn_layers); ++i) {
       a.h_in = hbuf[hi]; a.h_out = hbuf[hi ^ 1];
       a.w1 = h->w1pm[k][i]; a.wc = h->wcpm[k][i]; a.b1 = h->b1pm[k][i]; a.w2 = h->w2[k][i]; a.b2 = h->b2[k][i];
@@ -2818,7 +2873,13 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
         else if (narrow) {
           if (seeds) {
             a.seed = seeds + (size_t)(k * c.wn_layers + i) * w.P * a.seed_nt * 8 * 8 * 64;
-            WN_LAUNCH((k_wn_layer8<true, 1, true, true>), (k_wn_layer8<false, 1, true, true>), 512, 32768 + 8 * 1024);
+            if (n32) {
+              WnArgs a16 = a;
+              a16.w1 = i == 0 ? h->w1f_16[k] : h->w1_16[k][i]; a16.wc = h->wc_16[k][i]; a16.w2 = last ? h->w2_16[k][i] : h->w2r_16[k][i];
+              a16.flat_cols = 0; a16.groups = nullptr;
+              if (last) k_wn_layer_mixed<true><<<lgrid, 512, 32768 + 8 * 1024, s>>>(a, a16, n32);
+              else k_wn_layer_mixed<false><<<lgrid, 512, 32768 + 8 * 1024, s>>>(a, a16, n32);
+            } else WN_LAUNCH((k_wn_layer8<true, 1, true, true>), (k_wn_layer8<false, 1, true, true>), 512, 32768 + 8 * 1024);
           } else if (w8mode == 0) WN_LAUNCH((k_wn_layer<true, 1, false, true, true>), (k_wn_layer<false, 1, false, true, true>), 256, 32768 + 1024);
           else WN_LAUNCH((k_wn_layer8<true, 1, true>), (k_wn_layer8<false, 1, true>), 512, 32768 + 8 * 1024);   // + the end rows' 8 K-slice partials
         } else if (w8mode == 2) WN_LAUNCH((k_wn_layer8<true, 2, true>), (k_wn_layer8<false, 2, true>), 512, 65536 + 2048);
@@ -2996,7 +3057,8 @@ extern "C" int facppg_wg_seed_layout(const facppg_wg* h, int T, int* Tqp, int* m
 }
 
 extern "C" int facppg_wg_cond_seed(facppg_wg* h, const float* melp_dev, int T, int frame0, int nframes, int block_tiles,
-                                   int layers_per_workgroup, float* seeds_dev, size_t seed_bytes, void* stream_) {
+                                   int layers_per_workgroup, int flow0, int nflows, float* seeds_dev, size_t seed_bytes,
+                                   const int32_t* skip_dev, void* stream_) {
   FACPPG_REQUIRE(h && melp_dev && seeds_dev, FACPPG_EINVAL, "NULL argument");
   const facppg_wg_config& c = h->cfg;
   const PmLayout w = pm_layout(c, 1, T);
@@ -3006,9 +3068,11 @@ extern "C" int facppg_wg_cond_seed(facppg_wg* h, const float* melp_dev, int T, i
   FACPPG_REQUIRE(frame0 >= 0 && frame0 % 32 == 0 && nframes > 0 && frame0 + nframes <= w.Tr, FACPPG_EINVAL,
                  "frames [%d, %d): the first must be a multiple of 32 and the range inside the %d padded frames", frame0, frame0 + nframes, w.Tr);
   FACPPG_REQUIRE(block_tiles >= 1 && block_tiles <= 4 && layers_per_workgroup >= 1, FACPPG_EINVAL, "block_tiles in 1..4, layers_per_workgroup >= 1");
+  if (nflows <= 0) { flow0 = 0; nflows = c.n_flows; }
+  FACPPG_REQUIRE(flow0 >= 0 && flow0 + nflows <= c.n_flows, FACPPG_EINVAL, "flows [%d, %d) of %d", flow0, flow0 + nflows, c.n_flows);
   SeedArgs a;
   memset(&a, 0, sizeof(a));
-  a.melp = melp_dev; a.seeds = (float4*)seeds_dev;
+  a.melp = melp_dev; a.seeds = (float4*)seeds_dev; a.skip = skip_dev;
   for (int k = 0; k < c.n_flows; ++k) a.ltab[k] = h->ltab[k];
   a.layers_total = c.n_flows * c.wn_layers; a.wn_layers = c.wn_layers; a.lpw = layers_per_workgroup;
   a.P = w.P; a.Tqp = w.Tqp; a.seed_nt = w.Tr / 32;
@@ -3017,15 +3081,30 @@ extern "C" int facppg_wg_cond_seed(facppg_wg* h, const float* melp_dev, int T, i
   a.ncmax = h->kcp / KCH; a.kc = h->kc; a.ngc = h->kcp / 8; a.hop = c.hop_length; a.ksize = c.upsample_kernel;
   const size_t lds = (size_t)a.ncmax * KCH * 32 * block_tiles * sizeof(float);
   FACPPG_REQUIRE(lds <= 160 * 1024, FACPPG_EUNSUPPORTED, "block_tiles = %d needs %zu bytes of LDS", block_tiles, lds);
-  const int lgroups = (a.layers_total + a.lpw - 1) / a.lpw;
-  const unsigned grid = (unsigned)(lgroups * w.P * a.nblk);
+  a.layer0 = flow0 * c.wn_layers; a.layer1 = (flow0 + nflows) * c.wn_layers;
+  const int lgroups = (a.layer1 - a.layer0 + a.lpw - 1) / a.lpw;
+  a.items = lgroups * w.P * a.nblk;
+  // FACPPG_SEED_WGS bounds the workgroups of a launch (a multiple of 8; 0 = one per item): the kernel streams 2 GB of weight images
+  // per pass, and next to a latency-bound decoder a slower stream can be the better neighbour.  FACPPG_SEED_NT=0: ordinary
+  // (L2-allocating) loads and stores instead of non-temporal ones.  Both read per call: experiments.
+  const char* wgs_env = getenv("FACPPG_SEED_WGS");
+  const int max_wgs = wgs_env ? atoi(wgs_env) / 8 * 8 : 0;
+  const unsigned grid = (unsigned)(max_wgs > 0 && max_wgs < a.items ? max_wgs : a.items);
+  const char* nt_env = getenv("FACPPG_SEED_NT");
+  const bool nt = !nt_env || atoi(nt_env) != 0;
   hipStream_t s = (hipStream_t)stream_;
+#define SEED_LAUNCH(N)                                         \
+  do {                                                         \
+    if (nt) k_cond_seed<N, true><<<grid, 512, lds, s>>>(a);    \
+    else k_cond_seed<N, false><<<grid, 512, lds, s>>>(a);      \
+  } while (0)
   switch (block_tiles) {
-    case 1: k_cond_seed<1><<<grid, 512, lds, s>>>(a); break;
-    case 2: k_cond_seed<2><<<grid, 512, lds, s>>>(a); break;
-    case 3: k_cond_seed<3><<<grid, 512, lds, s>>>(a); break;
-    default: k_cond_seed<4><<<grid, 512, lds, s>>>(a); break;
+    case 1: SEED_LAUNCH(1); break;
+    case 2: SEED_LAUNCH(2); break;
+    case 3: SEED_LAUNCH(3); break;
+    default: SEED_LAUNCH(4); break;
   }
+#undef SEED_LAUNCH
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
 }
@@ -3039,15 +3118,15 @@ extern "C" int facppg_wg_mel_pad(const facppg_wg* h, const float* mel_dev, int T
   return FACPPG_OK;
 }
 
-extern "C" int facppg_wg_infer_seeded(facppg_wg* h, const float* melp_dev, int T, const float* seeds_dev, int seeded_frames,
+extern "C" int facppg_wg_infer_seeded(facppg_wg* h, const float* melp_dev, int T_layout, int T, const float* seeds_dev, int seeded_frames,
                                       const float* z_dev, uint64_t seed, float sigma, float* audio_dev, void* ws_, size_t ws_bytes,
-                                      void* stream_) {
+                                      void* const* flow_events, void* stream_) {
   FACPPG_REQUIRE(h && melp_dev && seeds_dev && audio_dev && ws_, FACPPG_EINVAL, "NULL argument");
-  FACPPG_REQUIRE(T > 0, FACPPG_EINVAL, "T must be positive (got %d)", T);
-  const size_t need = facppg_wg_workspace_bytes(h, 1, T);
+  FACPPG_REQUIRE(T > 0 && T_layout >= T, FACPPG_EINVAL, "need 0 < T <= T_layout (got %d, %d)", T, T_layout);
+  const size_t need = facppg_wg_workspace_bytes(h, 1, T_layout);
   FACPPG_REQUIRE(ws_bytes >= need, FACPPG_EWORKSPACE, "workspace has %zu bytes, need %zu", ws_bytes, need);
   return wg_infer_pm(h, nullptr, nullptr, z_dev, seed, sigma, 1, T, audio_dev, (char*)ws_, (hipStream_t)stream_, melp_dev,
-                     (const float4*)seeds_dev, seeded_frames);
+                     (const float4*)seeds_dev, seeded_frames, T_layout, flow_events);
 }
 
 extern "C" int facppg_wg_draw_noise(const facppg_wg* h, const uint64_t* seeds_dev, int B, int T, float* z_dev, void* stream_) {

@@ -108,9 +108,9 @@ def _declare(lib):
         "facppg_wg_last_layer_ms": (c.c_int, [vp, c.POINTER(f32), c.POINTER(c.c_int)]),
         "facppg_wg_last_launch_shape": (c.c_int, [vp, c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)]),
         "facppg_wg_seed_layout": (c.c_int, [vp, c.c_int, c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(sz)]),
-        "facppg_wg_cond_seed": (c.c_int, [vp, vp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, vp, sz, vp]),
+        "facppg_wg_cond_seed": (c.c_int, [vp, vp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, vp, sz, vp, vp]),
         "facppg_wg_mel_pad": (c.c_int, [vp, vp, c.c_int, c.c_int, vp, vp]),
-        "facppg_wg_infer_seeded": (c.c_int, [vp, vp, c.c_int, vp, c.c_int, vp, c.c_uint64, f32, vp, vp, sz, vp]),
+        "facppg_wg_infer_seeded": (c.c_int, [vp, vp, c.c_int, c.c_int, vp, c.c_int, vp, c.c_uint64, f32, vp, vp, sz, vp, vp]),
         "facppg_stft_create": (c.c_int, [c.c_int, c.c_int, vp, vp, vp, vp, c.c_int, c.c_int, vp, c.POINTER(vp)]),
         "facppg_stft_destroy": (None, [vp]),
         "facppg_stft_workspace_bytes": (sz, [vp, c.c_int, c.c_int]),
@@ -126,6 +126,11 @@ def _declare(lib):
         "facppg_taco_set_decoder_workgroups": (c.c_int, [vp, c.c_int]),
         "facppg_taco_set_decoder_heaters": (c.c_int, [vp, c.c_int]),
         "facppg_taco_last_decoder_launch": (c.c_int, [vp, c.POINTER(c.c_int), c.POINTER(c.c_int)]),
+        "facppg_taco_set_frame_stream": (c.c_int, [vp, vp, c.c_int]),
+        "facppg_taco_last_decode_streamed": (c.c_int, [vp, c.POINTER(c.c_int)]),
+        "facppg_taco_collect_frames": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, vp, c.c_int, vp, vp, vp]),
+        "facppg_taco_postnet_stream_workspace_bytes": (sz, [vp, c.c_int]),
+        "facppg_taco_postnet_range": (c.c_int, [vp, vp, c.c_int, c.c_int, c.c_int, c.c_int, vp, c.c_int, vp, sz, c.c_int, vp, vp]),
         "facppg_taco_postnet_workspace_bytes": (sz, [vp, c.c_int, c.c_int]),
         "facppg_taco_encode": (c.c_int, [vp, vp, vp, vp, u64, c.c_int, c.c_int, vp, vp, vp, sz, vp]),
         "facppg_taco_decode": (c.c_int, [vp, vp, vp, vp, vp, vp, u64, c.c_int, c.c_int, c.c_int, vp, vp, vp, vp, vp, sz, vp]),

@@ -52,6 +52,202 @@ class Synthesizer(object):
         return tout[0]
 
 
+class ConditioningStream(object):
+    """One utterance at a time (the metric's "batch = 1" case): work that depends on the mel frames ALONE, done while the decoder
+    is still producing them, on the ~180 CUs its launch leaves empty.
+
+    The split decoder publishes every frame the moment it exists (facppg_taco_set_frame_stream); on a second HIP stream, gated
+    on those frames (facppg_taco_collect_frames), this object runs per block of frames
+      * the postnet as a streaming convolution stack (facppg_taco_postnet_range: same sums, same order, same bits as the one-shot
+        launch) straight into the vocoder's zero-margined mel buffer, and
+      * the conditioning part of every WaveNet layer's gate GEMM (facppg_wg_cond_seed: bias + the folded conditioning chunks, the
+        MFMA sequence the layer kernel itself would run first) into a seed buffer,
+    so that behind the decoder only the last frames' share is left, and WaveGlow's layer launches start from the seeds with 12 K
+    chunks instead of 17 (first layers 1 instead of 6): 29 % of the vocoder's FLOPs off the critical path, same samples bit for
+    bit (tests/test_gpu_stream.py).  Reference: Postnet.forward (model.py:178-184, 604-605), WN.forward's cond_layers
+    (glow.py:154-175) and the upsampling they read (glow.py:253-259).
+
+    A pass over a block of frames streams every (flow, layer, phase) conditioning image once -- 2 GB at hop 256 -- whatever the
+    block's width, so the blocks are as wide as the frames' arrival allows (FACPPG_STREAM_CHUNK frames, default 64) and only the
+    last one before the expected end is 32 frames, which keeps the share that has to wait for the decoder's end small."""
+
+    LAG = None   # frames of mel the postnet's output trails its input by (pad * layers; from the model)
+
+    def __init__(self, tacotron, waveglow):
+        self.tacotron, self.waveglow = tacotron, waveglow
+        self.key = None
+        self.active = False
+
+    @staticmethod
+    def usable(tacotron, waveglow):
+        """The streamed path exists for the reference's shapes on the folded, phase-major vocoder kernels."""
+        if os.environ.get("FACPPG_STREAM", "1") == "0" or os.environ.get("FACPPG_WG_UNFOLDED", "0") not in ("", "0"):
+            return False
+        if os.environ.get("FACPPG_WG_EDGE_FOLD", "1") == "0" or getattr(tacotron, "decoder_workgroups", 0):
+            return False
+        return waveglow.WN[0].n_layers == 8 and waveglow.n_group == 8
+
+    def _buffers(self, dev, steps):
+        from facppg import lib as _lib
+        key = (dev, steps)
+        if self.key == key:
+            return
+        L = _lib.load()
+        hp = self.tacotron._hp
+        self.NF = hp["n_acoustic_feat_dims"]
+        self.lag = (hp["postnet_kernel_size"] - 1) // 2 * hp["postnet_n_convolutions"]
+        self.tqp, self.margin, seed_bytes = self.waveglow.seed_layout(steps, dev)
+        self.words = torch.zeros(steps * self.NF + 512, dtype=torch.int64, device=dev)    # {value, frame + 1} words + the void flags
+        self.void = self.words[steps * self.NF:].view(torch.int32)                        # one per block (up to 1024)
+        self.mel = torch.zeros(self.NF, steps, dtype=torch.float32, device=dev)           # collected frames, channel-major
+        self.melp = torch.zeros(self.NF, self.tqp, dtype=torch.float32, device=dev)       # mel_post, the vocoder's zero-margined layout
+        self.seeds = torch.empty(seed_bytes // 4, dtype=torch.float32, device=dev)
+        self.post_ws = torch.empty(L.facppg_taco_postnet_stream_workspace_bytes(self.tacotron._handle(dev), steps), dtype=torch.uint8,
+                                   device=dev)
+        # The seed passes fill every CU the decoder leaves; the postnet's launches next to them are a few workgroups each and must not
+        # queue for a slot behind thousands of the pass's own (measured: 260 us for a 22 us launch): the seed stream gets the lowest
+        # priority, the postnet stream the highest (FACPPG_STREAM_PRIO=0: both default).
+        lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, 0)
+        if os.environ.get("FACPPG_STREAM_PRIO", "1") == "0":
+            lo = hi = 0
+        self.side = torch.cuda.Stream(device=dev, priority=max(lo, hi))          # the seed passes (largest number = lowest priority)
+        # frame collection + the streaming postnet, one block ahead of them (FACPPG_STREAM_ONE=1: on the same stream, experiments)
+        self.post = self.side if os.environ.get("FACPPG_STREAM_ONE") == "1" else torch.cuda.Stream(device=dev, priority=min(lo, hi))
+        self.prio = (lo, hi)
+        self.key = key
+
+    def plan(self, steps, Tin):
+        """[(frames of mel needed, first seeded frame, end of seeded frames)] -- blocks that can be formed before the utterance ends
+        if it runs to about min(steps, Tin) frames; whatever is not covered is left for finish()."""
+        chunk = max(32, int(os.environ.get("FACPPG_STREAM_CHUNK", "64")) // 32 * 32)
+        last = max(32, int(os.environ.get("FACPPG_STREAM_LAST", "32")) // 32 * 32)
+        end = min(steps, max(Tin, 1))
+        s_end = (end - self.lag) // 32 * 32                       # seeded frames before the expected end
+        cuts, s = [], 0
+        while s < s_end and len(cuts) < 1000:
+            rest = s_end - s
+            w = rest if rest <= last else min(chunk, rest - last)
+            cuts.append((s + w + self.lag, s, s + w))
+            s += w
+        s_lim = (steps - self.lag) // 32 * 32                     # the decoder may run on to its step limit: a few more blocks
+        extra = 0
+        while s < s_lim and extra < 2 and len(cuts) < 1000:
+            w = min(chunk, s_lim - s)
+            cuts.append((s + w + self.lag, s, s + w))
+            s += w
+            extra += 1
+        self.n_extra = extra
+        return cuts
+
+    # ---- called by Tacotron2.inference
+    def begin(self, tacotron, handle, dev, steps, Tin):
+        """Before the decoder launch, on its stream: zeroed frame words.  Returns them (None: not usable for this call)."""
+        self.active = False
+        if not self.usable(tacotron, self.waveglow) or steps < 64:
+            return None
+        self._buffers(dev, steps)
+        self.dev, self.steps, self.Tin, self.taco_handle = dev, steps, Tin, handle
+        self.words.zero_()
+        self.melp.zero_()
+        self.ready = torch.cuda.Event()
+        self.ready.record(torch.cuda.current_stream(dev))
+        return self.words
+
+    def cancel(self):
+        self.active = False
+
+    def enqueue(self, out_len):
+        """The decoder has been launched and publishes its frames: enqueue every planned block on the side stream."""
+        from facppg import lib as _lib
+        L = _lib.load()
+        dev, steps = self.dev, self.steps
+        self.cuts = self.plan(steps, self.Tin)
+        self.wg_handle = self.waveglow._handle(dev)
+        f_prev = 0
+        groups = max(1, int(os.environ.get("FACPPG_STREAM_GROUPS", "3")))
+        lpw = max(1, int(os.environ.get("FACPPG_STREAM_LPW", "1")))
+        self.block_events = []
+        self.post.wait_event(self.ready)
+        with torch.cuda.device(dev):
+            for k, (f_new, s_a, s_b) in enumerate(self.cuts):
+                void = self.void[k:k + 1]
+                with torch.cuda.stream(self.post):
+                    st = _lib.current_stream(dev)
+                    _lib.check(L.facppg_taco_collect_frames(self.taco_handle, _lib.ptr(self.words), _lib.ptr(out_len), f_prev, f_new,
+                                                            _lib.ptr(self.mel), steps, _lib.ptr(void),
+                                                            _lib.ptr(self.void[k - 1:k]) if k else None, st))
+                    _lib.check(L.facppg_taco_postnet_range(self.taco_handle, _lib.ptr(self.mel), steps, f_prev, f_new, 0,
+                                                           self.melp.data_ptr() + 4 * self.margin, self.tqp, _lib.ptr(self.post_ws),
+                                                           self.post_ws.numel(), steps, _lib.ptr(void), st))
+                    final = torch.cuda.Event()
+                    final.record(self.post)
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(final)                # mel_post is final up to s_b
+                    # The blocks around the expected end are formed flow group by flow group in the order the vocoder walks the
+                    # flows (last flow first), an event behind each group: the vocoder can then start on the first group's seeds
+                    # while the pass is still forming the others'.
+                    late = k >= len(self.cuts) - 1 - self.n_extra
+                    nf = self.waveglow.n_flows
+                    parts = [(nf * (groups - 1 - g) // groups, nf * (groups - g) // groups) for g in range(groups)] if late else [(0, nf)]
+                    evs = []
+                    for lo, hi in parts:
+                        self.waveglow.cond_seed(self.melp, steps, s_a, s_b - s_a, self.seeds, block_tiles=min(4, (s_b - s_a) // 32),
+                                                layers_per_workgroup=lpw, skip=void, handle=self.wg_handle,
+                                                flows=(lo, hi - lo))
+                        ev = torch.cuda.Event()
+                        ev.record(self.side)
+                        evs.append((lo, hi, ev))
+                    self.block_events = evs
+                f_prev = f_new
+        self.active = True
+
+    def finish(self, Tout, out_len):
+        """The decoder has ended at Tout frames (known on the host): what the blocks could not cover, on the caller's stream.
+        Returns mel_post [1, NF, Tout] (a view of the vocoder's mel buffer)."""
+        from facppg import lib as _lib
+        L = _lib.load()
+        dev, steps = self.dev, self.steps
+        cur = torch.cuda.current_stream(dev)
+        # everything up to the first flow group of the last block; the other groups' events gate their flows (vocode)
+        if self.block_events:
+            cur.wait_event(self.block_events[0][2])
+        self.flow_events = {hi - 1: ev for lo, hi, ev in self.block_events[1:]}
+        f_done = s_done = 0
+        for f_new, s_a, s_b in self.cuts:
+            if f_new <= Tout:
+                f_done, s_done = f_new, s_b
+        with torch.cuda.device(dev):
+            st = _lib.current_stream(dev)
+            if Tout > f_done:
+                _lib.check(L.facppg_taco_collect_frames(self.taco_handle, _lib.ptr(self.words), _lib.ptr(out_len), f_done, Tout,
+                                                        _lib.ptr(self.mel), steps, None, None, st))
+            _lib.check(L.facppg_taco_postnet_range(self.taco_handle, _lib.ptr(self.mel), steps, f_done, Tout, Tout,
+                                                   self.melp.data_ptr() + 4 * self.margin, self.tqp, _lib.ptr(self.post_ws),
+                                                   self.post_ws.numel(), steps, None, st))
+        self.Tout, self.seeded = Tout, s_done
+        return self.melp[:, self.margin:self.margin + Tout].unsqueeze(0)
+
+    # ---- called by the vocoder stage
+    def vocode(self, sigma, z=None, seed=None):
+        """WaveGlow.infer of the streamed utterance from the seeds (the frames behind the last block get theirs here)."""
+        T, s_done = self.Tout, self.seeded
+        s_all = -(-T // 32) * 32
+        # The frames behind the last block: as unseeded 16-frame tiles inside the layer launches themselves (k_wn_layer_mixed) while
+        # the launch still gives every CU at most one workgroup; otherwise (and with FACPPG_STREAM_TAIL=seed) one more seed pass
+        # over them in front of the vocoder.
+        P = self.waveglow.upsample.stride[0] // 8
+        mixed_wgs = P * (s_done // 32 + -(-(T - s_done) // 16))
+        tail = os.environ.get("FACPPG_STREAM_TAIL", "auto")
+        in_kernel = s_done > 0 and s_done < T and tail != "seed" and (tail == "mixed" or mixed_wgs <= 256 or mixed_wgs >= 1024)
+        if s_all > s_done and not in_kernel:
+            self.waveglow.cond_seed(self.melp, self.steps, s_done, s_all - s_done, self.seeds, block_tiles=1, layers_per_workgroup=2,
+                                    handle=self.wg_handle)
+            s_done = s_all
+        self.active = False
+        return self.waveglow.infer_seeded(self.melp, T, self.seeds, s_done, sigma=sigma, z=z, seed=seed, handle=self.wg_handle,
+                                          T_layout=self.steps, flow_events=self.flow_events)
+
+
 class StageTimer(object):
     """hipEvent timestamps on the launch stream between the stages of one synthesize() call (the kernels run on
     torch's current stream, so torch.cuda.Event brackets them).  ``mark(name)`` closes stage ``name``."""
@@ -92,7 +288,7 @@ def pad_ppgs(ppgs, device=None):
     return x, lens
 
 
-def _acoustic(ppgs, tacotron, seed, dropout_masks, utterance_seeds, step_limits, timer=None, while_decoding=None):
+def _acoustic(ppgs, tacotron, seed, dropout_masks, utterance_seeds, step_limits, timer=None, while_decoding=None, consumer=None):
     """PPG upload + Tacotron2.inference on the current stream -> (mel_post [B, 80, Tout], [Tout_i]).  Blocks the host once,
     for the decoder's output lengths."""
     dev = next(tacotron.parameters()).device
@@ -101,17 +297,23 @@ def _acoustic(ppgs, tacotron, seed, dropout_masks, utterance_seeds, step_limits,
         timer.mark("ppg_upload")
     _, mel_post, _, _ = tacotron.inference(x, lengths=lens if len(lens) > 1 else None, dropout_masks=dropout_masks,
                                            seed=seed, utterance_seeds=utterance_seeds, step_limits=step_limits,
-                                           while_decoding=while_decoding, **({"timer": timer} if timer is not None else {}))
+                                           while_decoding=while_decoding, frame_consumer=consumer if len(lens) == 1 else None,
+                                           **({"timer": timer} if timer is not None else {}))
     return mel_post.contiguous(), [int(v) for v in tacotron.last_output_lengths]
 
 
-def _vocode(mel_post, tout, waveglow, denoiser, sigma, strength, seed, z, utterance_seeds, timer=None):
+def _vocode(mel_post, tout, waveglow, denoiser, sigma, strength, seed, z, utterance_seeds, timer=None, consumer=None):
     """WaveGlow.infer + Denoiser on the current stream -> audio [B, Tout_max * hop] on the device; no host waits beyond the
     small uploads (lengths, seeds)."""
     hop = waveglow.upsample.stride[0]
     multi = len(tout) > 1
     wg_seeds = None if utterance_seeds is None else [int(v) + 1 for v in utterance_seeds]
-    audio = waveglow.infer(mel_post, sigma=sigma, z=z, lengths=tout if multi else None, seed=seed, utterance_seeds=wg_seeds)
+    if consumer is not None and consumer.active:
+        if wg_seeds is not None:
+            z = waveglow.draw_noise(wg_seeds, tout[0], mel_post.device)
+        audio = consumer.vocode(sigma, z=z, seed=seed)
+    else:
+        audio = waveglow.infer(mel_post, sigma=sigma, z=z, lengths=tout if multi else None, seed=seed, utterance_seeds=wg_seeds)
     if timer is not None:
         timer.mark("waveglow")
     if denoiser is not None:
@@ -139,14 +341,20 @@ def synthesize(ppgs, tacotron, waveglow, denoiser=None, sigma=0.6, strength=0.00
     with torch.no_grad():
         dev = next(tacotron.parameters()).device
         own = getattr(tacotron, "decoder_heaters", 0)
+        consumer = None
+        if len(ppgs) == 1 and ConditioningStream.usable(tacotron, waveglow):
+            consumer = waveglow.__dict__.get("_facppg_cond_stream")
+            if consumer is None or consumer.tacotron is not tacotron:
+                consumer = waveglow.__dict__["_facppg_cond_stream"] = ConditioningStream(tacotron, waveglow)
         if not own:
-            tacotron.decoder_heaters = int(decoder_heaters)
+            tacotron.decoder_heaters = int(decoder_heaters) if consumer is None else 0
         try:
             mel_post, tout = _acoustic(ppgs, tacotron, seed, dropout_masks, utterance_seeds, step_limits, timer,
-                                       while_decoding=lambda: waveglow.prepare(dev))     # host work under the decoder's milliseconds
+                                       while_decoding=None if consumer is not None else (lambda: waveglow.prepare(dev)),
+                                       consumer=consumer)
         finally:
             tacotron.decoder_heaters = own
-        audio = _vocode(mel_post, tout, waveglow, denoiser, sigma, strength, seed, z, utterance_seeds, timer)
+        audio = _vocode(mel_post, tout, waveglow, denoiser, sigma, strength, seed, z, utterance_seeds, timer, consumer)
     if return_device:
         return [audio[b, :tout[b] * hop] for b in range(len(tout))], tout
     host = audio.cpu().numpy()

@@ -1010,18 +1010,22 @@ class WaveGlow(torch.nn.Module):
             _lib.check(_lib.load().facppg_wg_mel_pad(self._handle(dev), _lib.ptr(m), T, m.stride(0), _lib.ptr(out), _lib.current_stream(dev)))
         return out
 
-    def cond_seed(self, melp, T, frame0, nframes, seeds, block_tiles=1, layers_per_workgroup=4):
+    def cond_seed(self, melp, T, frame0, nframes, seeds, block_tiles=1, layers_per_workgroup=4, skip=None, handle=None, flows=None):
         """Form the gate accumulators' seeds (bias + conditioning sums, k_cond_seed) of frames [frame0, frame0 + nframes) of the
-        utterance whose zero-margined mel frames are ``melp``, for every flow, layer and phase, on the current stream."""
+        utterance whose zero-margined mel frames are ``melp``, for every flow (or flows = (first, count)), layer and phase, on the
+        current stream."""
         dev = melp.device
+        f0, nf = flows if flows is not None else (0, 0)
         with torch.cuda.device(dev):
-            _lib.check(_lib.load().facppg_wg_cond_seed(self._handle(dev), _lib.ptr(melp), int(T), int(frame0), int(nframes), int(block_tiles),
-                                                       int(layers_per_workgroup), _lib.ptr(seeds), seeds.numel() * seeds.element_size(),
-                                                       _lib.current_stream(dev)))
+            _lib.check(_lib.load().facppg_wg_cond_seed(handle if handle is not None else self._handle(dev), _lib.ptr(melp), int(T), int(frame0),
+                                                       int(nframes), int(block_tiles), int(layers_per_workgroup), int(f0), int(nf), _lib.ptr(seeds),
+                                                       seeds.numel() * seeds.element_size(), _lib.ptr(skip), _lib.current_stream(dev)))
 
-    def infer_seeded(self, melp, T, seeds, seeded_frames, sigma=1.0, z=None, seed=None, handle=None):
+    def infer_seeded(self, melp, T, seeds, seeded_frames, sigma=1.0, z=None, seed=None, handle=None, T_layout=None, flow_events=None):
         """WaveGlow.infer of ONE utterance (glow.py:252-293) whose layers start from ``seeds``: audio [1, T*hop].  Same samples
-        as infer() on the same mel frames, bit for bit."""
+        as infer() on the same mel frames, bit for bit.  T_layout >= T: the frame count ``melp`` and ``seeds`` were laid out for.
+        flow_events: {flow: torch.cuda.Event} the launches of that flow wait for (its seeds are still being formed elsewhere)."""
+        T_layout = T if T_layout is None else int(T_layout)
         dev = melp.device
         hop = self.upsample.stride[0]
         zt = None
@@ -1034,12 +1038,17 @@ class WaveGlow(torch.nn.Module):
         if seed is None:
             seed = int(torch.empty((), dtype=torch.int64).random_().item())
         h = handle if handle is not None else self._handle(dev)
-        ws = self._infer_workspace(1, T, dev, 0, h)
+        ws = self._infer_workspace(1, T_layout, dev, 0, h)
         audio = torch.empty(1, T * hop, dtype=torch.float32, device=dev)
+        evs = None
+        if flow_events:
+            evs = (_lib.ctypes.c_void_p * self.n_flows)()
+            for k, ev in flow_events.items():
+                evs[k] = ev.cuda_event
         with torch.cuda.device(dev):
-            _lib.check(_lib.load().facppg_wg_infer_seeded(h, _lib.ptr(melp), int(T), _lib.ptr(seeds), int(seeded_frames), _lib.ptr(zt),
+            _lib.check(_lib.load().facppg_wg_infer_seeded(h, _lib.ptr(melp), T_layout, int(T), _lib.ptr(seeds), int(seeded_frames), _lib.ptr(zt),
                                                           seed & 0xFFFFFFFFFFFFFFFF, float(sigma), _lib.ptr(audio), _lib.ptr(ws), ws.numel(),
-                                                          _lib.current_stream(dev)))
+                                                          evs, _lib.current_stream(dev)))
         return audio
 
     def prepare(self, device):

@@ -1,0 +1,81 @@
+"""GPU: the streamed batch-1 path (facppg.pipeline.ConditioningStream: the postnet and the conditioning part of every WaveNet
+layer's gate GEMM run on a second stream WHILE the split decoder is still producing frames) against the path it replaces --
+the same utterance with FACPPG_STREAM=0 -- bit for bit, at lengths that end on and off block boundaries, with the decoder
+running to its step limit and stopping early on its gate (blocks that never become final are void)."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import masks_from_seed
+from facppg import synth
+
+pytestmark = pytest.mark.gpu
+
+HOP = 256
+
+
+@pytest.fixture(scope="module")
+def vocoder():
+    from waveglow.denoiser import Denoiser
+    from waveglow.glow import WaveGlow
+    cfg = dict(synth.WAVEGLOW_CONFIG, hop_length=HOP)
+    wg = WaveGlow.remove_weightnorm(WaveGlow(**cfg))
+    wg.load_state_dict(synth.waveglow_state_dict(cfg))
+    wg = wg.cuda().eval()
+    return cfg, wg, Denoiser(wg, hop_length=HOP, mode="zeros")
+
+
+def acoustic(steps, gate_bias):
+    from common.hparams import create_hparams_stage
+    from script.train_ppg2mel import load_model
+    hp = create_hparams_stage(max_decoder_steps=steps)
+    with contextlib.redirect_stdout(io.StringIO()):
+        taco = load_model(hp)
+    taco.load_state_dict(synth.tacotron_state_dict(hp, gate_bias=gate_bias))
+    taco.eval()
+    return hp, taco
+
+
+def run(taco, wg, den, ppg, em, dm, zs, stream, monkeypatch):
+    from facppg import pipeline
+    monkeypatch.setenv("FACPPG_STREAM", "1" if stream else "0")
+    seen = {}
+    inference = taco.inference
+
+    def spy(*a, **kw):
+        out = inference(*a, **kw)
+        seen["mel_post"] = out[1].detach().clone()
+        seen["streamed"] = kw.get("frame_consumer") is not None and kw["frame_consumer"].active
+        return out
+    taco.inference = spy
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            wavs, tout = pipeline.synthesize([ppg], taco, wg, den, sigma=0.6, strength=0.005, dropout_masks=(em, dm), z=zs)
+    finally:
+        del taco.inference
+    return wavs[0], tout[0], seen
+
+
+@pytest.mark.parametrize("Tin,steps,gate_bias", [(200, 200, -10.0), (170, 170, -10.0), (96, 96, -10.0), (75, 75, -10.0),
+                                                 (130, 400, -10.0), (150, 1000, -0.02), (64, 64, -10.0)])
+def test_streamed_utterance_equals_the_unstreamed_path_bit_for_bit(vocoder, Tin, steps, gate_bias, monkeypatch):
+    cfg, wg, den = vocoder
+    hp, taco = acoustic(steps, gate_bias)
+    ppg = synth.synthetic_ppg(Tin, 5816, seed=Tin, alpha=0.002)
+    em = masks_from_seed(21, (2, 1, Tin, hp.symbols_embedding_dim))
+    dm = masks_from_seed(22, (steps, 2, 1, hp.prenet_dim))
+    ref, t_ref, seen_ref = run(taco, wg, den, ppg, em, dm, None, False, monkeypatch)
+    zs = synth.synthetic_z(1, t_ref * HOP // 8, cfg, seed=23)
+    ref, t_ref, seen_ref = run(taco, wg, den, ppg, em, dm, zs, False, monkeypatch)
+    out, t_out, seen = run(taco, wg, den, ppg, em, dm, zs, True, monkeypatch)
+    assert not seen_ref["streamed"] and seen["streamed"] == (steps >= 64)
+    assert taco.last_decoder_launch()[0] == "split"
+    assert t_out == t_ref and (gate_bias > -1 or t_ref == steps)
+    print("Tin %d steps %d: Tout %d, streamed %s, blocks %s" % (Tin, steps, t_out, seen["streamed"],
+                                                               wg.__dict__["_facppg_cond_stream"].cuts if seen["streamed"] else None))
+    assert torch.equal(seen["mel_post"], seen_ref["mel_post"])                     # the streaming postnet: same bits
+    assert out.shape == ref.shape == (t_ref * HOP,) and np.array_equal(out, ref)    # ... and so the samples

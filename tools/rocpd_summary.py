@@ -33,5 +33,29 @@ def pmc(db, flt=""):
         print("%-90s %-14s %7d %16.1f %16.1f %16.1f %12.2f" % (n[:90], cn, k, a, mn, mx, d / 1e3))
 
 
+def timeline(db, anchor="k_decoder", which="-1"):
+    """Every kernel from `before_us` before the start of the `which`-th (0-based, negative from the end) launch of a kernel whose
+    name contains `anchor` until the next such launch: start offset, duration, queue, grid, name -- who ran next to whom."""
+    c = sqlite3.connect(db)
+    cols = [r[1] for r in c.execute("pragma table_info(kernels)").fetchall()]
+    q = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
+    rows = c.execute("select start, end, name, %s, grid_x, workgroup_x from kernels order by start" % q).fetchall()
+    anchors = [i for i, r in enumerate(rows) if anchor in r[2]]
+    if not anchors:
+        print("no kernel named like", anchor, "-- columns:", cols)
+        return
+    i0 = anchors[int(which)]
+    nxt = [i for i in anchors if i > i0]
+    t0 = rows[i0][0]
+    lo = t0 - 2500000
+    hi = rows[nxt[0]][0] - 2500000 if nxt else rows[-1][1]
+    print("%10s %10s %6s %8s  %s" % ("start_us", "dur_us", "queue", "wgs", "kernel"))
+    for st, en, name, qu, gx, wx in rows:
+        if st < lo or st > hi:
+            continue
+        short = name.replace("(anonymous namespace)::", "").replace("facppg::", "").replace("void ", "").split("(")[0][:70]
+        print("%10.1f %10.1f %6s %8d  %s" % ((st - t0) / 1e3, (en - st) / 1e3, qu, gx // max(wx, 1), short))
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](*sys.argv[2:])
+    {"stats": stats, "pmc": pmc, "timeline": timeline}[sys.argv[1]](*sys.argv[2:])

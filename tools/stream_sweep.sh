@@ -1,0 +1,10 @@
+cd $GRAFT_REPO_ROOT
+run() { echo "== $*"; env "$@" MODES=1 timeout 120 python tools/stream_probe.py 2>&1 | grep "FACPPG_STREAM="; }
+timeout 300 python -m pytest tests/test_gpu_stream.py -x -q 2>&1 | tail -3; python -c "import torch; print(torch.cuda.Stream.priority_range())"
+run A=1
+run FACPPG_STREAM_LPW=2
+run FACPPG_STREAM_LPW=4
+run FACPPG_STREAM_PRIO=0
+run FACPPG_STREAM_GROUPS=1
+run FACPPG_STREAM_CHUNK=32
+run FACPPG_STREAM_LAST=64
