@@ -358,12 +358,11 @@ class EndToEnd(object):
                      for i, n in enumerate(self.lens)]
         self.samples = sum(self.lens) * HOP
 
-    def step(self, i, timer=None, decoder_heaters=-1):
+    def step(self, i, timer=None):
         from facppg import pipeline
         with contextlib.redirect_stdout(sys.stderr):     # the model prints the reference's "Reached max decoder steps"
             return pipeline.synthesize(self.ppgs, self.tacotron, self.waveglow, self.denoiser, sigma=0.6, strength=0.005, seed=i,
-                                       return_device=True, step_limits=self.lens if len(self.lens) > 1 else None, timer=timer,
-                                       decoder_heaters=decoder_heaters)
+                                       return_device=True, step_limits=self.lens if len(self.lens) > 1 else None, timer=timer)
 
     def stream(self, jobs, **kw):
         """facppg.pipeline.Synthesizer.stream over this object's models (script.synthesize_corpus.synthesize_shard calls it)."""
@@ -700,22 +699,6 @@ class E2EWorkload(object):
         timer = pipeline.StageTimer()
         self.e.step(10 ** 6, timer=timer)
         st = timer.stages_ms()
-        if b1:
-            # what the decoder launch's heater workgroups are worth (facppg.pipeline.synthesize's default; same samples): the same
-            # step without them, 10 steps after 2
-            for i in range(2):
-                self.e.step(2 * 10 ** 6 + i, decoder_heaters=0)
-            torch.cuda.synchronize(self.dev)
-            t0 = time.perf_counter()
-            for i in range(10):
-                self.e.step(3 * 10 ** 6 + i, decoder_heaters=0)
-            torch.cuda.synchronize(self.dev)
-            out["without_decoder_heaters"] = {
-                "ms_per_step": (time.perf_counter() - t0) / 10 * 1e3, "steps": 10, "warmup": 2,
-                "what": "the timed steps run facppg.pipeline.synthesize as it is called by default: the batch-1 decoder launch carries "
-                        "heater workgroups (matrix instructions on registers, no memory traffic) on the ~180 CUs it leaves empty, so that "
-                        "the vocoder does not start ~10 % slow behind milliseconds of low activity (measured; cause not identified); same step with decoder_heaters=0 "
-                        "(FACPPG_DECODER_HEATERS=0 switches them off everywhere)"}
         out["config"] = {"workload": "BASELINE configs[2]: " + self.e.describe() if not b1 else
                          "the metric's own case, real-time factor at batch = 1 (SURVEY.md 8d config 1 at the metric's 22.05 kHz / hop 256): "
                          + self.e.describe() + "; one utterance per step, nothing overlapped across steps",

@@ -181,9 +181,6 @@ class Tacotron2(nn.Module):
     # CUs the decoder may occupy (facppg_taco_set_decoder_workgroups); 0 = the whole device.  facppg.pipeline.synthesize_stream
     # sets it while the decoder runs under the previous batch's vocoder.
     decoder_workgroups = 0
-    # heater workgroups of the small-batch decoder launch (facppg_taco_set_decoder_heaters): 0 none, -1 all that fit.
-    # facppg.pipeline.synthesize sets -1 for its own call: it is the latency path, the vocoder follows at once.
-    decoder_heaters = 0
 
     def _handle(self, dev):
         h = self.__dict__.get("_facppg_handle")
@@ -321,7 +318,6 @@ class Tacotron2(nn.Module):
         align = torch.zeros(B, steps, Tin, device=dev)
         out_len = torch.zeros(B, dtype=torch.int32, device=dev)
         _lib.check(L.facppg_taco_set_decoder_workgroups(h, int(self.decoder_workgroups)))
-        _lib.check(L.facppg_taco_set_decoder_heaters(h, int(self.decoder_heaters)))
         streaming = False
         if frame_consumer is not None and B == 1:
             words = frame_consumer.begin(self, h, dev, steps, Tin)          # (zeroed on this stream, ahead of the decoder launch)

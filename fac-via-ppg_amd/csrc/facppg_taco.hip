@@ -35,7 +35,6 @@ struct facppg_taco {
   int device;
   int coop_limit;   // workgroups the cooperative (co-resident) kernels may use: from the occupancy calculator, see facppg_taco_create
   int decoder_wg_limit;   // facppg_taco_set_decoder_workgroups: a tighter bound for the decoder alone (0 = none)
-  int decoder_heaters;    // facppg_taco_set_decoder_heaters: heater workgroups of the split decoder (0 none, -1 all that fit)
   unsigned long long* frame_stream;   // facppg_taco_set_frame_stream: tagged mel frames as the split decoder emits them (B = 1), or null
   int frame_stream_frames;
   int last_streamed;         // the most recent decode published its frames there
@@ -370,9 +369,8 @@ struct DecArgs {
   int B, Tin, E, P, A, D, AD, NF, NFIL, KSZ, window, max_steps, U;
   int b0;                // k_decoder_coop: first utterance of this launch (large batches run in chunks)
   float gate_thr;
-  // k_decoder_split: worker workgroups per group, and HEATER workgroups behind them (see there)
-  int nwk, heaters, heat_sleep, heat_lead, dbg_flags;
-  unsigned* heat_done;   // [groups] main workgroups of the group that have finished
+  // k_decoder_split: worker workgroups per group
+  int nwk, dbg_flags;
   // k_decoder_split, B = 1: every mel value of frame t is ALSO published as a {value, t + 1} word at melx[t * NF + row] the moment
   // its projection row is formed (agent-scope store: visible to kernels on other streams while this launch is still running --
   // the plain stores to `mel` are only guaranteed visible once it has ended); facppg_taco_collect_frames reads them
@@ -1250,41 +1248,6 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
   const size_t xstride = (size_t)(p.NF + 1 + 2 * p.P + p.A + p.E + p.D + 8);
   const int KA = p.P + p.E + p.A, KD = p.A + p.E + p.D, KP = p.D + p.E;
   if (tid < SNU) s_stop[tid] = 0;
-  if (blk >= NU + p.nwk) {   // ------------------------------------------ heater
-    // MEASURED (tools/idle_gap_probe.py): WaveGlow.infer takes 7.9 ms on a chip that was busy just before, 8.7 ms behind 6 ms
-    // of idle or behind this decoder (76 of 256 CUs busy for ~4 ms), and keeping the other CUs busy during the decoder's last
-    // milliseconds recovers ~0.4 ms of that.  WHY is not established: the obvious guess, a lowered shader clock, is NOT what the
-    // GPU's sysfs reports (tools/clock_probe.py: sclk ~2400 MHz, mclk and fclk constant, idle or busy, at 20 ms sampling) --
-    // some faster power-management effect, or something else.  The CUs the decoder leaves empty therefore run matrix
-    // instructions on registers -- no memory traffic, own CUs (every workgroup of this launch holds a CU's LDS) -- until the
-    // group's main workgroups are done: an empirical remedy.
-    const int need = min(NU, p.B - grp * NU);
-    if (p.heat_lead > 0) {
-      // heat only the last heat_lead frames before the group's first utterance reaches its step limit (the frame count is the
-      // tag of its gate word); until then the heaters sleep
-      const unsigned long long* gatew = p.xsplit + (size_t)(grp * NU) * xstride + p.NF;
-      const int start = dec_step_limit(p, grp * NU) - p.heat_lead;
-      while ((int)(__hip_atomic_load(gatew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) < start &&
-             __hip_atomic_load(p.heat_done + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)need)
-        __builtin_amdgcn_s_sleep(64);
-    }
-    const float a = 1.0f + 1e-3f * (float)(tid & 63), bq = 0.5f - 1e-3f * (float)(tid >> 6);
-    f32x16 acc;
-    float sink = 0.0f;
-    for (unsigned it = 0;; ++it) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc = mfma32x32x2(a, bq, acc);   // ~1 000 cycles
-      sink += acc[0];
-      if ((it & 31) == 31) {
-        if (__hip_atomic_load(p.heat_done + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)need || it > (1u << 24)) break;
-      }
-      for (int i = 0; i < p.heat_sleep; ++i) __builtin_amdgcn_s_sleep(1);   // duty cycle: 64 cycles of sleep per unit
-    }
-    if (sink == 12345.678f && p.prof) p.prof[15] = 1;   // (keeps the loop)
-    return;
-  }
   if (blk >= NU) {   // ------------------------------------------------ worker
     const int wg = blk - NU, unit0 = wg * SU, row0 = wg * SSC;
     // per utterance: in_att [prenet | ctx | ah], in_dec [ah | ctx | dh], in_proj [dh | ctx], xin (previous mel
@@ -1491,7 +1454,6 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
       if (s_stop[0]) {
         if (tid == 0) {
           __hip_atomic_store(p.out_len + b, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (a frame collector on another stream watches it)
-          if (p.heaters) __hip_atomic_fetch_add(p.heat_done + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         break;
       }
@@ -1872,7 +1834,7 @@ extern "C" int facppg_taco_encode(facppg_taco* h, const float* ppg_dev, const in
 }
 
 namespace {
-struct DecWs { size_t mask, xchg, prof, xsplit, heat, total; };
+struct DecWs { size_t mask, xchg, prof, xsplit, total; };
 DecWs dec_ws(const facppg_taco_config& c, int B, int max_steps) {
   DecWs w;
   size_t off = 0;
@@ -1881,7 +1843,6 @@ DecWs dec_ws(const facppg_taco_config& c, int B, int max_steps) {
   w.xchg = take((size_t)B * 2 * c.attention_rnn_dim * 8);
   w.prof = take(32 * 8);
   w.xsplit = take((size_t)B * (c.n_acoustic_feat_dims + 1 + 2 * c.prenet_dim + c.attention_rnn_dim + c.encoder_embedding_dim + c.decoder_rnn_dim + 8) * 8);
-  w.heat = take((size_t)B * 4);
   w.total = off;
   return w;
 }
@@ -2006,25 +1967,13 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
                    : NU == 3 ? (const void*)k_decoder_split<3> : (const void*)k_decoder_split<4>;
     FACPPG_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ssm));
     void* args[] = {(void*)&a};
-    // heater workgroups (see k_decoder_split) on the CUs this launch leaves empty: FACPPG_DECODER_HEATERS = n | -1 (all that
-    // stay co-resident); only when the decoder has the chip to itself (no workgroup bound set by an overlapping caller)
     const int groups = (B + NU - 1) / NU;
-    const char* heat_env = getenv("FACPPG_DECODER_HEATERS");   // (overrides the handle's setting: experiments, or 0 to switch them off)
-    int heaters = heat_env ? atoi(heat_env) : h->decoder_heaters;
-    const int room = (int)(wg_limit / groups) - (h->split_nwk + NU);
-    if (heaters < 0 || heaters > room) heaters = room > 0 ? room : 0;
-    if (h->decoder_wg_limit > 0) heaters = 0;
-    a.nwk = h->split_nwk; a.heaters = heaters; a.heat_done = (unsigned*)(ws + w.heat);
+    a.nwk = h->split_nwk;
     a.melx = (B == 1 && h->frame_stream && h->frame_stream_frames >= max_steps) ? h->frame_stream : nullptr;
     h->last_streamed = a.melx != nullptr;
     a.dbg_flags = getenv("FACPPG_DECODER_NO_ROWS") ? 1 : 0;
-    a.heat_sleep = getenv("FACPPG_DECODER_HEAT_SLEEP") ? atoi(getenv("FACPPG_DECODER_HEAT_SLEEP")) : 0;
-    // heat only the last frames before the step limit (1.7 ms at 21 us per frame): as good as heating the whole decode
-    // (tools/heater_sweep.sh: 13.91 vs 13.95-13.99 ms per end-to-end step, 14.22-14.32 without) at a third of the energy, and the
-    // decoder itself stays undisturbed until then; an utterance whose gate stops it earlier simply gets none.  0 = from the start.
-    a.heat_lead = getenv("FACPPG_DECODER_HEAT_LEAD") ? atoi(getenv("FACPPG_DECODER_HEAT_LEAD")) : 80;
-    FACPPG_HIP_CHECK(launch_coop(fn, dim3(h->split_nwk + NU + heaters, groups), dim3(NTC), args, ssm, s));
-    h->last_mode = 2; h->last_wgs = (h->split_nwk + NU + heaters) * groups;
+    FACPPG_HIP_CHECK(launch_coop(fn, dim3(h->split_nwk + NU, groups), dim3(NTC), args, ssm, s));
+    h->last_mode = 2; h->last_wgs = (h->split_nwk + NU) * groups;
     if (a.prof) {
       long long pr[32];
       FACPPG_HIP_CHECK(hipMemcpyAsync(pr, a.prof, sizeof(pr), hipMemcpyDeviceToHost, s));
@@ -2110,12 +2059,6 @@ extern "C" size_t facppg_taco_postnet_workspace_bytes(const facppg_taco* h, int 
 extern "C" int facppg_taco_set_decoder_workgroups(facppg_taco* h, int max_workgroups) {
   FACPPG_REQUIRE(h && max_workgroups >= 0, FACPPG_EINVAL, "NULL handle or negative limit");
   h->decoder_wg_limit = max_workgroups;
-  return FACPPG_OK;
-}
-
-extern "C" int facppg_taco_set_decoder_heaters(facppg_taco* h, int heaters) {
-  FACPPG_REQUIRE(h && heaters >= -1, FACPPG_EINVAL, "NULL handle or heaters < -1");
-  h->decoder_heaters = heaters;
   return FACPPG_OK;
 }
 

@@ -595,44 +595,34 @@ __global__ __launch_bounds__(256) void k_rowsum_f32(const RowSumF32* __restrict_
   }
 }
 
-}  // namespace
-}  // namespace facppg
 
-extern "C" size_t facppg_wn_weight_grads_workspace_bytes(int n_layers) {
-  return (size_t)(6 * n_layers + 2) * sizeof(facppg::WgradF32Prob) + (size_t)(3 * n_layers + 2) * sizeof(facppg::RowSumF32) + 512;
-}
-
-// Lr = round_up(L, 64), Lp = 128 + Lr + 128 as in facppg_wn_forward_save / facppg_wn_backward_data, whose tensors these are.
-extern "C" int facppg_wn_weight_grads(int n_in, int n_layers, const float* a0_dev, const float* spect_pad_dev, const float* h_all_dev,
-                                      const float* ts_all_dev, const float* skip_dev, const float* dout_dev,
-                                      const float* dpre_all_dev, const float* dh_all_dev, const float* dskip_dev, int B, int L,
-                                      const facppg_wn_grads* g, void* ws_, size_t ws_bytes, void* stream_) {
-  using namespace facppg;
-  FACPPG_REQUIRE(a0_dev && spect_pad_dev && h_all_dev && ts_all_dev && skip_dev && dout_dev && dpre_all_dev && dh_all_dev && dskip_dev &&
-                     g && ws_, FACPPG_EINVAL, "NULL argument");
-  FACPPG_REQUIRE(n_in >= 1 && n_in <= 4 && n_layers >= 1 && n_layers <= 8 && B > 0 && L > 0, FACPPG_EINVAL,
-                 "n_in %d, n_layers %d, B %d, L %d out of range", n_in, n_layers, B, L);
-  FACPPG_REQUIRE(ws_bytes >= facppg_wn_weight_grads_workspace_bytes(n_layers), FACPPG_EWORKSPACE, "workspace has %zu bytes, need %zu",
-                 ws_bytes, facppg_wn_weight_grads_workspace_bytes(n_layers));
-  hipStream_t s = (hipStream_t)stream_;
+// The tables of facppg_wn_weight_grads, built on the device (one thread; ~75 entries): see there.
+struct WnGradTableArgs {
+  const float *a0, *spect, *h_all, *ts_all, *skip, *dout, *dpre_all, *dh_all, *dskip;
+  facppg_wn_grads g;
+  int n_in, n_layers, B, L;
+};
+__global__ void k_wn_grad_tables(WnGradTableArgs t, WgradF32Prob* __restrict__ probs, RowSumF32* __restrict__ rows) {
   constexpr int CH = 256, NC = 640, HALO_ = 128;
+  const int n_in = t.n_in, n_layers = t.n_layers, B = t.B, L = t.L;
   const int Lr = round_up(L, 64), Lp = HALO_ + Lr + HALO_;
   const size_t dh_sz = (size_t)B * CH * Lr, dp_sz = (size_t)B * 2 * CH * Lr, h_sz = (size_t)B * CH * Lp;
-  std::vector<WgradF32Prob> probs;
-  std::vector<RowSumF32> rows;
-  int first = 0;
+  const facppg_wn_grads* g = &t.g;
+  int np = 0, nr = 0, first = 0;
   auto prob = [&](const float* A, long a_bs, int lda, int M, const float* X, const float* X2, long x_bs, int ldx, int K, float* out,
                   int so_m, int so_k) {
     WgradF32Prob q;
     q.A = A; q.X = X; q.X2 = X2; q.out = out; q.a_bs = a_bs; q.x_bs = x_bs; q.lda = lda; q.ldx = ldx; q.M = M; q.K = K; q.so_m = so_m; q.so_k = so_k;
-    probs.push_back(q);
+    probs[np++] = q;
   };
   auto rowsum = [&](const float* src, long bs, int ld, int n, float* out, float* out2) {
     RowSumF32 r;
     r.src = src; r.out = out; r.out2 = out2; r.bs = bs; r.ld = ld; r.rows = n; r.first = first;
     first += n;
-    rows.push_back(r);
+    rows[nr++] = r;
   };
+  const float *a0_dev = t.a0, *spect_pad_dev = t.spect, *h_all_dev = t.h_all, *ts_all_dev = t.ts_all, *skip_dev = t.skip, *dout_dev = t.dout,
+              *dpre_all_dev = t.dpre_all, *dh_all_dev = t.dh_all, *dskip_dev = t.dskip;
   // start conv (glow.py:130-131): d start.w[m][c] = sum dh_0[m][n] a0[c][n]
   prob(dh_all_dev, (long)CH * Lr, Lr, CH, a0_dev, nullptr, (long)n_in * L, L, n_in, g->start_w, n_in, 1);
   rowsum(dh_all_dev, (long)CH * Lr, Lr, CH, g->start_b, nullptr);
@@ -660,13 +650,43 @@ extern "C" int facppg_wn_weight_grads(int n_in, int n_layers, const float* a0_de
   // end conv (glow.py:160-164): d end.w[m][c] = sum dout[m][n] skip[c][n]
   prob(dout_dev, (long)2 * n_in * L, L, 2 * n_in, skip_dev, nullptr, (long)CH * Lr, Lr, CH, g->end_w, CH, 1);
   rowsum(dout_dev, (long)2 * n_in * L, L, 2 * n_in, g->end_b, nullptr);
+}
+}  // namespace
+}  // namespace facppg
+
+extern "C" size_t facppg_wn_weight_grads_workspace_bytes(int n_layers) {
+  return (size_t)(6 * n_layers + 2) * sizeof(facppg::WgradF32Prob) + (size_t)(3 * n_layers + 2) * sizeof(facppg::RowSumF32) + 512;
+}
+
+// Lr = round_up(L, 64), Lp = 128 + Lr + 128 as in facppg_wn_forward_save / facppg_wn_backward_data, whose tensors these are.
+extern "C" int facppg_wn_weight_grads(int n_in, int n_layers, const float* a0_dev, const float* spect_pad_dev, const float* h_all_dev,
+                                      const float* ts_all_dev, const float* skip_dev, const float* dout_dev,
+                                      const float* dpre_all_dev, const float* dh_all_dev, const float* dskip_dev, int B, int L,
+                                      const facppg_wn_grads* g, void* ws_, size_t ws_bytes, void* stream_) {
+  using namespace facppg;
+  FACPPG_REQUIRE(a0_dev && spect_pad_dev && h_all_dev && ts_all_dev && skip_dev && dout_dev && dpre_all_dev && dh_all_dev && dskip_dev &&
+                     g && ws_, FACPPG_EINVAL, "NULL argument");
+  FACPPG_REQUIRE(n_in >= 1 && n_in <= 4 && n_layers >= 1 && n_layers <= 8 && B > 0 && L > 0, FACPPG_EINVAL,
+                 "n_in %d, n_layers %d, B %d, L %d out of range", n_in, n_layers, B, L);
+  FACPPG_REQUIRE(ws_bytes >= facppg_wn_weight_grads_workspace_bytes(n_layers), FACPPG_EWORKSPACE, "workspace has %zu bytes, need %zu",
+                 ws_bytes, facppg_wn_weight_grads_workspace_bytes(n_layers));
+  hipStream_t s = (hipStream_t)stream_;
+  constexpr int CH = 256, NC = 640;
+  // The problem / row-sum tables are built ON THE DEVICE by a one-thread launch from this call's arguments (k_wn_grad_tables):
+  // nothing is copied from host memory, so the call neither stalls the host behind the stream (a copy from pageable memory
+  // waits for the stream to reach it -- 12 times per backward pass) nor, under stream capture, leaves the graph a copy node
+  // that re-reads a host buffer freed on return.
+  WnGradTableArgs t;
+  t.a0 = a0_dev; t.spect = spect_pad_dev; t.h_all = h_all_dev; t.ts_all = ts_all_dev; t.skip = skip_dev; t.dout = dout_dev;
+  t.dpre_all = dpre_all_dev; t.dh_all = dh_all_dev; t.dskip = dskip_dev; t.g = *g; t.n_in = n_in; t.n_layers = n_layers; t.B = B; t.L = L;
+  const int n_probs = 6 * n_layers + 1, n_rows = 3 * n_layers + 1;
+  const int first = CH + n_layers * 2 * CH + (2 * n_layers - 1) * CH + 2 * n_in;   // rows the row-sum launch walks
   char* ws = (char*)ws_;
   WgradF32Prob* probs_dev = (WgradF32Prob*)ws;
-  RowSumF32* rows_dev = (RowSumF32*)(ws + round_up((int)(probs.size() * sizeof(WgradF32Prob)), 256));
-  FACPPG_HIP_CHECK(hipMemcpyAsync(probs_dev, probs.data(), probs.size() * sizeof(WgradF32Prob), hipMemcpyHostToDevice, s));
-  FACPPG_HIP_CHECK(hipMemcpyAsync(rows_dev, rows.data(), rows.size() * sizeof(RowSumF32), hipMemcpyHostToDevice, s));
-  k_wgrad_f32<<<dim3((NC + WG_TK - 1) / WG_TK, (2 * CH + WG_TM - 1) / WG_TM, (unsigned)probs.size()), 256, 0, s>>>(probs_dev, B, L);
-  k_rowsum_f32<<<first, 256, 0, s>>>(rows_dev, (int)rows.size(), B, L);
+  RowSumF32* rows_dev = (RowSumF32*)(ws + round_up((int)(n_probs * sizeof(WgradF32Prob)), 256));
+  k_wn_grad_tables<<<1, 1, 0, s>>>(t, probs_dev, rows_dev);
+  k_wgrad_f32<<<dim3((NC + WG_TK - 1) / WG_TK, (2 * CH + WG_TM - 1) / WG_TM, (unsigned)n_probs), 256, 0, s>>>(probs_dev, B, L);
+  k_rowsum_f32<<<first, 256, 0, s>>>(rows_dev, n_rows, B, L);
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
 }

@@ -1366,6 +1366,8 @@ struct SeedArgs {
   const int* skip;          // optional (device): *skip != 0 -> the launch does nothing (the frames never became final)
   int items;                // work items = layer groups x phases x blocks (a bounded launch has fewer workgroups than that)
   int layer0, layer1;       // the layers of this launch: [layer0, layer1) of layers_total (flow-major: layer = flow * wn_layers + i)
+  int* counter;             // bounded launch: the next item to hand out (zero at launch), or null: item = blockIdx, + gridDim, ...
+  int debug;                // FACPPG_SEED_DEBUG (timing experiments): 1 = no stores, 2 = every layer streams layer 0's images
 };
 
 template <bool NT>
@@ -1386,7 +1388,10 @@ __global__ __launch_bounds__(512, NCB <= 2 ? 4 : 2) void k_cond_seed(SeedArgs p)
   if (p.skip && *p.skip) return;
   // a launch may be bounded to fewer workgroups than it has work items (p.items): each then walks items blockIdx, + gridDim, ...
   // (gridDim a multiple of 8: an item stays on the XCD its index names)
-  for (int lin = (int)blockIdx.x; lin < p.items; lin += (int)gridDim.x) {
+  for (int lin = (int)blockIdx.x;;) {
+  // (bounded launch with a counter: the first gridDim items are the workgroups' own, the counter hands out the rest -- no
+  // workgroup idles while another still has a queue of its own)
+  if (lin >= p.items) break;
   // workgroup i lands on XCD i % 8: the blocks that share a (layer, phase) image run back to back on one XCD
   int lg, ph, blk;
   {
@@ -1399,7 +1404,6 @@ __global__ __launch_bounds__(512, NCB <= 2 ? 4 : 2) void k_cond_seed(SeedArgs p)
     }
   }
   const int l0 = p.layer0 + lg * p.lpw, l1 = min(l0 + p.lpw, p.layer1);
-  if (l0 >= l1) continue;
   // conditioning chunks of this phase (pm_chunks): late phases reach one mel frame less
   const int nj = (p.ksize - 1 - 8 * ph) / p.hop + 1;
   const int ncc = min(p.ncmax, (nj * NMEL + KCH - 1) / KCH);
@@ -1437,6 +1441,7 @@ __global__ __launch_bounds__(512, NCB <= 2 ? 4 : 2) void k_cond_seed(SeedArgs p)
   const int ng = 8 * ncc;
   const size_t wave_off = (size_t)ph * p.ngc * 1024 + (wq * 4 + sub) * 64 + lane;
   auto layer_ptrs = [&](int l) __attribute__((always_inline)) {
+    if (p.debug & 2) l = 0;
     const WnLayerPtrs* t = reinterpret_cast<const WnLayerPtrs*>(p.ltab[l / p.wn_layers]) + (l % p.wn_layers);
     return t;
   };
@@ -1501,12 +1506,19 @@ __global__ __launch_bounds__(512, NCB <= 2 ? 4 : 2) void k_cond_seed(SeedArgs p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4s x = {acc[rb][cb][4 * q + 0], acc[rb][cb][4 * q + 1], acc[rb][cb][4 * q + 2], acc[rb][cb][4 * q + 3]};
+          if (p.debug & 1) continue;   // (experiments: no stores)
           if constexpr (NT) __builtin_nontemporal_store(x, (FACPPG_AS1 f32x4s*)(dst + (rb * 4 + q) * 64));
           else *(FACPPG_AS1 f32x4s*)(dst + (rb * 4 + q) * 64) = x;
         }
     }
   }
   __syncthreads();   // (the next item restages the LDS image)
+  if (p.counter) {   // (the image is dead: its first word carries the next item to every wave)
+    if (tid == 0) reinterpret_cast<int*>(smem)[0] = (int)gridDim.x + atomicAdd(p.counter, 1);
+    __syncthreads();
+    lin = reinterpret_cast<const int*>(smem)[0];
+    __syncthreads();
+  } else lin += (int)gridDim.x;
   }
 }
 
@@ -3058,7 +3070,7 @@ extern "C" int facppg_wg_seed_layout(const facppg_wg* h, int T, int* Tqp, int* m
 
 extern "C" int facppg_wg_cond_seed(facppg_wg* h, const float* melp_dev, int T, int frame0, int nframes, int block_tiles,
                                    int layers_per_workgroup, int flow0, int nflows, float* seeds_dev, size_t seed_bytes,
-                                   const int32_t* skip_dev, void* stream_) {
+                                   const int32_t* skip_dev, int max_workgroups, int32_t* counter_dev, void* stream_) {
   FACPPG_REQUIRE(h && melp_dev && seeds_dev, FACPPG_EINVAL, "NULL argument");
   const facppg_wg_config& c = h->cfg;
   const PmLayout w = pm_layout(c, 1, T);
@@ -3088,8 +3100,10 @@ extern "C" int facppg_wg_cond_seed(facppg_wg* h, const float* melp_dev, int T, i
   // per pass, and next to a latency-bound decoder a slower stream can be the better neighbour.  FACPPG_SEED_NT=0: ordinary
   // (L2-allocating) loads and stores instead of non-temporal ones.  Both read per call: experiments.
   const char* wgs_env = getenv("FACPPG_SEED_WGS");
-  const int max_wgs = wgs_env ? atoi(wgs_env) / 8 * 8 : 0;
+  const int max_wgs = (wgs_env ? atoi(wgs_env) : max_workgroups) / 8 * 8;
+  a.counter = max_wgs > 0 && max_wgs < a.items ? counter_dev : nullptr;   // (a caller-zeroed word; without one the items are strided)
   const unsigned grid = (unsigned)(max_wgs > 0 && max_wgs < a.items ? max_wgs : a.items);
+  a.debug = getenv("FACPPG_SEED_DEBUG") ? atoi(getenv("FACPPG_SEED_DEBUG")) : 0;
   const char* nt_env = getenv("FACPPG_SEED_NT");
   const bool nt = !nt_env || atoi(nt_env) != 0;
   hipStream_t s = (hipStream_t)stream_;

@@ -1235,15 +1235,27 @@ int wgp_infer(facppg_wg* h, const float* mel_dev, const float* z_dev, uint64_t s
     }
     FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
   }
+  // All P * NSL workgroups hand over to one another through flags and must be co-resident (one per CU: each holds most of a
+  // CU's LDS): a COOPERATIVE launch, which checks that the grid fits and never shares the device with another cooperative
+  // launch -- two of these in flight at once (two threads or streams serving batch-1 requests) could otherwise each hold part
+  // of the CUs and wait for workgroups that were never dispatched.  FACPPG_COOP_PLAIN=1: an ordinary launch (profilers).
+  const void* fn = nullptr;
   switch (w.NB) {
-    case 7: k_wg_persist<7><<<grid, 512, lds, s>>>(a); break;
-    case 9: k_wg_persist<9><<<grid, 512, lds, s>>>(a); break;
-    case 10: k_wg_persist<10><<<grid, 512, lds, s>>>(a); break;
-    case 11: k_wg_persist<11><<<grid, 512, lds, s>>>(a); break;
-    case 12: k_wg_persist<12><<<grid, 512, lds, s>>>(a); break;
-    case 13: k_wg_persist<13><<<grid, 512, lds, s>>>(a); break;
-    default: k_wg_persist<16><<<grid, 512, lds, s>>>(a); break;
+    case 7: fn = (const void*)k_wg_persist<7>; break;
+    case 9: fn = (const void*)k_wg_persist<9>; break;
+    case 10: fn = (const void*)k_wg_persist<10>; break;
+    case 11: fn = (const void*)k_wg_persist<11>; break;
+    case 12: fn = (const void*)k_wg_persist<12>; break;
+    case 13: fn = (const void*)k_wg_persist<13>; break;
+    default: fn = (const void*)k_wg_persist<16>; break;
   }
+  {
+    void* args[] = {(void*)&a};
+    const char* plain = getenv("FACPPG_COOP_PLAIN");
+    if (plain && atoi(plain) != 0) FACPPG_HIP_CHECK(hipLaunchKernel(fn, dim3(grid), dim3(512), args, lds, s));
+    else FACPPG_HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(grid), dim3(512), args, lds, s));
+  }
+  h->ev_layers = h->cfg.n_flows * h->cfg.wn_layers;   // (the event pair brackets the whole network: facppg_wg_last_layer_ms divides by this)
   if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
   h->last_tile = w.NBc; h->last_waves = 8; h->last_tiles = (int)grid;
   FACPPG_HIP_CHECK(hipGetLastError());

@@ -108,7 +108,7 @@ def _declare(lib):
         "facppg_wg_last_layer_ms": (c.c_int, [vp, c.POINTER(f32), c.POINTER(c.c_int)]),
         "facppg_wg_last_launch_shape": (c.c_int, [vp, c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)]),
         "facppg_wg_seed_layout": (c.c_int, [vp, c.c_int, c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(sz)]),
-        "facppg_wg_cond_seed": (c.c_int, [vp, vp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, vp, sz, vp, vp]),
+        "facppg_wg_cond_seed": (c.c_int, [vp, vp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, vp, sz, vp, c.c_int, vp, vp]),
         "facppg_wg_mel_pad": (c.c_int, [vp, vp, c.c_int, c.c_int, vp, vp]),
         "facppg_wg_infer_seeded": (c.c_int, [vp, vp, c.c_int, c.c_int, vp, c.c_int, vp, c.c_uint64, f32, vp, vp, sz, vp, vp]),
         "facppg_stft_create": (c.c_int, [c.c_int, c.c_int, vp, vp, vp, vp, c.c_int, c.c_int, vp, c.POINTER(vp)]),
@@ -124,7 +124,6 @@ def _declare(lib):
         "facppg_taco_workspace_bytes": (sz, [vp, c.c_int, c.c_int]),
         "facppg_taco_decode_workspace_bytes": (sz, [vp, c.c_int, c.c_int]),
         "facppg_taco_set_decoder_workgroups": (c.c_int, [vp, c.c_int]),
-        "facppg_taco_set_decoder_heaters": (c.c_int, [vp, c.c_int]),
         "facppg_taco_last_decoder_launch": (c.c_int, [vp, c.POINTER(c.c_int), c.POINTER(c.c_int)]),
         "facppg_taco_set_frame_stream": (c.c_int, [vp, vp, c.c_int]),
         "facppg_taco_last_decode_streamed": (c.c_int, [vp, c.POINTER(c.c_int)]),

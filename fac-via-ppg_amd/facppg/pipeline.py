@@ -98,7 +98,8 @@ class ConditioningStream(object):
         self.lag = (hp["postnet_kernel_size"] - 1) // 2 * hp["postnet_n_convolutions"]
         self.tqp, self.margin, seed_bytes = self.waveglow.seed_layout(steps, dev)
         self.words = torch.zeros(steps * self.NF + 512, dtype=torch.int64, device=dev)    # {value, frame + 1} words + the void flags
-        self.void = self.words[steps * self.NF:].view(torch.int32)                        # one per block (up to 1024)
+        self.void = self.words[steps * self.NF:].view(torch.int32)[:512]                  # one per block
+        self.counters = self.words[steps * self.NF:].view(torch.int32)[512:]              # one per bounded seed launch
         self.mel = torch.zeros(self.NF, steps, dtype=torch.float32, device=dev)           # collected frames, channel-major
         self.melp = torch.zeros(self.NF, self.tqp, dtype=torch.float32, device=dev)       # mel_post, the vocoder's zero-margined layout
         self.seeds = torch.empty(seed_bytes // 4, dtype=torch.float32, device=dev)
@@ -124,14 +125,17 @@ class ConditioningStream(object):
         end = min(steps, max(Tin, 1))
         s_end = (end - self.lag) // 32 * 32                       # seeded frames before the expected end
         cuts, s = [], 0
-        while s < s_end and len(cuts) < 1000:
+        widths = [int(v) // 32 * 32 for v in os.environ.get("FACPPG_STREAM_PLAN", "").split(",") if v.strip()]   # (experiments)
+        while s < s_end and len(cuts) < 120:
             rest = s_end - s
             w = rest if rest <= last else min(chunk, rest - last)
+            if widths:
+                w = max(32, min(widths.pop(0), rest))
             cuts.append((s + w + self.lag, s, s + w))
             s += w
         s_lim = (steps - self.lag) // 32 * 32                     # the decoder may run on to its step limit: a few more blocks
         extra = 0
-        while s < s_lim and extra < 2 and len(cuts) < 1000:
+        while s < s_lim and extra < 2 and len(cuts) < 120:
             w = min(chunk, s_lim - s)
             cuts.append((s + w + self.lag, s, s + w))
             s += w
@@ -164,9 +168,24 @@ class ConditioningStream(object):
         self.cuts = self.plan(steps, self.Tin)
         self.wg_handle = self.waveglow._handle(dev)
         f_prev = 0
-        groups = max(1, int(os.environ.get("FACPPG_STREAM_GROUPS", "3")))
+        groups = max(1, int(os.environ.get("FACPPG_STREAM_GROUPS", "1")))
         lpw = max(1, int(os.environ.get("FACPPG_STREAM_LPW", "1")))
-        self.block_events = []
+        # The seed passes take every CU the decoder leaves -- two workgroups each -- except `spare` of them: the postnet's launches
+        # (and the decoder's successor on the main stream) are a few workgroups that must find a free CU at once, not when a pass's
+        # workgroup happens to retire (measured: 175 us for a 22 us launch next to an unbounded pass).
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        spare = int(os.environ.get("FACPPG_STREAM_SPARE_CUS", "8"))
+        bound = max(16, 2 * (n_cu - self.tacotron.last_decoder_launch()[1] - spare)) if spare >= 0 else 0
+        self.n_launch = 0
+        self.flow_events, self.deferred, self.last_final = {}, [], None
+
+        def seed_pass(job):
+            s_a, n, bt, void, lo, hi = job
+            self.waveglow.cond_seed(self.melp, steps, s_a, n, self.seeds, block_tiles=bt, layers_per_workgroup=lpw, skip=void,
+                                    handle=self.wg_handle, flows=(lo, hi - lo), max_workgroups=bound,
+                                    counter=self.counters[self.n_launch:self.n_launch + 1] if self.n_launch < 500 else None)
+            self.n_launch += 1
+        self.seed_pass = seed_pass
         self.post.wait_event(self.ready)
         with torch.cuda.device(dev):
             for k, (f_new, s_a, s_b) in enumerate(self.cuts):
@@ -181,23 +200,29 @@ class ConditioningStream(object):
                                                            self.post_ws.numel(), steps, _lib.ptr(void), st))
                     final = torch.cuda.Event()
                     final.record(self.post)
+                    self.last_final = final
                 with torch.cuda.stream(self.side):
                     self.side.wait_event(final)                # mel_post is final up to s_b
-                    # The blocks around the expected end are formed flow group by flow group in the order the vocoder walks the
-                    # flows (last flow first), an event behind each group: the vocoder can then start on the first group's seeds
-                    # while the pass is still forming the others'.
+                    # FACPPG_STREAM_GROUPS > 1 (off by default: measured no gain, profiles/r05_experiments.txt): the blocks around the
+                    # expected end are formed flow group by flow group in the order the vocoder walks the flows (last flow first), an
+                    # event behind each group, so that the vocoder can start on the first group's seeds.
                     late = k >= len(self.cuts) - 1 - self.n_extra
                     nf = self.waveglow.n_flows
                     parts = [(nf * (groups - 1 - g) // groups, nf * (groups - g) // groups) for g in range(groups)] if late else [(0, nf)]
-                    evs = []
-                    for lo, hi in parts:
-                        self.waveglow.cond_seed(self.melp, steps, s_a, s_b - s_a, self.seeds, block_tiles=min(4, (s_b - s_a) // 32),
-                                                layers_per_workgroup=lpw, skip=void, handle=self.wg_handle,
-                                                flows=(lo, hi - lo))
-                        ev = torch.cuda.Event()
-                        ev.record(self.side)
-                        evs.append((lo, hi, ev))
-                    self.block_events = evs
+                    bt = min(4, (s_b - s_a) // 32)
+                    for g, (lo, hi) in enumerate(parts):
+                        job = (s_a, s_b - s_a, bt, void, lo, hi)
+                        if g == 0:
+                            seed_pass(job)
+                            ev = torch.cuda.Event()
+                            ev.record(self.side)
+                            self.flow_events[hi - 1] = ev
+                        else:
+                            # ... and only the first group's launch is queued now: the others follow when the caller's stream has run
+                            # what is left of the postnet (finish) -- a seed pass next to that chain of small launches makes every one
+                            # of them 3-5 times slower (tools/postnet_under_seed_probe.py), and those seeds are not needed for
+                            # milliseconds
+                            self.deferred.append(job)
                 f_prev = f_new
         self.active = True
 
@@ -208,10 +233,9 @@ class ConditioningStream(object):
         L = _lib.load()
         dev, steps = self.dev, self.steps
         cur = torch.cuda.current_stream(dev)
-        # everything up to the first flow group of the last block; the other groups' events gate their flows (vocode)
-        if self.block_events:
-            cur.wait_event(self.block_events[0][2])
-        self.flow_events = {hi - 1: ev for lo, hi, ev in self.block_events[1:]}
+        # what is left of the postnet needs the postnet stream's blocks only; the seed passes' events gate the vocoder's flows (vocode)
+        if self.last_final is not None:
+            cur.wait_event(self.last_final)
         f_done = s_done = 0
         for f_new, s_a, s_b in self.cuts:
             if f_new <= Tout:
@@ -224,6 +248,17 @@ class ConditioningStream(object):
             _lib.check(L.facppg_taco_postnet_range(self.taco_handle, _lib.ptr(self.mel), steps, f_done, Tout, Tout,
                                                    self.melp.data_ptr() + 4 * self.margin, self.tqp, _lib.ptr(self.post_ws),
                                                    self.post_ws.numel(), steps, None, st))
+            if self.deferred:                                  # the late blocks' remaining flow groups, behind the chain above
+                tail_done = torch.cuda.Event()
+                tail_done.record(cur)
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(tail_done)
+                    for job in self.deferred:
+                        self.seed_pass(job)
+                        ev = torch.cuda.Event()
+                        ev.record(self.side)
+                        self.flow_events[job[5] - 1] = ev
+                self.deferred = []
         self.Tout, self.seeded = Tout, s_done
         return self.melp[:, self.margin:self.margin + Tout].unsqueeze(0)
 
@@ -324,14 +359,11 @@ def _vocode(mel_post, tout, waveglow, denoiser, sigma, strength, seed, z, uttera
 
 
 def synthesize(ppgs, tacotron, waveglow, denoiser=None, sigma=0.6, strength=0.005, seed=None, dropout_masks=None, z=None,
-               return_device=False, utterance_seeds=None, step_limits=None, timer=None, decoder_heaters=-1):
+               return_device=False, utterance_seeds=None, step_limits=None, timer=None):
     """Returns (list of float32 waveforms [N_i], list of mel lengths).  Models must be on the GPU.
 
-    decoder_heaters: this is the latency path -- one batch, the vocoder right behind the acoustic model -- so the small-batch
-    decoder launch carries heater workgroups on the CUs it leaves empty (Tacotron2.decoder_heaters; -1 = all that fit, 0 = none;
-    same samples either way): measured, the vocoder otherwise starts ~10 % slower behind the decoder's milliseconds of low
-    activity (0.4-0.6 ms of a 14 ms utterance; cause not identified -- the GPU's reported clocks do not move).  A model that already carries its own setting keeps it.
-
+    One utterance (the latency path, the metric's "batch = 1"): the postnet and the conditioning part of the vocoder's gate GEMMs
+    run while the decoder is still producing frames (ConditioningStream; FACPPG_STREAM=0 switches it off) -- same samples.
     utterance_seeds: one integer per utterance -- its dropout and noise streams then depend on that seed alone,
     so the result for an utterance is the same whatever batch, batch size or GPU it is synthesised in.
     step_limits: per-utterance max_decoder_steps (e.g. its PPG length)."""
@@ -339,21 +371,15 @@ def synthesize(ppgs, tacotron, waveglow, denoiser=None, sigma=0.6, strength=0.00
         timer.__init__()
     hop = waveglow.upsample.stride[0]
     with torch.no_grad():
-        dev = next(tacotron.parameters()).device
-        own = getattr(tacotron, "decoder_heaters", 0)
+        dev = next(waveglow.parameters()).device
         consumer = None
         if len(ppgs) == 1 and ConditioningStream.usable(tacotron, waveglow):
             consumer = waveglow.__dict__.get("_facppg_cond_stream")
             if consumer is None or consumer.tacotron is not tacotron:
                 consumer = waveglow.__dict__["_facppg_cond_stream"] = ConditioningStream(tacotron, waveglow)
-        if not own:
-            tacotron.decoder_heaters = int(decoder_heaters) if consumer is None else 0
-        try:
-            mel_post, tout = _acoustic(ppgs, tacotron, seed, dropout_masks, utterance_seeds, step_limits, timer,
-                                       while_decoding=None if consumer is not None else (lambda: waveglow.prepare(dev)),
-                                       consumer=consumer)
-        finally:
-            tacotron.decoder_heaters = own
+        mel_post, tout = _acoustic(ppgs, tacotron, seed, dropout_masks, utterance_seeds, step_limits, timer,
+                                   while_decoding=None if consumer is not None else (lambda: waveglow.prepare(dev)),   # host work under the decoder's milliseconds
+                                   consumer=consumer)
         audio = _vocode(mel_post, tout, waveglow, denoiser, sigma, strength, seed, z, utterance_seeds, timer, consumer)
     if return_device:
         return [audio[b, :tout[b] * hop] for b in range(len(tout))], tout

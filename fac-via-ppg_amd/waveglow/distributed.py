@@ -164,6 +164,28 @@ class GradientExchange(object):
         self.last_exchange_ms = None
         self.hooked = False
         self._hook_handles = []
+        self.capture_group = None                       # see prepare_capture_group
+
+    def prepare_capture_group(self):
+        """A process group of its own for the collectives that are CAPTURED into a HIP graph (collective call: every rank, before
+        its first capture).  c10d's watchdog thread polls the end events of the eager collectives it still holds; on this HIP
+        stack an event query fails -- and the watchdog aborts the process -- once the event's stream has joined a capture
+        ("operation not permitted on an event last recorded in a capturing stream"), whether or not that record was captured.
+        The stream in question is the process group's own: so the captured collectives get a group whose stream is the only one
+        that ever joins a capture and that never runs an eager collective (works issued under capture are not handed to the
+        watchdog), while the default group -- warm-up steps, broadcasts, fallback steps -- never sees a capture.  With the default
+        group bound to its device (init_process_group(device_id=...)) the new communicator is split off and connected eagerly,
+        without a collective; otherwise one eager all_reduce initialises it here and the watchdog is given time to retire it."""
+        if self.capture_group is not None or not self.cuda or dist.get_backend() == "gloo":
+            return self.capture_group
+        self.capture_group = dist.new_group()
+        if not getattr(dist.distributed_c10d._get_default_group(), "bound_device_id", None):
+            import time
+            probe = torch.zeros(1, device=self.flat[0].device)
+            dist.all_reduce(probe, group=self.capture_group)
+            torch.cuda.synchronize()
+            time.sleep(0.5)
+        return self.capture_group
 
     # ---- one bucket
     def _grads(self, i, static):
@@ -192,7 +214,8 @@ class GradientExchange(object):
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 pack()
-                self.pending[i] = dist.all_reduce(flat, async_op=True)
+                group = self.capture_group if torch.cuda.is_current_stream_capturing() else None
+                self.pending[i] = dist.all_reduce(flat, async_op=True, group=group)
         else:
             pack()
             _collective(dist.all_reduce, flat)

@@ -1010,16 +1010,19 @@ class WaveGlow(torch.nn.Module):
             _lib.check(_lib.load().facppg_wg_mel_pad(self._handle(dev), _lib.ptr(m), T, m.stride(0), _lib.ptr(out), _lib.current_stream(dev)))
         return out
 
-    def cond_seed(self, melp, T, frame0, nframes, seeds, block_tiles=1, layers_per_workgroup=4, skip=None, handle=None, flows=None):
+    def cond_seed(self, melp, T, frame0, nframes, seeds, block_tiles=1, layers_per_workgroup=4, skip=None, handle=None, flows=None,
+                  max_workgroups=0, counter=None):
         """Form the gate accumulators' seeds (bias + conditioning sums, k_cond_seed) of frames [frame0, frame0 + nframes) of the
         utterance whose zero-margined mel frames are ``melp``, for every flow (or flows = (first, count)), layer and phase, on the
-        current stream."""
+        current stream.  max_workgroups > 0 bounds the launch (its workgroups then take the work items from ``counter``, a zeroed
+        int32 on the device): the CUs it does not fill stay free for whoever else needs one right away."""
         dev = melp.device
         f0, nf = flows if flows is not None else (0, 0)
         with torch.cuda.device(dev):
             _lib.check(_lib.load().facppg_wg_cond_seed(handle if handle is not None else self._handle(dev), _lib.ptr(melp), int(T), int(frame0),
                                                        int(nframes), int(block_tiles), int(layers_per_workgroup), int(f0), int(nf), _lib.ptr(seeds),
-                                                       seeds.numel() * seeds.element_size(), _lib.ptr(skip), _lib.current_stream(dev)))
+                                                       seeds.numel() * seeds.element_size(), _lib.ptr(skip), int(max_workgroups), _lib.ptr(counter),
+                                                       _lib.current_stream(dev)))
 
     def infer_seeded(self, melp, T, seeds, seeded_frames, sigma=1.0, z=None, seed=None, handle=None, T_layout=None, flow_events=None):
         """WaveGlow.infer of ONE utterance (glow.py:252-293) whose layers start from ``seeds``: audio [1, T*hop].  Same samples

@@ -23,7 +23,6 @@ exhausted, an op that cannot be captured, out of memory in the graph's pool) tur
 good, with a warning.
 """
 import os
-import time
 import warnings
 
 import torch
@@ -94,14 +93,11 @@ class GraphedTrainStep:
         self.optimizer.zero_grad(set_to_none=True)   # the captured backward allocates the gradients in the graph's pool
         torch.cuda.synchronize()
         if self.exchange is not None and self.exchange.hooked:
-            # OBSERVED once (world 1, RCCL): the process aborted from c10d's watchdog thread with "HIP error: operation not
-            # permitted on an event last recorded in a capturing stream" while this capture was in progress.  INFERRED, not
-            # verified: the watchdog was still polling the end events of the warm-up steps' (completed) collectives, and HIP
-            # rejects an event query once the event's stream (the process group's internal one) has joined a capture.  Evidence
-            # for the pause below is one stress probe only (tools/capture_race_probe.py, repeated captures in one process: abort
-            # after 13 without it, 60 clean with 400 ms -- and one unexplained segfault at capture 28 with it); 12 ordinary bench
-            # runs did not reproduce the abort with or without it.  A mitigation, then, not a fix of an understood cause.
-            time.sleep(float(os.environ.get("FACPPG_CAPTURE_SETTLE_MS", "1000")) * 1e-3)
+            # The captured collectives run on a process group of their own (GradientExchange.prepare_capture_group): c10d's watchdog
+            # aborts the process if it polls an eager collective's event after that group's stream has joined a capture, so the
+            # stream that joins captures never carries an eager collective.  (Round 4 slept for a second here instead.)
+            self.exchange.prepare_capture_group()
+            torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         whole_step = self.sync_gradients is None or (self.exchange is not None and self.exchange.hooked)
         # thread_local: other threads (a DataLoader worker pinning memory, a logger) may touch the allocator meanwhile

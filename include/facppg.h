@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FACPPG_VERSION 102 /* 0.1.1 */
+#define FACPPG_VERSION 103 /* 0.1.2 */
 
 #define FACPPG_OK 0
 #define FACPPG_EINVAL (-1)       /* bad argument (NULL pointer, non-positive size, ...) */
@@ -270,6 +270,37 @@ int facppg_wg_last_layer_ms(facppg_wg* h, float* avg_ms, int* n_launches);
  * Lets the parity tests assert WHICH instantiation of k_wn_layer (glow.py:154-175) they compared with the oracle. */
 int facppg_wg_last_launch_shape(const facppg_wg* h, int* tile_frames, int* waves, int* n_tiles);
 
+/* ---- ONE utterance whose mel frames arrive over time (the metric's "batch = 1" case): the conditioning part of every WN
+ * layer's gate GEMM ahead of the layers.  No reference counterpart as code -- the reference computes cond_layers[i](spect)
+ * inside WN.forward (glow.py:154-175) on the upsampled mel (glow.py:253-259) -- but the same arithmetic: the fused layer
+ * kernel accumulates bias + the folded conditioning chunks BEFORE any dilated tap, and that part depends on the mel frames
+ * alone.  facppg_wg_cond_seed forms it for a block of frames and every (flow, layer, phase) with the layer kernel's own MFMA
+ * sequence and parks the accumulators in `seeds`; facppg_wg_infer_seeded starts the layers from them (12 K chunks instead
+ * of 17; first layers 1 instead of 6).  Same samples as facppg_wg_infer, bit for bit (tests/test_gpu_stream.py).
+ *
+ * facppg_wg_seed_layout: for an utterance of at most T frames, *Tqp = row length of the zero-margined mel buffer
+ *   melp [n_mel][Tqp] (frame q at column *margin + q; the margins and every frame that is not (yet) there must be zero),
+ *   *seed_bytes = size of the seed buffer.
+ * facppg_wg_mel_pad: mel_dev [n_mel][ld] (T frames) -> melp_dev (zero margins written too).
+ * facppg_wg_cond_seed: seeds of frames [frame0, frame0 + nframes) (frame0 a multiple of 32; the frames and the 3 before them
+ *   must be final in melp), for flows [flow0, flow0 + nflows) (nflows <= 0: all).  block_tiles (1..4) 32-frame tiles share one
+ *   pass over a weight image; layers_per_workgroup layers share one staging of the mel window.  *skip_dev != 0 (device, may be
+ *   NULL): the launch does nothing.  max_workgroups > 0 bounds the launch to that many workgroups, which take the remaining
+ *   work items from *counter_dev (a zeroed int32 on the device; NULL: strided) -- the CUs it leaves stay free for other streams.
+ * facppg_wg_infer_seeded: WaveGlow.infer (glow.py:252-293) of the T frames in melp_dev, laid out (melp, seeds) for T_layout >= T
+ *   frames.  Frames [0, seeded_frames) start from the seeds (seeded_frames a multiple of 32); the frames behind them run as
+ *   unseeded 16-frame tiles of the same launches.  flow_events: NULL or n_flows hipEvent_t (NULL entries allowed): the launches
+ *   of flow k first wait for flow_events[k] on `stream` (its seeds are still being formed on another stream).  z_dev / seed /
+ *   sigma / audio_dev [T*hop] / workspace (facppg_wg_workspace_bytes(h, 1, T_layout)) as in facppg_wg_infer. */
+int facppg_wg_seed_layout(const facppg_wg* h, int T, int* Tqp, int* margin, size_t* seed_bytes);
+int facppg_wg_mel_pad(const facppg_wg* h, const float* mel_dev, int T, int ld, float* melp_dev, void* stream);
+int facppg_wg_cond_seed(facppg_wg* h, const float* melp_dev, int T, int frame0, int nframes, int block_tiles,
+                        int layers_per_workgroup, int flow0, int nflows, float* seeds_dev, size_t seed_bytes,
+                        const int32_t* skip_dev, int max_workgroups, int32_t* counter_dev, void* stream);
+int facppg_wg_infer_seeded(facppg_wg* h, const float* melp_dev, int T_layout, int T, const float* seeds_dev,
+                           int seeded_frames, const float* z_dev, uint64_t seed, float sigma, float* audio_dev,
+                           void* workspace_dev, size_t workspace_bytes, void* const* flow_events, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * STFT / mel analysis / denoiser (src/common/stft.py, src/common/layers.py,
  * src/waveglow/denoiser.py)
@@ -364,19 +395,40 @@ size_t facppg_taco_postnet_workspace_bytes(const facppg_taco* h, int B, int T);
  * away from the vocoder.  A tighter bound selects wider weight slices per workgroup, which cuts the LSTM sums differently:
  * results agree with the unbounded launch to rounding (1e-6 relative on the mel), not bit for bit. */
 int facppg_taco_set_decoder_workgroups(facppg_taco* h, int max_workgroups);
-/* Heater workgroups for the small-batch (split) decoder launch; 0 = none (default), n > 0 = that many, -1 = as many as stay
- * co-resident.  No reference counterpart: MEASURED, the vocoder runs ~10 % slower for its first milliseconds behind a batch-1
- * decoder (~76 of 256 CUs busy for milliseconds) or behind idle time than on a chip that was busy just before
- * (tools/idle_gap_probe.py); the cause is not identified (the GPU's reported clocks do not change, tools/clock_probe.py).  Heaters are extra workgroups of the same cooperative launch that run matrix instructions on
- * registers -- no memory traffic, CUs of their own (every workgroup of that launch holds a CU's LDS) -- during the last
- * FACPPG_DECODER_HEAT_LEAD (80) frames before the step limit, until the utterances' attention workgroups are done.  Results are unchanged bit for bit; the launch then holds the whole chip, so a caller that runs
- * something else next to the decoder (facppg_taco_set_decoder_workgroups > 0) gets none.  FACPPG_DECODER_HEATERS overrides. */
-int facppg_taco_set_decoder_heaters(facppg_taco* h, int heaters);
 /* Which decoder kernel the most recent facppg_taco_decode launched (tests assert the shape they mean to cover, as
  * facppg_wg_last_launch_shape does for the vocoder): *mode = 0 one workgroup per utterance (k_decoder), 1 cooperative
  * slices (k_decoder_coop), 2 split (k_decoder_split: one attention workgroup per utterance + register-resident dense-layer
  * workers); *workgroups = workgroups of that launch.  The reference has one code path (model.py:489-535). */
 int facppg_taco_last_decoder_launch(const facppg_taco* h, int* mode, int* workgroups);
+
+/* ---- the decoder's frames while it is still producing them (B = 1, split decoder).  The reference's decoder appends a frame per
+ * step to a Python list (model.py:516-531) and the postnet runs on the finished spectrogram (model.py:604-605); here a
+ * consumer on another stream may start on the frames as they appear.
+ * facppg_taco_set_frame_stream: words_dev = [frames * n_feat] 8-byte words, ZEROED by the caller before every decode, or NULL
+ *   to switch publishing off.  The next facppg_taco_decode with B = 1 whose launch is the split decoder and whose max_steps <=
+ *   frames then stores every mel value of frame t ALSO as the word {value, t + 1} at words[t * n_feat + row] with an
+ *   agent-scope store the moment it exists (the plain mel_dev stores are only guaranteed visible once the launch has ended).
+ *   facppg_taco_last_decode_streamed tells whether the most recent decode did.
+ * facppg_taco_collect_frames: waits (bounded in wall-clock time, FACPPG_POLL_LIMIT) for frames [frame_a, frame_b) and writes
+ *   them channel-major into mel_dev [n_feat][ld].  If the decoder stops short of frame_b (out_length_dev, the decode call's
+ *   output, becomes > 0 and <= a wanted frame) the block is VOID: *void_flag_dev = 1 and nothing more is waited for; a block
+ *   whose predecessor is void (*prev_flag_dev != 0) is void at once.  Either flag may be NULL.
+ * facppg_taco_postnet_range: Postnet.forward + residual (model.py:178-184, 604-605) as a streaming convolution stack.  With f
+ *   frames of mel known, layer j (1-based) is final up to f - j*pad columns; the call extends every layer from the f_prev-frame
+ *   frontier to the f_new-frame one (its inputs: mel_dev [n_feat][ld], the layers' own earlier columns in the workspace) and
+ *   writes the new final columns of mel_post_dev [n_feat][ld_post].  final_T > 0 (= f_new): the utterance has ended there --
+ *   every layer runs up to final_T with the convolutions' zero padding behind it.  Every output column is the sum, in the
+ *   order, of facppg_taco_postnet's: same bits.  The workspace (facppg_taco_postnet_stream_workspace_bytes(h, max_frames))
+ *   carries the layers' columns from call to call.  *skip_dev != 0 (device, may be NULL): the call's launches do nothing. */
+int facppg_taco_set_frame_stream(facppg_taco* h, void* words_dev, int frames);
+int facppg_taco_last_decode_streamed(const facppg_taco* h, int* streamed);
+int facppg_taco_collect_frames(const facppg_taco* h, const void* words_dev, const int32_t* out_length_dev, int frame_a,
+                               int frame_b, float* mel_dev, int ld, int32_t* void_flag_dev, const int32_t* prev_flag_dev,
+                               void* stream);
+size_t facppg_taco_postnet_stream_workspace_bytes(const facppg_taco* h, int max_frames);
+int facppg_taco_postnet_range(facppg_taco* h, const float* mel_dev, int ld, int f_prev, int f_new, int final_T,
+                              float* mel_post_dev, int ld_post, void* workspace_dev, size_t workspace_bytes,
+                              int max_frames, const int32_t* skip_dev, void* stream);
 
 /* Replaces Encoder.inference (model.py:237-249) and the memory_layer projection
  * (model.py:334).  ppg_dev [B][n_symbols][Tin]; lengths_dev NULL or [B] valid frame counts

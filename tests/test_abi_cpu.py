@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "libfacppg_hip.so does not export %s" % n
     assert sorted(flib.exported_symbols()) == [n for n in names if n in flib.exported_symbols()]
-    assert L.facppg_version() == 102
+    assert L.facppg_version() == 103
 
 
 def test_single_hip_runtime():

@@ -64,6 +64,10 @@ def run(taco, wg, den, ppg, em, dm, zs, stream, monkeypatch):
                                                  (130, 400, -10.0), (150, 1000, -0.02), (64, 64, -10.0)])
 def test_streamed_utterance_equals_the_unstreamed_path_bit_for_bit(vocoder, Tin, steps, gate_bias, monkeypatch):
     cfg, wg, den = vocoder
+    if Tin in (170, 130):          # (the optional modes of the stream: flow-ordered late blocks; unbounded seed passes)
+        monkeypatch.setenv("FACPPG_STREAM_GROUPS", "3")
+    if Tin == 96:
+        monkeypatch.setenv("FACPPG_STREAM_SPARE_CUS", "-1")
     hp, taco = acoustic(steps, gate_bias)
     ppg = synth.synthetic_ppg(Tin, 5816, seed=Tin, alpha=0.002)
     em = masks_from_seed(21, (2, 1, Tin, hp.symbols_embedding_dim))

@@ -192,34 +192,3 @@ def test_large_batch_runs_in_chunks_and_matches_single_runs():
         assert torch.count_nonzero(mel_post[b, :, To:]) == 0
 
 
-@pytest.mark.parametrize("lens", [[40], [24, 9, 17], [11, 24, 9, 17, 13]])
-def test_decoder_heater_workgroups_change_nothing_but_the_launch(lens, monkeypatch):
-    """Tacotron2.decoder_heaters (facppg_taco_set_decoder_heaters; facppg.pipeline.synthesize switches it on): extra workgroups
-    of the small-batch decoder launch that run matrix instructions on registers on the CUs the decoder leaves empty, so that the
-    vocoder behind it does not start slow (a measured effect of low activity whose cause is not identified).  They own no data: every output must be bit for bit what the
-    launch without them gives -- all that fit (-1), a handful (5), and with the environment override switching them off."""
-    monkeypatch.setenv("FACPPG_DECODER_MODE", "split")
-    d, hp, sd, ppg, em, dm = tacotron_case("stop")
-    m = build(hp, sd)
-    B, Tin, steps = len(lens), max(lens), int(d["max_steps"])
-    g = np.random.Generator(np.random.PCG64(33))
-    from facppg import synth
-    x = torch.zeros(B, ppg.shape[1], Tin)
-    for b, n in enumerate(lens):
-        x[b, :, :n] = torch.from_numpy(synth.synthetic_ppg(n, ppg.shape[1], seed=70 + b)).t()
-    emb = (g.random((2, B, Tin, 600)) < 0.5).astype(np.uint8)
-    dmb = (g.random((steps, 2, B, 300)) < 0.5).astype(np.uint8)
-
-    def run(heaters):
-        m.decoder_heaters = heaters
-        out = m.inference(x.cuda(), lengths=lens if B > 1 else None, dropout_masks=(emb, dmb))
-        return out, m.last_output_lengths.tolist()
-
-    ref, ref_lens = run(0)
-    for heaters in (-1, 5):
-        got, got_lens = run(heaters)
-        assert got_lens == ref_lens
-        assert all(torch.equal(a, b) for a, b in zip(got, ref))
-    monkeypatch.setenv("FACPPG_DECODER_HEATERS", "0")
-    got, got_lens = run(-1)
-    assert got_lens == ref_lens and all(torch.equal(a, b) for a, b in zip(got, ref))

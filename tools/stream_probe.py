@@ -1,6 +1,6 @@
-"""Round 5: the streamed batch-1 step (ConditioningStream) vs the unstreamed one: host-clock ms per step and stage events."""
-import contextlib
-import io
+"""Round 5: the streamed batch-1 step (ConditioningStream) under different settings, INTERLEAVED in one process (boxes differ by
+a few per cent; so do minutes on one box): CONFIGS = ';'-separated env settings 'K=V,K=V', each run REPS times for N steps in
+round-robin order; prints the median ms/step per setting and the stage events of one further step."""
 import os
 import sys
 import time
@@ -15,28 +15,45 @@ import bench  # noqa: E402
 from facppg import pipeline  # noqa: E402
 
 
+def setenv(cfg):
+    keys = []
+    for kv in cfg.split(","):
+        if "=" in kv:
+            k, v = kv.split("=", 1)
+            os.environ[k] = v
+            keys.append(k)
+    return keys
+
+
 def main():
     dev = torch.device("cuda", 0)
     T = int(os.environ.get("T", "200"))
     e = bench.EndToEnd(dev, [T])
-    for mode in os.environ.get("MODES", "0,1").split(","):
-        os.environ["FACPPG_STREAM"] = mode
-        for i in range(4):
-            e.step(i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = 20
-        for i in range(n):
-            e.step(10 + i)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / n * 1e3
+    configs = os.environ.get("CONFIGS", "FACPPG_STREAM=0;FACPPG_STREAM=1").split(";")
+    reps, n = int(os.environ.get("REPS", "3")), int(os.environ.get("N", "10"))
+    res = {c: [] for c in configs}
+    for r in range(reps):
+        for c in configs:
+            keys = setenv(c)
+            for i in range(3):
+                e.step(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                e.step(10 + i)
+            torch.cuda.synchronize()
+            res[c].append((time.perf_counter() - t0) / n * 1e3)
+            for k in keys:
+                del os.environ[k]
+    for c in configs:
+        keys = setenv(c)
         timer = pipeline.StageTimer()
         e.step(99, timer=timer)
         st = timer.stages_ms()
-        cs = e.waveglow.__dict__.get("_facppg_cond_stream")
-        print("FACPPG_STREAM=%s chunk=%s: %.3f ms/step; stages %s; blocks %s" % (
-            mode, os.environ.get("FACPPG_STREAM_CHUNK", "64"), ms, {k: round(v, 3) for k, v in st.items()},
-            getattr(cs, "cuts", None) if mode == "1" else None))
+        for k in keys:
+            del os.environ[k]
+        print("%-60s median %.3f ms/step (%s); stages %s" % (c, sorted(res[c])[len(res[c]) // 2], " ".join("%.2f" % v for v in res[c]),
+                                                              {k: round(v, 2) for k, v in st.items()}))
 
 
 if __name__ == "__main__":
