@@ -77,6 +77,7 @@ class ConditioningStream(object):
         self.tacotron, self.waveglow = tacotron, waveglow
         self.key = None
         self.active = False
+        self.profile = False       # True: hipEvents around every seed pass of the following utterances (pass_ms)
 
     @staticmethod
     def usable(tacotron, waveglow):
@@ -181,11 +182,19 @@ class ConditioningStream(object):
 
         def seed_pass(job):
             s_a, n, bt, void, lo, hi = job
+            if self.profile:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(self.side)
             self.waveglow.cond_seed(self.melp, steps, s_a, n, self.seeds, block_tiles=bt, layers_per_workgroup=lpw, skip=void,
                                     handle=self.wg_handle, flows=(lo, hi - lo), max_workgroups=bound,
                                     counter=self.counters[self.n_launch:self.n_launch + 1] if self.n_launch < 500 else None)
             self.n_launch += 1
+            if self.profile:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(self.side)
+                self.pass_events.append((n, hi - lo, e0, e1))
         self.seed_pass = seed_pass
+        self.pass_events = []
         self.post.wait_event(self.ready)
         with torch.cuda.device(dev):
             for k, (f_new, s_a, s_b) in enumerate(self.cuts):
@@ -261,6 +270,14 @@ class ConditioningStream(object):
                 self.deferred = []
         self.Tout, self.seeded = Tout, s_done
         return self.melp[:, self.margin:self.margin + Tout].unsqueeze(0)
+
+    def pass_ms(self):
+        """[(frames, flows, ms)] of the seed passes of the most recent utterance (profile = True); synchronises them."""
+        out = []
+        for n, nf, e0, e1 in self.pass_events:
+            e1.synchronize()
+            out.append((n, nf, e0.elapsed_time(e1)))
+        return out
 
     # ---- called by the vocoder stage
     def vocode(self, sigma, z=None, seed=None):

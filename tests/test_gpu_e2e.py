@@ -412,7 +412,7 @@ def test_metric_shape_matches_reference_golden():
     """The headline's own shape against what the REFERENCE produced for it (tests/golden/e2e_metric.npz, written by
     make_golden.py gen_e2e_metric from the imported reference: generate_synthesis.py:74-98 on PPG [200 x 5816], 200 decoder steps,
     hop 256, sigma 0.6, Denoiser(hop_length=256)) -- the models and the call bench.py's EndToEnd times, default launch selection
-    (asserted: the split decoder and 32-frame / 8-wave vocoder tiles), injected dropout masks and z: mel <= 1e-4, N = 51 200
+    (asserted: the split decoder, the streamed path, 32-frame / 8-wave seeded vocoder tiles), injected dropout masks and z: mel <= 1e-4, N = 51 200
     exactly, waveform RMS <= 1e-3 before and after the denoiser."""
     from test_oracle_golden import metric_case
     from facppg import pipeline
@@ -430,17 +430,25 @@ def test_metric_shape_matches_reference_golden():
     wg = wg.cuda().eval()
     den = Denoiser(wg, hop_length=hop, mode="zeros")
     seen = {}
-    infer = wg.infer
+    inference = taco.inference
 
-    def spy(spect, **kw):
-        seen["mel_post"] = spect.detach().cpu().numpy()
-        seen["audio"] = infer(spect, **kw)
-        return seen["audio"]
-    wg.infer = spy
-    with contextlib.redirect_stdout(io.StringIO()):
-        wavs, tout = pipeline.synthesize([ppg], taco, wg, den, sigma=float(d["sigma"]), strength=float(d["strength"]),
-                                         dropout_masks=(em, dm), z=zs)
-    del wg.infer
+    def spy(*a, **kw):
+        out = inference(*a, **kw)
+        seen["mel_post"] = out[1].detach().cpu().numpy()
+        seen["streamed"] = kw.get("frame_consumer") is not None and kw["frame_consumer"].active
+        return out
+
+    def den_spy(audio, **kw):
+        seen["audio"] = audio.detach().clone()
+        return den(audio, **kw)
+    taco.inference = spy
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            wavs, tout = pipeline.synthesize([ppg], taco, wg, den_spy, sigma=float(d["sigma"]), strength=float(d["strength"]),
+                                             dropout_masks=(em, dm), z=zs)
+    finally:
+        del taco.inference
+    assert seen["streamed"]                     # the default batch-1 path: postnet + conditioning seeds under the decoder
     assert taco.last_decoder_launch()[0] == "split"
     assert wg.last_launch_shape()[:2] == (32, 8)
     assert tout == [Tout] and wavs[0].shape == (Tout * hop,) == (51200,)                      # integer: N = Tout * hop
