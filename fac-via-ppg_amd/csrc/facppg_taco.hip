@@ -35,6 +35,7 @@ struct facppg_taco {
   int device;
   int coop_limit;   // workgroups the cooperative (co-resident) kernels may use: from the occupancy calculator, see facppg_taco_create
   int decoder_wg_limit;   // facppg_taco_set_decoder_workgroups: a tighter bound for the decoder alone (0 = none)
+  int wall_khz;              // the device's constant-rate clock (facppg_taco_collect_frames bounds its wait in it)
   unsigned long long* frame_stream;   // facppg_taco_set_frame_stream: tagged mel frames as the split decoder emits them (B = 1), or null
   int frame_stream_frames;
   int last_streamed;         // the most recent decode published its frames there
@@ -1593,6 +1594,7 @@ extern "C" int facppg_taco_create(const facppg_taco_config* cfg, const float* ws
       }
     }
   }
+  (void)hipDeviceGetAttribute(&h->wall_khz, hipDeviceAttributeWallClockRate, device);
   const facppg_taco_config& c = *cfg;
   const int S = c.symbols_embedding_dim, E = c.encoder_embedding_dim, H = E / 2, K = c.encoder_kernel_size;
   const int P = c.prenet_dim, A = c.attention_rnn_dim, D = c.decoder_rnn_dim, AD = c.attention_dim, NF = c.n_acoustic_feat_dims;
@@ -2066,20 +2068,22 @@ extern "C" int facppg_taco_set_decoder_workgroups(facppg_taco* h, int max_workgr
 // Streaming the decoder's frames into the postnet while the decoder is still running (B = 1, split decoder).
 // ------------------------------------------------------------------------------------------
 namespace {
-// frames [fa, fb) of the tagged stream -> dst[row][f] (channel-major, ld).  A word is waited for (bounded in wall-clock time like
-// every poll of this file); if the decoder has stopped short of a frame (out_len set, frame >= out_len) the whole block is void:
+// frames [fa, fb) of the tagged stream -> dst[row][f] (channel-major, ld).  A word is waited for at most `limit` wall-clock ticks
+// (FACPPG_STREAM_WAIT_MS, default 100 ms: the decoder emits a frame every 20 us); a frame that does not show up in that time does
+// NOT trap -- the block is declared void like one the decoder stopped short of, and the caller's tail covers its frames: a
+// profiler that serialises kernels (rocprofv3 counter passes) may run this launch BEFORE the decoder it waits for, and the
+// result must then be late, not wrong or fatal.  If the decoder has stopped short of a frame (out_len set, frame >= out_len) the whole block is void:
 // *void_flag = 1 -- every launch of THIS block that is handed the flag does nothing, and the caller handles those frames once it
 // knows the length.  A block behind a void block is void as well (prev_flag).  One flag per block: blocks overlap in time (the
 // seed pass of block k runs while block k + 1 is being collected), a shared flag would cut a valid block's launches short.
 __global__ __launch_bounds__(256) void k_collect_frames(const unsigned long long* __restrict__ melx, const int* __restrict__ out_len,
                                                         int NF, int fa, int fb, float* __restrict__ dst, int ld, int* void_flag,
-                                                        const int* prev_flag) {
+                                                        const int* prev_flag, unsigned long long limit) {
   if (prev_flag && __hip_atomic_load(prev_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
     if (void_flag) __hip_atomic_store(void_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   const int n = (fb - fa) * NF;
-  const unsigned long long limit = g_poll_limit_ticks;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int f = fa + i / NF, row = i - (f - fa) * NF;
     const unsigned long long* w = melx + (size_t)f * NF + row;
@@ -2094,10 +2098,13 @@ __global__ __launch_bounds__(256) void k_collect_frames(const unsigned long long
         return;
       }
       __builtin_amdgcn_s_sleep(32);
-      if ((++spins & 1023u) == 0 && limit) {
+      if ((++spins & 255u) == 0 && limit) {
         const unsigned long long now = wall_clock64();
         if (!t0) t0 = now;
-        else if (now - t0 > limit) __builtin_trap();
+        else if (now - t0 > limit) {   // the frames are not coming (in time): leave them to the caller's tail
+          if (void_flag) __hip_atomic_store(void_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return;
+        }
       }
     }
     dst[(size_t)row * ld + f] = __uint_as_float((unsigned)v);
@@ -2123,9 +2130,13 @@ extern "C" int facppg_taco_collect_frames(const facppg_taco* h, const void* word
   FACPPG_REQUIRE(h && words_dev && out_length_dev && mel_dev, FACPPG_EINVAL, "NULL argument");
   FACPPG_REQUIRE(frame_a >= 0 && frame_b > frame_a && frame_b <= ld, FACPPG_EINVAL, "frames [%d, %d) with ld %d", frame_a, frame_b, ld);
   const int n = (frame_b - frame_a) * h->c.n_acoustic_feat_dims;
+  const char* wait_env = getenv("FACPPG_STREAM_WAIT_MS");
+  const double wait_ms = wait_env ? strtod(wait_env, nullptr) : 100.0;
+  // (without a void flag -- the caller's tail, behind the decoder on its own stream -- the wait is the process-wide poll limit's)
+  const unsigned long long limit = void_flag_dev && wait_ms > 0 && h->wall_khz > 0 ? (unsigned long long)(wait_ms * h->wall_khz) : 0ull;
   k_collect_frames<<<(n + 255) / 256 < 8 ? (n + 255) / 256 : 8, 256, 0, (hipStream_t)stream_>>>(
       (const unsigned long long*)words_dev, out_length_dev, h->c.n_acoustic_feat_dims, frame_a, frame_b, mel_dev, ld, void_flag_dev,
-      prev_flag_dev);
+      prev_flag_dev, limit);
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
 }

@@ -42,7 +42,7 @@ def main():
     fetch, write = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
     positions = bench.BATCH * bench.FRAMES * bench.HOP // 8
     out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_bench.sh) -- "
-                     "python bench.py --workload infer --no-cpu-baseline --steps 1 --warmup 0 (k_wn_layer_b1_t200: + --infer-batch 1 --infer-frames 200)",
+                     "python bench.py --workload infer --no-cpu-baseline --steps 1 --warmup 0 (k_wn_layer_b1_t200, k_cond_seed: python tools/seeded_workload.py, the headline utterance's vocoder launches)",
            "correction": "gfx950 FETCH_SIZE reports 1/2 of coalesced reads (MI355X_MICROARCH.md, HBM section) -> fetch doubled; checked in "
                          "this same run on k_flow_end4, whose compulsory traffic is known (see its entry); Infinity-Cache hits are "
                          "included, so this is L2-miss traffic, an upper bound on HBM bytes"}
@@ -50,7 +50,10 @@ def main():
     wn = "void facppg::(anonymous namespace)::k_wn_layer"
     entries = [("k_wn_layer", wn, positions * 1984.0, fetch, write), ("k_flow_end4", "void facppg::(anonymous namespace)::k_flow_end4", None, fetch, write)]
     if b1 is not None:      # the metric's batch-1 utterance: python bench.py --workload infer --infer-batch 1 --infer-frames 200
-        entries.append(("k_wn_layer_b1_t200", wn, 200 * bench.HOP // 8 * 1984.0, b1[0], b1[1]))
+        # (tools/seeded_workload.py: the streamed utterance's launches -- 160 seeded + 40 unseeded frames; algorithmic bytes per
+        #  position as for k_wn_layer + the seeds a seeded tile reads, 512 rows x 4 B per position; k_cond_seed: one pass)
+        entries.append(("k_wn_layer_b1_t200", wn + "_mixed", 200 * bench.HOP // 8 * 1984.0 + 160 * bench.HOP // 8 * 2048.0, b1[0], b1[1]))
+        entries.append(("k_cond_seed", "void facppg::(anonymous namespace)::k_cond_seed", None, b1[0], b1[1]))
     for key, prefix, algo, ft, wt in entries:
         f, w = family(ft, prefix), family(wt, prefix)
         if f is None or w is None:

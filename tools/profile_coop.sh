@@ -11,6 +11,8 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $W/stats -o r -- $B --steps 10 -
 python tools/rocpd_summary.py stats $W/stats/r_results.db | cut -c1-190 > $O/e2e_kernel_stats_B1_T200.txt
 python tools/rocpd_summary.py timeline $W/stats/r_results.db k_decoder -3 | cut -c1-150 > $O/e2e_timeline_B1_T200.txt
 if [ -z "$NO_PMC" ]; then
+# (counter passes serialise the kernels: the streamed path's frame collectors would wait for a decoder that is queued behind them)
+export FACPPG_STREAM=0
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_VALU GRBM_GUI_ACTIVE -d $W/sq -o r -- $B --steps 2 --warmup 1 > $W/sq.log 2>&1; echo "sq rc=$?"; tail -2 $W/sq.log
 python tools/rocpd_summary.py pmc $W/sq/r_results.db k_decoder | cut -c1-190 > $O/e2e_pmc_sq_decoder_B1_T200.txt
 python tools/rocpd_summary.py pmc $W/sq/r_results.db k_bilstm | cut -c1-190 >> $O/e2e_pmc_sq_decoder_B1_T200.txt
