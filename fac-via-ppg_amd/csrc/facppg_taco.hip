@@ -1440,8 +1440,11 @@ __global__ __launch_bounds__(NTC) void k_decoder_split(DecArgs p) {
     attn_window_range(p.window, t, len, &lo, &hi);
     attn_features<NTC>(p, L, lo, min(64, hi - lo + 1), tid);   // needs only frame t-1's weights
     __syncthreads();
+    PROF(6)
     attn_energy_pre<NTC>(p, L, pm, lo, min(64, hi - lo + 1), tid, stash);   // ... and so does this part of the energies
+    PROF(7)
     if (rows_on) { ctx_rows_update(p, mem, hi_prev, hi, tid, crows); hi_prev = hi; }   // ... and the window's entering memory row
+    PROF(14)
     asm volatile("" ::: "memory");   // (the 96 registers of query weights requested next must not be hoisted over it: spills)
     float4 wq[QR];
 #pragma unroll
@@ -1980,8 +1983,8 @@ extern "C" int facppg_taco_decode(facppg_taco* h, const float* memory_dev, const
       long long pr[32];
       FACPPG_HIP_CHECK(hipMemcpyAsync(pr, a.prof, sizeof(pr), hipMemcpyDeviceToHost, s));
       FACPPG_HIP_CHECK(hipStreamSynchronize(s));
-      fprintf(stderr, "[facppg split decoder prof (main), shader cycles] features %lld wait_gate %lld wait_ah %lld attention %lld | att: query %lld energy %lld softmax %lld update %lld context %lld\n",
-              pr[2], pr[0], pr[3], pr[5], pr[8], pr[10], pr[11], pr[12], pr[13]);
+      fprintf(stderr, "[facppg split decoder prof (main), shader cycles] location features %lld energy_pre %lld entering row %lld query weights requested %lld wait_gate %lld wait_ah %lld attention %lld | att: query %lld energy %lld softmax %lld update %lld context %lld\n",
+              pr[6], pr[7], pr[14], pr[2], pr[0], pr[3], pr[5], pr[8], pr[10], pr[11], pr[12], pr[13]);
       fprintf(stderr, "[facppg split decoder prof (worker 0), shader cycles] proj+prenet1 %lld | gather gate,X1 %lld | prenet2 %lld | gather X2 %lld | "
               "att LSTM %lld | gather AH %lld | gather CTX %lld | dec LSTM + gather DH %lld | barrier %lld\n",
               pr[16], pr[17], pr[18], pr[19], pr[20], pr[21], pr[22], pr[23], pr[24]);

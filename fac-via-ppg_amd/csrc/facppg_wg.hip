@@ -61,8 +61,8 @@ constexpr int NG1 = K1 / 8;   // 176 k-groups of 8
 constexpr int NG2 = C / 8;    // 32
 constexpr int NCH1 = K1 / KCH;  // 22 chunks
 #ifndef FACPPG_COST16_FULL
-#define FACPPG_COST16_FULL 105   // microseconds per round of 16-frame tiles: full round / at most one workgroup per CU
-#define FACPPG_COST16_HALF 57
+#define FACPPG_COST16_FULL 92    // microseconds per round of 16-frame tiles: full round / at most one workgroup per CU (round 5: one
+#define FACPPG_COST16_HALF 51    // ds_read_b128 per k group; before: 105 / 57)
 #endif
 #ifndef FACPPG_WN_W128_DEFAULT
 #define FACPPG_WN_W128_DEFAULT 0
@@ -1570,7 +1570,15 @@ __device__ __forceinline__ void wn_layer16_tile(const WnArgs& p, const int ph, c
     const f2u v = *reinterpret_cast<const f2u*>(src);
     stg = make_float2(v.x, v.y);
   };
-  auto stage_write = [&](int buf) __attribute__((always_inline)) { *reinterpret_cast<float2*>(smem + buf * (KCH * TN16) + srow * TN16 + scol) = stg; };
+  // LDS image of a chunk: [16-wide k group g][lane quarter kq][column][s] -- the four k rows 16 g + k16(s, kq), s = 0..3, that
+  // lane (column, kq) feeds into the group's four MFMAs are 16 contiguous bytes: ONE ds_read_b128 per group instead of four
+  // ds_read_b32 with a wait each (the 32-frame kernels' K4 image, see load_b).  Row r16 = k16(s, kq) <-> s = 2 (r16 >> 3) +
+  // ((r16 >> 1) & 1), kq = 2 (r16 & 1) + ((r16 >> 2) & 1).
+  const int sw_r = srow & 15, sw_base = (((srow >> 4) * 4 + 2 * (sw_r & 1) + ((sw_r >> 2) & 1)) * TN16) * 4 + 2 * (sw_r >> 3) + ((sw_r >> 1) & 1);
+  auto stage_write = [&](int buf) __attribute__((always_inline)) {
+    float* dst = smem + buf * (KCH * TN16) + sw_base + scol * 4;
+    dst[0] = stg.x; dst[4] = stg.y;
+  };
   auto load_a = [&](float4 (&a)[4], int gg) __attribute__((always_inline)) {   // gg = 16-wide K group over [conv | cond]
     const float4* src = gg < NGC16 ? wave_c + (size_t)gg * 2048 : wave_a + (size_t)(gg - NGC16) * 2048;
 #pragma unroll
@@ -1590,14 +1598,13 @@ __device__ __forceinline__ void wn_layer16_tile(const WnArgs& p, const int ph, c
   __syncthreads();
   for (int c = 0; c < nch; ++c) {
     stage_load(c + 1 < nch ? c + 1 : c);
-    const float* lb = smem + (c & 1) * (KCH * TN16) + k16(0, kq) * TN16 + pl;
+    const float* lb = smem + (c & 1) * (KCH * TN16) + (kq * TN16 + pl) * 4;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       load_a(ar[(g + RING - 1) % RING], c * 4 + g + RING - 1);
       __builtin_amdgcn_sched_barrier(0);
-      float bq[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) bq[s] = lb[(16 * g + k16(s, 0)) * TN16];
+      const float4 b4 = *reinterpret_cast<const float4*>(lb + g * (4 * TN16 * 4));
+      const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -1613,7 +1620,8 @@ __device__ __forceinline__ void wn_layer16_tile(const WnArgs& p, const int ph, c
 #pragma unroll
   for (int rbl = 0; rbl < 2; ++rbl)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) smem[(chb + 16 * rbl + 4 * kq + r) * TN16 + pl] = gate_tanh_sigmoid(acc[rbl][r], acc[rbl + 2][r]);
+    for (int r = 0; r < 4; ++r)   // channel chb + 16 rbl + 4 kq + r into the same [group][kq][column][s] image
+      smem[(((2 * w8 + rbl) * 4 + 2 * (r & 1) + (kq & 1)) * TN16 + pl) * 4 + 2 * (kq >> 1) + ((r >> 1) & 1)] = gate_tanh_sigmoid(acc[rbl][r], acc[rbl + 2][r]);
   __syncthreads();
   // res_skip 1x1 conv: blocks rbl 0,1 = res rows chb.., rbl 2,3 = skip rows 256+chb.. (LAST: rbl 0,1 = skip rows chb..)
   constexpr int NB2 = EF ? (LAST ? 0 : 2) : LAST ? 2 : 4;   // EF: res rows only (image laid out like a LAST layer's 256 rows)
@@ -1634,7 +1642,7 @@ __device__ __forceinline__ void wn_layer16_tile(const WnArgs& p, const int ph, c
   }
   if constexpr (NB2 > 0) {
     const float4* ap2 = p.w2 + (w8 * NB2) * 64 + lane;   // [g16][NB2*8 blocks][64]
-    const float* lb = smem + k16(0, kq) * TN16 + pl;
+    const float* lb = smem + (kq * TN16 + pl) * 4;
     auto load_a2 = [&](float4 (&a)[4], int g) __attribute__((always_inline)) {
 #pragma unroll
       for (int rbl = 0; rbl < NB2; ++rbl) a[rbl] = ap2[(size_t)g * (NB2 * 8 * 64) + rbl * 64];
@@ -1646,9 +1654,8 @@ __device__ __forceinline__ void wn_layer16_tile(const WnArgs& p, const int ph, c
       for (int g = 0; g < 4; ++g) {
         load_a2(ar[(g + RING - 1) % RING], c * 4 + g + RING - 1);
         __builtin_amdgcn_sched_barrier(0);
-        float bq[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) bq[s] = lb[(64 * c + 16 * g + k16(s, 0)) * TN16];
+        const float4 b4 = *reinterpret_cast<const float4*>(lb + (4 * c + g) * (4 * TN16 * 4));
+        const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -1665,10 +1672,11 @@ __device__ __forceinline__ void wn_layer16_tile(const WnArgs& p, const int ph, c
     const float4* wimg = reinterpret_cast<const float4*>(p.we) + w8 * 128 + lane * 2;
     const float4 a0 = wimg[0], a1 = wimg[1];
     const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-    const float* gb = smem + (32 * w8 + kq) * TN16 + pl;
+    // (gated channel 32 w8 + 4 g + kq in the [group][kq][column][s] image)
     f32x4 e = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int g = 0; g < 8; ++g) e = mfma16x16x4(av[g], gb[(4 * g) * TN16], e);
+    for (int g = 0; g < 8; ++g)
+      e = mfma16x16x4(av[g], smem[(((2 * w8 + (g >> 2)) * 4 + 2 * (kq & 1) + (g & 1)) * TN16 + pl) * 4 + 2 * ((g & 3) >> 1) + (kq >> 1)], e);
     if (kq < 2) {
       float* part = smem + C * TN16 + (w8 * 8 + 4 * kq) * TN16 + pl;
 #pragma unroll

@@ -68,8 +68,10 @@ class ConditioningStream(object):
     (glow.py:154-175) and the upsampling they read (glow.py:253-259).
 
     A pass over a block of frames streams every (flow, layer, phase) conditioning image once -- 2 GB at hop 256 -- whatever the
-    block's width, so the blocks are as wide as the frames' arrival allows (FACPPG_STREAM_CHUNK frames, default 64) and only the
-    last one before the expected end is 32 frames, which keeps the share that has to wait for the decoder's end small."""
+    block's width (FACPPG_STREAM_CHUNK frames: 32 for utterances up to 320 frames, 64 beyond, the last one before the expected
+    end always 32, which keeps the share that has to wait for the decoder's end small).  What the blocks cannot cover -- the frames
+    that become final only when the decoder ends -- runs as UNSEEDED 16-frame tiles inside the vocoder's own layer launches
+    (k_wn_layer_mixed) rather than as one more pass in front of them."""
 
     LAG = None   # frames of mel the postnet's output trails its input by (pad * layers; from the model)
 
@@ -121,9 +123,12 @@ class ConditioningStream(object):
     def plan(self, steps, Tin):
         """[(frames of mel needed, first seeded frame, end of seeded frames)] -- blocks that can be formed before the utterance ends
         if it runs to about min(steps, Tin) frames; whatever is not covered is left for finish()."""
-        chunk = max(32, int(os.environ.get("FACPPG_STREAM_CHUNK", "64")) // 32 * 32)
-        last = max(32, int(os.environ.get("FACPPG_STREAM_LAST", "32")) // 32 * 32)
         end = min(steps, max(Tin, 1))
+        # 32-frame blocks keep every block's postnet chain clear of the previous block's pass (a block every 0.62 ms, chain + pass
+        # 0.6 ms) at 2 GB of weight images per block; utterances of several seconds take 64-frame blocks (half the HBM traffic
+        # next to the decoder) except for the last one before the expected end
+        chunk = max(32, int(os.environ.get("FACPPG_STREAM_CHUNK", "32" if end <= 320 else "64")) // 32 * 32)
+        last = max(32, int(os.environ.get("FACPPG_STREAM_LAST", "32")) // 32 * 32)
         s_end = (end - self.lag) // 32 * 32                       # seeded frames before the expected end
         cuts, s = [], 0
         widths = [int(v) // 32 * 32 for v in os.environ.get("FACPPG_STREAM_PLAN", "").split(",") if v.strip()]   # (experiments)

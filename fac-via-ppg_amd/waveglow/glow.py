@@ -907,7 +907,7 @@ class WaveGlow(torch.nn.Module):
         return zt
 
     # ---- two concurrent half-batches for ragged batches
-    _ROUND_COSTS = ((64, 331, 185), (32, 181, 94), (16, 105, 57))   # frames per tile, us per full / half round (csrc/facppg_wg.hip)
+    _ROUND_COSTS = ((64, 331, 185), (32, 181, 94), (16, 92, 51))   # frames per tile, us per full / half round (csrc/facppg_wg.hip)
 
     def _tail_loss(self, lengths, hop):
         """Fraction of a WN-layer launch of this ragged batch that the chip idles through in its last round of workgroup

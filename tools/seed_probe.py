@@ -47,7 +47,15 @@ def main():
         m.cond_seed(melp, T, 0, nfr, seeds)
         t_s, out = timed(lambda: m.infer_seeded(melp, T, seeds, nfr, sigma=0.6, z=zs))
         print("T %d: plain 32-frame tiles %.3f ms, seeded %.3f ms, equal %s, shape %s" % (T, t_ref, t_s, torch.equal(ref, out), m.last_launch_shape()))
-        if T == 200:
+        s_part = (T - 10) // 32 * 32
+        if s_part > 0 and s_part < T:
+            t_m, out_m = timed(lambda: m.infer_seeded(melp, T, seeds, s_part, sigma=0.6, z=zs))
+            os.environ["FACPPG_WN_TILE"] = "16"
+            t_16, out_16 = timed(lambda: m.infer(mel, sigma=0.6, z=zs))
+            del os.environ["FACPPG_WN_TILE"]
+            print("   mixed (%d seeded + %d unseeded frames) %.3f ms, equal %s, shape %s; plain 16-frame tiles %.3f ms, equal %s" % (
+                s_part, T - s_part, t_m, torch.equal(ref, out_m), m.last_launch_shape(), t_16, torch.equal(ref, out_16)))
+        if T == 200 and os.environ.get("PRODUCER"):
             for bt, lpw in ((1, 1), (1, 2), (1, 4), (1, 8), (2, 2), (2, 4), (2, 8), (3, 4), (4, 4), (4, 8)):
                 seeds.fill_(float("nan"))
                 t_p, _ = timed(lambda: m.cond_seed(melp, T, 0, nfr, seeds, block_tiles=bt, layers_per_workgroup=lpw))
