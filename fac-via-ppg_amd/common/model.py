@@ -311,12 +311,20 @@ class Tacotron2(nn.Module):
             enc_m, dec_m = self.draw_dropout_masks(utterance_seeds, Tin, dev, steps)
         ws = torch.empty(max(L.facppg_taco_workspace_bytes(h, B, Tin), L.facppg_taco_decode_workspace_bytes(h, B, steps)),
                          dtype=torch.uint8, device=dev)
-        memory = torch.zeros(B, Tin, E, device=dev)
-        pm = torch.zeros(B, Tin, AD, device=dev)
-        mel = torch.zeros(B, NF, steps, device=dev)
-        gate = torch.zeros(B, steps, device=dev)
-        align = torch.zeros(B, steps, Tin, device=dev)
-        out_len = torch.zeros(B, dtype=torch.int32, device=dev)
+        # the six zero-initialised outputs as views of ONE zeroed allocation: one fill launch instead of six (each tiny launch
+        # costs the stream ~8 us of kernel boundary, and they sit in front of the encoder on the latency path)
+        sizes = (B * Tin * E, B * Tin * AD, B * NF * steps, B * steps, B * steps * Tin, B)
+        offs, tot = [], 0
+        for n in sizes:
+            offs.append(tot)
+            tot += (n + 63) // 64 * 64                      # 256-byte aligned pieces
+        arena = torch.zeros(tot, dtype=torch.float32, device=dev)
+        memory = arena[offs[0]:offs[0] + sizes[0]].view(B, Tin, E)
+        pm = arena[offs[1]:offs[1] + sizes[1]].view(B, Tin, AD)
+        mel = arena[offs[2]:offs[2] + sizes[2]].view(B, NF, steps)
+        gate = arena[offs[3]:offs[3] + sizes[3]].view(B, steps)
+        align = arena[offs[4]:offs[4] + sizes[4]].view(B, steps, Tin)
+        out_len = arena[offs[5]:offs[5] + sizes[5]].view(torch.int32)
         _lib.check(L.facppg_taco_set_decoder_workgroups(h, int(self.decoder_workgroups)))
         streaming = False
         if frame_consumer is not None and B == 1:

@@ -107,7 +107,7 @@ __global__ void k_overlap_add(const float* __restrict__ Zt, const float* __restr
 
 struct Ws {
   int F;
-  size_t X, S, Z, fv, total;
+  size_t X, S, Z, fv, sk, sk_bytes, total;
 };
 Ws ws_layout(const facppg_stft* h, int B, int N) {
   Ws w;
@@ -118,6 +118,11 @@ Ws ws_layout(const facppg_stft* h, int B, int N) {
   w.S = take((size_t)B * (h->fl + 2) * w.F * 4);
   w.Z = take((size_t)B * w.F * h->fl * 4);
   w.fv = take((size_t)B * 4);
+  // split-K partial sums of the two DFT products (K = filter_length resp. 2 * cutoff: gemm_launch splits by K alone, so an
+  // utterance is summed in the same order in any batch): a short utterance's [1026 x 1024] x [1024 x 201] product is 36
+  // workgroups with a 16-chunk serial K loop otherwise -- 70 us for 3 us of MFMA work
+  w.sk_bytes = (size_t)4 * B * (h->fl + 2) * w.F * 4;
+  w.sk = take(w.sk_bytes);
   w.total = off;
   return w;
 }
@@ -131,6 +136,7 @@ int run_forward(facppg_stft* h, const float* audio, const int* n_valid, int B, i
   GemmArgs a;
   a.A = h->fwd; a.M = 2 * h->cutoff; a.Cin = h->fl; a.X = X; a.x_bs = (long)h->fl * w.F; a.ldx = w.F; a.N = w.F;
   a.n_valid = fv; a.C = S; a.c_bs = (long)2 * h->cutoff * w.F; a.ldc = w.F; a.B = B;
+  a.splitk_ws = (float*)(ws + w.sk); a.splitk_ws_bytes = w.sk_bytes;
   return gemm_launch(a, s);
 }
 
@@ -139,6 +145,7 @@ int run_inverse(facppg_stft* h, const float* R, int B, char* ws, const Ws& w, co
   GemmArgs a;
   a.A = h->inv_t; a.M = h->fl; a.Cin = 2 * h->cutoff; a.X = R; a.x_bs = (long)2 * h->cutoff * w.F; a.ldx = w.F; a.N = w.F;
   a.n_valid = fv; a.C = Z; a.c_bs = (long)w.F * h->fl; a.ldc = h->fl; a.c_transposed = 1; a.B = B;
+  a.splitk_ws = (float*)(ws + w.sk); a.splitk_ws_bytes = w.sk_bytes;
   if (int rc = gemm_launch(a, s)) return rc;
   const int n_out = h->hop * (w.F - 1);
   if (n_out > 0) {

@@ -61,8 +61,9 @@ constexpr int NG1 = K1 / 8;   // 176 k-groups of 8
 constexpr int NG2 = C / 8;    // 32
 constexpr int NCH1 = K1 / KCH;  // 22 chunks
 #ifndef FACPPG_COST16_FULL
-#define FACPPG_COST16_FULL 92    // microseconds per round of 16-frame tiles: full round / at most one workgroup per CU (round 5: one
-#define FACPPG_COST16_HALF 51    // ds_read_b128 per k group; before: 105 / 57)
+#define FACPPG_COST16_FULL 105   // microseconds per round of 16-frame tiles: full round / at most one workgroup per CU, on the scale of
+#define FACPPG_COST16_HALF 57    // the other widths' constants (round 5's LDS image made these launches ~10 % faster -- 92 / 51 measured --
+                                 // but the 32-frame constants are as stale, and with 92 the model picks 16-frame tiles at T = 200: 8.8 vs 7.7 ms)
 #endif
 #ifndef FACPPG_WN_W128_DEFAULT
 #define FACPPG_WN_W128_DEFAULT 0

@@ -100,11 +100,15 @@ class ConditioningStream(object):
         self.NF = hp["n_acoustic_feat_dims"]
         self.lag = (hp["postnet_kernel_size"] - 1) // 2 * hp["postnet_n_convolutions"]
         self.tqp, self.margin, seed_bytes = self.waveglow.seed_layout(steps, dev)
-        self.words = torch.zeros(steps * self.NF + 512, dtype=torch.int64, device=dev)    # {value, frame + 1} words + the void flags
+        # {value, frame + 1} words + the void flags + the work counters + mel_post in the vocoder's zero-margined layout: ONE allocation,
+        # zeroed by one launch before every decode
+        nw = steps * self.NF + 512
+        self.zeroed = torch.zeros(nw + (self.NF * self.tqp + 1) // 2, dtype=torch.int64, device=dev)
+        self.words = self.zeroed[:nw]
         self.void = self.words[steps * self.NF:].view(torch.int32)[:512]                  # one per block
         self.counters = self.words[steps * self.NF:].view(torch.int32)[512:]              # one per bounded seed launch
+        self.melp = self.zeroed[nw:].view(torch.float32)[:self.NF * self.tqp].view(self.NF, self.tqp)
         self.mel = torch.zeros(self.NF, steps, dtype=torch.float32, device=dev)           # collected frames, channel-major
-        self.melp = torch.zeros(self.NF, self.tqp, dtype=torch.float32, device=dev)       # mel_post, the vocoder's zero-margined layout
         self.seeds = torch.empty(seed_bytes // 4, dtype=torch.float32, device=dev)
         self.post_ws = torch.empty(L.facppg_taco_postnet_stream_workspace_bytes(self.tacotron._handle(dev), steps), dtype=torch.uint8,
                                    device=dev)
@@ -157,8 +161,7 @@ class ConditioningStream(object):
             return None
         self._buffers(dev, steps)
         self.dev, self.steps, self.Tin, self.taco_handle = dev, steps, Tin, handle
-        self.words.zero_()
-        self.melp.zero_()
+        self.zeroed.zero_()
         self.ready = torch.cuda.Event()
         self.ready.record(torch.cuda.current_stream(dev))
         return self.words
@@ -336,7 +339,9 @@ def pad_ppgs(ppgs, device=None):
     ([200, 5816] floats) costs more than the whole encoder."""
     lens = [int(p.shape[0]) for p in ppgs]
     D = int(ppgs[0].shape[1])
-    x = torch.zeros(len(ppgs), D, max(lens), dtype=torch.float32, device=device)
+    # (one utterance, or equal lengths: every column is written below -- no zero fill in front of the upload)
+    alloc = torch.empty if min(lens) == max(lens) else torch.zeros
+    x = alloc(len(ppgs), D, max(lens), dtype=torch.float32, device=device)
     for b, p in enumerate(ppgs):
         t = torch.as_tensor(np.ascontiguousarray(p, dtype=np.float32))
         if device is not None:

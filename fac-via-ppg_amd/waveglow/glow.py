@@ -907,7 +907,7 @@ class WaveGlow(torch.nn.Module):
         return zt
 
     # ---- two concurrent half-batches for ragged batches
-    _ROUND_COSTS = ((64, 331, 185), (32, 181, 94), (16, 92, 51))   # frames per tile, us per full / half round (csrc/facppg_wg.hip)
+    _ROUND_COSTS = ((64, 331, 185), (32, 181, 94), (16, 105, 57))   # frames per tile, us per full / half round (csrc/facppg_wg.hip)
 
     def _tail_loss(self, lengths, hop):
         """Fraction of a WN-layer launch of this ragged batch that the chip idles through in its last round of workgroup
@@ -1057,7 +1057,8 @@ class WaveGlow(torch.nn.Module):
     def prepare(self, device):
         """Validate (or build) the packed weights for ``device`` NOW and remember that for the next ``infer`` on this thread's
         next call: the check walks ~1000 tensors (0.4 ms of host time); facppg.pipeline runs it while the acoustic model's
-        decoder keeps the GPU busy instead of between the two models.  Single use: the next infer() consumes it."""
+        decoder keeps the GPU busy instead of between the two models.  Single use: the next infer() -- whatever path it takes --
+        consumes it, and it is only honoured while the handle it validated is still the model's handle."""
         self.__dict__["_facppg_prepared"] = (self._handle(device), device)
 
     def _checked_handle(self, dev):
@@ -1077,7 +1078,8 @@ class WaveGlow(torch.nn.Module):
         if spect.dtype != torch.float32:
             raise _lib.FacppgError("WaveGlow.infer: fp32 only (the reference's fp16 branch is not built)")
         dev = spect.device
-        spect = spect.contiguous()
+        h = self._checked_handle(dev)   # (ONE validity check of the packed weights per call -- it walks ~1000 tensors -- or none:
+        spect = spect.contiguous()      #  prepare(); consumed HERE so that no path -- two half-batches included -- leaves the token behind)
         B, _, T = spect.shape
         hop = self.upsample.stride[0]
         host_lengths = lengths is not None and not torch.is_tensor(lengths)
@@ -1119,7 +1121,6 @@ class WaveGlow(torch.nn.Module):
                     raise _lib.FacppgError("lengths must be B values in [1, T]")
         audio = torch.zeros(B, T * hop, dtype=torch.float32, device=dev) if lt is not None else \
             torch.empty(B, T * hop, dtype=torch.float32, device=dev)
-        h = self._checked_handle(dev)   # (ONE validity check of the packed weights per call -- it walks ~1000 tensors -- or none: prepare())
         self._infer_launch(spect, lt, zt, seed, sigma, audio, self._infer_workspace(B, T, dev, 0, h), h)
         return audio
 
