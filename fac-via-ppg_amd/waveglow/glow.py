@@ -712,6 +712,7 @@ class WaveGlow(torch.nn.Module):
 
     def _release(self):
         self.__dict__.pop("_facppg_prepared", None)
+        self.__dict__.pop("_facppg_cond_stream", None)    # its buffers belong to the handle's weights and device
         h = self.__dict__.pop("_facppg_handle", None)
         if h is not None:
             _lib.load().facppg_wg_destroy(h[0])
@@ -767,6 +768,7 @@ class WaveGlow(torch.nn.Module):
         d.pop("_facppg_handle", None)
         d.pop("_facppg_prepared", None)
         d.pop("_facppg_ws", None)
+        d.pop("_facppg_cond_stream", None)                # (facppg.pipeline.ConditioningStream: streams, events, GBs of seeds)
         return d
 
     def __del__(self):
