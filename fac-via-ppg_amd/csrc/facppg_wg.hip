@@ -3100,8 +3100,19 @@ extern "C" int facppg_wg_cond_seed(facppg_wg* h, const float* melp_dev, int T, i
   const int ntiles = (nframes + 31) / 32;
   a.tile0 = frame0 / 32; a.nblk = (ntiles + block_tiles - 1) / block_tiles;
   a.ncmax = h->kcp / KCH; a.kc = h->kc; a.ngc = h->kcp / 8; a.hop = c.hop_length; a.ksize = c.upsample_kernel;
-  const size_t lds = (size_t)a.ncmax * KCH * 32 * block_tiles * sizeof(float);
+  size_t lds = (size_t)a.ncmax * KCH * 32 * block_tiles * sizeof(float);
   FACPPG_REQUIRE(lds <= 160 * 1024, FACPPG_EUNSUPPORTED, "block_tiles = %d needs %zu bytes of LDS", block_tiles, lds);
+  // A BOUNDED launch (max_workgroups > 0: the caller shares the GPU with other streams) asks for a CU's whole LDS per workgroup:
+  // one workgroup per CU and nothing else next to it.  Measured (tools/postnet_under_seed_probe.py): the dispatcher places another
+  // stream's small workgroups on the CUs a pass already runs on, where they share its LDS bandwidth and matrix pipe -- a chain of
+  // ten 15 us launches took 0.4-0.7 ms next to a pass of 16-344 workgroups, 0.20-0.22 ms when the pass's workgroups own their CUs
+  // (0.15 alone); a 32-frame pass is HBM-bound and no slower with one workgroup per CU than with two.  FACPPG_SEED_LDS (KiB)
+  // overrides (0: what the kernel needs).
+  {
+    const char* le = getenv("FACPPG_SEED_LDS");
+    const size_t want = le ? (size_t)atoi(le) * 1024 : (max_workgroups > 0 ? (size_t)160 * 1024 : 0);
+    lds = std::max(lds, std::min((size_t)160 * 1024, want));
+  }
   a.layer0 = flow0 * c.wn_layers; a.layer1 = (flow0 + nflows) * c.wn_layers;
   const int lgroups = (a.layer1 - a.layer0 + a.lpw - 1) / a.lpw;
   a.items = lgroups * w.P * a.nblk;

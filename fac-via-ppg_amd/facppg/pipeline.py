@@ -179,12 +179,12 @@ class ConditioningStream(object):
         f_prev = 0
         groups = max(1, int(os.environ.get("FACPPG_STREAM_GROUPS", "1")))
         lpw = max(1, int(os.environ.get("FACPPG_STREAM_LPW", "1")))
-        # The seed passes take every CU the decoder leaves -- two workgroups each -- except `spare` of them: the postnet's launches
-        # (and the decoder's successor on the main stream) are a few workgroups that must find a free CU at once, not when a pass's
-        # workgroup happens to retire (measured: 175 us for a 22 us launch next to an unbounded pass).
+        # The seed passes take the CUs the decoder leaves except `spare` of them, ONE workgroup per CU that holds the CU's whole LDS
+        # (a bounded launch does, see facppg_wg_cond_seed): the dispatcher otherwise places the postnet's small workgroups -- and the
+        # first launches behind the decoder on the main stream -- next to a pass's workgroups, where they crawl (3-5x, measured).
         n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
         spare = int(os.environ.get("FACPPG_STREAM_SPARE_CUS", "8"))
-        bound = max(16, 2 * (n_cu - self.tacotron.last_decoder_launch()[1] - spare)) if spare >= 0 else 0
+        bound = max(16, n_cu - self.tacotron.last_decoder_launch()[1] - spare) if spare >= 0 else 0
         self.n_launch = 0
         self.flow_events, self.deferred, self.last_final = {}, [], None
 

@@ -76,21 +76,22 @@ def main():
     t = timed_postnet(3)
     torch.cuda.synchronize()
     print("next to a one-thread spin kernel, postnet on the default stream: %.3f ms" % t)
-    for nt in ("3:1", "3:3", "0:1", "0:3"):
-        nt, npass = nt.split(":")
+    for nt in ("0:3:0", "0:3:80", "0:3:160"):
+        nt, npass, ldsk = nt.split(":")
         os.environ["FACPPG_SEED_DEBUG"] = nt
-        for wgs in (0, 16, 344):
+        os.environ["FACPPG_SEED_LDS"] = ldsk
+        for wgs in (16, 64, 344):
             counter.zero_()
             torch.cuda.synchronize()
             s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             with torch.cuda.stream(side):
                 s0.record()
                 for i in range(int(npass)):
-                    wg.cond_seed(melp, T, 0, 64, seeds, block_tiles=2, layers_per_workgroup=1, max_workgroups=wgs, counter=counter[i:i + 1])
+                    wg.cond_seed(melp, T, 0, 32, seeds, block_tiles=1, layers_per_workgroup=1, max_workgroups=wgs, counter=counter[i:i + 1])
                 s1.record()
             t = timed_postnet(3)
             torch.cuda.synchronize()
-            print("debug=%s %s pass(es) bounded to %3d workgroups (%.2f ms): postnet %.3f ms" % (nt, npass, wgs, s0.elapsed_time(s1), t))
+            print("lds>=%s KiB, %s pass(es) bounded to %3d workgroups (%.2f ms): postnet %.3f ms" % (ldsk, npass, wgs, s0.elapsed_time(s1), t))
 
 
 if __name__ == "__main__":
