@@ -1956,19 +1956,23 @@ __device__ __forceinline__ void start_conv(const EdgeArgs& p, int b, int h_off, 
   }
 }
 
-template <int HN>
+// QS (few positions: one short utterance): 64 positions per workgroup, the four waves take 64 start-conv channels each -- a
+// thread that walks all 256 channel rows alone is a chain of 256 dependent-address stores (38 us for 200 frames x 32 phases)
+template <int HN, bool QS = false>
 __global__ __launch_bounds__(256) void k_begin(EdgeArgs p) {
   const int b = blockIdx.y;
+  const int pl = QS ? (int)(threadIdx.x & 63) : (int)threadIdx.x, wq = QS ? (int)(threadIdx.x >> 6) : 0;
   int pos, h_off, sk_off;
-  if (!edge_pos(p, b, blockIdx.x * blockDim.x + threadIdx.x, pos, h_off, sk_off)) return;
+  if (!edge_pos(p, b, blockIdx.x * (QS ? 64 : 256) + pl, pos, h_off, sk_off)) return;
   float a[2 * HN];
 #pragma unroll
   for (int j = 0; j < 2 * HN; ++j) {
     a[j] = p.sigma * p.z0[((size_t)b * 2 * HN + j) * p.L + pos];
-    p.aud_out[((size_t)b * 8 + j) * p.La + pos] = a[j];
+    if (wq == 0) p.aud_out[((size_t)b * 8 + j) * p.La + pos] = a[j];
   }
-  start_conv<HN>(p, b, h_off, a + (p.swap_next ? HN : 0));
-  if (p.folded) write_xa<HN>(p, b, h_off, a + (p.swap_next ? HN : 0));
+  if constexpr (QS) start_conv<HN>(p, b, h_off, a + (p.swap_next ? HN : 0), 64 * wq, 64);
+  else start_conv<HN>(p, b, h_off, a + (p.swap_next ? HN : 0));
+  if (p.folded && wq == 0) write_xa<HN>(p, b, h_off, a + (p.swap_next ? HN : 0));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2705,7 +2709,10 @@ static void launch_flow_end(bool early, bool qs, dim3 grid, hipStream_t s, const
 }
 
 template <int HN>
-static void launch_begin(dim3 grid, hipStream_t s, const EdgeArgs& a) { k_begin<HN><<<grid, 256, 0, s>>>(a); }
+static void launch_begin(dim3 grid, hipStream_t s, const EdgeArgs& a, bool qs = false) {
+  if (qs) k_begin<HN, true><<<dim3((a.T + 63) / 64, grid.y, grid.z), 256, 0, s>>>(a);
+  else k_begin<HN><<<grid, 256, 0, s>>>(a);
+}
 
 // WaveGlow.infer on the phase-major layout (folded conditioning): no spect tensor, no upsample kernel.
 // seeds (B = 1): the gate accumulators of every layer start from k_cond_seed's buffer (facppg_wg_cond_seed) for the first
@@ -2755,10 +2762,10 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
     e.z0 = z; e.aud_out = aud[ai]; e.h_out = hbuf[hi]; e.start_w = h->start_w[k]; e.start_b = h->start_b[k];
     e.swap_next = c.alternate_halves && (k & 1);
     switch (h->n_half[k]) {
-      case 1: launch_begin<1>(egrid, s, e); break;
-      case 2: launch_begin<2>(egrid, s, e); break;
-      case 3: launch_begin<3>(egrid, s, e); break;
-      case 4: launch_begin<4>(egrid, s, e); break;
+      case 1: launch_begin<1>(egrid, s, e, fqs); break;
+      case 2: launch_begin<2>(egrid, s, e, fqs); break;
+      case 3: launch_begin<3>(egrid, s, e, fqs); break;
+      case 4: launch_begin<4>(egrid, s, e, fqs); break;
       default: FACPPG_REQUIRE(false, FACPPG_EUNSUPPORTED, "n_half %d", h->n_half[k]);
     }
   }

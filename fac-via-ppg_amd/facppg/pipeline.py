@@ -361,6 +361,8 @@ def _acoustic(ppgs, tacotron, seed, dropout_masks, utterance_seeds, step_limits,
                                            seed=seed, utterance_seeds=utterance_seeds, step_limits=step_limits,
                                            while_decoding=while_decoding, frame_consumer=consumer if len(lens) == 1 else None,
                                            **({"timer": timer} if timer is not None else {}))
+    if consumer is not None and consumer.active:      # (the vocoder reads the stream's own mel buffer: no copy on the latency path)
+        return mel_post, [int(v) for v in tacotron.last_output_lengths]
     return mel_post.contiguous(), [int(v) for v in tacotron.last_output_lengths]
 
 
