@@ -1,7 +1,9 @@
 /* Plain-C client of libfacppg_hip.so: proves include/facppg.h is a self-contained C header and that the
  * library can be driven without Python or torch (device memory through the HIP runtime C API only).
  * Runs WaveGlow.infer twice on random weights with the same seed and checks: error codes, determinism,
- * finite output, and the EINVAL / EWORKSPACE paths.  Built and run by tests/test_gpu_abi_c.py. */
+ * finite output, the EINVAL / EWORKSPACE paths, and the seeded path of ONE utterance (facppg_wg_mel_pad -> facppg_wg_cond_seed ->
+ * facppg_wg_infer_seeded: all-seeded and with an unseeded tail) against facppg_wg_infer, bit for bit.
+ * Built and run by tests/test_gpu_abi_c.py. */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -107,6 +109,43 @@ int main(void) {
     }
     if (facppg_segment_sums(segs, 2, sws, 8, dout, NULL) != FACPPG_EINVAL) { fprintf(stderr, "expected EINVAL for a short workspace\n"); return 6; }
     free(hv);
+  }
+  /* one utterance through the seeded entry points: the same samples as facppg_wg_infer, bit for bit */
+  {
+    const int T1 = 72;
+    const size_t n1 = (size_t)T1 * cfg.hop_length;
+    int tqp = 0, margin = 0;
+    size_t seed_bytes = 0;
+    CHECK_RC(facppg_wg_seed_layout(h, T1, &tqp, &margin, &seed_bytes));
+    float *dmel1 = NULL, *dmelp = NULL, *dseeds = NULL, *daud1 = NULL;
+    void* ws1 = NULL;
+    const size_t wsb1 = facppg_wg_workspace_bytes(h, 1, T1);
+    CHECK_HIP(hipMalloc((void**)&dmel1, (size_t)80 * T1 * sizeof(float)));
+    CHECK_HIP(hipMalloc((void**)&dmelp, (size_t)80 * tqp * sizeof(float)));
+    CHECK_HIP(hipMalloc((void**)&dseeds, seed_bytes));
+    CHECK_HIP(hipMalloc((void**)&daud1, n1 * sizeof(float)));
+    CHECK_HIP(hipMalloc(&ws1, wsb1));
+    float* hm1 = (float*)malloc((size_t)80 * T1 * sizeof(float));
+    for (size_t i = 0; i < (size_t)80 * T1; ++i) { s = s * 1664525u + 1013904223u; hm1[i] = -5.0f + 2.0f * ((float)(s >> 8) / 16777216.0f - 0.5f); }
+    CHECK_HIP(hipMemcpy(dmel1, hm1, (size_t)80 * T1 * sizeof(float), hipMemcpyHostToDevice));
+    float* r0 = (float*)malloc(n1 * sizeof(float));
+    float* r1 = (float*)malloc(n1 * sizeof(float));
+    CHECK_RC(facppg_wg_infer(h, dmel1, NULL, NULL, 4242u, 0.6f, 1, T1, daud1, ws1, wsb1, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    CHECK_HIP(hipMemcpy(r0, daud1, n1 * sizeof(float), hipMemcpyDeviceToHost));
+    CHECK_RC(facppg_wg_mel_pad(h, dmel1, T1, T1, dmelp, NULL));
+    for (int mode = 0; mode < 2; ++mode) {   /* 0: every frame seeded (96 >= 72); 1: 64 seeded frames + an unseeded tail */
+      const int seeded = mode ? 64 : 96;
+      CHECK_HIP(hipMemset(dseeds, 0xff, seed_bytes));
+      CHECK_RC(facppg_wg_cond_seed(h, dmelp, T1, 0, seeded, 1, 2, 0, 0, dseeds, seed_bytes, NULL, 0, NULL, NULL));
+      CHECK_RC(facppg_wg_infer_seeded(h, dmelp, T1, T1, dseeds, seeded, NULL, 4242u, 0.6f, daud1, ws1, wsb1, NULL, NULL));
+      CHECK_HIP(hipDeviceSynchronize());
+      CHECK_HIP(hipMemcpy(r1, daud1, n1 * sizeof(float), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < n1; ++i)
+        if (r0[i] != r1[i]) { fprintf(stderr, "seeded path (mode %d) differs from facppg_wg_infer at sample %zu: %g vs %g\n", mode, i, r1[i], r0[i]); return 7; }
+    }
+    if (facppg_wg_cond_seed(h, dmelp, T1, 16, 32, 1, 2, 0, 0, dseeds, seed_bytes, NULL, 0, NULL, NULL) != FACPPG_EINVAL) { fprintf(stderr, "expected EINVAL for a block that does not start on a tile\n"); return 7; }
+    free(hm1); free(r0); free(r1);
   }
   facppg_wg_destroy(h);
   printf("abi_smoke ok: version %d, %zu weights, %zu samples, rms %.4f, workspace %zu bytes\n", facppg_version(), nw, n_audio, rms, wsb);
