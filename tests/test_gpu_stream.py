@@ -83,3 +83,28 @@ def test_streamed_utterance_equals_the_unstreamed_path_bit_for_bit(vocoder, Tin,
                                                                wg.__dict__["_facppg_cond_stream"].cuts if seen["streamed"] else None))
     assert torch.equal(seen["mel_post"], seen_ref["mel_post"])                     # the streaming postnet: same bits
     assert out.shape == ref.shape == (t_ref * HOP,) and np.array_equal(out, ref)    # ... and so the samples
+
+
+def test_stream_buffers_are_reused_across_utterances(vocoder, monkeypatch):
+    """The stream's buffers (frame words, void flags, work counters, mel buffer, seeds) live with the models and are reused by
+    every utterance of the same step limit: three different utterances in a row, each streamed and unstreamed, and the first one
+    again at the end -- every streamed result equals its unstreamed one bit for bit (nothing of an earlier utterance leaks)."""
+    cfg, wg, den = vocoder
+    steps = 136
+    hp, taco = acoustic(steps, -10.0)
+    cases = []
+    for i, Tin in enumerate((136, 90, 120)):
+        ppg = synth.synthetic_ppg(Tin, 5816, seed=70 + i, alpha=0.002)
+        em = masks_from_seed(31 + i, (2, 1, Tin, hp.symbols_embedding_dim))
+        dm = masks_from_seed(41 + i, (steps, 2, 1, hp.prenet_dim))
+        zs = synth.synthetic_z(1, steps * HOP // 8, cfg, seed=51 + i)
+        cases.append((ppg, em, dm, zs))
+    refs = [run(taco, wg, den, *c, False, monkeypatch)[0] for c in cases]
+    stream_obj = None
+    for i in (0, 1, 2, 0):
+        out, t_out, seen = run(taco, wg, den, *cases[i], True, monkeypatch)
+        assert seen["streamed"] and t_out == steps
+        cs = wg.__dict__["_facppg_cond_stream"]
+        assert stream_obj is None or cs is stream_obj            # the same object, the same buffers
+        stream_obj = cs
+        assert np.array_equal(out, refs[i]), i
