@@ -335,11 +335,14 @@ class Tacotron2(nn.Module):
                                             _lib.ptr(pm), _lib.ptr(ws), ws.numel(), st))
             if timer is not None:
                 timer.mark("encoder")
-            _lib.check(L.facppg_taco_decode(h, _lib.ptr(memory), _lib.ptr(pm), _lib.ptr(lt), _lib.ptr(sl), _lib.ptr(dec_m), seed, B, Tin,
-                                            steps, _lib.ptr(mel), _lib.ptr(gate), _lib.ptr(align), _lib.ptr(out_len),
-                                            _lib.ptr(ws), ws.numel(), st))
+            try:
+                _lib.check(L.facppg_taco_decode(h, _lib.ptr(memory), _lib.ptr(pm), _lib.ptr(lt), _lib.ptr(sl), _lib.ptr(dec_m), seed, B, Tin,
+                                                steps, _lib.ptr(mel), _lib.ptr(gate), _lib.ptr(align), _lib.ptr(out_len),
+                                                _lib.ptr(ws), ws.numel(), st))
+            finally:
+                if frame_consumer is not None and B == 1:     # (whatever happened: no later decode publishes into this call's buffer)
+                    L.facppg_taco_set_frame_stream(h, None, 0)
             if frame_consumer is not None and B == 1:
-                _lib.check(L.facppg_taco_set_frame_stream(h, None, 0))
                 flag = _lib.ctypes.c_int()
                 _lib.check(L.facppg_taco_last_decode_streamed(h, _lib.ctypes.byref(flag)))
                 streaming = bool(flag.value)

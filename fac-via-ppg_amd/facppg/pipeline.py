@@ -161,6 +161,9 @@ class ConditioningStream(object):
             return None
         self._buffers(dev, steps)
         self.dev, self.steps, self.Tin, self.taco_handle = dev, steps, Tin, handle
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_stream(self.side)      # (an utterance that was abandoned half way -- an exception between the decoder and the vocoder --
+        cur.wait_stream(self.post)      #  may have left launches behind on the side streams: they read the buffers zeroed next)
         self.zeroed.zero_()
         self.ready = torch.cuda.Event()
         self.ready.record(torch.cuda.current_stream(dev))
