@@ -1368,7 +1368,6 @@ struct SeedArgs {
   int items;                // work items = layer groups x phases x blocks (a bounded launch has fewer workgroups than that)
   int layer0, layer1;       // the layers of this launch: [layer0, layer1) of layers_total (flow-major: layer = flow * wn_layers + i)
   int* counter;             // bounded launch: the next item to hand out (zero at launch), or null: item = blockIdx, + gridDim, ...
-  int debug;                // FACPPG_SEED_DEBUG (timing experiments): 1 = no stores, 2 = every layer streams layer 0's images
 };
 
 template <bool NT>
@@ -1442,7 +1441,6 @@ __global__ __launch_bounds__(512, NCB <= 2 ? 4 : 2) void k_cond_seed(SeedArgs p)
   const int ng = 8 * ncc;
   const size_t wave_off = (size_t)ph * p.ngc * 1024 + (wq * 4 + sub) * 64 + lane;
   auto layer_ptrs = [&](int l) __attribute__((always_inline)) {
-    if (p.debug & 2) l = 0;
     const WnLayerPtrs* t = reinterpret_cast<const WnLayerPtrs*>(p.ltab[l / p.wn_layers]) + (l % p.wn_layers);
     return t;
   };
@@ -1507,7 +1505,6 @@ __global__ __launch_bounds__(512, NCB <= 2 ? 4 : 2) void k_cond_seed(SeedArgs p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4s x = {acc[rb][cb][4 * q + 0], acc[rb][cb][4 * q + 1], acc[rb][cb][4 * q + 2], acc[rb][cb][4 * q + 3]};
-          if (p.debug & 1) continue;   // (experiments: no stores)
           if constexpr (NT) __builtin_nontemporal_store(x, (FACPPG_AS1 f32x4s*)(dst + (rb * 4 + q) * 64));
           else *(FACPPG_AS1 f32x4s*)(dst + (rb * 4 + q) * 64) = x;
         }
@@ -3130,7 +3127,6 @@ extern "C" int facppg_wg_cond_seed(facppg_wg* h, const float* melp_dev, int T, i
   const int max_wgs = (wgs_env ? atoi(wgs_env) : max_workgroups) / 8 * 8;
   a.counter = max_wgs > 0 && max_wgs < a.items ? counter_dev : nullptr;   // (a caller-zeroed word; without one the items are strided)
   const unsigned grid = (unsigned)(max_wgs > 0 && max_wgs < a.items ? max_wgs : a.items);
-  a.debug = getenv("FACPPG_SEED_DEBUG") ? atoi(getenv("FACPPG_SEED_DEBUG")) : 0;
   const char* nt_env = getenv("FACPPG_SEED_NT");
   const bool nt = !nt_env || atoi(nt_env) != 0;
   hipStream_t s = (hipStream_t)stream_;

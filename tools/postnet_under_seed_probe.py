@@ -76,9 +76,10 @@ def main():
     t = timed_postnet(3)
     torch.cuda.synchronize()
     print("next to a one-thread spin kernel, postnet on the default stream: %.3f ms" % t)
+    # (the round's earlier variants of this probe also ran passes that stored nothing / read one image -- a debug switch of
+    #  k_cond_seed that is gone from the shipping kernel; their results are in profiles/r05_experiments.txt section 6)
     for nt in ("0:3:0", "0:3:80", "0:3:160"):
         nt, npass, ldsk = nt.split(":")
-        os.environ["FACPPG_SEED_DEBUG"] = nt
         os.environ["FACPPG_SEED_LDS"] = ldsk
         for wgs in (16, 64, 344):
             counter.zero_()
