@@ -157,7 +157,10 @@ class ConditioningStream(object):
     def begin(self, tacotron, handle, dev, steps, Tin):
         """Before the decoder launch, on its stream: zeroed frame words.  Returns them (None: not usable for this call)."""
         self.active = False
-        if not self.usable(tacotron, self.waveglow) or steps < 64:
+        # Short utterances do not gain: up to 128 frames the unstreamed vocoder runs 16-frame tiles, one per CU, and a layer launch
+        # lasts as long as ONE tile either way (measured, tools/stream_T_sweep.sh: 64 frames 6.9 -> 8.1 ms, 100 frames 8.2 -> 9.0
+        # streamed; 130 frames 10.0 -> 9.7, 200 frames 13.3 -> 11.5, 1000 frames 53.9 -> 48.5).  FACPPG_STREAM_MIN_FRAMES overrides.
+        if not self.usable(tacotron, self.waveglow) or min(steps, Tin) < int(os.environ.get("FACPPG_STREAM_MIN_FRAMES", "128")):
             return None
         self._buffers(dev, steps)
         self.dev, self.steps, self.Tin, self.taco_handle = dev, steps, Tin, handle
@@ -300,8 +303,13 @@ class ConditioningStream(object):
         # over them in front of the vocoder.
         P = self.waveglow.upsample.stride[0] // 8
         mixed_wgs = P * (s_done // 32 + -(-(T - s_done) // 16))
+        seeded_wgs = P * (s_all // 32)
+        n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
         tail = os.environ.get("FACPPG_STREAM_TAIL", "auto")
-        in_kernel = s_done > 0 and s_done < T and tail != "seed" and (tail == "mixed" or mixed_wgs <= 256 or mixed_wgs >= 1024)
+        # ... i.e. while the mixed launch needs no more ROUNDS of one workgroup per CU than the all-seeded one would (measured: 230
+        # frames, 288 against 256 workgroups: 17.5 against 13.4 ms per step; 300 / 350 / 450 frames, two rounds either way: the
+        # mixed launch is 0.35 - 0.85 ms ahead of the extra pass)
+        in_kernel = s_done > 0 and s_done < T and tail != "seed" and (tail == "mixed" or -(-mixed_wgs // n_cu) <= -(-seeded_wgs // n_cu))
         if s_all > s_done and not in_kernel:
             self.waveglow.cond_seed(self.melp, self.steps, s_done, s_all - s_done, self.seeds, block_tiles=1, layers_per_workgroup=2,
                                     handle=self.wg_handle)
@@ -410,7 +418,8 @@ def synthesize(ppgs, tacotron, waveglow, denoiser=None, sigma=0.6, strength=0.00
             if consumer is None or consumer.tacotron is not tacotron:
                 consumer = waveglow.__dict__["_facppg_cond_stream"] = ConditioningStream(tacotron, waveglow)
         mel_post, tout = _acoustic(ppgs, tacotron, seed, dropout_masks, utterance_seeds, step_limits, timer,
-                                   while_decoding=None if consumer is not None else (lambda: waveglow.prepare(dev)),   # host work under the decoder's milliseconds
+                                   # host work under the decoder's milliseconds: the vocoder's weight check (the stream does its own)
+                                   while_decoding=lambda: None if (consumer is not None and consumer.active) else waveglow.prepare(dev),
                                    consumer=consumer)
         audio = _vocode(mel_post, tout, waveglow, denoiser, sigma, strength, seed, z, utterance_seeds, timer, consumer)
     if return_device:

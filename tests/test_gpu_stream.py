@@ -43,6 +43,7 @@ def acoustic(steps, gate_bias):
 def run(taco, wg, den, ppg, em, dm, zs, stream, monkeypatch):
     from facppg import pipeline
     monkeypatch.setenv("FACPPG_STREAM", "1" if stream else "0")
+    monkeypatch.setenv("FACPPG_STREAM_MIN_FRAMES", "64")     # (short utterances are not streamed by default: they do not gain)
     seen = {}
     inference = taco.inference
 
@@ -76,7 +77,7 @@ def test_streamed_utterance_equals_the_unstreamed_path_bit_for_bit(vocoder, Tin,
     zs = synth.synthetic_z(1, t_ref * HOP // 8, cfg, seed=23)
     ref, t_ref, seen_ref = run(taco, wg, den, ppg, em, dm, zs, False, monkeypatch)
     out, t_out, seen = run(taco, wg, den, ppg, em, dm, zs, True, monkeypatch)
-    assert not seen_ref["streamed"] and seen["streamed"] == (steps >= 64)
+    assert not seen_ref["streamed"] and seen["streamed"] == (min(steps, Tin) >= 64)
     assert taco.last_decoder_launch()[0] == "split"
     assert t_out == t_ref and (gate_bias > -1 or t_ref == steps)
     print("Tin %d steps %d: Tout %d, streamed %s, blocks %s" % (Tin, steps, t_out, seen["streamed"],
