@@ -23,6 +23,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
+#include <vector>
 
 #include "facppg_common.h"
 
@@ -45,13 +47,24 @@ constexpr int MAXSEG = 8;
 // batch item's rows (rows >= L are zero)
 __host__ __device__ inline int pad_len(int L) { return round_up(L, BN); }
 
-__device__ __forceinline__ bf16_t f2bf(float f) {   // round to nearest even
-  unsigned u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// fp32 -> bf16, round to nearest even: v_cvt_pk_bf16_f32 (gfx950), one instruction per PAIR (the integer sequence -- bfe, add3,
+// and, perm -- was a fifth of the gate epilogue's instructions)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2(f, 0.0f) & 0xffffu); }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
-__device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+// the WN gate (glow.py:8-14 fused_add_tanh_sigmoid_multiply): T = tanh(x) = (1 - e^-2x) / (1 + e^-2x), S = sigmoid(y); v_exp_f32
+// and v_rcp_f32 directly (__fdividef compiles to the full IEEE division sequence: ~10 instructions per quotient, half of the
+// gate epilogue).  Shared by k_bgemm<EP_GATE> and k_wn_fwd, which must agree bit for bit.
+__device__ __forceinline__ void gate_ts(float x, float y, float& T, float& S) {
+  const float ea = __builtin_amdgcn_exp2f(fminf(fmaxf(x, -15.0f), 15.0f) * -2.8853900817779268f);
+  T = (1.0f - ea) * __builtin_amdgcn_rcpf(1.0f + ea);
+  S = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.4426950408889634f));
+}
 __device__ __forceinline__ float lo2f(unsigned v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float hi2f(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
 
@@ -71,6 +84,16 @@ struct PackArgs {
   int M, KG, k_base, Cin, taps, gate_rows;
   long sm, sc, st, off;
 };
+// accumulator r of lane half kh in gate row block mb <-> bias entry: tanh rows r < 8, sigmoid rows r >= 8 (+ C)
+__device__ __forceinline__ void gate_bias_rows(const float* __restrict__ bias, int mb, int kh, float (&bi)[16]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float4 bt = *reinterpret_cast<const float4*>(bias + 16 * mb + 8 * q + 4 * kh);
+    const float4 bs = *reinterpret_cast<const float4*>(bias + C + 16 * mb + 8 * q + 4 * kh);
+    bi[4 * q] = bt.x; bi[4 * q + 1] = bt.y; bi[4 * q + 2] = bt.z; bi[4 * q + 3] = bt.w;
+    bi[8 + 4 * q] = bs.x; bi[8 + 4 * q + 1] = bs.y; bi[8 + 4 * q + 2] = bs.z; bi[8 + 4 * q + 3] = bs.w;
+  }
+}
 __device__ __forceinline__ int gate_row_src(int mb, int rho) { return (rho >= 16 ? C : 0) + 16 * mb + ((rho >> 3) & 1) * 8 + (rho & 7); }
 
 constexpr int MAXPACK = 32;
@@ -139,10 +162,7 @@ __device__ __forceinline__ void bgemm_store4(const BGemmArgs& p, int b, int n, i
     float T[4], S[4], a[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const float x = v[t] + p.bias[ch + t], y = v2[t] + p.bias[C + ch + t];
-      const float ea = __expf(-2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
-      T[t] = __fdividef(1.0f - ea, 1.0f + ea);
-      S[t] = __fdividef(1.0f, 1.0f + __expf(-y));
+      gate_ts(v[t], v2[t], T[t], S[t]);
       a[t] = T[t] * S[t];
     }
     const size_t row = (size_t)b * p.Lr + n;
@@ -227,10 +247,20 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs p) {
   for (int s = 0; s < p.nseg; ++s) nchunks += p.seg[s].nch / KC;
 
   f32x16 acc[NCB];
+  if constexpr (MODE == EP_GATE) {
+    // the gate's accumulators START from the bias (b_in + b_cond) of their rows -- as k_wn_fwd's do, bit for bit
+    float bi[16];
+    gate_bias_rows(p.bias, active ? mb : 0, kh, bi);
 #pragma unroll
-  for (int cb = 0; cb < NCB; ++cb)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) acc[cb][r] = bi[r];
+  } else {
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+  }
 
   // the chunk whose loads are issued next: (segment, channel offset), walked incrementally
   int seg_i = 0, seg_c = 0;
@@ -340,6 +370,291 @@ int bgemm_launch(const BGemmArgs& a, hipStream_t s) {
   }
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_wn_fwd: ONE launch per WN layer of the training forward (glow.py:160-173): gate GEMM [512 x 1408] -> tanh * sigmoid
+// -> res/skip GEMM [512 x 256] for a tile of FN positions, the gated tile handed over in LDS.  Same operand images, same
+// K order (tap 0 | tap 1 | tap 2 | cond) and the same 16-entry MFMA steps as k_bgemm<EP_GATE> followed by
+// k_bgemm<EP_RESSKIP>, so every stored value (acts, ts, h_out, skip) has the SAME BITS as the two-launch path
+// (tests/test_gpu_train_bf16.py).  Shape: 8 waves, wave w owns gate row blocks 2w, 2w+1 (channels 32w .. 32w+31, both halves) x
+// 64 positions: 4 MFMAs per pair of A fragments (global -> registers, a ring refilled one 128-entry chunk ahead) and pair
+// of B fragments (LDS [position][k], pitch 272 B): half the LDS reads per MFMA of the 32 x 128 wave tile of k_bgemm, one
+// barrier per 128 reduction entries instead of per 64, one launch ramp per layer instead of two.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int FN = 64, FKC = 128, FLDB = FKC + 8, FLDA = C + 8, FLDT = 2 * C + 8, FLDO = 2 * C + 4;
+constexpr size_t kWnFwdLds = (size_t)FN * FLDO * 4;   // 132 096 B: staging (34 816) -> gated + tanh|sigmoid tiles (100 352) -> fp32 res/skip tile
+constexpr int FNCH = (3 * C + NCOND) / FKC;   // 11 chunks
+struct WnFwdArgs {
+  const uint4* A1;          // gate image, KG = 88, gate-interleaved rows
+  const uint4* A2;          // res/skip image, KG = 16, M2 rows
+  const bf16_t* h_in; bf16_t* h_out; long h_bs;     // [B][HALO + Lr + HALO][256]
+  const bf16_t* spect; long sp_bs;                  // [B][Lr][640]
+  const float* b1; const float* b2;
+  bf16_t* acts; bf16_t* ts; float* skip;            // [B][Lr][256 | 512 | 256]
+  int L, Lr, B, d, first, last, ntiles;
+  unsigned long long* stamps;   // STAMP builds only: [tile][16] wall_clock64 (100 MHz) values of wave 0
+};
+
+template <bool STAMP>
+__global__ __launch_bounds__(512) void k_wn_fwd(WnFwdArgs p) {
+  // staging [2][FN][FLDB] during the gate GEMM; then the gated tile [FN][FLDA] + tanh|sigmoid [FN][FLDT]; then fp32 [FN][FLDO]
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+  static_assert(kWnFwdLds >= (size_t)2 * FN * FLDB * 2 && kWnFwdLds >= (size_t)FN * (FLDA + FLDT) * 2, "LDS phases");
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
+  // consecutive tiles (which share tap rows) go to the same XCD: workgroup lin runs on XCD lin % 8
+  const int per = (p.ntiles + 7) >> 3;
+  const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (tile >= p.ntiles) return;
+  const int ncol = (p.L + FN - 1) / FN;
+  const int b = tile / ncol, n0 = (tile - b * ncol) * FN;
+  int stamp_i = 0;
+  auto stamp = [&]() {
+    if constexpr (STAMP) {
+      if (tid == 0) p.stamps[(size_t)tile * 16 + stamp_i] = wall_clock64();
+      ++stamp_i;
+    }
+  };
+  stamp();
+  const int srow = tid >> 3, sk = tid & 7;
+  constexpr int KG1 = (3 * C + NCOND) / 16, KG2 = C / 16;
+  const uint4* ap0 = p.A1 + (size_t)(2 * w) * KG1 * 64 + lane;
+  const uint4* ap1 = ap0 + (size_t)KG1 * 64;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float bi[16];     // the accumulators start from the summed biases of their rows
+    gate_bias_rows(p.b1, 2 * w + i, kh, bi);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][cb][r] = bi[r];
+  }
+
+  auto stage_load = [&](int c, uint4 (&stg)[2]) {
+    c = min(c, FNCH - 1);       // the last iterations re-read the last chunk (unconditional requests, see k_bgemm)
+    const bf16_t* src;
+    if (c < 6) src = p.h_in + (size_t)b * p.h_bs + (size_t)(HALO + ((c >> 1) - 1) * p.d + n0 + srow) * C + (c & 1) * FKC + 8 * sk;
+    else src = p.spect + (size_t)b * p.sp_bs + (size_t)(n0 + srow) * NCOND + (c - 6) * FKC + 8 * sk;
+    stg[0] = nt_load16(src);
+    stg[1] = nt_load16(src + 64);
+  };
+  auto stage_write = [&](int buf, const uint4 (&stg)[2]) {
+    bf16_t* d = lds + buf * (FN * FLDB) + srow * FLDB + 8 * sk;
+    *reinterpret_cast<uint4*>(d) = stg[0];
+    *reinterpret_cast<uint4*>(d + 64) = stg[1];
+  };
+  uint4 st[2], ar[8][2];
+  stage_load(0, st);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) { ar[s][0] = ap0[(size_t)s * 64]; ar[s][1] = ap1[(size_t)s * 64]; }
+  stage_write(0, st);
+  stage_load(1, st);
+  __syncthreads();
+  for (int c = 0; c < FNCH; ++c) {
+    // chunk c+1 (requested one iteration ago) goes to the other buffer, whose last readers left through the barrier below
+    stage_write((c + 1) & 1, st);
+    stage_load(c + 2, st);
+    __builtin_amdgcn_sched_barrier(0);   // requests stay where they are written (hipcc otherwise sinks them to the end of the iteration, next to their use)
+    const bf16_t* lb = lds + (c & 1) * (FN * FLDB) + li * FLDB + 8 * kh;
+    const size_t gnext = (size_t)(min(c + 1, FNCH - 1) * 8) * 64;
+    uint4 bc0 = *reinterpret_cast<const uint4*>(lb), bc1 = *reinterpret_cast<const uint4*>(lb + 32 * FLDB);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      uint4 bn0 = bc0, bn1 = bc1;
+      if (s < 7) {   // fragments of the next step requested before this step's MFMAs
+        bn0 = *reinterpret_cast<const uint4*>(lb + 16 * (s + 1));
+        bn1 = *reinterpret_cast<const uint4*>(lb + 32 * FLDB + 16 * (s + 1));
+      }
+      acc[0][0] = mfma_bf16(ar[s][0], bc0, acc[0][0]);
+      acc[0][1] = mfma_bf16(ar[s][0], bc1, acc[0][1]);
+      acc[1][0] = mfma_bf16(ar[s][1], bc0, acc[1][0]);
+      acc[1][1] = mfma_bf16(ar[s][1], bc1, acc[1][1]);
+      ar[s][0] = ap0[gnext + (size_t)s * 64];
+      ar[s][1] = ap1[gnext + (size_t)s * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      bc0 = bn0; bc1 = bn1;
+    }
+    __syncthreads();
+    stamp();
+  }
+  // res/skip image: first half of the reduction requested now, under the gate arithmetic
+  const int M2 = p.last ? C : 2 * C;
+  const bool active2 = 64 * w < M2;
+  const uint4* rp0 = p.A2 + (size_t)(active2 ? 2 * w : 0) * KG2 * 64 + lane;
+  const uint4* rp1 = rp0 + (size_t)KG2 * 64;
+  uint4 a2[8][2];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) { a2[g][0] = rp0[(size_t)g * 64]; a2[g][1] = rp1[(size_t)g * 64]; }
+  const int nrows = min(FN, p.L - n0);    // rows >= L are never written (they stay zero)
+  // what the second epilogue adds to, requested now: h_in rows (8 channels per piece) and the running skip sum (4 per piece)
+  const size_t hrow0 = (size_t)b * p.h_bs + (size_t)(HALO + n0) * C, srow0 = ((size_t)b * p.Lr + n0) * C;
+  uint4 hin[4];
+  float4 sold[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + 512 * j;
+    hin[j] = *reinterpret_cast<const uint4*>(p.h_in + hrow0 + (size_t)e * 8);        // (rows < Lr exist; unused ones are never stored)
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int e = tid + 512 * j;
+    sold[j] = *reinterpret_cast<const float4*>(p.skip + srow0 + (size_t)e * 4);
+  }
+  // gate: lane holds tanh rows (acc 0..7) and the matching sigmoid rows (acc 8..15) of channels 16 mb + 8 q + 4 kh + {0..3}.
+  // Everything goes to LDS tiles [position][channel] first and leaves the CU as whole rows (16 bytes per lane, a tile is ONE
+  // contiguous block of acts / ts): the lane-per-position stores of 8 bytes cost 7 - 13 us per tile, more than the GEMM.
+  bf16_t* lts = lds + FN * FLDA;          // [FN][FLDT] tanh | sigmoid
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int ch = 16 * (2 * w + i) + 8 * q + 4 * kh;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        float T[4], S[4], a[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          gate_ts(acc[i][cb][4 * q + t], acc[i][cb][8 + 4 * q + t], T[t], S[t]);
+          a[t] = T[t] * S[t];
+        }
+        const int row = cb * 32 + li;
+        *reinterpret_cast<uint2*>(lds + row * FLDA + ch) = make_uint2(pack2(a[0], a[1]), pack2(a[2], a[3]));
+        *reinterpret_cast<uint2*>(lts + row * FLDT + ch) = make_uint2(pack2(T[0], T[1]), pack2(T[2], T[3]));
+        *reinterpret_cast<uint2*>(lts + row * FLDT + C + ch) = make_uint2(pack2(S[0], S[1]), pack2(S[2], S[3]));
+      }
+    }
+  __syncthreads();
+  stamp();
+  if (active2) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][cb][r] = 0.0f;
+    const bf16_t* la = lds + li * FLDA + 8 * kh;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const uint4 b0 = *reinterpret_cast<const uint4*>(la + 16 * g);
+      const uint4 b1 = *reinterpret_cast<const uint4*>(la + 32 * FLDA + 16 * g);
+      acc[0][0] = mfma_bf16(a2[g & 7][0], b0, acc[0][0]);
+      acc[0][1] = mfma_bf16(a2[g & 7][0], b1, acc[0][1]);
+      acc[1][0] = mfma_bf16(a2[g & 7][1], b0, acc[1][0]);
+      acc[1][1] = mfma_bf16(a2[g & 7][1], b1, acc[1][1]);
+      if (g < 8) { a2[g][0] = rp0[(size_t)(g + 8) * 64]; a2[g][1] = rp1[(size_t)(g + 8) * 64]; }
+    }
+  }
+  // acts / ts leave as whole rows (fire and forget) behind the second GEMM's MFMAs
+  {
+    bf16_t* ga = p.acts + srow0;
+    bf16_t* gt = p.ts + 2 * srow0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = tid + 512 * j, row = e >> 5, c8 = (e & 31) * 8;
+      if (row < nrows) *reinterpret_cast<uint4*>(ga + (size_t)e * 8) = *reinterpret_cast<const uint4*>(lds + row * FLDA + c8);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = tid + 512 * j, row = e >> 6, c8 = (e & 63) * 8;
+      if (row < nrows) *reinterpret_cast<uint4*>(gt + (size_t)e * 8) = *reinterpret_cast<const uint4*>(lts + row * FLDT + c8);
+    }
+  }
+  __syncthreads();      // every wave is through with the gated tile: the fp32 tile [FN][FLDO] of v + bias takes the LDS over
+  stamp();
+  float* lo = reinterpret_cast<float*>(lds);
+  if (active2) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = 32 * (2 * w + i) + 8 * q + 4 * kh;      // rows m .. m+3 of this lane
+        const float4 bb = *reinterpret_cast<const float4*>(p.b2 + m);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+          *reinterpret_cast<float4*>(lo + (cb * 32 + li) * FLDO + m) =
+              make_float4(acc[i][cb][4 * q] + bb.x, acc[i][cb][4 * q + 1] + bb.y, acc[i][cb][4 * q + 2] + bb.z, acc[i][cb][4 * q + 3] + bb.w);
+      }
+  }
+  __syncthreads();
+  // res rows (< 256 unless last): h_out = (res + bias) + h_in; skip rows: skip = skip + (v + bias) -- whole rows per wave
+  if (!p.last) {
+    bf16_t* gh = p.h_out + hrow0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = tid + 512 * j, row = e >> 5, c8 = (e & 31) * 8;
+      if (row >= nrows) continue;
+      const float4 r0 = *reinterpret_cast<const float4*>(lo + row * FLDO + c8), r1 = *reinterpret_cast<const float4*>(lo + row * FLDO + c8 + 4);
+      const uint4 h = hin[j];
+      *reinterpret_cast<uint4*>(gh + (size_t)e * 8) =
+          make_uint4(pack2(r0.x + lo2f(h.x), r0.y + hi2f(h.x)), pack2(r0.z + lo2f(h.y), r0.w + hi2f(h.y)),
+                     pack2(r1.x + lo2f(h.z), r1.y + hi2f(h.z)), pack2(r1.z + lo2f(h.w), r1.w + hi2f(h.w)));
+    }
+  }
+  {
+    float* gs = p.skip + srow0;
+    const int c0 = p.last ? 0 : C;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = tid + 512 * j, row = e >> 6, c4 = (e & 63) * 4;
+      if (row >= nrows) continue;
+      const float4 v = *reinterpret_cast<const float4*>(lo + row * FLDO + c0 + c4);
+      float4 sv = p.first ? make_float4(0.f, 0.f, 0.f, 0.f) : sold[j];
+      sv.x += v.x; sv.y += v.y; sv.z += v.z; sv.w += v.w;
+      *reinterpret_cast<float4*>(gs + (size_t)e * 4) = sv;
+    }
+  }
+  stamp();
+  if constexpr (STAMP) { __builtin_amdgcn_s_waitcnt(0); stamp(); }
+}
+
+int wn_fwd_launch(WnFwdArgs& a, hipStream_t s) {
+  a.ntiles = ((a.L + FN - 1) / FN) * a.B;
+  const int per = (a.ntiles + 7) / 8;
+  {
+    // > 64 KB of dynamic LDS needs the attribute on every device the kernel runs on (see k_wgrad)
+    static unsigned long long attr_devices = 0;
+    int dev = 0;
+    FACPPG_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 64 || !((attr_devices >> dev) & 1ull)) {
+      FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wn_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWnFwdLds));
+      FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wn_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWnFwdLds));
+      if (dev < 64) attr_devices |= 1ull << dev;
+    }
+  }
+  if (const char* path = getenv("FACPPG_WN_FWD_STAMPS")) {   // debugging aid: per-phase cycle stamps of every tile, appended to `path`
+    unsigned long long* d = nullptr;
+    const size_t n = (size_t)a.ntiles * 16;
+    FACPPG_HIP_CHECK(hipMalloc(&d, n * 8));
+    FACPPG_HIP_CHECK(hipMemsetAsync(d, 0, n * 8, s));
+    a.stamps = d;
+    k_wn_fwd<true><<<dim3(8 * per), 512, kWnFwdLds, s>>>(a);
+    std::vector<unsigned long long> h(n);
+    FACPPG_HIP_CHECK(hipMemcpyAsync(h.data(), d, n * 8, hipMemcpyDeviceToHost, s));
+    FACPPG_HIP_CHECK(hipStreamSynchronize(s));
+    FACPPG_HIP_CHECK(hipFree(d));
+    if (FILE* f = fopen(path, "a")) {
+      fprintf(f, "launch ntiles %d d %d last %d\n", a.ntiles, a.d, a.last);
+      for (int t = 0; t < a.ntiles; ++t) {
+        for (int j = 0; j < 16; ++j) fprintf(f, "%llu ", h[(size_t)t * 16 + j] ? h[(size_t)t * 16 + j] - h[(size_t)t * 16] : 0ull);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+    return FACPPG_OK;
+  }
+  k_wn_fwd<false><<<dim3(8 * per), 512, kWnFwdLds, s>>>(a);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+// One launch per layer once its tiles fill most of the chip (a tile streams ALL of the layer's weights into its CU: with few
+// tiles -- batch 3: 60 -- the two-launch layer, which deals the weight rows over four times as many workgroups, is the faster
+// one: 24 against 25 us per layer; batch 12: 60 against 32 us).  FACPPG_TRAIN_FUSED_FWD=1 / 0 forces either path (the
+// bit-equality test and A/B timing).
+bool fused_fwd_enabled(int B, int L) {
+  if (const char* e = getenv("FACPPG_TRAIN_FUSED_FWD")) return e[0] != '0';
+  return (long)((L + FN - 1) / FN) * B >= 160;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1129,9 +1444,22 @@ extern "C" int facppg_wn_forward_bf16(const facppg_wn_weights* wts, int n_in, in
   }
   const dim3 egrid((L + 3) / 4, B);
   k_t_start<<<egrid, 256, 0, s>>>(a0_dev, wts->start_w, wts->start_b, (bf16_t*)(S + st.h), n_in, L, Lp);
+  const bool fused = fused_fwd_enabled(B, L);
   for (int i = 0; i < nl; ++i) {
     const int last = i == nl - 1, d = 1 << i;
     const bf16_t* h_in = (const bf16_t*)(S + st.h + st.h_one * i);
+    if (fused) {
+      WnFwdArgs f;
+      memset(&f, 0, sizeof(f));
+      f.A1 = (const uint4*)(W + sc.w1 + sc.w1_one * i); f.A2 = (const uint4*)(W + sc.w2 + sc.w2_one * i);
+      f.h_in = h_in; f.h_out = (bf16_t*)(S + st.h + st.h_one * (i + 1)); f.h_bs = (long)Lp * C;
+      f.spect = (const bf16_t*)spect_pm_dev; f.sp_bs = (long)Lr * NCOND;
+      f.b1 = b1 + 2 * C * i; f.b2 = wts->rs_b[i];
+      f.acts = (bf16_t*)(S + st.acts + st.acts_one * i); f.ts = (bf16_t*)(S + st.ts + st.ts_one * i); f.skip = (float*)(S + st.skip);
+      f.L = L; f.Lr = Lr; f.B = B; f.d = d; f.first = i == 0; f.last = last;
+      if (int rc = wn_fwd_launch(f, s)) return rc;
+      continue;
+    }
     BGemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = (const uint4*)(W + sc.w1 + sc.w1_one * i); g.KG = K1 / 16; g.M = 2 * C; g.N = L; g.B = B; g.nseg = 4;
