@@ -94,6 +94,11 @@ __device__ __forceinline__ void gate_bias_rows(const float* __restrict__ bias, i
     bi[8 + 4 * q] = bs.x; bi[8 + 4 * q + 1] = bs.y; bi[8 + 4 * q + 2] = bs.z; bi[8 + 4 * q + 3] = bs.w;
   }
 }
+// d(tanh * sigmoid) w.r.t. the two pre-activations (shared by k_bgemm<EP_BWD_GATE> and k_wn_bwd, which agree bit for bit)
+__device__ __forceinline__ void gate_bwd(float v, float T, float S, float& dt, float& ds) {
+  dt = v * S * (1.0f - T * T);
+  ds = v * T * S * (1.0f - S);
+}
 __device__ __forceinline__ int gate_row_src(int mb, int rho) { return (rho >= 16 ? C : 0) + 16 * mb + ((rho >> 3) & 1) * 8 + (rho & 7); }
 
 constexpr int MAXPACK = 32;
@@ -192,7 +197,7 @@ __device__ __forceinline__ void bgemm_store4(const BGemmArgs& p, int b, int n, i
     const float T[4] = {lo2f(Tp.x), hi2f(Tp.x), lo2f(Tp.y), hi2f(Tp.y)}, S[4] = {lo2f(Sp.x), hi2f(Sp.x), lo2f(Sp.y), hi2f(Sp.y)};
     float dt[4], ds[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { dt[t] = v[t] * S[t] * (1.0f - T[t] * T[t]); ds[t] = v[t] * T[t] * S[t] * (1.0f - S[t]); }
+    for (int t = 0; t < 4; ++t) gate_bwd(v[t], T[t], S[t], dt[t], ds[t]);
     bf16_t* d = p.dpre + (size_t)b * p.dpre_bs + (size_t)(HALO + n) * 2 * C + ch;
     *reinterpret_cast<uint2*>(d) = make_uint2(pack2(dt[0], dt[1]), pack2(dt[2], dt[3]));
     *reinterpret_cast<uint2*>(d + C) = make_uint2(pack2(ds[0], ds[1]), pack2(ds[2], ds[3]));
@@ -382,8 +387,24 @@ int bgemm_launch(const BGemmArgs& a, hipStream_t s) {
 // of B fragments (LDS [position][k], pitch 272 B): half the LDS reads per MFMA of the 32 x 128 wave tile of k_bgemm, one
 // barrier per 128 reduction entries instead of per 64, one launch ramp per layer instead of two.
 // ------------------------------------------------------------------------------------------------------------
+// debugging aid shared by the two fused kernels: per-phase wall_clock64 stamps of every tile, appended to the file
+int dump_stamps(const char* path, const char* what, const unsigned long long* dev, int ntiles, int per_tile, int d, hipStream_t s) {
+  std::vector<unsigned long long> h((size_t)ntiles * per_tile);
+  FACPPG_HIP_CHECK(hipMemcpyAsync(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost, s));
+  FACPPG_HIP_CHECK(hipStreamSynchronize(s));
+  if (FILE* f = fopen(path, "a")) {
+    fprintf(f, "launch %s ntiles %d d %d\n", what, ntiles, d);
+    for (int t = 0; t < ntiles; ++t) {
+      for (int j = 0; j < per_tile; ++j) fprintf(f, "%llu ", h[(size_t)t * per_tile + j] ? h[(size_t)t * per_tile + j] - h[(size_t)t * per_tile] : 0ull);
+      fprintf(f, "\n");
+    }
+    fclose(f);
+  }
+  return FACPPG_OK;
+}
+
 constexpr int FN = 64, FKC = 128, FLDB = FKC + 8, FLDA = C + 8, FLDT = 2 * C + 8, FLDO = 2 * C + 4;
-constexpr size_t kWnFwdLds = (size_t)FN * FLDO * 4;   // 132 096 B: staging (34 816) -> gated + tanh|sigmoid tiles (100 352) -> fp32 res/skip tile
+// LDS of k_wn_fwd: TN * FLDO * 4 bytes: staging (TN * 544) -> gated + tanh|sigmoid tiles (TN * 1568) -> fp32 res/skip tile (TN * 2064)
 constexpr int FNCH = (3 * C + NCOND) / FKC;   // 11 chunks
 struct WnFwdArgs {
   const uint4* A1;          // gate image, KG = 88, gate-interleaved rows
@@ -396,18 +417,20 @@ struct WnFwdArgs {
   unsigned long long* stamps;   // STAMP builds only: [tile][16] wall_clock64 (100 MHz) values of wave 0
 };
 
-template <bool STAMP>
+// TN positions per tile: 64, or 32 when 64-position tiles would leave most of the chip idle (batch 3: 60 tiles)
+template <int TN, bool STAMP>
 __global__ __launch_bounds__(512) void k_wn_fwd(WnFwdArgs p) {
-  // staging [2][FN][FLDB] during the gate GEMM; then the gated tile [FN][FLDA] + tanh|sigmoid [FN][FLDT]; then fp32 [FN][FLDO]
+  constexpr int NCB = TN / 32;      // 32-position column blocks per wave
+  // staging [2][TN][FLDB] during the gate GEMM; then the gated tile [TN][FLDA] + tanh|sigmoid [TN][FLDT]; then fp32 [TN][FLDO]
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
-  static_assert(kWnFwdLds >= (size_t)2 * FN * FLDB * 2 && kWnFwdLds >= (size_t)FN * (FLDA + FLDT) * 2, "LDS phases");
+  static_assert((size_t)FLDO * 4 >= (size_t)2 * FLDB * 2 && (size_t)FLDO * 4 >= (size_t)(FLDA + FLDT) * 2, "LDS phases");
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
   // consecutive tiles (which share tap rows) go to the same XCD: workgroup lin runs on XCD lin % 8
   const int per = (p.ntiles + 7) >> 3;
   const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (tile >= p.ntiles) return;
-  const int ncol = (p.L + FN - 1) / FN;
-  const int b = tile / ncol, n0 = (tile - b * ncol) * FN;
+  const int ncol = (p.L + TN - 1) / TN;
+  const int b = tile / ncol, n0 = (tile - b * ncol) * TN;
   int stamp_i = 0;
   auto stamp = [&]() {
     if constexpr (STAMP) {
@@ -416,65 +439,73 @@ __global__ __launch_bounds__(512) void k_wn_fwd(WnFwdArgs p) {
     }
   };
   stamp();
-  const int srow = tid >> 3, sk = tid & 7;
   constexpr int KG1 = (3 * C + NCOND) / 16, KG2 = C / 16;
   const uint4* ap0 = p.A1 + (size_t)(2 * w) * KG1 * 64 + lane;
   const uint4* ap1 = ap0 + (size_t)KG1 * 64;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NCB];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     float bi[16];     // the accumulators start from the summed biases of their rows
     gate_bias_rows(p.b1, 2 * w + i, kh, bi);
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][cb][r] = bi[r];
   }
 
-  auto stage_load = [&](int c, uint4 (&stg)[2]) {
+  // staging: a chunk is TN rows of 16 sixteen-byte pieces; thread -> pieces tid + 512 j (16 lanes per row)
+  auto stage_load = [&](int c, uint4 (&stg)[NCB]) {
     c = min(c, FNCH - 1);       // the last iterations re-read the last chunk (unconditional requests, see k_bgemm)
-    const bf16_t* src;
-    if (c < 6) src = p.h_in + (size_t)b * p.h_bs + (size_t)(HALO + ((c >> 1) - 1) * p.d + n0 + srow) * C + (c & 1) * FKC + 8 * sk;
-    else src = p.spect + (size_t)b * p.sp_bs + (size_t)(n0 + srow) * NCOND + (c - 6) * FKC + 8 * sk;
-    stg[0] = nt_load16(src);
-    stg[1] = nt_load16(src + 64);
+#pragma unroll
+    for (int j = 0; j < NCB; ++j) {
+      const int e = tid + 512 * j, row = e >> 4, k8 = (e & 15) * 8;
+      const bf16_t* src;
+      if (c < 6) src = p.h_in + (size_t)b * p.h_bs + (size_t)(HALO + ((c >> 1) - 1) * p.d + n0 + row) * C + (c & 1) * FKC + k8;
+      else src = p.spect + (size_t)b * p.sp_bs + (size_t)(n0 + row) * NCOND + (c - 6) * FKC + k8;
+      stg[j] = nt_load16(src);
+    }
   };
-  auto stage_write = [&](int buf, const uint4 (&stg)[2]) {
-    bf16_t* d = lds + buf * (FN * FLDB) + srow * FLDB + 8 * sk;
-    *reinterpret_cast<uint4*>(d) = stg[0];
-    *reinterpret_cast<uint4*>(d + 64) = stg[1];
+  auto stage_write = [&](int buf, const uint4 (&stg)[NCB]) {
+#pragma unroll
+    for (int j = 0; j < NCB; ++j) {
+      const int e = tid + 512 * j;
+      *reinterpret_cast<uint4*>(lds + buf * (TN * FLDB) + (e >> 4) * FLDB + (e & 15) * 8) = stg[j];
+    }
   };
-  uint4 st[2], ar[8][2];
-  stage_load(0, st);
+  uint4 st[2][NCB], ar[8][2];     // activation chunks are requested TWO chunks ahead (register ring st[chunk & 1])
+  stage_load(0, st[0]);
 #pragma unroll
   for (int s = 0; s < 8; ++s) { ar[s][0] = ap0[(size_t)s * 64]; ar[s][1] = ap1[(size_t)s * 64]; }
-  stage_write(0, st);
-  stage_load(1, st);
+  stage_load(1, st[1]);
+  stage_write(0, st[0]);
+  stage_load(2, st[0]);
   __syncthreads();
+#pragma unroll
   for (int c = 0; c < FNCH; ++c) {
-    // chunk c+1 (requested one iteration ago) goes to the other buffer, whose last readers left through the barrier below
-    stage_write((c + 1) & 1, st);
-    stage_load(c + 2, st);
+    // chunk c+1 (requested two iterations ago) goes to the other buffer, whose last readers left through the barrier below
+    stage_write((c + 1) & 1, st[(c + 1) & 1]);
+    stage_load(c + 3, st[(c + 1) & 1]);
     __builtin_amdgcn_sched_barrier(0);   // requests stay where they are written (hipcc otherwise sinks them to the end of the iteration, next to their use)
-    const bf16_t* lb = lds + (c & 1) * (FN * FLDB) + li * FLDB + 8 * kh;
+    const bf16_t* lb = lds + (c & 1) * (TN * FLDB) + li * FLDB + 8 * kh;
     const size_t gnext = (size_t)(min(c + 1, FNCH - 1) * 8) * 64;
-    uint4 bc0 = *reinterpret_cast<const uint4*>(lb), bc1 = *reinterpret_cast<const uint4*>(lb + 32 * FLDB);
+    uint4 bc[NCB], bn[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) bc[cb] = *reinterpret_cast<const uint4*>(lb + cb * 32 * FLDB);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      uint4 bn0 = bc0, bn1 = bc1;
-      if (s < 7) {   // fragments of the next step requested before this step's MFMAs
-        bn0 = *reinterpret_cast<const uint4*>(lb + 16 * (s + 1));
-        bn1 = *reinterpret_cast<const uint4*>(lb + 32 * FLDB + 16 * (s + 1));
-      }
-      acc[0][0] = mfma_bf16(ar[s][0], bc0, acc[0][0]);
-      acc[0][1] = mfma_bf16(ar[s][0], bc1, acc[0][1]);
-      acc[1][0] = mfma_bf16(ar[s][1], bc0, acc[1][0]);
-      acc[1][1] = mfma_bf16(ar[s][1], bc1, acc[1][1]);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)   // fragments of the next step requested before this step's MFMAs
+        bn[cb] = s < 7 ? *reinterpret_cast<const uint4*>(lb + cb * 32 * FLDB + 16 * (s + 1)) : bc[cb];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[i][cb] = mfma_bf16(ar[s][i], bc[cb], acc[i][cb]);
       ar[s][0] = ap0[gnext + (size_t)s * 64];
       ar[s][1] = ap1[gnext + (size_t)s * 64];
       __builtin_amdgcn_sched_barrier(0);
-      bc0 = bn0; bc1 = bn1;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) bc[cb] = bn[cb];
     }
     __syncthreads();
     stamp();
@@ -487,32 +518,26 @@ __global__ __launch_bounds__(512) void k_wn_fwd(WnFwdArgs p) {
   uint4 a2[8][2];
 #pragma unroll
   for (int g = 0; g < 8; ++g) { a2[g][0] = rp0[(size_t)g * 64]; a2[g][1] = rp1[(size_t)g * 64]; }
-  const int nrows = min(FN, p.L - n0);    // rows >= L are never written (they stay zero)
+  const int nrows = min(TN, p.L - n0);    // rows >= L are never written (they stay zero)
   // what the second epilogue adds to, requested now: h_in rows (8 channels per piece) and the running skip sum (4 per piece)
   const size_t hrow0 = (size_t)b * p.h_bs + (size_t)(HALO + n0) * C, srow0 = ((size_t)b * p.Lr + n0) * C;
-  uint4 hin[4];
-  float4 sold[8];
+  uint4 hin[2 * NCB];
+  float4 sold[4 * NCB];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int e = tid + 512 * j;
-    hin[j] = *reinterpret_cast<const uint4*>(p.h_in + hrow0 + (size_t)e * 8);        // (rows < Lr exist; unused ones are never stored)
-  }
+  for (int j = 0; j < 2 * NCB; ++j) hin[j] = *reinterpret_cast<const uint4*>(p.h_in + hrow0 + (size_t)(tid + 512 * j) * 8);   // (rows < Lr exist; unused ones are never stored)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int e = tid + 512 * j;
-    sold[j] = *reinterpret_cast<const float4*>(p.skip + srow0 + (size_t)e * 4);
-  }
+  for (int j = 0; j < 4 * NCB; ++j) sold[j] = *reinterpret_cast<const float4*>(p.skip + srow0 + (size_t)(tid + 512 * j) * 4);
   // gate: lane holds tanh rows (acc 0..7) and the matching sigmoid rows (acc 8..15) of channels 16 mb + 8 q + 4 kh + {0..3}.
   // Everything goes to LDS tiles [position][channel] first and leaves the CU as whole rows (16 bytes per lane, a tile is ONE
   // contiguous block of acts / ts): the lane-per-position stores of 8 bytes cost 7 - 13 us per tile, more than the GEMM.
-  bf16_t* lts = lds + FN * FLDA;          // [FN][FLDT] tanh | sigmoid
+  bf16_t* lts = lds + TN * FLDA;          // [TN][FLDT] tanh | sigmoid
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int ch = 16 * (2 * w + i) + 8 * q + 4 * kh;
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
+      for (int cb = 0; cb < NCB; ++cb) {
         float T[4], S[4], a[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -531,18 +556,19 @@ __global__ __launch_bounds__(512) void k_wn_fwd(WnFwdArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
+      for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][cb][r] = 0.0f;
     const bf16_t* la = lds + li * FLDA + 8 * kh;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const uint4 b0 = *reinterpret_cast<const uint4*>(la + 16 * g);
-      const uint4 b1 = *reinterpret_cast<const uint4*>(la + 32 * FLDA + 16 * g);
-      acc[0][0] = mfma_bf16(a2[g & 7][0], b0, acc[0][0]);
-      acc[0][1] = mfma_bf16(a2[g & 7][0], b1, acc[0][1]);
-      acc[1][0] = mfma_bf16(a2[g & 7][1], b0, acc[1][0]);
-      acc[1][1] = mfma_bf16(a2[g & 7][1], b1, acc[1][1]);
+      uint4 bf[NCB];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) bf[cb] = *reinterpret_cast<const uint4*>(la + cb * 32 * FLDA + 16 * g);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[i][cb] = mfma_bf16(a2[g & 7][i], bf[cb], acc[i][cb]);
       if (g < 8) { a2[g][0] = rp0[(size_t)(g + 8) * 64]; a2[g][1] = rp1[(size_t)(g + 8) * 64]; }
     }
   }
@@ -551,17 +577,17 @@ __global__ __launch_bounds__(512) void k_wn_fwd(WnFwdArgs p) {
     bf16_t* ga = p.acts + srow0;
     bf16_t* gt = p.ts + 2 * srow0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2 * NCB; ++j) {
       const int e = tid + 512 * j, row = e >> 5, c8 = (e & 31) * 8;
       if (row < nrows) *reinterpret_cast<uint4*>(ga + (size_t)e * 8) = *reinterpret_cast<const uint4*>(lds + row * FLDA + c8);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 4 * NCB; ++j) {
       const int e = tid + 512 * j, row = e >> 6, c8 = (e & 63) * 8;
       if (row < nrows) *reinterpret_cast<uint4*>(gt + (size_t)e * 8) = *reinterpret_cast<const uint4*>(lts + row * FLDT + c8);
     }
   }
-  __syncthreads();      // every wave is through with the gated tile: the fp32 tile [FN][FLDO] of v + bias takes the LDS over
+  __syncthreads();      // every wave is through with the gated tile: the fp32 tile [TN][FLDO] of v + bias takes the LDS over
   stamp();
   float* lo = reinterpret_cast<float*>(lds);
   if (active2) {
@@ -572,7 +598,7 @@ __global__ __launch_bounds__(512) void k_wn_fwd(WnFwdArgs p) {
         const int m = 32 * (2 * w + i) + 8 * q + 4 * kh;      // rows m .. m+3 of this lane
         const float4 bb = *reinterpret_cast<const float4*>(p.b2 + m);
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < NCB; ++cb)
           *reinterpret_cast<float4*>(lo + (cb * 32 + li) * FLDO + m) =
               make_float4(acc[i][cb][4 * q] + bb.x, acc[i][cb][4 * q + 1] + bb.y, acc[i][cb][4 * q + 2] + bb.z, acc[i][cb][4 * q + 3] + bb.w);
       }
@@ -582,7 +608,7 @@ __global__ __launch_bounds__(512) void k_wn_fwd(WnFwdArgs p) {
   if (!p.last) {
     bf16_t* gh = p.h_out + hrow0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2 * NCB; ++j) {
       const int e = tid + 512 * j, row = e >> 5, c8 = (e & 31) * 8;
       if (row >= nrows) continue;
       const float4 r0 = *reinterpret_cast<const float4*>(lo + row * FLDO + c8), r1 = *reinterpret_cast<const float4*>(lo + row * FLDO + c8 + 4);
@@ -596,7 +622,7 @@ __global__ __launch_bounds__(512) void k_wn_fwd(WnFwdArgs p) {
     float* gs = p.skip + srow0;
     const int c0 = p.last ? 0 : C;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 4 * NCB; ++j) {
       const int e = tid + 512 * j, row = e >> 6, c4 = (e & 63) * 4;
       if (row >= nrows) continue;
       const float4 v = *reinterpret_cast<const float4*>(lo + row * FLDO + c0 + c4);
@@ -609,8 +635,10 @@ __global__ __launch_bounds__(512) void k_wn_fwd(WnFwdArgs p) {
   if constexpr (STAMP) { __builtin_amdgcn_s_waitcnt(0); stamp(); }
 }
 
-int wn_fwd_launch(WnFwdArgs& a, hipStream_t s) {
-  a.ntiles = ((a.L + FN - 1) / FN) * a.B;
+template <int TN>
+int wn_fwd_launch_t(WnFwdArgs& a, hipStream_t s) {
+  constexpr size_t ldsb = (size_t)TN * FLDO * 4;     // 132 096 B (64 positions) / 66 048 B (32)
+  a.ntiles = ((a.L + TN - 1) / TN) * a.B;
   const int per = (a.ntiles + 7) / 8;
   {
     // > 64 KB of dynamic LDS needs the attribute on every device the kernel runs on (see k_wgrad)
@@ -618,35 +646,32 @@ int wn_fwd_launch(WnFwdArgs& a, hipStream_t s) {
     int dev = 0;
     FACPPG_HIP_CHECK(hipGetDevice(&dev));
     if (dev >= 64 || !((attr_devices >> dev) & 1ull)) {
-      FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wn_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWnFwdLds));
-      FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wn_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWnFwdLds));
+      FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wn_fwd<TN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+      FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wn_fwd<TN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
       if (dev < 64) attr_devices |= 1ull << dev;
     }
   }
-  if (const char* path = getenv("FACPPG_WN_FWD_STAMPS")) {   // debugging aid: per-phase cycle stamps of every tile, appended to `path`
+  if (const char* path = getenv("FACPPG_WN_FWD_STAMPS")) {   // debugging aid: per-phase stamps of every tile, appended to `path`
     unsigned long long* d = nullptr;
-    const size_t n = (size_t)a.ntiles * 16;
-    FACPPG_HIP_CHECK(hipMalloc(&d, n * 8));
-    FACPPG_HIP_CHECK(hipMemsetAsync(d, 0, n * 8, s));
+    FACPPG_HIP_CHECK(hipMalloc(&d, (size_t)a.ntiles * 16 * 8));
+    FACPPG_HIP_CHECK(hipMemsetAsync(d, 0, (size_t)a.ntiles * 16 * 8, s));
     a.stamps = d;
-    k_wn_fwd<true><<<dim3(8 * per), 512, kWnFwdLds, s>>>(a);
-    std::vector<unsigned long long> h(n);
-    FACPPG_HIP_CHECK(hipMemcpyAsync(h.data(), d, n * 8, hipMemcpyDeviceToHost, s));
-    FACPPG_HIP_CHECK(hipStreamSynchronize(s));
+    k_wn_fwd<TN, true><<<dim3(8 * per), 512, ldsb, s>>>(a);
+    const int rc = dump_stamps(path, "fwd", d, a.ntiles, 16, a.d, s);
     FACPPG_HIP_CHECK(hipFree(d));
-    if (FILE* f = fopen(path, "a")) {
-      fprintf(f, "launch ntiles %d d %d last %d\n", a.ntiles, a.d, a.last);
-      for (int t = 0; t < a.ntiles; ++t) {
-        for (int j = 0; j < 16; ++j) fprintf(f, "%llu ", h[(size_t)t * 16 + j] ? h[(size_t)t * 16 + j] - h[(size_t)t * 16] : 0ull);
-        fprintf(f, "\n");
-      }
-      fclose(f);
-    }
-    return FACPPG_OK;
+    return rc;
   }
-  k_wn_fwd<false><<<dim3(8 * per), 512, kWnFwdLds, s>>>(a);
+  k_wn_fwd<TN, false><<<dim3(8 * per), 512, ldsb, s>>>(a);
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
+}
+// 64-position tiles once they give 160 workgroups, else 32-position tiles (FACPPG_TRAIN_TILE=64 / 32 forces one)
+int tile_positions(int B, int L) {
+  if (const char* e = getenv("FACPPG_TRAIN_TILE")) return atoi(e) == 32 ? 32 : 64;
+  return (long)((L + 63) / 64) * B >= 160 ? 64 : 32;
+}
+int wn_fwd_launch(WnFwdArgs& a, hipStream_t s) {
+  return tile_positions(a.B, a.L) == 64 ? wn_fwd_launch_t<64>(a, s) : wn_fwd_launch_t<32>(a, s);
 }
 // One launch per layer once its tiles fill most of the chip (a tile streams ALL of the layer's weights into its CU: with few
 // tiles -- batch 3: 60 -- the two-launch layer, which deals the weight rows over four times as many workgroups, is the faster
@@ -655,6 +680,243 @@ int wn_fwd_launch(WnFwdArgs& a, hipStream_t s) {
 bool fused_fwd_enabled(int B, int L) {
   if (const char* e = getenv("FACPPG_TRAIN_FUSED_FWD")) return e[0] != '0';
   return (long)((L + FN - 1) / FN) * B >= 160;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_wn_bwd: ONE launch per WN layer of the backward's data-gradient chain: the transposed dilated conv of layer i
+//   dh_i = dh_{i+1} + sum_tap Win_i[:, :, tap]^T dpre_i(n - (tap - 1) d)                    [256 x 1536]
+// and, on the same positions (the res/skip conv is 1 x 1), the gate backward of layer i-1
+//   dpre_{i-1} = gate'(ts_{i-1}) * Wrs_{i-1}^T [dh_i ; dskip]                              [256 x 512]
+// with the dh_i tile handed over in LDS -- the two launches k_bgemm<EP_BWD_CONV>(i), k_bgemm<EP_BWD_GATE>(i-1) of the
+// layer loop, same operand images, same K order, same bits.  Shape as k_wn_fwd: tiles of FN positions, 8 waves x 32 rows,
+// A fragments from global through a register ring one 128-entry chunk ahead, B operand through LDS.  What the epilogues
+// add to / multiply with (dh_{i+1}, tanh | sigmoid of layer i-1) is brought into LDS as whole rows at the start, updated
+// IN PLACE by the lanes that own the cells, and leaves as whole rows.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int BNCH = 3 * 2 * C / FKC;   // 12 chunks
+struct WnBwdArgs {
+  const uint4* A1;          // layer i: Win^T image, M = 256, KG = 96 (tap-major)
+  const uint4* A2;          // layer i-1: Wrs^T image, M = 256, KG = 32 (res rows | skip rows)
+  const bf16_t* dpre_i; long dpre_bs;      // [B][HALO + Lr + HALO][512]
+  const bf16_t* dh_next;                   // dh_{i+1} [B][Lr][256]; null for the last layer
+  bf16_t* dh_out;                          // dh_i
+  const bf16_t* dskip;                     // [B][Lr][256]
+  const bf16_t* ts;                        // layer i-1 [B][Lr][512]
+  bf16_t* dpre_out;                        // dpre_{i-1}
+  int L, Lr, B, d, ntiles;
+  unsigned long long* stamps;   // STAMP builds only
+};
+
+template <int TN, bool STAMP>
+__global__ __launch_bounds__(512) void k_wn_bwd(WnBwdArgs p) {
+  constexpr int NCB = TN / 32;
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+  bf16_t* const ldh = lds + 2 * TN * FLDB;     // [TN][FLDA]: dh_{i+1} -> dh_i
+  bf16_t* const lts = ldh + TN * FLDA;         // [TN][FLDT]: tanh | sigmoid -> dpre_{i-1}
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
+  const int per = (p.ntiles + 7) >> 3;
+  const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (tile >= p.ntiles) return;
+  const int ncol = (p.L + TN - 1) / TN;
+  const int b = tile / ncol, n0 = (tile - b * ncol) * TN;
+  const int nrows = min(TN, p.L - n0);
+  int stamp_i = 0;
+  auto stamp = [&]() {
+    if constexpr (STAMP) {
+      if (tid == 0) p.stamps[(size_t)tile * 24 + stamp_i] = wall_clock64();
+      ++stamp_i;
+    }
+  };
+  stamp();
+  constexpr int KG1 = 3 * 2 * C / 16, KG2 = 2 * C / 16;
+  const uint4* ap = p.A1 + (size_t)w * KG1 * 64 + lane;
+  const size_t srow0 = ((size_t)b * p.Lr + n0) * C;
+
+  f32x16 acc[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+
+  auto stage_load = [&](int c, uint4 (&stg)[NCB]) {      // pieces tid + 512 j of the chunk's TN rows x 16 sixteen-byte pieces
+    c = min(c, BNCH - 1);
+#pragma unroll
+    for (int j = 0; j < NCB; ++j) {
+      const int e = tid + 512 * j;
+      stg[j] = nt_load16(p.dpre_i + (size_t)b * p.dpre_bs + (size_t)(HALO - ((c >> 2) - 1) * p.d + n0 + (e >> 4)) * (2 * C) + (c & 3) * FKC + (e & 15) * 8);
+    }
+  };
+  auto stage_write = [&](int buf, const uint4 (&stg)[NCB]) {
+#pragma unroll
+    for (int j = 0; j < NCB; ++j) {
+      const int e = tid + 512 * j;
+      *reinterpret_cast<uint4*>(lds + buf * (TN * FLDB) + (e >> 4) * FLDB + (e & 15) * 8) = stg[j];
+    }
+  };
+  uint4 st[2][NCB], ar[8];
+  stage_load(0, st[0]);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) ar[s] = ap[(size_t)s * 64];
+  {
+    // whole rows of dh_{i+1} and of layer i-1's tanh | sigmoid (HBM reads: written a forward pass ago) into their LDS tiles, here in the
+    // prologue: 4.7 - 6.5 us before the first MFMA instead of 1.6, but vmcnt retires in order -- requested inside the chunk loop every
+    // weight fragment requested after them waits for them (measured: + 3 us per tile mid-loop, + 9 us from the last chunk)
+    const bf16_t* dn = p.dh_next ? p.dh_next : p.dskip;
+    uint4 pd[2 * NCB], pt[4 * NCB];
+#pragma unroll
+    for (int j = 0; j < 2 * NCB; ++j) pd[j] = *reinterpret_cast<const uint4*>(dn + srow0 + (size_t)(tid + 512 * j) * 8);
+#pragma unroll
+    for (int j = 0; j < 4 * NCB; ++j) pt[j] = *reinterpret_cast<const uint4*>(p.ts + 2 * srow0 + (size_t)(tid + 512 * j) * 8);
+    stage_load(1, st[1]);
+    stage_write(0, st[0]);
+    stage_load(2, st[0]);
+#pragma unroll
+    for (int j = 0; j < 2 * NCB; ++j) {
+      const int e = tid + 512 * j;
+      *reinterpret_cast<uint4*>(ldh + (e >> 5) * FLDA + (e & 31) * 8) = p.dh_next ? pd[j] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4 * NCB; ++j) {
+      const int e = tid + 512 * j;
+      *reinterpret_cast<uint4*>(lts + (e >> 6) * FLDT + (e & 63) * 8) = pt[j];
+    }
+  }
+  __syncthreads();
+  stamp();
+#pragma unroll
+  for (int c = 0; c < BNCH; ++c) {
+    stage_write((c + 1) & 1, st[(c + 1) & 1]);
+    stage_load(c + 3, st[(c + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16_t* lb = lds + (c & 1) * (TN * FLDB) + li * FLDB + 8 * kh;
+    const size_t gnext = (size_t)(min(c + 1, BNCH - 1) * 8) * 64;
+    uint4 bc[NCB], bn[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) bc[cb] = *reinterpret_cast<const uint4*>(lb + cb * 32 * FLDB);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) bn[cb] = s < 7 ? *reinterpret_cast<const uint4*>(lb + cb * 32 * FLDB + 16 * (s + 1)) : bc[cb];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma_bf16(ar[s], bc[cb], acc[cb]);
+      ar[s] = ap[gnext + (size_t)s * 64];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) bc[cb] = bn[cb];
+    }
+    __syncthreads();
+    stamp();
+  }
+  // second GEMM's image (first half of its reduction) and the dskip rows, requested ahead of the first epilogue
+  const uint4* rp = p.A2 + (size_t)w * KG2 * 64 + lane;
+  uint4 a2[16], dsk[2 * NCB];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) a2[g] = rp[(size_t)g * 64];
+#pragma unroll
+  for (int j = 0; j < 2 * NCB; ++j) dsk[j] = *reinterpret_cast<const uint4*>(p.dskip + srow0 + (size_t)(tid + 512 * j) * 8);
+  // dh_i = dh_{i+1} + v, in place: lane (li, kh) owns rows 32 w + 8 q + 4 kh + {0..3} at positions 32 cb + li
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      uint2* cell = reinterpret_cast<uint2*>(ldh + (cb * 32 + li) * FLDA + 32 * w + 8 * q + 4 * kh);
+      const uint2 dn = *cell;
+      *cell = make_uint2(pack2(acc[cb][4 * q] + lo2f(dn.x), acc[cb][4 * q + 1] + hi2f(dn.x)),
+                         pack2(acc[cb][4 * q + 2] + lo2f(dn.y), acc[cb][4 * q + 3] + hi2f(dn.y)));
+    }
+  bf16_t* const lsk = lds;                     // [TN][FLDA] dskip rows, over the staging buffers (their readers are through the loop's last barrier)
+#pragma unroll
+  for (int j = 0; j < 2 * NCB; ++j) {
+    const int e = tid + 512 * j;
+    *reinterpret_cast<uint4*>(lsk + (e >> 5) * FLDA + (e & 31) * 8) = dsk[j];
+  }
+  __syncthreads();
+  stamp();
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+#pragma unroll
+  for (int g = 0; g < 32; ++g) {
+    const bf16_t* lt = (g < 16 ? ldh : lsk) + li * FLDA + 8 * kh + 16 * (g & 15);
+    uint4 bf[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) bf[cb] = *reinterpret_cast<const uint4*>(lt + cb * 32 * FLDA);
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma_bf16(a2[g & 15], bf[cb], acc[cb]);
+    if (g < 16) a2[g] = rp[(size_t)(g + 16) * 64];
+  }
+  stamp();
+  // dh_i leaves as whole rows (its tile is complete since the barrier above)
+#pragma unroll
+  for (int j = 0; j < 2 * NCB; ++j) {
+    const int e = tid + 512 * j, row = e >> 5;
+    if (row < nrows) *reinterpret_cast<uint4*>(p.dh_out + srow0 + (size_t)e * 8) = *reinterpret_cast<const uint4*>(ldh + row * FLDA + (e & 31) * 8);
+  }
+  // gate backward in place: tanh | sigmoid cells of this lane -> d tanh-pre | d sigmoid-pre
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      uint2* cT = reinterpret_cast<uint2*>(lts + (cb * 32 + li) * FLDT + 32 * w + 8 * q + 4 * kh);
+      uint2* cS = reinterpret_cast<uint2*>(lts + (cb * 32 + li) * FLDT + C + 32 * w + 8 * q + 4 * kh);
+      const uint2 Tp = *cT, Sp = *cS;
+      const float T[4] = {lo2f(Tp.x), hi2f(Tp.x), lo2f(Tp.y), hi2f(Tp.y)}, S[4] = {lo2f(Sp.x), hi2f(Sp.x), lo2f(Sp.y), hi2f(Sp.y)};
+      float dt[4], ds[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) gate_bwd(acc[cb][4 * q + t], T[t], S[t], dt[t], ds[t]);
+      *cT = make_uint2(pack2(dt[0], dt[1]), pack2(dt[2], dt[3]));
+      *cS = make_uint2(pack2(ds[0], ds[1]), pack2(ds[2], ds[3]));
+    }
+  __syncthreads();
+  stamp();
+  bf16_t* gp = p.dpre_out + (size_t)b * p.dpre_bs + (size_t)(HALO + n0) * (2 * C);
+#pragma unroll
+  for (int j = 0; j < 4 * NCB; ++j) {
+    const int e = tid + 512 * j, row = e >> 6;
+    if (row < nrows) *reinterpret_cast<uint4*>(gp + (size_t)e * 8) = *reinterpret_cast<const uint4*>(lts + row * FLDT + (e & 63) * 8);
+  }
+  if constexpr (STAMP) { __builtin_amdgcn_s_waitcnt(0); stamp(); }
+}
+
+template <int TN>
+int wn_bwd_launch_t(WnBwdArgs& a, hipStream_t s) {
+  constexpr size_t ldsb = ((size_t)2 * TN * FLDB + (size_t)TN * FLDA + (size_t)TN * FLDT) * 2;   // 135 168 B (64 positions) / 67 584 B (32)
+  a.ntiles = ((a.L + TN - 1) / TN) * a.B;
+  const int per = (a.ntiles + 7) / 8;
+  {
+    static unsigned long long attr_devices = 0;
+    int dev = 0;
+    FACPPG_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 64 || !((attr_devices >> dev) & 1ull)) {
+      FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wn_bwd<TN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+      FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wn_bwd<TN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+      if (dev < 64) attr_devices |= 1ull << dev;
+    }
+  }
+  if (const char* path = getenv("FACPPG_WN_BWD_STAMPS")) {
+    unsigned long long* d = nullptr;
+    FACPPG_HIP_CHECK(hipMalloc(&d, (size_t)a.ntiles * 24 * 8));
+    FACPPG_HIP_CHECK(hipMemsetAsync(d, 0, (size_t)a.ntiles * 24 * 8, s));
+    a.stamps = d;
+    k_wn_bwd<TN, true><<<dim3(8 * per), 512, ldsb, s>>>(a);
+    const int rc = dump_stamps(path, "bwd", d, a.ntiles, 24, a.d, s);
+    FACPPG_HIP_CHECK(hipFree(d));
+    return rc;
+  }
+  k_wn_bwd<TN, false><<<dim3(8 * per), 512, ldsb, s>>>(a);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+int wn_bwd_launch(WnBwdArgs& a, hipStream_t s) {
+  return tile_positions(a.B, a.L) == 64 ? wn_bwd_launch_t<64>(a, s) : wn_bwd_launch_t<32>(a, s);
+}
+// FACPPG_TRAIN_FUSED_BWD=1 / 0 forces either path.  The backward pair is worth one launch much earlier than the forward pair (its
+// tiles stream 1 MB of weights, not 1.7, and the two launches it replaces are the more latency-bound ones): batch 3 (60 tiles)
+// 21 us against 10.6 + 14.9.
+bool fused_bwd_enabled(int B, int L) {
+  if (const char* e = getenv("FACPPG_TRAIN_FUSED_BWD")) return e[0] != '0';
+  return (long)((L + FN - 1) / FN) * B >= 40;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1533,23 +1795,49 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
     k_small_wgrad_sum<<<dim3(C / 16, 9), 256, 0, s>>>(part, SMALL_PARTS, nout, gr->end_w, C, 1, nullptr);
     k_small_rowsum<<<nout, 256, 0, s>>>(dout_dev, gr->end_b, nout, B, L);
   }
-  for (int i = nl - 1; i >= 0; --i) {
-    const int last = i == nl - 1, d = 1 << i;
-    bf16_t* dpre = (bf16_t*)(W + sc.dpre + sc.dpre_one * i);
+  const bool fused = fused_bwd_enabled(B, L);
+  auto gate_bwd_launch = [&](int i) -> int {      // dpre_i = gate'(ts_i) * Wrs_i^T [dh_{i+1} ; dskip]
+    const int last = i == nl - 1;
     const bf16_t* dh_next = (const bf16_t*)(W + sc.dh + sc.dh_one * (i + 1));
     BGemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = (const uint4*)(W + sc.rst + sc.rst_one * i); g.KG = (last ? C : 2 * C) / 16; g.M = C; g.N = L; g.B = B;
     if (last) { g.nseg = 1; g.seg[0] = Seg{dskip, (long)Lr * C, C, 0, C}; }
     else { g.nseg = 2; g.seg[0] = Seg{dh_next, (long)Lr * C, C, 0, C}; g.seg[1] = Seg{dskip, (long)Lr * C, C, 0, C}; }
-    g.mode = EP_BWD_GATE; g.Lr = Lr; g.ts = (bf16_t*)(S + st.ts + st.ts_one * i); g.dpre = dpre; g.dpre_bs = (long)Lp * 2 * C;
-    if (int rc = bgemm_launch(g, s)) return rc;
+    g.mode = EP_BWD_GATE; g.Lr = Lr; g.ts = (bf16_t*)(S + st.ts + st.ts_one * i); g.dpre = (bf16_t*)(W + sc.dpre + sc.dpre_one * i);
+    g.dpre_bs = (long)Lp * 2 * C;
+    return bgemm_launch(g, s);
+  };
+  auto conv_bwd_launch = [&](int i) -> int {      // dh_i = dh_{i+1} + sum_tap Win_i^T dpre_i(shifted)
+    const int last = i == nl - 1, d = 1 << i;
+    const bf16_t* dpre = (const bf16_t*)(W + sc.dpre + sc.dpre_one * i);
     BGemmArgs t;
     memset(&t, 0, sizeof(t));
     t.A = (const uint4*)(W + sc.int_ + sc.int_one * i); t.KG = 3 * 2 * C / 16; t.M = C; t.N = L; t.B = B; t.nseg = 3;
     for (int tp = 0; tp < 3; ++tp) t.seg[tp] = Seg{dpre, (long)Lp * 2 * C, 2 * C, HALO - (tp - 1) * d, 2 * C};
-    t.mode = EP_BWD_CONV; t.Lr = Lr; t.dh_next = last ? nullptr : dh_next; t.dh_out = (bf16_t*)(W + sc.dh + sc.dh_one * i);
-    if (int rc = bgemm_launch(t, s)) return rc;
+    t.mode = EP_BWD_CONV; t.Lr = Lr; t.dh_next = last ? nullptr : (const bf16_t*)(W + sc.dh + sc.dh_one * (i + 1));
+    t.dh_out = (bf16_t*)(W + sc.dh + sc.dh_one * i);
+    return bgemm_launch(t, s);
+  };
+  if (fused && nl > 1) {
+    if (int rc = gate_bwd_launch(nl - 1)) return rc;
+    for (int i = nl - 1; i >= 1; --i) {           // conv backward of layer i + gate backward of layer i-1 in one launch
+      WnBwdArgs f;
+      memset(&f, 0, sizeof(f));
+      f.A1 = (const uint4*)(W + sc.int_ + sc.int_one * i); f.A2 = (const uint4*)(W + sc.rst + sc.rst_one * (i - 1));
+      f.dpre_i = (const bf16_t*)(W + sc.dpre + sc.dpre_one * i); f.dpre_bs = (long)Lp * 2 * C;
+      f.dh_next = i == nl - 1 ? nullptr : (const bf16_t*)(W + sc.dh + sc.dh_one * (i + 1));
+      f.dh_out = (bf16_t*)(W + sc.dh + sc.dh_one * i); f.dskip = dskip;
+      f.ts = (const bf16_t*)(S + st.ts + st.ts_one * (i - 1)); f.dpre_out = (bf16_t*)(W + sc.dpre + sc.dpre_one * (i - 1));
+      f.L = L; f.Lr = Lr; f.B = B; f.d = 1 << i;
+      if (int rc = wn_bwd_launch(f, s)) return rc;
+    }
+    if (int rc = conv_bwd_launch(0)) return rc;
+  } else {
+    for (int i = nl - 1; i >= 0; --i) {
+      if (int rc = gate_bwd_launch(i)) return rc;
+      if (int rc = conv_bwd_launch(i)) return rc;
+    }
   }
   {  // dspect over all layers at once
     BGemmArgs c;
