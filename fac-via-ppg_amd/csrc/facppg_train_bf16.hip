@@ -379,7 +379,7 @@ int bgemm_launch(const BGemmArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------------------
 // k_wn_fwd: ONE launch per WN layer of the training forward (glow.py:160-173): gate GEMM [512 x 1408] -> tanh * sigmoid
-// -> res/skip GEMM [512 x 256] for a tile of FN positions, the gated tile handed over in LDS.  Same operand images, same
+// -> res/skip GEMM [512 x 256] for a tile of TN (64 or 32) positions, the gated tile handed over in LDS.  Same operand images, same
 // K order (tap 0 | tap 1 | tap 2 | cond) and the same 16-entry MFMA steps as k_bgemm<EP_GATE> followed by
 // k_bgemm<EP_RESSKIP>, so every stored value (acts, ts, h_out, skip) has the SAME BITS as the two-launch path
 // (tests/test_gpu_train_bf16.py).  Shape: 8 waves, wave w owns gate row blocks 2w, 2w+1 (channels 32w .. 32w+31, both halves) x
@@ -403,7 +403,7 @@ int dump_stamps(const char* path, const char* what, const unsigned long long* de
   return FACPPG_OK;
 }
 
-constexpr int FN = 64, FKC = 128, FLDB = FKC + 8, FLDA = C + 8, FLDT = 2 * C + 8, FLDO = 2 * C + 4;
+constexpr int FKC = 128, FLDB = FKC + 8, FLDA = C + 8, FLDT = 2 * C + 8, FLDO = 2 * C + 4;
 // LDS of k_wn_fwd: TN * FLDO * 4 bytes: staging (TN * 544) -> gated + tanh|sigmoid tiles (TN * 1568) -> fp32 res/skip tile (TN * 2064)
 constexpr int FNCH = (3 * C + NCOND) / FKC;   // 11 chunks
 struct WnFwdArgs {
@@ -674,12 +674,12 @@ int wn_fwd_launch(WnFwdArgs& a, hipStream_t s) {
   return tile_positions(a.B, a.L) == 64 ? wn_fwd_launch_t<64>(a, s) : wn_fwd_launch_t<32>(a, s);
 }
 // One launch per layer once its tiles fill most of the chip (a tile streams ALL of the layer's weights into its CU: with few
-// tiles -- batch 3: 60 -- the two-launch layer, which deals the weight rows over four times as many workgroups, is the faster
-// one: 24 against 25 us per layer; batch 12: 60 against 32 us).  FACPPG_TRAIN_FUSED_FWD=1 / 0 forces either path (the
-// bit-equality test and A/B timing).
+// tiles the two-launch layer, which deals the weight rows over four times as many workgroups, is as fast or faster).  Measured,
+// whole step, segment 10 000: batch 3 (120 tiles of 32 positions) 10.25 ms fused / 10.20 two launches; batch 6 (240 of 32) 12.7 /
+// 13.6; batch 12 (240 of 64) 18.5 / 20.4.  FACPPG_TRAIN_FUSED_FWD=1 / 0 forces either path (the bit-equality test and A/B timing).
 bool fused_fwd_enabled(int B, int L) {
   if (const char* e = getenv("FACPPG_TRAIN_FUSED_FWD")) return e[0] != '0';
-  return (long)((L + FN - 1) / FN) * B >= 160;
+  return (long)((L + 31) / 32) * B >= 160;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -688,7 +688,7 @@ bool fused_fwd_enabled(int B, int L) {
 // and, on the same positions (the res/skip conv is 1 x 1), the gate backward of layer i-1
 //   dpre_{i-1} = gate'(ts_{i-1}) * Wrs_{i-1}^T [dh_i ; dskip]                              [256 x 512]
 // with the dh_i tile handed over in LDS -- the two launches k_bgemm<EP_BWD_CONV>(i), k_bgemm<EP_BWD_GATE>(i-1) of the
-// layer loop, same operand images, same K order, same bits.  Shape as k_wn_fwd: tiles of FN positions, 8 waves x 32 rows,
+// layer loop, same operand images, same K order, same bits.  Shape as k_wn_fwd: tiles of TN positions, 8 waves x 32 rows,
 // A fragments from global through a register ring one 128-entry chunk ahead, B operand through LDS.  What the epilogues
 // add to / multiply with (dh_{i+1}, tanh | sigmoid of layer i-1) is brought into LDS as whole rows at the start, updated
 // IN PLACE by the lanes that own the cells, and leaves as whole rows.
@@ -912,11 +912,11 @@ int wn_bwd_launch(WnBwdArgs& a, hipStream_t s) {
   return tile_positions(a.B, a.L) == 64 ? wn_bwd_launch_t<64>(a, s) : wn_bwd_launch_t<32>(a, s);
 }
 // FACPPG_TRAIN_FUSED_BWD=1 / 0 forces either path.  The backward pair is worth one launch much earlier than the forward pair (its
-// tiles stream 1 MB of weights, not 1.7, and the two launches it replaces are the more latency-bound ones): batch 3 (60 tiles)
-// 21 us against 10.6 + 14.9.
+// tiles stream 1 MB of weights, not 1.7, and the two launches it replaces are the more latency-bound ones): batch 3, whole step,
+// 10.8 ms two launches / 10.5 fused with 64-position tiles / 10.2 with 32.
 bool fused_bwd_enabled(int B, int L) {
   if (const char* e = getenv("FACPPG_TRAIN_FUSED_BWD")) return e[0] != '0';
-  return (long)((L + FN - 1) / FN) * B >= 40;
+  return (long)((L + 31) / 32) * B >= 40;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -938,6 +938,7 @@ struct WgradArgs {
   WgradProb prob[MAXPROB];
   int B, L, Lr;
   size_t pstride;    // floats per (problem, split) partial = max M * max K of the batch
+  int xcd_map, tiles_k, tiles_m, ngroups;   // XCD-aware workgroup order (k_wgrad)
   int nsplit;        // the B * ceil(L/64) position chunks are dealt to nsplit workgroups per output tile ...
   float* part;       // ... which leave partial sums [prob][split][M][K] here (nsplit > 1); k_wgrad_reduce adds them in order
 };
@@ -960,9 +961,20 @@ __device__ __forceinline__ void transpose8x8(const uint4 (&r)[8], uint4 (&t)[8])
 __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
   extern __shared__ __attribute__((aligned(16))) bf16_t lds_dyn[];      // [buffer][A | B][channel][position], double-buffered: one barrier per chunk
   bf16_t (*lds)[2][128 * LDP] = reinterpret_cast<bf16_t (*)[2][128 * LDP]>(lds_dyn);
-  const int pi = blockIdx.z / wa.nsplit, split = blockIdx.z - pi * wa.nsplit;
+  // The output tiles of one (problem, split) read the SAME position range of dY and X: they are dealt to ONE XCD back to back
+  // (workgroup lin runs on XCD lin % 8), so that XCD's L2 fetches the rows once; groups go round the XCDs.
+  int pi, split, m0, k0;
+  if (wa.xcd_map) {
+    const int tg = wa.tiles_k * wa.tiles_m, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int grp = (j / tg) * 8 + x, t = j % tg;
+    if (grp >= wa.ngroups) return;
+    pi = grp / wa.nsplit; split = grp - pi * wa.nsplit;
+    k0 = (t % wa.tiles_k) * 128; m0 = (t / wa.tiles_k) * 128;
+  } else {
+    pi = blockIdx.z / wa.nsplit; split = blockIdx.z - pi * wa.nsplit;
+    m0 = blockIdx.y * 128; k0 = blockIdx.x * 128;
+  }
   const WgradProb& p = wa.prob[pi];
-  const int m0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
   if (m0 >= p.M || k0 >= p.K) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
   const int wm = w >> 1, wk = w & 1;
@@ -1096,7 +1108,12 @@ int wgrad_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size
       if (dev < 64) attr_devices |= 1ull << dev;
     }
   }
-  k_wgrad<<<dim3((maxK + 127) / 128, (maxM + 127) / 128, nprob * ns), 256, kWgradLds, s>>>(wa);
+  {
+    static const bool no_map = [] { const char* e = getenv("FACPPG_WGRAD_NO_XCD_MAP"); return e && e[0] == '1'; }();
+    wa.tiles_k = (maxK + 127) / 128; wa.tiles_m = (maxM + 127) / 128; wa.ngroups = nprob * ns; wa.xcd_map = no_map ? 0 : 1;
+    if (wa.xcd_map) k_wgrad<<<dim3(8 * ((wa.ngroups + 7) / 8) * wa.tiles_k * wa.tiles_m), 256, kWgradLds, s>>>(wa);
+    else k_wgrad<<<dim3(wa.tiles_k, wa.tiles_m, nprob * ns), 256, kWgradLds, s>>>(wa);
+  }
   if (ns > 1) k_wgrad_reduce<<<dim3((maxM * maxK + 255) / 256, nprob), 256, 0, s>>>(wa);
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
