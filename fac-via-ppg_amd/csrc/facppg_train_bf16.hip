@@ -920,6 +920,131 @@ bool fused_bwd_enabled(int B, int L) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_dspect: the conditioning gradient of one flow, dspect[b][n][j] (+)= sum_i sum_o Wcond_i[o][j] * dpre_i[b][n][o]
+// ([640 x nl*512] x positions), fp32 out.  Same program shape as k_wn_bwd's first GEMM: a workgroup owns 64 positions and HALF of
+// the 640 output channels -- 10 waves x 32 rows, A fragments of the `condt` image from L2 through a register ring one
+// 128-entry chunk ahead, the dpre rows two chunks ahead through LDS -- and the fp32 tile leaves through LDS as whole rows
+// (1 280 contiguous bytes per position).  Replaces k_bgemm<EP_ACC_F32> here (128 x 128 tiles, 4 waves, lane-per-position
+// float4 read-modify-writes): 136 -> see DESIGN.md us per flow at batch 12.  Same K order, same bits.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int DLDO = NCOND / 2 + 4;     // fp32 tile pitch
+constexpr size_t kDspectLds = (size_t)64 * DLDO * 4;   // 82 944 B (staging 34 816 B first)
+struct DspectArgs {
+  const uint4* A;                  // condt image: M = 640, KG = nl * 32
+  const bf16_t* dpre; long dpre_one, dpre_bs;   // layer i at dpre + i * dpre_one (elements); [B][HALO + Lr + HALO][512]
+  float* out;                      // [B][Lr][640]
+  int nl, L, Lr, B, accumulate, ntiles;
+};
+__global__ __launch_bounds__(640) void k_dspect(DspectArgs p) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+  constexpr int TN = 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
+  // (row half, position tile): the two halves of a position tile are neighbours on one XCD (they read the same dpre rows)
+  const int per = (p.ntiles + 7) >> 3;
+  const int t2 = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (t2 >= p.ntiles) return;
+  const int mt = t2 & 1, tile = t2 >> 1;
+  const int ncol = (p.L + TN - 1) / TN;
+  const int b = tile / ncol, n0 = (tile - b * ncol) * TN;
+  const int nrows = min(TN, p.L - n0);
+  const int KG = p.nl * (2 * C / 16), nch = p.nl * (2 * C / FKC);
+  const uint4* ap = p.A + (size_t)(10 * mt + w) * KG * 64 + lane;
+  const int st_t = tid & 511;       // waves 8 and 9 repeat the pieces of waves 0 and 1 (same values to the same cells): no branch round a request
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+  auto stage_load = [&](int c, uint4 (&stg)[2]) {
+    c = min(c, nch - 1);
+    const bf16_t* base = p.dpre + (size_t)(c >> 2) * p.dpre_one + (size_t)b * p.dpre_bs + (size_t)(HALO + n0) * (2 * C) + (c & 3) * FKC;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = st_t + 512 * j;
+      stg[j] = nt_load16(base + (size_t)(e >> 4) * (2 * C) + (e & 15) * 8);
+    }
+  };
+  auto stage_write = [&](int buf, const uint4 (&stg)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = st_t + 512 * j;
+      *reinterpret_cast<uint4*>(lds + buf * (TN * FLDB) + (e >> 4) * FLDB + (e & 15) * 8) = stg[j];
+    }
+  };
+  uint4 st[2][2], ar[8];
+  stage_load(0, st[0]);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) ar[s] = ap[(size_t)s * 64];
+  stage_load(1, st[1]);
+  stage_write(0, st[0]);
+  stage_load(2, st[0]);
+  __syncthreads();
+  auto chunk = [&](int c, uint4 (&stn)[2]) {
+    stage_write((c + 1) & 1, stn);
+    stage_load(c + 3, stn);
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16_t* lb = lds + (c & 1) * (TN * FLDB) + li * FLDB + 8 * kh;
+    const size_t gnext = (size_t)(min(c + 1, nch - 1) * 8) * 64;
+    uint4 bc[2], bn[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) bc[cb] = *reinterpret_cast<const uint4*>(lb + cb * 32 * FLDB);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) bn[cb] = s < 7 ? *reinterpret_cast<const uint4*>(lb + cb * 32 * FLDB + 16 * (s + 1)) : bc[cb];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) acc[cb] = mfma_bf16(ar[s], bc[cb], acc[cb]);
+      ar[s] = ap[gnext + (size_t)s * 64];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) bc[cb] = bn[cb];
+    }
+    __syncthreads();
+  };
+  for (int c = 0; c < nch; c += 2) {     // (nch = 4 nl is even; the register ring of the staged rows is indexed statically)
+    chunk(c, st[1]);
+    chunk(c + 1, st[0]);
+  }
+  // fp32 tile [position][row of this half] over the staging buffers, then whole rows out
+  float* lo = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+      *reinterpret_cast<float4*>(lo + (cb * 32 + li) * DLDO + 32 * w + 8 * q + 4 * kh) =
+          make_float4(acc[cb][4 * q], acc[cb][4 * q + 1], acc[cb][4 * q + 2], acc[cb][4 * q + 3]);
+  __syncthreads();
+  float* go = p.out + ((size_t)b * p.Lr + n0) * NCOND + (NCOND / 2) * mt;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int e = tid + 640 * j, row = e / (NCOND / 8), c4 = (e - row * (NCOND / 8)) * 4;
+    if (row >= nrows) continue;
+    float4* dst = reinterpret_cast<float4*>(go + (size_t)row * NCOND + c4);
+    const float4 v = *reinterpret_cast<const float4*>(lo + row * DLDO + c4);
+    float4 o = p.accumulate ? *dst : make_float4(0.f, 0.f, 0.f, 0.f);
+    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+    *dst = o;
+  }
+}
+int dspect_launch(DspectArgs& a, hipStream_t s) {
+  a.ntiles = 2 * ((a.L + 63) / 64) * a.B;
+  const int per = (a.ntiles + 7) / 8;
+  {
+    static unsigned long long attr_devices = 0;
+    int dev = 0;
+    FACPPG_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 64 || !((attr_devices >> dev) & 1ull)) {
+      FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_dspect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDspectLds));
+      if (dev < 64) attr_devices |= 1ull << dev;
+    }
+  }
+  k_dspect<<<dim3(8 * per), 640, kDspectLds, s>>>(a);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // k_wgrad: out[m][k] = sum_{b, n < L} dY[b][n][m] * X[b][n + shift][k]   (fp32 out), batched over problems
 // (layers x taps) in blockIdx.z.  128 x 128 output tiles, 4 waves as 2 x 2 (64 x 64 each), 64 positions per
 // chunk; both operands are position-major in memory and are transposed 8 x 8 in registers on their way to the
@@ -1856,7 +1981,14 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
       if (int rc = conv_bwd_launch(i)) return rc;
     }
   }
-  {  // dspect over all layers at once
+  const char* e_ds = getenv("FACPPG_TRAIN_DSPECT_BGEMM");     // =1: the k_bgemm<EP_ACC_F32> launch (bit-equality test, A/B timing)
+  if (!(e_ds && e_ds[0] == '1')) {  // dspect over all layers at once
+    DspectArgs c;
+    memset(&c, 0, sizeof(c));
+    c.A = condt; c.dpre = (const bf16_t*)(W + sc.dpre); c.dpre_one = (long)(sc.dpre_one / 2); c.dpre_bs = (long)Lp * 2 * C;
+    c.out = dspect_pm_dev; c.nl = nl; c.L = L; c.Lr = Lr; c.B = B; c.accumulate = accumulate_dspect != 0;
+    if (int rc = dspect_launch(c, s)) return rc;
+  } else {
     BGemmArgs c;
     memset(&c, 0, sizeof(c));
     c.A = condt; c.KG = nl * 2 * C / 16; c.M = NCOND; c.N = L; c.B = B; c.nseg = nl;
