@@ -1064,6 +1064,7 @@ struct WgradArgs {
   int B, L, Lr;
   size_t pstride;    // floats per (problem, split) partial = max M * max K of the batch
   int xcd_map, tiles_k, tiles_m, ngroups;   // XCD-aware workgroup order (k_wgrad)
+  unsigned long long* stamps;               // debugging aid (FACPPG_WGRAD_STAMPS): [workgroup < 64][24] wall_clock64 values of thread 0
   int nsplit;        // the B * ceil(L/64) position chunks are dealt to nsplit workgroups per output tile ...
   float* part;       // ... which leave partial sums [prob][split][M][K] here (nsplit > 1); k_wgrad_reduce adds them in order
 };
@@ -1083,6 +1084,7 @@ __device__ __forceinline__ void transpose8x8(const uint4 (&r)[8], uint4 (&t)[8])
     }
 }
 
+template <bool STAMP>
 __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
   extern __shared__ __attribute__((aligned(16))) bf16_t lds_dyn[];      // [buffer][A | B][channel][position], double-buffered: one barrier per chunk
   bf16_t (*lds)[2][128 * LDP] = reinterpret_cast<bf16_t (*)[2][128 * LDP]>(lds_dyn);
@@ -1142,17 +1144,26 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   const int la_row = (64 * wm + li) * LDP, lb_row = (64 * wk + li) * LDP;
-  uint4 st0[8], st1[8];
+  // the rows of a chunk come from HBM or another tile's L2 lines and a chunk needs ALL of its 8 requests per thread: requested
+  // two chunks ahead the loop ran at the latency of its slowest request (0.88 us per chunk of 0.21 us of MFMA work, in-kernel
+  // stamps); the register ring is WG_PD chunks deep
+  constexpr int WG_PD = 2;     // 4 measured: the first workgroups of a launch run their chunks in 0.88 us instead of 1.2, the launch as a whole 164 us instead of 124 (more lines in flight evict more of what the neighbouring tiles re-read)
+  uint4 st[WG_PD][8];
   if (c_lo >= c_hi) return;          // (uniform per workgroup)
   const int c_last = c_hi - 1;
-  stage_load(c_lo, st0);
-  stage_write(0, st0);
-  stage_load(min(c_lo + 1, c_last), st0);
+  unsigned long long* stp = (STAMP && blockIdx.x < 64 && tid == 0) ? wa.stamps + (size_t)blockIdx.x * 24 : nullptr;   // (STAMP builds only: a store
+  int stn = 0;                                                                                                            //  behind a branch in the loop costs the prefetch)
+  if (STAMP && stp) stp[stn++] = wall_clock64();
+  stage_load(c_lo, st[0]);
+#pragma unroll
+  for (int u = 1; u < WG_PD; ++u) stage_load(min(c_lo + u, c_last), st[u]);
+  stage_write(0, st[0]);
   __syncthreads();
-  // iteration c: chunk c+2 requested, MFMAs of chunk c from LDS, then chunk c+1 (requested one iteration ago) replaces it
-  auto iter = [&](int c, uint4 (&s_nxt)[8], uint4 (&s_nxt2)[8]) {
-    stage_load(min(c + 2, c_last), s_nxt2);   // unconditional (see k_bgemm): the last two iterations re-read the last chunk
-    __builtin_amdgcn_sched_barrier(0);   // keep the requests two chunks ahead
+  // iteration c (ring slot k = (c - c_lo) % WG_PD, free since chunk c went to LDS an iteration ago): chunk c + WG_PD requested into
+  // slot k, MFMAs of chunk c from LDS, then chunk c+1 (slot k+1, requested WG_PD - 1 iterations ago) replaces chunk c-1 in LDS
+  auto iter = [&](int c, uint4 (&s_new)[8], uint4 (&s_nxt)[8]) {
+    stage_load(min(c + WG_PD, c_last), s_new);   // unconditional (see k_bgemm): the last iterations re-read the last chunk
+    __builtin_amdgcn_sched_barrier(0);   // keep the requests where they are
     const int buf = (c - c_lo) & 1;
     const bf16_t* la = &lds[buf][0][la_row];
     const bf16_t* lb = &lds[buf][1][lb_row];
@@ -1172,13 +1183,17 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
     // chunk c+1 goes to the OTHER buffer (last read in iteration c-1, which every wave left through the barrier below)
     stage_write(buf ^ 1, s_nxt);
     __syncthreads();
+    if constexpr (STAMP) { if (stp && stn < 22) stp[stn++] = wall_clock64(); }
   };
   int c = c_lo;
-  for (; c + 1 < c_hi; c += 2) {
-    iter(c, st0, st1);
-    iter(c + 1, st1, st0);
+  for (; c + WG_PD - 1 < c_hi; c += WG_PD) {
+#pragma unroll
+    for (int u = 0; u < WG_PD; ++u) iter(c + u, st[u], st[(u + 1) % WG_PD]);
   }
-  if (c < c_hi) iter(c, st0, st1);
+#pragma unroll
+  for (int u = 0; u < WG_PD - 1; ++u)
+    if (c + u < c_hi) iter(c + u, st[u], st[(u + 1) % WG_PD]);
+  if constexpr (STAMP) { if (stp) { stp[22] = wall_clock64(); stp[23] = (unsigned long long)(c_hi - c_lo); } }
   float* part = wa.nsplit > 1 ? wa.part + ((size_t)pi * wa.nsplit + split) * wa.pstride : nullptr;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -1189,6 +1204,122 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs wa) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + 64 * wm + 32 * i + 8 * (r >> 2) + (r & 3) + 4 * kh;
+        if (m >= p.M) continue;
+        if (part) part[(size_t)m * p.K + k] = acc[i][j][r];
+        else p.out[m * p.o_sm + k * p.o_sk] = acc[i][j][r];
+      }
+    }
+}
+
+// k_wgrad2: the same products on 256 x 256 output tiles -- 8 waves as 2 x 4, 128 x 64 each -- for the launches with enough positions
+// per workgroup.  Why: a 128 x 128 tile needs 32 KB of operand rows per 64 positions, i.e. per 512 MFMA cycles of its four waves;
+// k_wgrad's workgroups were measured (in-kernel stamps, tools/wgrad_phase_probe.py) at 0.9 - 1.2 us per chunk = 27 - 36 GB/s of
+// rows per CU, 9 TB/s over the chip, with the matrix pipe 23 % busy: the rows' delivery, not the MFMAs, sets the pace, and at
+// that tile size even the L1 fill rate (64 B/clk) caps the pipe at ~50 %.  A 256 x 256 tile needs half the bytes per FLOP.  Same
+// staging scheme (8 x 8 register transposes into [channel][position] images, column-block swizzle), same reduction order inside a
+// workgroup; the split of the positions over workgroups differs (ordered reduce, deterministic).
+__global__ __launch_bounds__(512) void k_wgrad2(WgradArgs wa) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds_dyn[];      // [buffer][A | B][256 channels][LDP]
+  bf16_t (*lds)[2][256 * LDP] = reinterpret_cast<bf16_t (*)[2][256 * LDP]>(lds_dyn);
+  const int tg = wa.tiles_k * wa.tiles_m, x = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int grp = (jx / tg) * 8 + x, t = jx % tg;
+  if (grp >= wa.ngroups) return;
+  const int pi = grp / wa.nsplit, split = grp - pi * wa.nsplit;
+  const int k0 = (t % wa.tiles_k) * 256, m0 = (t / wa.tiles_k) * 256;
+  const WgradProb& p = wa.prob[pi];
+  if (m0 >= p.M || k0 >= p.K) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
+  const int wm = w >> 2, wk = w & 3;
+  // staging role: threads 0..255 transpose dY blocks, 256..511 X blocks; block = (pb: 8 positions, cb8: 8 channels of 256)
+  const int isx = tid >> 8, blk = tid & 255, pb = blk >> 5, l32 = blk & 31, cb8 = 8 * (l32 & 3) + (l32 >> 2);
+  const int nlc = (wa.L + 63) / 64, nall = wa.B * nlc;
+  const int c_lo = (int)((long)nall * split / wa.nsplit), c_hi = (int)((long)nall * (split + 1) / wa.nsplit);
+  const bf16_t* src;
+  long sbs; int sld, srow0, ch0;
+  if (!isx) {
+    const bool second = p.dy1 && m0 >= p.msplit;
+    src = second ? p.dy1 : p.dy0; sbs = p.dy_bs; sld = p.ldy; srow0 = p.dy_row0;
+    ch0 = min((second ? m0 - p.msplit : m0) + 8 * cb8, (second ? p.M - p.msplit : (p.dy1 ? p.msplit : p.M)) - 8);
+  } else {
+    src = p.x; sbs = p.x_bs; sld = p.ldx; srow0 = p.x_row0;
+    ch0 = min(k0 + 8 * cb8, p.K - 8);     // a tile that reaches past K (640 = 2.5 tiles) re-reads the last channels; those columns are never stored
+  }
+  // the operand side (dY / X) is the same for a whole wave: its base, strides and the chunk's row are kept in SGPRs (readfirstlane),
+  // a request is scalar base + one loop-invariant 32-bit lane offset -- per-lane 64-bit row addresses cost the registers this
+  // kernel does not have (acc 128 + two staged chunks 64 + fragments 24)
+  const unsigned long long src_u = (unsigned long long)src;
+  typedef __attribute__((address_space(1))) const char* gchar_p;          // (rebuilt from integers: say that it is GLOBAL memory, or the loads become flat_load)
+  typedef __attribute__((address_space(1))) const u32x4* gu32x4_p;
+  const gchar_p src_s = (gchar_p)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(src_u >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)src_u));
+  const long sbs_s = ((long)__builtin_amdgcn_readfirstlane((int)(sbs >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sbs);
+  const int sld_s = __builtin_amdgcn_readfirstlane(sld), srow0_s = __builtin_amdgcn_readfirstlane(srow0);
+  const unsigned voff = (unsigned)((8 * pb * sld + ch0) * 2);
+  auto stage_load = [&](int c, uint4 (&stg)[8]) {
+    const int b = c / nlc, n = (c - b * nlc) * 64;
+    const gchar_p s0 = src_s + ((size_t)b * sbs_s + (size_t)(srow0_s + n) * sld_s) * 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const u32x4 v = *(gu32x4_p)(s0 + (size_t)i * sld_s * 2 + voff);
+      stg[i] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+  };
+  auto stage_write = [&](int buf, const uint4 (&stg)[8]) {
+    uint4 tt[8];
+    transpose8x8(stg, tt);
+    bf16_t* d = &lds[buf][isx][(8 * cb8) * LDP + 8 * ((pb + (cb8 >> 2)) & 7)];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(d + c * LDP) = tt[c];
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  const int la_row = (128 * wm + li) * LDP, lb_row = (64 * wk + li) * LDP;
+  // ONE staged chunk in registers (acc 128 + fragments 24 leave no room for two: a second set spilled LDS addresses into the
+  // loop, each reload behind an s_waitcnt vmcnt(0)): chunk c+1 goes to the free LDS buffer at the TOP of iteration c (its last
+  // readers left through the barrier), then chunk c+2 is requested into the same registers and has the iteration to arrive
+  uint4 st[8];
+  if (c_lo >= c_hi) return;
+  const int c_last = c_hi - 1;
+  stage_load(c_lo, st);
+  stage_write(0, st);
+  stage_load(min(c_lo + 1, c_last), st);
+  __syncthreads();
+  for (int c = c_lo; c < c_hi; ++c) {
+    const int buf = (c - c_lo) & 1;
+    stage_write(buf ^ 1, st);
+    stage_load(min(c + 2, c_last), st);
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16_t* la = &lds[buf][0][la_row];
+    const bf16_t* lb = &lds[buf][1][lb_row];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      uint4 av[4], bv[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const uint4*>(la + i * 32 * LDP + 8 * ((2 * s + kh + i) & 7));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const uint4*>(lb + j * 32 * LDP + 8 * ((2 * s + kh + 2 * wk + j) & 7));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  float* part = wa.nsplit > 1 ? wa.part + ((size_t)pi * wa.nsplit + split) * wa.pstride : nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + 64 * wk + 32 * j + li;
+      if (k >= p.K) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 128 * wm + 32 * i + 8 * (r >> 2) + (r & 3) + 4 * kh;
         if (m >= p.M) continue;
         if (part) part[(size_t)m * p.K + k] = acc[i][j][r];
         else p.out[m * p.o_sm + k * p.o_sk] = acc[i][j][r];
@@ -1210,8 +1341,42 @@ __global__ void k_wgrad_reduce(WgradArgs wa) {
 
 constexpr int WG_MAXSPLIT = 8;
 // launches one batch of problems that share (M, K) tile counts; partial buffer: nprob * nsplit * maxM * maxK floats
+// 256 x 256 tiles (k_wgrad2) when they give >= 32 tiles and every workgroup then has >= 24 chunks of positions; FACPPG_WGRAD_TILE=128|256 forces
+int wgrad2_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size_t part_bytes, hipStream_t s, bool* done) {
+  *done = false;
+  const int tk = (maxK + 255) / 256, tm = (maxM + 255) / 256, tiles = tk * tm * nprob;
+  const int nall = wa.B * ((wa.L + 63) / 64);
+  int ns = std::max(1, std::min(256 / tiles, 8));      // one workgroup per CU (144 KB of LDS each): never more than 256
+  while (ns > 1 && (size_t)nprob * ns * maxM * maxK * 4 > part_bytes) --ns;
+  const char* e = getenv("FACPPG_WGRAD_TILE");
+  const bool want = e ? atoi(e) == 256 : (tiles >= 32 && nall / ns >= 24);
+  if (!want) return FACPPG_OK;
+  wa.nsplit = ns; wa.part = part; wa.pstride = (size_t)maxM * maxK;
+  wa.tiles_k = tk; wa.tiles_m = tm; wa.ngroups = nprob * ns; wa.xcd_map = 1;
+  constexpr size_t kLds = (size_t)2 * 2 * 256 * LDP * sizeof(bf16_t);   // 147 456 B
+  {
+    static unsigned long long attr_devices = 0;
+    int dev = 0;
+    FACPPG_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 64 || !((attr_devices >> dev) & 1ull)) {
+      FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wgrad2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+      if (dev < 64) attr_devices |= 1ull << dev;
+    }
+  }
+  k_wgrad2<<<dim3(8 * ((wa.ngroups + 7) / 8) * tk * tm), 512, kLds, s>>>(wa);
+  if (ns > 1) k_wgrad_reduce<<<dim3((maxM * maxK + 255) / 256, nprob), 256, 0, s>>>(wa);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  *done = true;
+  return FACPPG_OK;
+}
+
 int wgrad_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size_t part_bytes, hipStream_t s) {
   FACPPG_REQUIRE(maxM % 128 == 0 && maxK % 128 == 0, FACPPG_EINVAL, "k_wgrad: M and K must be multiples of 128 (got %d, %d)", maxM, maxK);
+  {
+    bool done = false;
+    if (int rc = wgrad2_launch(wa, nprob, maxM, maxK, part, part_bytes, s, &done)) return rc;
+    if (done) return FACPPG_OK;
+  }
   const int tiles = ((maxK + 127) / 128) * ((maxM + 127) / 128) * nprob;
   const int nall = wa.B * ((wa.L + 63) / 64);
   // about ONE workgroup per CU (two fit, 73 KB of LDS each): measured at batch 3 / 12, whole step, aiming at 64 / 128 / 256 / 384 /
@@ -1229,15 +1394,37 @@ int wgrad_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size
     int dev = 0;
     FACPPG_HIP_CHECK(hipGetDevice(&dev));
     if (dev >= 64 || !((attr_devices >> dev) & 1ull)) {
-      FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgradLds));
+      FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wgrad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgradLds));
+      FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wgrad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgradLds));
       if (dev < 64) attr_devices |= 1ull << dev;
     }
   }
   {
     static const bool no_map = [] { const char* e = getenv("FACPPG_WGRAD_NO_XCD_MAP"); return e && e[0] == '1'; }();
     wa.tiles_k = (maxK + 127) / 128; wa.tiles_m = (maxM + 127) / 128; wa.ngroups = nprob * ns; wa.xcd_map = no_map ? 0 : 1;
-    if (wa.xcd_map) k_wgrad<<<dim3(8 * ((wa.ngroups + 7) / 8) * wa.tiles_k * wa.tiles_m), 256, kWgradLds, s>>>(wa);
-    else k_wgrad<<<dim3(wa.tiles_k, wa.tiles_m, nprob * ns), 256, kWgradLds, s>>>(wa);
+    const char* spath = getenv("FACPPG_WGRAD_STAMPS");
+    if (spath) {
+      FACPPG_HIP_CHECK(hipMalloc(&wa.stamps, 64 * 24 * 8));
+      FACPPG_HIP_CHECK(hipMemsetAsync(wa.stamps, 0, 64 * 24 * 8, s));
+    }
+    const dim3 grid = wa.xcd_map ? dim3(8 * ((wa.ngroups + 7) / 8) * wa.tiles_k * wa.tiles_m) : dim3(wa.tiles_k, wa.tiles_m, nprob * ns);
+    if (spath) k_wgrad<true><<<grid, 256, kWgradLds, s>>>(wa);
+    else k_wgrad<false><<<grid, 256, kWgradLds, s>>>(wa);
+    if (spath) {
+      unsigned long long h[64 * 24];
+      FACPPG_HIP_CHECK(hipMemcpyAsync(h, wa.stamps, sizeof(h), hipMemcpyDeviceToHost, s));
+      FACPPG_HIP_CHECK(hipStreamSynchronize(s));
+      FACPPG_HIP_CHECK(hipFree(wa.stamps));
+      wa.stamps = nullptr;
+      if (FILE* f = fopen(spath, "a")) {
+        fprintf(f, "launch wgrad nprob %d M %d K %d nsplit %d\n", nprob, maxM, maxK, ns);
+        for (int t = 0; t < 64; ++t) {
+          for (int j = 0; j < 24; ++j) fprintf(f, "%llu ", j == 23 ? h[t * 24 + j] : (h[t * 24 + j] ? h[t * 24 + j] - h[t * 24] : 0ull));
+          fprintf(f, "\n");
+        }
+        fclose(f);
+      }
+    }
   }
   if (ns > 1) k_wgrad_reduce<<<dim3((maxM * maxK + 255) / 256, nprob), 256, 0, s>>>(wa);
   FACPPG_HIP_CHECK(hipGetLastError());
@@ -1665,7 +1852,7 @@ ScratchLayout scratch_layout(int nl, int B, int Lr) {
   s.dpre = take(s.dpre_one * nl); s.dh = take(s.dh_one * (nl + 1)); s.dskip = take(s.dh_one);
   s.part = take((size_t)SMALL_PARTS * 9 * C * 4);
   s.cspart = take((size_t)MAXCS * CS_SLICES * 1024 * 4);
-  s.wgpart_bytes = (size_t)3 * nl * 4 * (2 * C) * C * 4;      // 4 splits of the largest batch (3 taps x layers x [512 x 256])
+  s.wgpart_bytes = (size_t)3 * nl * 5 * (2 * C) * C * 4;      // 5 splits of the largest batch (3 taps x layers x [512 x 256]; k_wgrad2)
   s.wgpart = take(s.wgpart_bytes);
   s.total = off;
   return s;
