@@ -10,6 +10,6 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTI
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
   i=$((i+1))
   STEPS=2 timeout 400 rocprofv3 --kernel-trace --pmc $set -d $W/$i -o r -- python tools/time_train_step.py $B > $W/$i.log 2>&1; echo "set $i rc=$? $(tail -1 $W/$i.log)"
-  python tools/rocpd_summary.py pmc $W/$i/r_results.db "k_" | grep "k_bgemm\|k_wgrad(\|k_wn_fwd\|k_wn_bwd" | cut -c1-60,90-200 > $O/train_pmc_set${i}_B$B.txt
+  python tools/rocpd_summary.py pmc $W/$i/r_results.db "k_" | grep "k_bgemm\|k_wgrad\|k_wn_fwd\|k_wn_bwd\|k_dspect" | cut -c1-60,90-200 > $O/train_pmc_set${i}_B$B.txt
 done
 ls -la $O
