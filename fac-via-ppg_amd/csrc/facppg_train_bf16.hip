@@ -759,8 +759,11 @@ __global__ __launch_bounds__(512) void k_wn_bwd(WnBwdArgs p) {
   for (int s = 0; s < 8; ++s) ar[s] = ap[(size_t)s * 64];
   {
     // whole rows of dh_{i+1} and of layer i-1's tanh | sigmoid (HBM reads: written a forward pass ago) into their LDS tiles, here in the
-    // prologue: 4.7 - 6.5 us before the first MFMA instead of 1.6, but vmcnt retires in order -- requested inside the chunk loop every
-    // weight fragment requested after them waits for them (measured: + 3 us per tile mid-loop, + 9 us from the last chunk)
+    // prologue: 4.7 - 6.5 us before the first MFMA instead of 1.6.  Everything else measured worse: requested inside the chunk loop,
+    // every weight fragment requested after them waits for them (vmcnt retires in order: + 3 us per tile mid-loop, + 9 us from the last
+    // chunk); brought in by a NINTH wave as LDS-DMA spans spread over the loop (no request of its own to hold back), the chunks
+    // that run next to its requests take 2.0 - 2.2 us instead of 1.0 -- the CU's one vector-memory path serves the waves' requests in
+    // order too (step 17.59 -> 17.88 ms at batch 12)
     const bf16_t* dn = p.dh_next ? p.dh_next : p.dskip;
     uint4 pd[2 * NCB], pt[4 * NCB];
 #pragma unroll
