@@ -91,11 +91,25 @@ __global__ __launch_bounds__(256) void k_conv1x1_wgrad_part(const float* __restr
     part[(size_t)blockIdx.x * C * C + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-__global__ void k_sum_parts(const float* __restrict__ part, float* __restrict__ out, int n_parts, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float v = 0.f;
-  for (int p = 0; p < n_parts; ++p) v += part[(size_t)p * n + i];
+// out[i] = sum of the partials of output i (n <= 64 outputs, the c x c mixing matrix): 16 groups of threads walk the partials on four
+// interleaved chains each and meet in LDS in group order -- a fixed order (bit-reproducible).  (One thread per output walking all
+// 512 partials as one dependent chain cost 14 us per launch at batch 12, 12 launches per step.)
+__global__ __launch_bounds__(1024) void k_sum_parts(const float* __restrict__ part, float* __restrict__ out, int n_parts, int n) {
+  __shared__ float red[16][64];
+  const int i = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int p0 = n_parts * q / 16, p1 = n_parts * (q + 1) / 16;
+  float v4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i < n)
+    for (int p = p0; p < p1; p += 4)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (p + u < p1) v4[u] += part[(size_t)(p + u) * n + i];
+  red[q][i] = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+  __syncthreads();
+  if (q || i >= n) return;
+  float v = red[0][i];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) v += red[k][i];
   out[i] = v;
 }
 
@@ -380,7 +394,7 @@ extern "C" int facppg_conv1x1_wgrad(const float* dout_dev, const float* z_dev, f
     case 8: k_conv1x1_wgrad_part<8><<<parts, 256, 0, s>>>(dout_dev, z_dev, part, B, L); break;
     default: FACPPG_REQUIRE(false, FACPPG_EUNSUPPORTED, "channel count %d (built: 2, 4, 6, 8)", c);
   }
-  k_sum_parts<<<1, 64, 0, s>>>(part, dw_dev, parts, c * c);
+  k_sum_parts<<<1, 1024, 0, s>>>(part, dw_dev, parts, c * c);
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
 }

@@ -1549,19 +1549,32 @@ __global__ void k_copy_skip_bias(SkipBiasCopy cp) { cp.dst[blockIdx.y][threadIdx
 
 // ---- the <= 8-channel edges of the stack ----------------------------------------------------------------------
 // start conv (glow.py:156): h0[b][HALO + n][c] = sum_j Ws[c][j] a0[b][j][n] + bs[c]
-__global__ void k_t_start(const float* __restrict__ a0, const float* __restrict__ w, const float* __restrict__ bias,
-                          bf16_t* __restrict__ h0, int nin, int L, int Lp) {
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y, c4 = (threadIdx.x & 63) * 4;
-  if (n >= L) return;
-  float v[4];
+// a thread owns 4 channels (weights and bias in registers) and walks 8 positions; a workgroup covers 32 positions.  (One position per
+// thread group -- 3 750 workgroups of ~40 instructions per thread at batch 12 -- took 20 us for 7.7 MB.)  Same FMA order per output.
+__global__ __launch_bounds__(256) void k_t_start(const float* __restrict__ a0, const float* __restrict__ w, const float* __restrict__ bias,
+                                                 bf16_t* __restrict__ h0, int nin, int L, int Lp) {
+  const int c4 = (threadIdx.x & 63) * 4, b = blockIdx.y, n0 = blockIdx.x * 32 + (threadIdx.x >> 6) * 8;
+  float wr[4][4], bv[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) v[t] = bias[c4 + t];
-  for (int j = 0; j < nin; ++j) {
-    const float a = a0[((size_t)b * nin + j) * L + n];
+  for (int t = 0; t < 4; ++t) {
+    bv[t] = bias[c4 + t];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) v[t] = fmaf(w[(c4 + t) * nin + j], a, v[t]);
+    for (int j = 0; j < 4; ++j) wr[t][j] = j < nin ? w[(c4 + t) * nin + j] : 0.0f;
   }
-  *reinterpret_cast<uint2*>(h0 + ((size_t)b * Lp + HALO + n) * C + c4) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int n = n0 + i;
+    if (n >= L) break;
+    float v[4] = {bv[0], bv[1], bv[2], bv[3]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < nin) {
+        const float a = a0[((size_t)b * nin + j) * L + n];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = fmaf(wr[t][j], a, v[t]);
+      }
+    *reinterpret_cast<uint2*>(h0 + ((size_t)b * Lp + HALO + n) * C + c4) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+  }
 }
 
 // end conv (glow.py:175): out[b][j][n] = sum_c We[j][c] skip[b][n][c] + be[j]; one wave per position
@@ -1701,21 +1714,36 @@ __global__ __launch_bounds__(256) void k_small_rowsum(const float* __restrict__ 
   }
   if (threadIdx.x == 0) out[j] = red[0];
 }
-// backward of the start conv w.r.t. its input: da0[b][j][n] = sum_c Ws[c][j] dh0[b][n][c]; one wave per position
+// backward of the start conv w.r.t. its input: da0[b][j][n] = sum_c Ws[c][j] dh0[b][n][c].  A wave takes 8 positions: lane = (position,
+// slice of 32 channels) reads 64 contiguous bytes of its row, forms its slice's dot products with the weights from LDS, and the 8
+// slices of a position meet in three shuffle steps (a wave per position with a 6-step reduction per input channel took 20 us).
 __global__ __launch_bounds__(256) void k_t_start_bwd(const bf16_t* __restrict__ dh0, const float* __restrict__ w, float* __restrict__ da0,
                                                      int nin, int L, int Lr) {
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y, lane = threadIdx.x & 63;
-  if (n >= L) return;
-  const uint2 d = *reinterpret_cast<const uint2*>(dh0 + ((size_t)b * Lr + n) * C + 4 * lane);
-  const float dv[4] = {lo2f(d.x), hi2f(d.x), lo2f(d.y), hi2f(d.y)};
-  for (int j = 0; j < nin; ++j) {
-    float v = 0.0f;
+  __shared__ float sw[C * 4];
+  for (int i = threadIdx.x; i < C * 4; i += 256) sw[i] = (i & 3) < nin ? w[(i >> 2) * nin + (i & 3)] : 0.0f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, ps = lane >> 3, sl = lane & 7, b = blockIdx.y;
+  const int n = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + ps;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (n < L) {
+    const uint4* row = reinterpret_cast<const uint4*>(dh0 + ((size_t)b * Lr + n) * C + 32 * sl);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) v = fmaf(w[(4 * lane + t) * nin + j], dv[t], v);
+    for (int q = 0; q < 4; ++q) {
+      const uint4 d = row[q];
+      const float dv[8] = {lo2f(d.x), hi2f(d.x), lo2f(d.y), hi2f(d.y), lo2f(d.z), hi2f(d.z), lo2f(d.w), hi2f(d.w)};
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if (lane == 0) da0[((size_t)b * nin + j) * L + n] = v;
+      for (int e = 0; e < 8; ++e) {
+        const float4 ww = *reinterpret_cast<const float4*>(sw + (32 * sl + 8 * q + e) * 4);
+        v[0] = fmaf(ww.x, dv[e], v[0]); v[1] = fmaf(ww.y, dv[e], v[1]); v[2] = fmaf(ww.z, dv[e], v[2]); v[3] = fmaf(ww.w, dv[e], v[3]);
+      }
+    }
   }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) v[j] += __shfl_xor(v[j], off, 64);
+  if (sl == 0 && n < L)
+    for (int j = 0; j < nin; ++j) da0[((size_t)b * nin + j) * L + n] = v[j];
 }
 
 // fp32 channel-major [B][Cn][ldi] (first L columns) -> bf16 position-major [B][Lr][Cn]; rows >= L zero
@@ -2037,7 +2065,7 @@ extern "C" int facppg_wn_forward_bf16(const facppg_wn_weights* wts, int n_in, in
     k_add2<<<dim3(2, nl), 256, 0, s>>>(ab, b1, 2 * C);
   }
   const dim3 egrid((L + 3) / 4, B);
-  k_t_start<<<egrid, 256, 0, s>>>(a0_dev, wts->start_w, wts->start_b, (bf16_t*)(S + st.h), n_in, L, Lp);
+  k_t_start<<<dim3((L + 31) / 32, B), 256, 0, s>>>(a0_dev, wts->start_w, wts->start_b, (bf16_t*)(S + st.h), n_in, L, Lp);
   const bool fused = fused_fwd_enabled(B, L);
   for (int i = 0; i < nl; ++i) {
     const int last = i == nl - 1, d = 1 << i;
@@ -2187,7 +2215,7 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
     if (int rc = bgemm_launch(c, s)) return rc;
   }
   const bf16_t* dh0 = (const bf16_t*)(W + sc.dh);
-  k_t_start_bwd<<<egrid, 256, 0, s>>>(dh0, wts->start_w, da0_dev, n_in, L, Lr);
+  k_t_start_bwd<<<dim3((L + 31) / 32, B), 256, 0, s>>>(dh0, wts->start_w, da0_dev, n_in, L, Lr);
   {  // start conv: weight [256][n_in] and bias [256] gradients
     float* part = (float*)(W + sc.part);
     k_small_wgrad_part<true><<<SMALL_PARTS, 256, 0, s>>>(a0_dev, dh0, (long)Lr * C, 0, part, n_in, B, L, SMALL_PARTS);
