@@ -1303,7 +1303,7 @@ __global__ __launch_bounds__(512) void k_wgrad2(WgradArgs wa) {
     for (int s = 0; s < 4; ++s) {
       uint4 av[4], bv[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const uint4*>(la + i * 32 * LDP + 8 * ((2 * s + kh + i) & 7));
+      for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const uint4*>(la + i * 32 * LDP + 8 * ((2 * s + kh + 4 * wm + i) & 7));   // column block (pb + (row >> 5)) & 7, as written
 #pragma unroll
       for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const uint4*>(lb + j * 32 * LDP + 8 * ((2 * s + kh + 2 * wk + j) & 7));
 #pragma unroll
@@ -1349,7 +1349,7 @@ int wgrad2_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, siz
   *done = false;
   const int tk = (maxK + 255) / 256, tm = (maxM + 255) / 256, tiles = tk * tm * nprob;
   const int nall = wa.B * ((wa.L + 63) / 64);
-  int ns = std::max(1, std::min(256 / tiles, 8));      // one workgroup per CU (144 KB of LDS each): never more than 256
+  int ns = std::max(1, std::min(std::min(256 / std::max(tiles, 1), 8), nall));      // one workgroup per CU (144 KB of LDS each): never more than 256; every split gets a chunk
   while (ns > 1 && (size_t)nprob * ns * maxM * maxK * 4 > part_bytes) --ns;
   const char* e = getenv("FACPPG_WGRAD_TILE");
   const bool want = e ? atoi(e) == 256 : (tiles >= 32 && nall / ns >= 24);
@@ -1403,7 +1403,8 @@ int wgrad_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size
     }
   }
   {
-    static const bool no_map = [] { const char* e = getenv("FACPPG_WGRAD_NO_XCD_MAP"); return e && e[0] == '1'; }();
+    const char* e_map = getenv("FACPPG_WGRAD_NO_XCD_MAP");
+    const bool no_map = e_map && e_map[0] == '1';
     wa.tiles_k = (maxK + 127) / 128; wa.tiles_m = (maxM + 127) / 128; wa.ngroups = nprob * ns; wa.xcd_map = no_map ? 0 : 1;
     const char* spath = getenv("FACPPG_WGRAD_STAMPS");
     if (spath) {
