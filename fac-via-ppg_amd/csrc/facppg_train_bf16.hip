@@ -1578,32 +1578,63 @@ __global__ __launch_bounds__(256) void k_t_start(const float* __restrict__ a0, c
   }
 }
 
-// end conv (glow.py:175): out[b][j][n] = sum_c We[j][c] skip[b][n][c] + be[j]; one wave per position
+// end conv (glow.py:175): out[b][j][n] = sum_c We[j][c] skip[b][n][c] + be[j].  A wave takes 8 positions: lane = (position, slice of 32
+// channels) reads 128 contiguous bytes of its fp32 row, forms its slice's <= 8 dot products with the weights from LDS ([c][j]), and the
+// 8 slices of a position meet in three shuffle steps (a wave per position with a 6-step reduction per output cost 12 us at batch 12).
 __global__ __launch_bounds__(256) void k_t_end(const float* __restrict__ skip, const float* __restrict__ w, const float* __restrict__ bias,
                                                float* __restrict__ out, int nout, int L, int Lr) {
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y, lane = threadIdx.x & 63;
-  if (n >= L) return;
-  const float4 s = *reinterpret_cast<const float4*>(skip + ((size_t)b * Lr + n) * C + 4 * lane);
-  for (int j = 0; j < nout; ++j) {
-    const float4 ww = *reinterpret_cast<const float4*>(w + j * C + 4 * lane);
-    float v = s.x * ww.x + s.y * ww.y + s.z * ww.z + s.w * ww.w;
+  __shared__ __attribute__((aligned(16))) float sw[C * 8];
+  for (int i = threadIdx.x; i < C * 8; i += 256) sw[i] = (i & 7) < nout ? w[(i & 7) * C + (i >> 3)] : 0.0f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, ps = lane >> 3, sl = lane & 7, b = blockIdx.y;
+  const int n = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + ps;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (n < L) {
+    const float4* row = reinterpret_cast<const float4*>(skip + ((size_t)b * Lr + n) * C + 32 * sl);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if (lane == 0) out[((size_t)b * nout + j) * L + n] = v + bias[j];
+    for (int q = 0; q < 8; ++q) {
+      const float4 x = row[q];
+      const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float4 w0 = *reinterpret_cast<const float4*>(sw + (32 * sl + 4 * q + e) * 8), w1 = *reinterpret_cast<const float4*>(sw + (32 * sl + 4 * q + e) * 8 + 4);
+        v[0] = fmaf(w0.x, xv[e], v[0]); v[1] = fmaf(w0.y, xv[e], v[1]); v[2] = fmaf(w0.z, xv[e], v[2]); v[3] = fmaf(w0.w, xv[e], v[3]);
+        v[4] = fmaf(w1.x, xv[e], v[4]); v[5] = fmaf(w1.y, xv[e], v[5]); v[6] = fmaf(w1.z, xv[e], v[6]); v[7] = fmaf(w1.w, xv[e], v[7]);
+      }
+    }
   }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) v[j] += __shfl_xor(v[j], off, 64);
+  if (sl == 0 && n < L)
+    for (int j = 0; j < nout; ++j) out[((size_t)b * nout + j) * L + n] = v[j] + bias[j];
 }
 
-// backward of the end conv w.r.t. its input: dskip[b][n][c] = sum_j We[j][c] dout[b][j][n]  (bf16)
-__global__ void k_t_end_bwd(const float* __restrict__ dout, const float* __restrict__ w, bf16_t* __restrict__ dskip, int nout, int L, int Lr) {
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y, c4 = (threadIdx.x & 63) * 4;
-  if (n >= L) return;
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int j = 0; j < nout; ++j) {
-    const float d = dout[((size_t)b * nout + j) * L + n];
+// backward of the end conv w.r.t. its input: dskip[b][n][c] = sum_j We[j][c] dout[b][j][n]  (bf16); a thread owns 4 channels (their
+// weights in registers) and walks 8 positions, a workgroup covers 32 positions; same FMA order per output as one position per thread
+__global__ __launch_bounds__(256) void k_t_end_bwd(const float* __restrict__ dout, const float* __restrict__ w, bf16_t* __restrict__ dskip,
+                                                   int nout, int L, int Lr) {
+  const int c4 = (threadIdx.x & 63) * 4, b = blockIdx.y, n0 = blockIdx.x * 32 + (threadIdx.x >> 6) * 8;
+  float wr[8][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) v[t] = fmaf(w[j * C + c4 + t], d, v[t]);
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wr[j][t] = j < nout ? w[j * C + c4 + t] : 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int n = n0 + i;
+    if (n >= L) break;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < nout) {
+        const float d = dout[((size_t)b * nout + j) * L + n];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = fmaf(wr[j][t], d, v[t]);
+      }
+    *reinterpret_cast<uint2*>(dskip + ((size_t)b * Lr + n) * C + c4) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
   }
-  *reinterpret_cast<uint2*>(dskip + ((size_t)b * Lr + n) * C + c4) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
 }
 
 // small-channel weight gradients: out[j][c] = sum_{b,n} small[b][j][n] * wide[b][n][c]  (j < nj <= 8, c < 256),
@@ -2065,7 +2096,6 @@ extern "C" int facppg_wn_forward_bf16(const facppg_wn_weights* wts, int n_in, in
     for (int i = 0; i < nl; ++i) { ab.a[i] = wts->in_b[i]; ab.b[i] = wts->cond_b[i]; }
     k_add2<<<dim3(2, nl), 256, 0, s>>>(ab, b1, 2 * C);
   }
-  const dim3 egrid((L + 3) / 4, B);
   k_t_start<<<dim3((L + 31) / 32, B), 256, 0, s>>>(a0_dev, wts->start_w, wts->start_b, (bf16_t*)(S + st.h), n_in, L, Lp);
   const bool fused = fused_fwd_enabled(B, L);
   for (int i = 0; i < nl; ++i) {
@@ -2099,7 +2129,7 @@ extern "C" int facppg_wn_forward_bf16(const facppg_wn_weights* wts, int n_in, in
     r.h_bs = (long)Lp * C; r.h_row0 = HALO; r.skip = (float*)(S + st.skip); r.first = i == 0; r.last = last;
     if (int rc = bgemm_launch(r, s)) return rc;
   }
-  k_t_end<<<egrid, 256, 0, s>>>((const float*)(S + st.skip), wts->end_w, wts->end_b, out_dev, 2 * n_in, L, Lr);
+  k_t_end<<<dim3((L + 31) / 32, B), 256, 0, s>>>((const float*)(S + st.skip), wts->end_w, wts->end_b, out_dev, 2 * n_in, L, Lr);
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
 }
@@ -2141,7 +2171,6 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
     if (int rc = pk.launch(s)) return rc;
   }
   bf16_t* dskip = (bf16_t*)(W + sc.dskip);
-  const dim3 egrid((L + 3) / 4, B);
   {
     ZeroRows z;
     z.add(W + sc.dpre, (long)nl * B, (long)Lp * 2 * C * 2, 2 * C * 2, HALO, HALO + L, Lp);
@@ -2149,7 +2178,7 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
     z.add(W + sc.dskip, B, (long)Lr * C * 2, C * 2, 0, L, Lr);
     z.launch(s);
   }
-  k_t_end_bwd<<<egrid, 256, 0, s>>>(dout_dev, wts->end_w, dskip, nout, L, Lr);
+  k_t_end_bwd<<<dim3((L + 31) / 32, B), 256, 0, s>>>(dout_dev, wts->end_w, dskip, nout, L, Lr);
   {  // end conv: weight [nout][256] and bias gradients
     float* part = (float*)(W + sc.part);
     k_small_wgrad_part<false><<<SMALL_PARTS, 256, 0, s>>>(dout_dev, S + st.skip, (long)Lr * C, 0, part, nout, B, L, SMALL_PARTS);
