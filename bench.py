@@ -322,6 +322,12 @@ def train_worker():
                             B, prec, "one replayed HIP graph per step" if graphed else "launch by launch"),
             "ms_per_step": t * 1e3, "samples_per_s": B * 10000 / t, "tflops": flops / t / 1e12,
             "frac_of_mfma_peak": flops / t / 1e12 / peak, "mfma_peak_tflops": peak, "loss_finite": bool(torch.isfinite(loss))}
+        try:                                                  # (outside the timed steps) every gradient of the last step is finite
+            gs = [p.grad for p in m.parameters() if p.grad is not None]
+            out["%s_B%d%s" % (prec, B, "_graph" if graphed else "")]["grads_finite"] = bool(
+                len(gs) > 0 and all(bool(x) for x in torch.isfinite(torch.stack(torch._foreach_norm(gs))).cpu()))
+        except Exception as e:                                # never let a diagnostic take the measurement down
+            out["%s_B%d%s" % (prec, B, "_graph" if graphed else "")]["grads_finite"] = "not checked: %r" % (e,)
         del stepper, opt
     print(json.dumps(out))
 
