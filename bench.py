@@ -322,6 +322,11 @@ def train_worker():
                             B, prec, "one replayed HIP graph per step" if graphed else "launch by launch"),
             "ms_per_step": t * 1e3, "samples_per_s": B * 10000 / t, "tflops": flops / t / 1e12,
             "frac_of_mfma_peak": flops / t / 1e12 / peak, "mfma_peak_tflops": peak, "loss_finite": bool(torch.isfinite(loss))}
+        if prec == "bf16":                                    # which launch structure the library picked for this batch (host-side query)
+            from facppg import lib as _flib
+            pl = _flib.load().facppg_wn_bf16_launch_plan(8, B, 10000 // 8)
+            out["%s_B%d%s" % (prec, B, "_graph" if graphed else "")]["launch_plan"] = {
+                "fused_forward_layer": bool(pl & 1), "fused_backward_layer": bool(pl & 2), "wgrad_tile": 256 if pl & 4 else 128, "tile_positions": pl >> 8}
         try:                                                  # (outside the timed steps) every gradient of the last step is finite
             gs = [p.grad for p in m.parameters() if p.grad is not None]
             out["%s_B%d%s" % (prec, B, "_graph" if graphed else "")]["grads_finite"] = bool(

@@ -1345,15 +1345,21 @@ __global__ void k_wgrad_reduce(WgradArgs wa) {
 constexpr int WG_MAXSPLIT = 8;
 // launches one batch of problems that share (M, K) tile counts; partial buffer: nprob * nsplit * maxM * maxK floats
 // 256 x 256 tiles (k_wgrad2) when they give >= 32 tiles and every workgroup then has >= 24 chunks of positions; FACPPG_WGRAD_TILE=128|256 forces
-int wgrad2_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size_t part_bytes, hipStream_t s, bool* done) {
-  *done = false;
-  const int tk = (maxK + 255) / 256, tm = (maxM + 255) / 256, tiles = tk * tm * nprob;
-  const int nall = wa.B * ((wa.L + 63) / 64);
+// the split count of a k_wgrad2 launch and whether the launch is the one to use (shared with facppg_wn_bf16_launch_plan)
+bool wgrad2_wanted(int nprob, int maxM, int maxK, int B, int L, size_t part_bytes, int* ns_out = nullptr) {
+  const int tiles = ((maxK + 255) / 256) * ((maxM + 255) / 256) * nprob;
+  const int nall = B * ((L + 63) / 64);
   int ns = std::max(1, std::min(std::min(256 / std::max(tiles, 1), 8), nall));      // one workgroup per CU (144 KB of LDS each): never more than 256; every split gets a chunk
   while (ns > 1 && (size_t)nprob * ns * maxM * maxK * 4 > part_bytes) --ns;
+  if (ns_out) *ns_out = ns;
   const char* e = getenv("FACPPG_WGRAD_TILE");
-  const bool want = e ? atoi(e) == 256 : (tiles >= 32 && nall / ns >= 24);
-  if (!want) return FACPPG_OK;
+  return e ? atoi(e) == 256 : (tiles >= 32 && nall / ns >= 24);
+}
+int wgrad2_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size_t part_bytes, hipStream_t s, bool* done) {
+  *done = false;
+  const int tk = (maxK + 255) / 256, tm = (maxM + 255) / 256;
+  int ns = 1;
+  if (!wgrad2_wanted(nprob, maxM, maxK, wa.B, wa.L, part_bytes, &ns)) return FACPPG_OK;
   wa.nsplit = ns; wa.part = part; wa.pstride = (size_t)maxM * maxK;
   wa.tiles_k = tk; wa.tiles_m = tm; wa.ngroups = nprob * ns; wa.xcd_map = 1;
   constexpr size_t kLds = (size_t)2 * 2 * 256 * LDP * sizeof(bf16_t);   // 147 456 B
@@ -1963,6 +1969,14 @@ extern "C" int facppg_wn_bf16_padded_len(int L) { return L > 0 ? pad_len(L) : 0;
 extern "C" size_t facppg_wn_bf16_state_bytes(int n_layers, int B, int L) {
   if (n_layers < 1 || n_layers > 8 || B <= 0 || L <= 0) return 0;
   return state_layout(n_layers, B, pad_len(L)).total;
+}
+extern "C" int facppg_wn_bf16_launch_plan(int n_layers, int B, int L) {
+  if (n_layers < 1 || n_layers > 8 || B <= 0 || L <= 0) return FACPPG_EINVAL;
+  int plan = tile_positions(B, L) << 8;
+  if (fused_fwd_enabled(B, L)) plan |= 1;
+  if (fused_bwd_enabled(B, L) && n_layers > 1) plan |= 2;
+  if (wgrad2_wanted(n_layers * 3, 2 * C, C, B, L, scratch_layout(n_layers, B, pad_len(L)).wgpart_bytes)) plan |= 4;
+  return plan;
 }
 extern "C" size_t facppg_wn_bf16_scratch_bytes(int n_layers, int B, int L) {
   if (n_layers < 1 || n_layers > 8 || B <= 0 || L <= 0) return 0;

@@ -91,6 +91,7 @@ def _declare(lib):
         "facppg_wn_bf16_padded_len": (c.c_int, [c.c_int]),
         "facppg_wn_bf16_state_bytes": (sz, [c.c_int, c.c_int, c.c_int]),
         "facppg_wn_bf16_scratch_bytes": (sz, [c.c_int, c.c_int, c.c_int]),
+        "facppg_wn_bf16_launch_plan": (c.c_int, [c.c_int, c.c_int, c.c_int]),
         "facppg_spect_to_bf16": (c.c_int, [vp, c.c_int, c.c_int, c.c_int, c.c_int, vp, vp]),
         "facppg_posmajor_to_f32": (c.c_int, [vp, c.c_int, c.c_int, c.c_int, vp, c.c_int, vp]),
         "facppg_wn_forward_bf16": (c.c_int, [c.POINTER(WnWeights), c.c_int, c.c_int, vp, vp, c.c_int, c.c_int, vp, vp, sz, vp, sz, vp]),

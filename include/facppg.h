@@ -226,6 +226,12 @@ typedef struct facppg_wn_grads {   /* fp32 outputs, same shapes as facppg_wn_wei
 int facppg_wn_bf16_padded_len(int L);
 size_t facppg_wn_bf16_state_bytes(int n_layers, int B, int L);    /* saved activations of one stack (forward -> backward) */
 size_t facppg_wn_bf16_scratch_bytes(int n_layers, int B, int L);  /* per-call scratch (packed bf16 weight images, gradients in flight) */
+/* Which launches facppg_wn_forward_bf16 / facppg_wn_backward_bf16 use for B items of L positions (glow.py:154-175 and its autograd
+ * backward), after the FACPPG_TRAIN_FUSED_FWD / _BWD, FACPPG_TRAIN_TILE and FACPPG_WGRAD_TILE overrides -- a diagnostic, host-side only:
+ * bit 0: one launch per layer forward (k_wn_fwd) instead of two; bit 1: one launch per layer in the backward chain (k_wn_bwd);
+ * bit 2: 256 x 256 weight-gradient tiles (k_wgrad2) for the tap and conditioning products; bits 8..15: positions per tile of the fused
+ * launches (64 or 32).  Negative: bad argument. */
+int facppg_wn_bf16_launch_plan(int n_layers, int B, int L);
 /* fp32 channel-major [B][channels][ld] (first L columns) -> bf16 position-major [B][Lr][channels], rows >= L zero */
 int facppg_spect_to_bf16(const float* spect_dev, int B, int channels, int L, int ld, void* out_dev, void* stream);
 /* fp32 position-major [B][Lr][channels] -> fp32 channel-major [B][channels][ld] (first L columns) */

@@ -48,6 +48,34 @@ def test_config_validation_without_device():
     assert L.facppg_wg_workspace_bytes(None, 1, 1) == 0
 
 
+def test_training_launch_plan(monkeypatch):
+    """Which launches the bf16 training step picks (host-side decision, no device needed): the reference's batch 3 keeps the
+    two-launch forward layer, fuses the backward chain at 32 positions per tile and forms the weight gradients on 128 x 128 tiles;
+    config 5's batch 12 (segment 10 000 -> 1 250 positions per item) runs every fused launch at 64 positions and the 256 x 256
+    weight-gradient tiles; the environment switches force either way (train_waveglow.py:121-134)."""
+    L = flib.load()
+    for k in ("FACPPG_TRAIN_FUSED_FWD", "FACPPG_TRAIN_FUSED_BWD", "FACPPG_TRAIN_TILE", "FACPPG_WGRAD_TILE"):
+        monkeypatch.delenv(k, raising=False)
+
+    def plan(B, Lg=1250, nl=8):
+        p = L.facppg_wn_bf16_launch_plan(nl, B, Lg)
+        return {"fwd": bool(p & 1), "bwd": bool(p & 2), "wgrad256": bool(p & 4), "tile": p >> 8}
+    assert plan(3) == {"fwd": False, "bwd": True, "wgrad256": False, "tile": 32}
+    assert plan(6) == {"fwd": True, "bwd": True, "wgrad256": True, "tile": 32}
+    assert plan(12) == {"fwd": True, "bwd": True, "wgrad256": True, "tile": 64}
+    assert plan(1, Lg=16) == {"fwd": False, "bwd": False, "wgrad256": False, "tile": 32}
+    assert plan(12, nl=1)["bwd"] is False                      # a one-layer stack has no (conv_i, gate_{i-1}) pair
+    assert L.facppg_wn_bf16_launch_plan(9, 3, 1250) < 0 and L.facppg_wn_bf16_launch_plan(8, 0, 1250) < 0
+    monkeypatch.setenv("FACPPG_TRAIN_FUSED_FWD", "0")
+    monkeypatch.setenv("FACPPG_TRAIN_FUSED_BWD", "0")
+    monkeypatch.setenv("FACPPG_WGRAD_TILE", "128")
+    assert plan(12) == {"fwd": False, "bwd": False, "wgrad256": False, "tile": 64}
+    monkeypatch.setenv("FACPPG_TRAIN_FUSED_FWD", "1")
+    monkeypatch.setenv("FACPPG_TRAIN_TILE", "32")
+    monkeypatch.setenv("FACPPG_WGRAD_TILE", "256")
+    assert plan(3) == {"fwd": True, "bwd": False, "wgrad256": True, "tile": 32}
+
+
 def test_no_cpu_fallback():
     from waveglow.glow import WaveGlow
     from facppg import synth
