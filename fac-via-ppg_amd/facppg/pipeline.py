@@ -183,7 +183,6 @@ class ConditioningStream(object):
         self.cuts = self.plan(steps, self.Tin)
         self.wg_handle = self.waveglow._handle(dev)
         f_prev = 0
-        groups = max(1, int(os.environ.get("FACPPG_STREAM_GROUPS", "1")))
         lpw = max(1, int(os.environ.get("FACPPG_STREAM_LPW", "1")))
         # The seed passes take the CUs the decoder leaves except `spare` of them, ONE workgroup per CU that holds the CU's whole LDS
         # (a bounded launch does, see facppg_wg_cond_seed): the dispatcher otherwise places the postnet's small workgroups -- and the
@@ -192,7 +191,7 @@ class ConditioningStream(object):
         spare = int(os.environ.get("FACPPG_STREAM_SPARE_CUS", "8"))
         bound = max(16, n_cu - self.tacotron.last_decoder_launch()[1] - spare) if spare >= 0 else 0
         self.n_launch = 0
-        self.flow_events, self.deferred, self.last_final = {}, [], None
+        self.last_final, self.finals, self.flow_events = None, [], {}
 
         def seed_pass(job):
             s_a, n, bt, void, lo, hi = job
@@ -224,28 +223,13 @@ class ConditioningStream(object):
                     final = torch.cuda.Event()
                     final.record(self.post)
                     self.last_final = final
+                    self.finals.append(final)
                 with torch.cuda.stream(self.side):
                     self.side.wait_event(final)                # mel_post is final up to s_b
-                    # FACPPG_STREAM_GROUPS > 1 (off by default: measured no gain, profiles/r05_experiments.txt): the blocks around the
-                    # expected end are formed flow group by flow group in the order the vocoder walks the flows (last flow first), an
-                    # event behind each group, so that the vocoder can start on the first group's seeds.
-                    late = k >= len(self.cuts) - 1 - self.n_extra
-                    nf = self.waveglow.n_flows
-                    parts = [(nf * (groups - 1 - g) // groups, nf * (groups - g) // groups) for g in range(groups)] if late else [(0, nf)]
-                    bt = min(4, (s_b - s_a) // 32)
-                    for g, (lo, hi) in enumerate(parts):
-                        job = (s_a, s_b - s_a, bt, void, lo, hi)
-                        if g == 0:
-                            seed_pass(job)
-                            ev = torch.cuda.Event()
-                            ev.record(self.side)
-                            self.flow_events[hi - 1] = ev
-                        else:
-                            # ... and only the first group's launch is queued now: the others follow when the caller's stream has run
-                            # what is left of the postnet (finish) -- a seed pass next to that chain of small launches makes every one
-                            # of them 3-5 times slower (tools/postnet_under_seed_probe.py), and those seeds are not needed for
-                            # milliseconds
-                            self.deferred.append(job)
+                    seed_pass((s_a, s_b - s_a, min(4, (s_b - s_a) // 32), void, 0, self.waveglow.n_flows))
+                    ev = torch.cuda.Event()
+                    ev.record(self.side)
+                    self.flow_events = {self.waveglow.n_flows - 1: ev}   # the vocoder's first launches (last flow) wait for the last pass
                 f_prev = f_new
         self.active = True
 
@@ -259,10 +243,21 @@ class ConditioningStream(object):
         # what is left of the postnet needs the postnet stream's blocks only; the seed passes' events gate the vocoder's flows (vocode)
         if self.last_final is not None:
             cur.wait_event(self.last_final)
+        # Which blocks were really formed: a block the decoder stopped short of is void (f_new > Tout, known from the length), but
+        # so is a block whose frames did not arrive within FACPPG_STREAM_WAIT_MS (k_collect_frames gave up: a profiler serialising
+        # kernels, cooperative launches queued behind another process) -- its postnet columns and seeds were never written, and
+        # every block behind it is void too.  The flags are read back here (the blocks up to the decoder's end finished
+        # milliseconds ago; the ones past it return the moment they see the length) and the tail below starts at the first void one.
+        n_cov = sum(1 for f_new, _, _ in self.cuts if f_new <= Tout)
+        self.void_blocks = 0
+        if n_cov:
+            self.finals[n_cov - 1].synchronize()          # (block k's flag is written ahead of its event)
+            void_host = self.void[:n_cov].cpu()
+            first_void = next((k for k in range(n_cov) if int(void_host[k])), n_cov)
+            self.void_blocks, n_cov = n_cov - first_void, first_void
         f_done = s_done = 0
-        for f_new, s_a, s_b in self.cuts:
-            if f_new <= Tout:
-                f_done, s_done = f_new, s_b
+        for f_new, s_a, s_b in self.cuts[:n_cov]:
+            f_done, s_done = f_new, s_b
         with torch.cuda.device(dev):
             st = _lib.current_stream(dev)
             if Tout > f_done:
@@ -271,17 +266,6 @@ class ConditioningStream(object):
             _lib.check(L.facppg_taco_postnet_range(self.taco_handle, _lib.ptr(self.mel), steps, f_done, Tout, Tout,
                                                    self.melp.data_ptr() + 4 * self.margin, self.tqp, _lib.ptr(self.post_ws),
                                                    self.post_ws.numel(), steps, None, st))
-            if self.deferred:                                  # the late blocks' remaining flow groups, behind the chain above
-                tail_done = torch.cuda.Event()
-                tail_done.record(cur)
-                with torch.cuda.stream(self.side):
-                    self.side.wait_event(tail_done)
-                    for job in self.deferred:
-                        self.seed_pass(job)
-                        ev = torch.cuda.Event()
-                        ev.record(self.side)
-                        self.flow_events[job[5] - 1] = ev
-                self.deferred = []
         self.Tout, self.seeded = Tout, s_done
         return self.melp[:, self.margin:self.margin + Tout].unsqueeze(0)
 

@@ -320,6 +320,63 @@ def gen_waveglow_train():
     save("waveglow_train.npz", **arrs)
 
 
+TRAIN_KEEP = ["upsample.weight", "upsample.bias", "WN.0.start.weight_v", "WN.0.start.weight_g", "WN.0.start.bias",
+              "WN.0.in_layers.0.weight_v", "WN.0.in_layers.0.weight_g", "WN.0.in_layers.0.bias",
+              "WN.0.in_layers.7.weight_v", "WN.5.cond_layers.3.weight_v", "WN.5.cond_layers.3.bias",
+              "WN.11.res_skip_layers.7.weight_v", "WN.11.res_skip_layers.6.weight_v", "WN.11.res_skip_layers.6.bias",
+              "WN.3.end.weight", "WN.3.end.bias", "WN.11.end.weight", "convinv.0.conv.weight", "convinv.4.conv.weight",
+              "convinv.11.conv.weight"]
+
+
+def cfg5_batch(B):
+    """The seeded training batch of gen_waveglow_train_cfg5 (regenerable: the audio is NOT committed).  Audio
+    [B, segment_length 10000] ~ N(0, 0.1^2) clipped to +-1 from PCG64(500 + B); mel [B, 80, 10000 // 160 + 1 = 63]
+    (the frame count Mel2Samp yields, mel2samp.py:107-118) from facppg.synth.synthetic_mel(seed 700 + B)."""
+    g = np.random.Generator(np.random.PCG64(500 + B))
+    wav = torch.from_numpy(np.clip(g.standard_normal((B, 10000), dtype=np.float32) * 0.1, -1, 1))
+    mel = synth.synthetic_mel(B, 10000 // 160 + 1, seed=700 + B)
+    return mel, wav
+
+
+def gen_waveglow_train_cfg5():
+    """BASELINE config 5 at ITS OWN shape (waveglow/config.json:8,14: batch_size 3, segment_length 10000, hop 160): the
+    imported reference's forward + WaveGlowLoss + autograd backward (train_waveglow.py:118-147, glow.py:43-59,208-250) on
+    the weight-normed model, at batch 3 (the reference's per-GPU batch) and at batch 12 (the second entry bench.py times,
+    where the bf16 launch plan flips to fused forward layers / 256 x 256 weight-gradient tiles / 64 positions per tile).
+    Commits loss, all 938 gradient norms and strided sub-samples of 20 gradients; the inputs regenerate from seeds."""
+    import time
+    from waveglow import glow
+    cfg = dict(synth.WAVEGLOW_CONFIG)
+    sd = synth.waveglow_state_dict(cfg)
+    wn_sd = {}
+    for k, v in sd.items():
+        if k.startswith("WN.") and k.endswith(".weight") and ".end." not in k:
+            wn_sd[k[:-6] + "weight_v"] = v
+            wn_sd[k[:-6] + "weight_g"] = v.flatten(1).norm(dim=1).view(-1, 1, 1)
+        else:
+            wn_sd[k] = v
+    for B in (3, 12):
+        m = glow.WaveGlow(**cfg)
+        m.load_state_dict(wn_sd, strict=True)
+        m.train()
+        mel, wav = cfg5_batch(B)
+        m.zero_grad()
+        t0 = time.time()
+        out = m((mel, wav))
+        loss = glow.WaveGlowLoss(0.7071)(out)
+        loss.backward()
+        print("reference step at B = %d x 10000: %.1f s, loss %.6f" % (B, time.time() - t0, float(loss)))
+        grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        arrs = {"loss": loss.detach(), "B": B, "segment_length": 10000, "hop": 160, "wav_seed": 500 + B, "mel_seed": 700 + B,
+                "wav_sha": np.frombuffer(sha(wav.numpy()).encode(), dtype=np.uint8),
+                "names": np.frombuffer(json.dumps(sorted(grads)).encode(), dtype=np.uint8),
+                "norms": np.array([float(grads[k].double().norm()) for k in sorted(grads)])}
+        for k in TRAIN_KEEP:
+            flat = grads[k].reshape(-1)
+            arrs["g:" + k] = flat[::max(1, -(-flat.numel() // 4096))].contiguous()
+        save("waveglow_train_cfg5_B%d.npz" % B, **arrs)
+
+
 def gen_e2e():
     """The body of the reference CLI (generate_synthesis.py:55-62,75-95) on synthetic checkpoints: PPG ->
     get_inference -> waveglow_audio(sigma 0.6, is_cuda_output=True) -> Denoiser('zeros')(strength 0.005), with the
@@ -436,6 +493,7 @@ def main():
     gen_denoiser_hop256()
     gen_waveglow_old()
     gen_waveglow_train()
+    gen_waveglow_train_cfg5()
     gen_tacotron()
     gen_e2e()
     gen_e2e_metric()

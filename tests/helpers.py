@@ -34,3 +34,17 @@ def tacotron_case(tag):
     enc_masks = masks_from_seed(int(d["enc_mask_seed"]), (2, 1, Tin, hp.symbols_embedding_dim))
     dec_masks = masks_from_seed(int(d["dec_mask_seed"]), (ms, 2, 1, hp.prenet_dim))
     return d, hp, sd, ppg, enc_masks, dec_masks
+
+
+def cfg5_batch(B):
+    """The seeded training batch of tests/golden/waveglow_train_cfg5_B<B>.npz (make_golden.py::cfg5_batch): audio
+    [B, 10000] ~ N(0, 0.1^2) clipped to +-1 from PCG64(500 + B), mel [B, 80, 63] from synthetic_mel(seed 700 + B)."""
+    from facppg import synth
+    g = np.random.Generator(np.random.PCG64(500 + B))
+    wav = torch.from_numpy(np.clip(g.standard_normal((B, 10000), dtype=np.float32) * 0.1, -1, 1))
+    return synth.synthetic_mel(B, 10000 // 160 + 1, seed=700 + B), wav
+
+
+def sha16(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]

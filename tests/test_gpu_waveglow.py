@@ -263,6 +263,38 @@ def test_training_step_loss_and_gradients_match_reference():
             assert np.abs(sub - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()) + 1e-6, key
 
 
+def test_training_step_fp32_at_config5_shape_matches_reference():
+    """The fp32 training path at BASELINE config 5's own shape (batch 3 x segment 10000, waveglow/config.json:8,14) vs the imported
+    reference's loss and gradients (tests/golden/waveglow_train_cfg5_B3.npz)."""
+    import json
+    from helpers import cfg5_batch
+    from test_gpu_e2e import weightnorm_state_dict
+    from waveglow.glow import WaveGlow, WaveGlowLoss
+    d = golden("waveglow_train_cfg5_B3.npz")
+    mel, wav = cfg5_batch(3)
+    cfg = dict(synth.WAVEGLOW_CONFIG)
+    m = WaveGlow(**cfg)
+    m.load_state_dict(weightnorm_state_dict(synth.waveglow_state_dict(cfg)), strict=True)
+    m = m.cuda().train()
+    m.zero_grad()
+    loss = WaveGlowLoss(0.7071)(m((mel.cuda(), wav.cuda())))
+    loss.backward()
+    print("loss", float(loss), "ref", float(d["loss"]))
+    assert abs(float(loss) - float(d["loss"])) <= 1e-5 * max(1.0, abs(float(d["loss"])))
+    names = json.loads(bytes(d["names"]).decode())
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    assert sorted(grads) == names
+    norms = np.array([float(grads[k].double().norm()) for k in names])
+    rel = np.abs(norms - d["norms"]) / np.maximum(d["norms"], 1e-6)
+    print("grad-norm rel err: max %.2e (%s)" % (rel.max(), names[int(rel.argmax())]))
+    assert rel.max() <= 1e-3
+    for key in d.files:
+        if key.startswith("g:"):
+            g = grads[key[2:]].detach().cpu().reshape(-1)
+            sub = g[::max(1, -(-g.numel() // 4096))].numpy()
+            assert np.abs(sub - d[key]).max() <= 2e-4 * max(1.0, np.abs(d[key]).max()) + 1e-6, key
+
+
 def test_legacy_glow_old_layout_and_convert_model():
     """waveglow.glow_old.WaveGlow (stride 256, alternating halves, glow_old.py:121-255) vs the
     reference's golden; convert_model.update_model merges separate res/skip layers."""

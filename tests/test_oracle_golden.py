@@ -164,6 +164,47 @@ def test_end_to_end_at_the_metric_shape():
     assert np.sqrt(np.mean((out.numpy().astype(np.float64) - d["audio_denoised"]) ** 2)) < 1e-5
 
 
+@pytest.mark.parametrize("B", [3, 12])
+def test_training_step_at_config5_shape(B):
+    """BASELINE config 5 at its own shape (waveglow/config.json:8,14: batch 3 x segment 10000, hop 160; and batch 12, the
+    second shape bench.py times): the oracle's forward + WaveGlowLoss (glow.py:208-250, 43-59) with torch autograd through
+    the weight-norm parametrisation w = g v / |v| against the imported reference's loss and its 938 gradient norms
+    (tests/golden/waveglow_train_cfg5_B*.npz).  The batch regenerates from its seeds (checked by hash)."""
+    from helpers import cfg5_batch, sha16
+    d = golden("waveglow_train_cfg5_B%d.npz" % B)
+    assert int(d["B"]) == B and int(d["segment_length"]) == 10000 and int(d["hop"]) == 160
+    mel, wav = cfg5_batch(B)
+    assert sha16(wav.numpy()) == bytes(d["wav_sha"]).decode()
+    cfg = dict(synth.WAVEGLOW_CONFIG)
+    sd = synth.waveglow_state_dict(cfg)
+    leaves, eff = {}, {}
+    for k, v in sd.items():
+        if k.startswith("WN.") and k.endswith(".weight") and ".end." not in k:
+            wv = v.clone().requires_grad_(True)
+            wg = v.flatten(1).norm(dim=1).view(-1, 1, 1).clone().requires_grad_(True)
+            leaves[k[:-6] + "weight_v"], leaves[k[:-6] + "weight_g"] = wv, wg
+            eff[k] = wg * wv / wv.flatten(1).norm(dim=1).view(-1, 1, 1)      # torch.nn.utils.weight_norm, dim 0
+        else:
+            leaves[k] = eff[k] = v.clone().requires_grad_(True)
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    z, log_s, log_det = owg.forward(eff, cfg, mel, wav)
+    loss = owg.loss(z, log_s, log_det, 0.7071)
+    loss.backward()
+    assert abs(float(loss) - float(d["loss"])) <= 1e-5 * max(1.0, abs(float(d["loss"])))
+    names = json.loads(bytes(d["names"]).decode())
+    assert sorted(leaves) == names
+    norms = np.array([float(leaves[k].grad.double().norm()) for k in names])
+    rel = np.abs(norms - d["norms"]) / np.maximum(d["norms"], 1e-6)
+    print("config 5, B = %d: loss %.6f (ref %.6f); grad-norm rel err max %.2e (%s)" % (B, float(loss), float(d["loss"]), rel.max(),
+                                                                                      names[int(rel.argmax())]))
+    assert rel.max() <= 1e-3
+    for key in d.files:
+        if key.startswith("g:"):
+            g = leaves[key[2:]].grad.reshape(-1)
+            sub = g[::max(1, -(-g.numel() // 4096))].numpy()
+            assert np.abs(sub - d[key]).max() <= 1e-4 * max(1.0, np.abs(d[key]).max()) + 1e-6, key
+
+
 def test_hparams_surface():
     from common import hparams
     with open(os.path.join(GOLDEN, "hparams.json")) as f:
