@@ -358,9 +358,8 @@ class Tacotron2(nn.Module):
             Tout = int(out_len_host.max())
             if Tout == int(self.decoder.max_decoder_steps):
                 print("Warning! Reached max decoder steps")     # model.py:527
-            if streaming:
-                mel_post = frame_consumer.finish(Tout, out_len)       # [1, NF, >= Tout] view: what is left of the postnet, on this stream
-            else:
+            mel_post = frame_consumer.finish(Tout, out_len) if streaming else None   # [1, NF, >= Tout] view: what is left of the postnet
+            if mel_post is None:
                 mel_post = torch.zeros_like(mel)
                 ws2 = torch.empty(L.facppg_taco_postnet_workspace_bytes(h, B, Tout), dtype=torch.uint8, device=dev)
                 _lib.check(L.facppg_taco_postnet(h, _lib.ptr(mel), _lib.ptr(out_len), B, Tout, steps, _lib.ptr(mel_post),

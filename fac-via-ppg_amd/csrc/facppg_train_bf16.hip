@@ -21,6 +21,7 @@
 // res/skip, gate backward, transposed-conv accumulate, plain), k_wgrad (NT products batched over layers and taps),
 // k_colsum (bias gradients) and the <= 8-channel start / end convs and their backward as streaming kernels.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <cstdio>
@@ -388,6 +389,15 @@ int bgemm_launch(const BGemmArgs& a, hipStream_t s) {
 // barrier per 128 reduction entries instead of per 64, one launch ramp per layer instead of two.
 // ------------------------------------------------------------------------------------------------------------
 // debugging aid shared by the two fused kernels: per-phase wall_clock64 stamps of every tile, appended to the file
+// The *_STAMPS debugging aids allocate, synchronise and free inside the launch helper: not while the stream is being captured into
+// a HIP graph (waveglow.graphed.GraphedTrainStep) -- there the variable is ignored.
+const char* stamps_path(const char* name, hipStream_t s) {
+  const char* path = getenv(name);
+  if (!path) return nullptr;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+  return path;
+}
 int dump_stamps(const char* path, const char* what, const unsigned long long* dev, int ntiles, int per_tile, int d, hipStream_t s) {
   std::vector<unsigned long long> h((size_t)ntiles * per_tile);
   FACPPG_HIP_CHECK(hipMemcpyAsync(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost, s));
@@ -642,16 +652,16 @@ int wn_fwd_launch_t(WnFwdArgs& a, hipStream_t s) {
   const int per = (a.ntiles + 7) / 8;
   {
     // > 64 KB of dynamic LDS needs the attribute on every device the kernel runs on (see k_wgrad)
-    static unsigned long long attr_devices = 0;
+    static std::atomic<unsigned long long> attr_devices{0};
     int dev = 0;
     FACPPG_HIP_CHECK(hipGetDevice(&dev));
-    if (dev >= 64 || !((attr_devices >> dev) & 1ull)) {
+    if (dev >= 64 || !((attr_devices.load(std::memory_order_relaxed) >> dev) & 1ull)) {
       FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wn_fwd<TN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
       FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wn_fwd<TN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-      if (dev < 64) attr_devices |= 1ull << dev;
+      if (dev < 64) attr_devices.fetch_or(1ull << dev, std::memory_order_relaxed);
     }
   }
-  if (const char* path = getenv("FACPPG_WN_FWD_STAMPS")) {   // debugging aid: per-phase stamps of every tile, appended to `path`
+  if (const char* path = stamps_path("FACPPG_WN_FWD_STAMPS", s)) {   // debugging aid: per-phase stamps of every tile, appended to `path`
     unsigned long long* d = nullptr;
     FACPPG_HIP_CHECK(hipMalloc(&d, (size_t)a.ntiles * 16 * 8));
     FACPPG_HIP_CHECK(hipMemsetAsync(d, 0, (size_t)a.ntiles * 16 * 8, s));
@@ -888,16 +898,16 @@ int wn_bwd_launch_t(WnBwdArgs& a, hipStream_t s) {
   a.ntiles = ((a.L + TN - 1) / TN) * a.B;
   const int per = (a.ntiles + 7) / 8;
   {
-    static unsigned long long attr_devices = 0;
+    static std::atomic<unsigned long long> attr_devices{0};
     int dev = 0;
     FACPPG_HIP_CHECK(hipGetDevice(&dev));
-    if (dev >= 64 || !((attr_devices >> dev) & 1ull)) {
+    if (dev >= 64 || !((attr_devices.load(std::memory_order_relaxed) >> dev) & 1ull)) {
       FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wn_bwd<TN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
       FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wn_bwd<TN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-      if (dev < 64) attr_devices |= 1ull << dev;
+      if (dev < 64) attr_devices.fetch_or(1ull << dev, std::memory_order_relaxed);
     }
   }
-  if (const char* path = getenv("FACPPG_WN_BWD_STAMPS")) {
+  if (const char* path = stamps_path("FACPPG_WN_BWD_STAMPS", s)) {
     unsigned long long* d = nullptr;
     FACPPG_HIP_CHECK(hipMalloc(&d, (size_t)a.ntiles * 24 * 8));
     FACPPG_HIP_CHECK(hipMemsetAsync(d, 0, (size_t)a.ntiles * 24 * 8, s));
@@ -1034,12 +1044,12 @@ int dspect_launch(DspectArgs& a, hipStream_t s) {
   a.ntiles = 2 * ((a.L + 63) / 64) * a.B;
   const int per = (a.ntiles + 7) / 8;
   {
-    static unsigned long long attr_devices = 0;
+    static std::atomic<unsigned long long> attr_devices{0};
     int dev = 0;
     FACPPG_HIP_CHECK(hipGetDevice(&dev));
-    if (dev >= 64 || !((attr_devices >> dev) & 1ull)) {
+    if (dev >= 64 || !((attr_devices.load(std::memory_order_relaxed) >> dev) & 1ull)) {
       FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_dspect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDspectLds));
-      if (dev < 64) attr_devices |= 1ull << dev;
+      if (dev < 64) attr_devices.fetch_or(1ull << dev, std::memory_order_relaxed);
     }
   }
   k_dspect<<<dim3(8 * per), 640, kDspectLds, s>>>(a);
@@ -1364,12 +1374,12 @@ int wgrad2_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, siz
   wa.tiles_k = tk; wa.tiles_m = tm; wa.ngroups = nprob * ns; wa.xcd_map = 1;
   constexpr size_t kLds = (size_t)2 * 2 * 256 * LDP * sizeof(bf16_t);   // 147 456 B
   {
-    static unsigned long long attr_devices = 0;
+    static std::atomic<unsigned long long> attr_devices{0};
     int dev = 0;
     FACPPG_HIP_CHECK(hipGetDevice(&dev));
-    if (dev >= 64 || !((attr_devices >> dev) & 1ull)) {
+    if (dev >= 64 || !((attr_devices.load(std::memory_order_relaxed) >> dev) & 1ull)) {
       FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wgrad2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
-      if (dev < 64) attr_devices |= 1ull << dev;
+      if (dev < 64) attr_devices.fetch_or(1ull << dev, std::memory_order_relaxed);
     }
   }
   k_wgrad2<<<dim3(8 * ((wa.ngroups + 7) / 8) * tk * tm), 512, kLds, s>>>(wa);
@@ -1399,20 +1409,20 @@ int wgrad_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size
   {
     // > 64 KB of dynamic LDS needs the attribute on EVERY device the kernel runs on (one bit per device; a second thread
     // setting it again is harmless)
-    static unsigned long long attr_devices = 0;
+    static std::atomic<unsigned long long> attr_devices{0};
     int dev = 0;
     FACPPG_HIP_CHECK(hipGetDevice(&dev));
-    if (dev >= 64 || !((attr_devices >> dev) & 1ull)) {
+    if (dev >= 64 || !((attr_devices.load(std::memory_order_relaxed) >> dev) & 1ull)) {
       FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wgrad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgradLds));
       FACPPG_HIP_CHECK(hipFuncSetAttribute((const void*)k_wgrad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgradLds));
-      if (dev < 64) attr_devices |= 1ull << dev;
+      if (dev < 64) attr_devices.fetch_or(1ull << dev, std::memory_order_relaxed);
     }
   }
   {
     const char* e_map = getenv("FACPPG_WGRAD_NO_XCD_MAP");
     const bool no_map = e_map && e_map[0] == '1';
     wa.tiles_k = (maxK + 127) / 128; wa.tiles_m = (maxM + 127) / 128; wa.ngroups = nprob * ns; wa.xcd_map = no_map ? 0 : 1;
-    const char* spath = getenv("FACPPG_WGRAD_STAMPS");
+    const char* spath = stamps_path("FACPPG_WGRAD_STAMPS", s);
     if (spath) {
       FACPPG_HIP_CHECK(hipMalloc(&wa.stamps, 64 * 24 * 8));
       FACPPG_HIP_CHECK(hipMemsetAsync(wa.stamps, 0, 64 * 24 * 8, s));

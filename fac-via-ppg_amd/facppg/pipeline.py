@@ -6,6 +6,7 @@ with per-utterance lengths threaded through every HIP call, so each utterance's 
 its own batch-1 run; everything stays on the device until the final copy of the audio.
 """
 import os
+import threading
 
 import numpy as np
 import torch
@@ -80,6 +81,7 @@ class ConditioningStream(object):
         self.key = None
         self.active = False
         self.profile = False       # True: hipEvents around every seed pass of the following utterances (pass_ms)
+        self.lock = threading.Lock()   # held by synthesize() for the whole utterance (buffers, streams and plan are per model pair)
 
     @staticmethod
     def usable(tacotron, waveglow):
@@ -90,39 +92,54 @@ class ConditioningStream(object):
             return False
         return waveglow.WN[0].n_layers == 8 and waveglow.n_group == 8
 
-    def _buffers(self, dev, steps):
+    SLACK = 64   # frames past the PPG's length the buffers are laid out for (an utterance that runs on past them is finished unstreamed)
+
+    def _buffers(self, dev, steps, cap):
+        """Views for one utterance: the frame words cover the decoder's step limit ``steps`` (it publishes every frame it makes), the
+        vocoder-side buffers (zero-margined mel, seeds, the streaming postnet's layers) are LAID OUT for ``cap`` <= steps frames --
+        the PPG's length plus SLACK, not max_decoder_steps: 64 KiB of seeds per (layer, phase, 32 frames) is 1.9 GB at 288 frames and
+        6.4 GB at 1000.  The allocations only ever grow (an utterance of another length re-uses them under its own layout) and the
+        two side streams are created once per device."""
         from facppg import lib as _lib
-        key = (dev, steps)
-        if self.key == key:
-            return
         L = _lib.load()
         hp = self.tacotron._hp
         self.NF = hp["n_acoustic_feat_dims"]
         self.lag = (hp["postnet_kernel_size"] - 1) // 2 * hp["postnet_n_convolutions"]
-        self.tqp, self.margin, seed_bytes = self.waveglow.seed_layout(steps, dev)
+        if self.key != dev:
+            self.store = {}
+            # The seed passes fill every CU the decoder leaves; the postnet's launches next to them are a few workgroups each and must
+            # not queue for a slot behind thousands of the pass's own (measured: 260 us for a 22 us launch): the seed stream gets the
+            # lowest priority, the postnet stream the highest (FACPPG_STREAM_PRIO=0: both default).
+            lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, 0)
+            if os.environ.get("FACPPG_STREAM_PRIO", "1") == "0":
+                lo = hi = 0
+            self.side = torch.cuda.Stream(device=dev, priority=max(lo, hi))          # the seed passes (largest number = lowest priority)
+            # frame collection + the streaming postnet, one block ahead of them (FACPPG_STREAM_ONE=1: on the same stream, experiments)
+            self.post = self.side if os.environ.get("FACPPG_STREAM_ONE") == "1" else torch.cuda.Stream(device=dev, priority=min(lo, hi))
+            self.prio = (lo, hi)
+            self.key = dev
+
+        def grown(name, numel, dtype, zero=False):
+            t = self.store.get(name)
+            if t is None or t.numel() < numel:
+                self.store[name] = t = (torch.zeros if zero else torch.empty)(numel, dtype=dtype, device=dev)
+            return t[:numel]
+        self.tqp, self.margin, seed_bytes = self.waveglow.seed_layout(cap, dev)
         # {value, frame + 1} words + the void flags + the work counters + mel_post in the vocoder's zero-margined layout: ONE allocation,
         # zeroed by one launch before every decode
         nw = steps * self.NF + 512
-        self.zeroed = torch.zeros(nw + (self.NF * self.tqp + 1) // 2, dtype=torch.int64, device=dev)
+        self.zeroed = grown("zeroed", nw + (self.NF * self.tqp + 1) // 2, torch.int64, zero=True)
         self.words = self.zeroed[:nw]
         self.void = self.words[steps * self.NF:].view(torch.int32)[:512]                  # one per block
         self.counters = self.words[steps * self.NF:].view(torch.int32)[512:]              # one per bounded seed launch
         self.melp = self.zeroed[nw:].view(torch.float32)[:self.NF * self.tqp].view(self.NF, self.tqp)
-        self.mel = torch.zeros(self.NF, steps, dtype=torch.float32, device=dev)           # collected frames, channel-major
-        self.seeds = torch.empty(seed_bytes // 4, dtype=torch.float32, device=dev)
-        self.post_ws = torch.empty(L.facppg_taco_postnet_stream_workspace_bytes(self.tacotron._handle(dev), steps), dtype=torch.uint8,
-                                   device=dev)
-        # The seed passes fill every CU the decoder leaves; the postnet's launches next to them are a few workgroups each and must not
-        # queue for a slot behind thousands of the pass's own (measured: 260 us for a 22 us launch): the seed stream gets the lowest
-        # priority, the postnet stream the highest (FACPPG_STREAM_PRIO=0: both default).
-        lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, 0)
-        if os.environ.get("FACPPG_STREAM_PRIO", "1") == "0":
-            lo = hi = 0
-        self.side = torch.cuda.Stream(device=dev, priority=max(lo, hi))          # the seed passes (largest number = lowest priority)
-        # frame collection + the streaming postnet, one block ahead of them (FACPPG_STREAM_ONE=1: on the same stream, experiments)
-        self.post = self.side if os.environ.get("FACPPG_STREAM_ONE") == "1" else torch.cuda.Stream(device=dev, priority=min(lo, hi))
-        self.prio = (lo, hi)
-        self.key = key
+        self.mel = grown("mel", self.NF * steps, torch.float32, zero=True).view(self.NF, steps)   # collected frames, channel-major
+        self.seeds = grown("seeds", seed_bytes // 4, torch.float32)
+        self.post_ws = grown("post_ws", L.facppg_taco_postnet_stream_workspace_bytes(self.tacotron._handle(dev), cap), torch.uint8)
+
+    def footprint_bytes(self):
+        """Device memory the stream holds on to between utterances."""
+        return sum(t.numel() * t.element_size() for t in getattr(self, "store", {}).values())
 
     def plan(self, steps, Tin):
         """[(frames of mel needed, first seeded frame, end of seeded frames)] -- blocks that can be formed before the utterance ends
@@ -143,7 +160,7 @@ class ConditioningStream(object):
                 w = max(32, min(widths.pop(0), rest))
             cuts.append((s + w + self.lag, s, s + w))
             s += w
-        s_lim = (steps - self.lag) // 32 * 32                     # the decoder may run on to its step limit: a few more blocks
+        s_lim = (min(steps, self.cap) - self.lag) // 32 * 32      # the decoder may run on towards its step limit: a few more blocks
         extra = 0
         while s < s_lim and extra < 2 and len(cuts) < 120:
             w = min(chunk, s_lim - s)
@@ -162,7 +179,12 @@ class ConditioningStream(object):
         # streamed; 130 frames 10.0 -> 9.7, 200 frames 13.3 -> 11.5, 1000 frames 53.9 -> 48.5).  FACPPG_STREAM_MIN_FRAMES overrides.
         if not self.usable(tacotron, self.waveglow) or min(steps, Tin) < int(os.environ.get("FACPPG_STREAM_MIN_FRAMES", "128")):
             return None
-        self._buffers(dev, steps)
+        self.cap = min(steps, -(-(Tin + self.SLACK) // 32) * 32)
+        try:
+            self._buffers(dev, steps, self.cap)
+        except torch.cuda.OutOfMemoryError:                 # (no room for the seeds next to whatever else lives here: run unstreamed)
+            self.key, self.store = None, {}
+            return None
         self.dev, self.steps, self.Tin, self.taco_handle = dev, steps, Tin, handle
         cur = torch.cuda.current_stream(dev)
         cur.wait_stream(self.side)      # (an utterance that was abandoned half way -- an exception between the decoder and the vocoder --
@@ -198,7 +220,7 @@ class ConditioningStream(object):
             if self.profile:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e0.record(self.side)
-            self.waveglow.cond_seed(self.melp, steps, s_a, n, self.seeds, block_tiles=bt, layers_per_workgroup=lpw, skip=void,
+            self.waveglow.cond_seed(self.melp, self.cap, s_a, n, self.seeds, block_tiles=bt, layers_per_workgroup=lpw, skip=void,
                                     handle=self.wg_handle, flows=(lo, hi - lo), max_workgroups=bound,
                                     counter=self.counters[self.n_launch:self.n_launch + 1] if self.n_launch < 500 else None)
             self.n_launch += 1
@@ -219,7 +241,7 @@ class ConditioningStream(object):
                                                             _lib.ptr(self.void[k - 1:k]) if k else None, st))
                     _lib.check(L.facppg_taco_postnet_range(self.taco_handle, _lib.ptr(self.mel), steps, f_prev, f_new, 0,
                                                            self.melp.data_ptr() + 4 * self.margin, self.tqp, _lib.ptr(self.post_ws),
-                                                           self.post_ws.numel(), steps, _lib.ptr(void), st))
+                                                           self.post_ws.numel(), self.cap, _lib.ptr(void), st))
                     final = torch.cuda.Event()
                     final.record(self.post)
                     self.last_final = final
@@ -235,11 +257,17 @@ class ConditioningStream(object):
 
     def finish(self, Tout, out_len):
         """The decoder has ended at Tout frames (known on the host): what the blocks could not cover, on the caller's stream.
-        Returns mel_post [1, NF, Tout] (a view of the vocoder's mel buffer)."""
+        Returns mel_post [1, NF, Tout] (a view of the vocoder's mel buffer, valid until the next streamed utterance on these models),
+        or None when the utterance outgrew the stream's layout: the caller then runs the one-shot postnet and the ordinary vocoder."""
         from facppg import lib as _lib
         L = _lib.load()
         dev, steps = self.dev, self.steps
         cur = torch.cuda.current_stream(dev)
+        if Tout > self.cap:       # the decoder ran on past the frames the buffers were laid out for (PPG length + SLACK): unstreamed
+            cur.wait_stream(self.post)
+            cur.wait_stream(self.side)
+            self.active = False
+            return None
         # what is left of the postnet needs the postnet stream's blocks only; the seed passes' events gate the vocoder's flows (vocode)
         if self.last_final is not None:
             cur.wait_event(self.last_final)
@@ -265,7 +293,7 @@ class ConditioningStream(object):
                                                         _lib.ptr(self.mel), steps, None, None, st))
             _lib.check(L.facppg_taco_postnet_range(self.taco_handle, _lib.ptr(self.mel), steps, f_done, Tout, Tout,
                                                    self.melp.data_ptr() + 4 * self.margin, self.tqp, _lib.ptr(self.post_ws),
-                                                   self.post_ws.numel(), steps, None, st))
+                                                   self.post_ws.numel(), self.cap, None, st))
         self.Tout, self.seeded = Tout, s_done
         return self.melp[:, self.margin:self.margin + Tout].unsqueeze(0)
 
@@ -295,12 +323,12 @@ class ConditioningStream(object):
         # mixed launch is 0.35 - 0.85 ms ahead of the extra pass)
         in_kernel = s_done > 0 and s_done < T and tail != "seed" and (tail == "mixed" or -(-mixed_wgs // n_cu) <= -(-seeded_wgs // n_cu))
         if s_all > s_done and not in_kernel:
-            self.waveglow.cond_seed(self.melp, self.steps, s_done, s_all - s_done, self.seeds, block_tiles=1, layers_per_workgroup=2,
+            self.waveglow.cond_seed(self.melp, self.cap, s_done, s_all - s_done, self.seeds, block_tiles=1, layers_per_workgroup=2,
                                     handle=self.wg_handle)
             s_done = s_all
         self.active = False
         return self.waveglow.infer_seeded(self.melp, T, self.seeds, s_done, sigma=sigma, z=z, seed=seed, handle=self.wg_handle,
-                                          T_layout=self.steps, flow_events=self.flow_events)
+                                          T_layout=self.cap, flow_events=self.flow_events)
 
 
 class StageTimer(object):
@@ -401,11 +429,19 @@ def synthesize(ppgs, tacotron, waveglow, denoiser=None, sigma=0.6, strength=0.00
             consumer = waveglow.__dict__.get("_facppg_cond_stream")
             if consumer is None or consumer.tacotron is not tacotron:
                 consumer = waveglow.__dict__["_facppg_cond_stream"] = ConditioningStream(tacotron, waveglow)
-        mel_post, tout = _acoustic(ppgs, tacotron, seed, dropout_masks, utterance_seeds, step_limits, timer,
-                                   # host work under the decoder's milliseconds: the vocoder's weight check (the stream does its own)
-                                   while_decoding=lambda: None if (consumer is not None and consumer.active) else waveglow.prepare(dev),
-                                   consumer=consumer)
-        audio = _vocode(mel_post, tout, waveglow, denoiser, sigma, strength, seed, z, utterance_seeds, timer, consumer)
+        # The stream's buffers and per-utterance state belong to the model pair: ONE utterance at a time goes through them.  A second
+        # thread serving another batch-1 request on the same models meanwhile takes the unstreamed path (same samples).
+        if consumer is not None and not consumer.lock.acquire(blocking=False):
+            consumer = None
+        try:
+            mel_post, tout = _acoustic(ppgs, tacotron, seed, dropout_masks, utterance_seeds, step_limits, timer,
+                                       # host work under the decoder's milliseconds: the vocoder's weight check (the stream does its own)
+                                       while_decoding=lambda: None if (consumer is not None and consumer.active) else waveglow.prepare(dev),
+                                       consumer=consumer)
+            audio = _vocode(mel_post, tout, waveglow, denoiser, sigma, strength, seed, z, utterance_seeds, timer, consumer)
+        finally:
+            if consumer is not None:
+                consumer.lock.release()
     if return_device:
         return [audio[b, :tout[b] * hop] for b in range(len(tout))], tout
     host = audio.cpu().numpy()
