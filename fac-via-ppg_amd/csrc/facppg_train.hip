@@ -296,59 +296,9 @@ __global__ void k_seg_sum_final(const double* __restrict__ part, float* __restri
 
 using namespace facppg;
 
-// log det W and W^-T of one small mixing matrix (c <= 8) by LU with partial pivoting, one thread: what torch.logdet and its
-// backward do through rocSOLVER in ~22 tiny launches per flow and direction (glow.py:100: log_det_W = B * L * logdet(W)).
-// det <= 0 follows torch.logdet: NaN for a negative determinant, -inf for a singular matrix.
+// log det W and W^-T of one small mixing matrix (c <= 8): facppg::logdet_wave (facppg_common.h), one wave per matrix
 __global__ __launch_bounds__(64) void k_logdet(const float* __restrict__ W, int c, float* __restrict__ logdet, float* __restrict__ winv_t) {
-  // one wave; lane (i, j) owns element [i][j] of the matrix and of the accumulating inverse (Gauss-Jordan on [A | I] with
-  // partial pivoting).  (A one-thread version with the two 8 x 8 arrays in scratch took 72 us per call.)
-  __shared__ float A[8][8], Iv[8][8];
-  __shared__ int s_piv, s_singular;
-  __shared__ float s_sign, s_log;
-  const int tid = threadIdx.x, i = tid >> 3, j = tid & 7;
-  const bool in = i < c && j < c;
-  A[i][j] = in ? W[i * c + j] : (i == j ? 1.0f : 0.0f);
-  Iv[i][j] = i == j ? 1.0f : 0.0f;
-  if (tid == 0) { s_sign = 1.0f; s_log = 0.0f; s_singular = 0; }
-  __syncthreads();
-  for (int k = 0; k < c; ++k) {
-    if (tid == 0) {
-      int piv = k;
-      float best = fabsf(A[k][k]);
-      for (int r = k + 1; r < c; ++r)
-        if (fabsf(A[r][k]) > best) { best = fabsf(A[r][k]); piv = r; }
-      s_piv = piv;
-      if (best == 0.0f) s_singular = 1;
-    }
-    __syncthreads();
-    if (s_singular) break;
-    const int piv = s_piv;
-    if (piv != k && i == k) {   // row k's lanes exchange rows k and piv
-      float t = A[k][j]; A[k][j] = A[piv][j]; A[piv][j] = t;
-      t = Iv[k][j]; Iv[k][j] = Iv[piv][j]; Iv[piv][j] = t;
-    }
-    __syncthreads();
-    const float d = A[k][k];
-    __syncthreads();
-    if (tid == 0) {
-      if (piv != k) s_sign = -s_sign;
-      if (d < 0.0f) s_sign = -s_sign;
-      s_log += logf(fabsf(d));
-    }
-    if (i == k) { const float r = 1.0f / d; A[k][j] *= r; Iv[k][j] *= r; }
-    __syncthreads();
-    const float f = A[i][k], akj = A[k][j], ikj = Iv[k][j];
-    __syncthreads();
-    if (i != k) { A[i][j] = fmaf(-f, akj, A[i][j]); Iv[i][j] = fmaf(-f, ikj, Iv[i][j]); }
-    __syncthreads();
-  }
-  if (s_singular) {
-    if (tid == 0) *logdet = -INFINITY;
-    if (in) winv_t[i * c + j] = NAN;
-    return;
-  }
-  if (tid == 0) *logdet = s_sign > 0.0f ? s_log : NAN;
-  if (in) winv_t[i * c + j] = Iv[j][i];
+  logdet_wave(W, c, logdet, winv_t);
 }
 
 extern "C" int facppg_logdet(const float* w_dev, int c, float* logdet_dev, float* winv_t_dev, void* stream) {

@@ -102,7 +102,7 @@ __device__ __forceinline__ void gate_bwd(float v, float T, float S, float& dt, f
 }
 __device__ __forceinline__ int gate_row_src(int mb, int rho) { return (rho >= 16 ? C : 0) + 16 * mb + ((rho >> 3) & 1) * 8 + (rho & 7); }
 
-constexpr int MAXPACK = 32;
+constexpr int MAXPACK = 48;   // (one flow's images of both directions; 48 x 72 B of kernel arguments)
 struct PackBatch { PackArgs e[MAXPACK]; };
 __global__ void k_pack_bf16(PackBatch pb) {
   const PackArgs& p = pb.e[blockIdx.y];
@@ -1352,6 +1352,42 @@ __global__ void k_wgrad_reduce(WgradArgs wa) {
   p.out[m * p.o_sm + k * p.o_sk] = v;
 }
 
+// The ordered sums of SEVERAL k_wgrad / k_wgrad2 launches' partials in one launch (a flow's tap, conditioning and res/skip products
+// each leave theirs in a region of their own): same sums in the same order as k_wgrad_reduce per launch.
+constexpr int MAXRED = 48;
+struct ReduceProb { const float* part; float* out; size_t pstride; long o_sm, o_sk; int nsplit, M, K; };
+struct ReduceSet {
+  ReduceProb p[MAXRED];
+  int n = 0, max_mk = 0;
+  void add(const WgradArgs& wa, int nprob) {
+    for (int i = 0; i < nprob && n < MAXRED; ++i) {
+      const WgradProb& q = wa.prob[i];
+      p[n++] = ReduceProb{wa.part + (size_t)i * wa.nsplit * wa.pstride, q.out, wa.pstride, q.o_sm, q.o_sk, wa.nsplit, q.M, q.K};
+      max_mk = std::max(max_mk, q.M * q.K);
+    }
+  }
+};
+struct ReduceArgs { ReduceProb p[MAXRED]; };
+__global__ void k_wgrad_reduce_multi(ReduceArgs ra) {
+  const ReduceProb& p = ra.p[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.M * p.K) return;
+  const float* part = p.part + i;
+  float v = 0.0f;
+  for (int s = 0; s < p.nsplit; ++s) v += part[(size_t)s * p.pstride];
+  const int m = i / p.K, k = i - m * p.K;
+  p.out[m * p.o_sm + k * p.o_sk] = v;
+}
+int reduce_launch(ReduceSet& rs, hipStream_t s) {
+  if (!rs.n) return FACPPG_OK;
+  ReduceArgs ra;
+  memcpy(ra.p, rs.p, sizeof(ReduceProb) * rs.n);
+  k_wgrad_reduce_multi<<<dim3((rs.max_mk + 255) / 256, rs.n), 256, 0, s>>>(ra);
+  FACPPG_HIP_CHECK(hipGetLastError());
+  rs.n = 0; rs.max_mk = 0;
+  return FACPPG_OK;
+}
+
 constexpr int WG_MAXSPLIT = 8;
 // launches one batch of problems that share (M, K) tile counts; partial buffer: nprob * nsplit * maxM * maxK floats
 // 256 x 256 tiles (k_wgrad2) when they give >= 32 tiles and every workgroup then has >= 24 chunks of positions; FACPPG_WGRAD_TILE=128|256 forces
@@ -1365,7 +1401,7 @@ bool wgrad2_wanted(int nprob, int maxM, int maxK, int B, int L, size_t part_byte
   const char* e = getenv("FACPPG_WGRAD_TILE");
   return e ? atoi(e) == 256 : (tiles >= 32 && nall / ns >= 24);
 }
-int wgrad2_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size_t part_bytes, hipStream_t s, bool* done) {
+int wgrad2_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size_t part_bytes, hipStream_t s, bool* done, ReduceSet* defer = nullptr) {
   *done = false;
   const int tk = (maxK + 255) / 256, tm = (maxM + 255) / 256;
   int ns = 1;
@@ -1383,17 +1419,22 @@ int wgrad2_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, siz
     }
   }
   k_wgrad2<<<dim3(8 * ((wa.ngroups + 7) / 8) * tk * tm), 512, kLds, s>>>(wa);
-  if (ns > 1) k_wgrad_reduce<<<dim3((maxM * maxK + 255) / 256, nprob), 256, 0, s>>>(wa);
+  if (ns > 1) {
+    if (defer) defer->add(wa, nprob);
+    else k_wgrad_reduce<<<dim3((maxM * maxK + 255) / 256, nprob), 256, 0, s>>>(wa);
+  }
   FACPPG_HIP_CHECK(hipGetLastError());
   *done = true;
   return FACPPG_OK;
 }
 
-int wgrad_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size_t part_bytes, hipStream_t s) {
+// defer: the partials' ordered sum is left to the caller's reduce_launch (one launch for several of these)
+int wgrad_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size_t part_bytes, hipStream_t s, ReduceSet* defer = nullptr) {
   FACPPG_REQUIRE(maxM % 128 == 0 && maxK % 128 == 0, FACPPG_EINVAL, "k_wgrad: M and K must be multiples of 128 (got %d, %d)", maxM, maxK);
+  FACPPG_REQUIRE(!defer || defer->n + nprob <= MAXRED, FACPPG_EINVAL, "too many deferred weight-gradient problems");
   {
     bool done = false;
-    if (int rc = wgrad2_launch(wa, nprob, maxM, maxK, part, part_bytes, s, &done)) return rc;
+    if (int rc = wgrad2_launch(wa, nprob, maxM, maxK, part, part_bytes, s, &done, defer)) return rc;
     if (done) return FACPPG_OK;
   }
   const int tiles = ((maxK + 127) / 128) * ((maxM + 127) / 128) * nprob;
@@ -1446,7 +1487,10 @@ int wgrad_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size
       }
     }
   }
-  if (ns > 1) k_wgrad_reduce<<<dim3((maxM * maxK + 255) / 256, nprob), 256, 0, s>>>(wa);
+  if (ns > 1) {
+    if (defer) defer->add(wa, nprob);
+    else k_wgrad_reduce<<<dim3((maxM * maxK + 255) / 256, nprob), 256, 0, s>>>(wa);
+  }
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
 }
@@ -1456,7 +1500,9 @@ int wgrad_launch(WgradArgs& wa, int nprob, int maxM, int maxK, float* part, size
 // order -- a fixed summation order whatever the grid, so the result is bit-reproducible.
 constexpr int CS_SLICES = 256, MAXCS = 16;
 struct ColsumProb { const void* y; long bs; int ld, row0, M; float* out; float* out2; };   // out2: optional second copy of the sums
-struct ColsumArgs { ColsumProb prob[MAXCS]; int B, L; float* part; };   // part [prob][CS_SLICES][1024]
+// part [prob][CS_SLICES][1024]; bc: further copies of problem bc_prob's sums (the skip half of every layer's res_skip bias gradient
+// is the column sum of the same dskip)
+struct ColsumArgs { ColsumProb prob[MAXCS]; int B, L; float* part; float* bc[8]; int nbc, bc_prob; };
 template <bool F32>
 __global__ __launch_bounds__(256) void k_colsum_part(ColsumArgs ca) {
   // a thread owns TWO adjacent channels (one 4-byte load of bf16, 8 bytes of fp32), the 256 threads cover M / 2 channel
@@ -1547,6 +1593,8 @@ __global__ __launch_bounds__(256) void k_colsum_sum(ColsumArgs ca, int group) {
   for (int k = 1; k < 8; ++k) v += red[k][o];
   p.out[mo] = v;
   if (p.out2) p.out2[mo] = v;
+  if (ca.nbc && (int)blockIdx.y == ca.bc_prob)
+    for (int i = 0; i < ca.nbc; ++i) ca.bc[i][mo] = v;
 }
 template <bool F32>
 int colsum_launch(ColsumArgs& ca, int nprob, int maxM, int group, hipStream_t s) {
@@ -1560,9 +1608,6 @@ int colsum_launch(ColsumArgs& ca, int nprob, int maxM, int group, hipStream_t s)
   return FACPPG_OK;
 }
 
-// the skip half of every layer's res_skip bias gradient is the same vector
-struct SkipBiasCopy { const float* src; float* dst[8]; int n; };
-__global__ void k_copy_skip_bias(SkipBiasCopy cp) { cp.dst[blockIdx.y][threadIdx.x] = cp.src[threadIdx.x]; }
 
 // ---- the <= 8-channel edges of the stack ----------------------------------------------------------------------
 // start conv (glow.py:156): h0[b][HALO + n][c] = sum_j Ws[c][j] a0[b][j][n] + bs[c]
@@ -2050,14 +2095,16 @@ extern "C" int facppg_upsample_regroup_backward(const float* mel_dev, const floa
 // Zero rows [0, r0) and [r1, rows) of every image of a [images][rows][row_bytes] buffer: the conv's zero padding (the
 // 128-row margins) and the rows between L and the 128-padded length, which the GEMM tiles read.  (Zeroing the whole
 // buffers instead cost 0.5 GB of memset per flow and direction at batch 12: 1.5 ms of a 27 ms step.)
-struct ZeroJob { char* base; long images, image_bytes; int row_bytes, r0, r1, rows; };
+struct ZeroJob { char* base; long images, image_bytes, per_group, group_stride; int row_bytes, r0, r1, rows; };
 struct ZeroBatch { ZeroJob job[3]; int n; };
-// up to three such buffers per launch (blockIdx.z = buffer): the forward zeroes h / ts / acts, the backward dpre / dh / dskip
+// up to three such buffers per launch (blockIdx.z = buffer): the forward zeroes h / ts / acts, the backward dpre / dh / dskip.
+// A buffer may be a strided set of `groups` such arrays (the same tensor of every flow's saved state: image y = group y / per_group).
 __global__ void k_zero_rows(ZeroBatch zb) {
   const ZeroJob& j = zb.job[blockIdx.z];
   if ((long)blockIdx.y >= j.images) return;
   const long head = (long)j.r0 * j.row_bytes, n16 = (head + (long)(j.rows - j.r1) * j.row_bytes) / 16;
-  char* img = j.base + (long)blockIdx.y * j.image_bytes;
+  const long g = (long)blockIdx.y / j.per_group, im = (long)blockIdx.y - g * j.per_group;
+  char* img = j.base + g * j.group_stride + im * j.image_bytes;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
     const long byte = i * 16;
     *reinterpret_cast<uint4*>(byte < head ? img + byte : img + (long)j.r1 * j.row_bytes + (byte - head)) = make_uint4(0, 0, 0, 0);
@@ -2068,11 +2115,11 @@ struct ZeroRows {
   ZeroBatch zb;
   long max_images = 0, max_n16 = 0;
   ZeroRows() { zb.n = 0; }
-  void add(void* base, long images, long image_bytes, int row_bytes, int r0, int r1, int rows) {
+  void add(void* base, long images, long image_bytes, int row_bytes, int r0, int r1, int rows, long groups = 1, long group_stride = 0) {
     const long n16 = ((long)r0 * row_bytes + (long)(rows - r1) * row_bytes) / 16;
-    if (n16 <= 0 || images <= 0) return;
-    zb.job[zb.n++] = ZeroJob{(char*)base, images, image_bytes, row_bytes, r0, r1, rows};
-    max_images = std::max(max_images, images);
+    if (n16 <= 0 || images <= 0 || groups <= 0) return;
+    zb.job[zb.n++] = ZeroJob{(char*)base, images * groups, image_bytes, images, group_stride, row_bytes, r0, r1, rows};
+    max_images = std::max(max_images, images * groups);
     max_n16 = std::max(max_n16, n16);
   }
   void launch(hipStream_t s) {
@@ -2081,6 +2128,90 @@ struct ZeroRows {
     k_zero_rows<<<dim3(gx, (unsigned)max_images, (unsigned)zb.n), 256, 0, s>>>(zb);
   }
 };
+
+// out[flow][layer][i] = a[flow][layer][i] + b[flow][layer][i]: the summed gate biases (in + cond) of several flows' stacks
+constexpr int ADD_FLOWS = 12;
+struct AddBatchN { const float* a[ADD_FLOWS * 8]; const float* b[ADD_FLOWS * 8]; float* out; long out_stride; };
+__global__ void k_add2_flows(AddBatchN ab, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+  if (i < n) ab.out[(size_t)f * ab.out_stride + (size_t)y * n + i] = ab.a[f * 8 + y][i] + ab.b[f * 8 + y][i];
+}
+
+// ---- the stack's launches, shared by the stand-alone WN entry points (facppg_wn_forward_bf16 / _backward_bf16) and the whole-model
+// group entry points (facppg_glow_bf16_*): where the packed operand images, the saved state and the gradients in flight live is
+// the caller's business.
+struct WnPacked {   // bf16 A-operand images of one flow's stack (+ the summed gate biases), see pack_flow_images
+  const uint4* w1; size_t w1_one; const uint4* w2; size_t w2_one; const uint4* rst; size_t rst_one; const uint4* int_; size_t int_one;
+  const uint4* condt; const float* b1;
+};
+struct WnWork {     // gradients in flight of one flow's backward + the partial-sum buffers of its reductions
+  char* dpre; size_t dpre_one; char* dh; size_t dh_one; bf16_t* dskip; float* cspart; float* wgpart; size_t wgpart_bytes;
+  int wgpart_regions;    // 3: a region of wgpart_bytes per weight-gradient launch of a flow -> ONE ordered reduce for the three; 1: one shared region
+};
+
+// forward image jobs of one flow: K order tap 0 | tap 1 | tap 2 | cond, gate-interleaved rows; res/skip rows as they are
+void add_forward_images(Packer& pk, const facppg_wn_weights* wts, int nl, char* w1, size_t w1_one, char* w2, size_t w2_one) {
+  for (int i = 0; i < nl; ++i) {
+    const int last = i == nl - 1;
+    uint4* d1 = (uint4*)(w1 + w1_one * i);
+    pk.add(wts->in_w[i], d1, 2 * C, K1 / 16, 0, C, 3, (long)C * 3, 3, 1, 0, 1);
+    pk.add(wts->cond_w[i], d1, 2 * C, K1 / 16, 3 * C, NCOND, 1, NCOND, 1, 0, 0, 1);
+    pk.add(wts->rs_w[i], (uint4*)(w2 + w2_one * i), last ? C : 2 * C, C / 16, 0, C, 1, C, 1, 0, 0, 0);
+  }
+}
+// transposed images for the backward
+void add_backward_images(Packer& pk, const facppg_wn_weights* wts, int nl, char* rst, size_t rst_one, char* int_, size_t int_one, uint4* condt) {
+  for (int i = 0; i < nl; ++i) {
+    const int last = i == nl - 1;
+    // dacts[c] = sum_r Wrs[r][c] * [dh_next (res rows) | dskip (skip rows)][r]; last layer: skip rows only
+    pk.add(wts->rs_w[i], (uint4*)(rst + rst_one * i), C, (last ? C : 2 * C) / 16, 0, last ? C : 2 * C, 1, 1, C, 0, 0, 0);
+    // dh[m] += sum_{tap,o} Win[o][m][tap] * dpre[n - (tap-1) d][o]
+    pk.add(wts->in_w[i], (uint4*)(int_ + int_one * i), C, 3 * 2 * C / 16, 0, 2 * C, 3, 3, (long)C * 3, 1, 0, 0);
+    // dspect[j] = sum_{i,o} Wcond_i[o][j] * dpre_i[o]: one image, K = nl * 512
+    pk.add(wts->cond_w[i], condt, NCOND, nl * 2 * C / 16, i * 2 * C, 2 * C, 1, 1, NCOND, 0, 0, 0);
+  }
+}
+
+// the nl layers of one stack from h_0 (already in `S`) to the skip sum (glow.py:158-174)
+int wn_layers_forward(const facppg_wn_weights* wts, int nl, const WnPacked& pw, const void* spect_pm_dev, int B, int L, char* S, hipStream_t s) {
+  const int Lr = pad_len(L), Lp = HALO + Lr + HALO;
+  const StateLayout st = state_layout(nl, B, Lr);
+  const bool fused = fused_fwd_enabled(B, L);
+  for (int i = 0; i < nl; ++i) {
+    const int last = i == nl - 1, d = 1 << i;
+    const bf16_t* h_in = (const bf16_t*)(S + st.h + st.h_one * i);
+    const uint4* A1 = (const uint4*)((const char*)pw.w1 + pw.w1_one * i);
+    const uint4* A2 = (const uint4*)((const char*)pw.w2 + pw.w2_one * i);
+    if (fused) {
+      WnFwdArgs f;
+      memset(&f, 0, sizeof(f));
+      f.A1 = A1; f.A2 = A2;
+      f.h_in = h_in; f.h_out = (bf16_t*)(S + st.h + st.h_one * (i + 1)); f.h_bs = (long)Lp * C;
+      f.spect = (const bf16_t*)spect_pm_dev; f.sp_bs = (long)Lr * NCOND;
+      f.b1 = pw.b1 + 2 * C * i; f.b2 = wts->rs_b[i];
+      f.acts = (bf16_t*)(S + st.acts + st.acts_one * i); f.ts = (bf16_t*)(S + st.ts + st.ts_one * i); f.skip = (float*)(S + st.skip);
+      f.L = L; f.Lr = Lr; f.B = B; f.d = d; f.first = i == 0; f.last = last;
+      if (int rc = wn_fwd_launch(f, s)) return rc;
+      continue;
+    }
+    BGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A1; g.KG = K1 / 16; g.M = 2 * C; g.N = L; g.B = B; g.nseg = 4;
+    for (int t = 0; t < 3; ++t) g.seg[t] = Seg{h_in, (long)Lp * C, C, HALO + (t - 1) * d, C};
+    g.seg[3] = Seg{(const bf16_t*)spect_pm_dev, (long)Lr * NCOND, NCOND, 0, NCOND};
+    g.mode = EP_GATE; g.bias = pw.b1 + 2 * C * i; g.Lr = Lr;
+    g.acts = (bf16_t*)(S + st.acts + st.acts_one * i); g.ts = (bf16_t*)(S + st.ts + st.ts_one * i);
+    if (int rc = bgemm_launch(g, s)) return rc;
+    BGemmArgs r;
+    memset(&r, 0, sizeof(r));
+    r.A = A2; r.KG = C / 16; r.M = last ? C : 2 * C; r.N = L; r.B = B; r.nseg = 1;
+    r.seg[0] = Seg{g.acts, (long)Lr * C, C, 0, C};
+    r.mode = EP_RESSKIP; r.bias = wts->rs_b[i]; r.Lr = Lr; r.h_in = h_in; r.h_out = (bf16_t*)(S + st.h + st.h_one * (i + 1));
+    r.h_bs = (long)Lp * C; r.h_row0 = HALO; r.skip = (float*)(S + st.skip); r.first = i == 0; r.last = last;
+    if (int rc = bgemm_launch(r, s)) return rc;
+  }
+  return FACPPG_OK;
+}
 
 // WN.forward (glow.py:154-175) with bf16 MFMA operands, keeping what the backward needs in `state`.
 extern "C" int facppg_wn_forward_bf16(const facppg_wn_weights* wts, int n_in, int nl, const float* a0_dev, const void* spect_pm_dev, int B,
@@ -2107,54 +2238,163 @@ extern "C" int facppg_wn_forward_bf16(const facppg_wn_weights* wts, int n_in, in
   }
   {
     Packer pk;
-    for (int i = 0; i < nl; ++i) {
-      const int last = i == nl - 1;
-      uint4* w1 = (uint4*)(W + sc.w1 + sc.w1_one * i);
-      // K order: tap 0 | tap 1 | tap 2 | cond; gate-interleaved rows
-      pk.add(wts->in_w[i], w1, 2 * C, K1 / 16, 0, C, 3, (long)C * 3, 3, 1, 0, 1);
-      pk.add(wts->cond_w[i], w1, 2 * C, K1 / 16, 3 * C, NCOND, 1, NCOND, 1, 0, 0, 1);
-      pk.add(wts->rs_w[i], (uint4*)(W + sc.w2 + sc.w2_one * i), last ? C : 2 * C, C / 16, 0, C, 1, C, 1, 0, 0, 0);
-    }
+    add_forward_images(pk, wts, nl, W + sc.w1, sc.w1_one, W + sc.w2, sc.w2_one);
     if (int rc = pk.launch(s)) return rc;
     AddBatch ab;
     for (int i = 0; i < nl; ++i) { ab.a[i] = wts->in_b[i]; ab.b[i] = wts->cond_b[i]; }
     k_add2<<<dim3(2, nl), 256, 0, s>>>(ab, b1, 2 * C);
   }
   k_t_start<<<dim3((L + 31) / 32, B), 256, 0, s>>>(a0_dev, wts->start_w, wts->start_b, (bf16_t*)(S + st.h), n_in, L, Lp);
-  const bool fused = fused_fwd_enabled(B, L);
-  for (int i = 0; i < nl; ++i) {
-    const int last = i == nl - 1, d = 1 << i;
-    const bf16_t* h_in = (const bf16_t*)(S + st.h + st.h_one * i);
-    if (fused) {
-      WnFwdArgs f;
-      memset(&f, 0, sizeof(f));
-      f.A1 = (const uint4*)(W + sc.w1 + sc.w1_one * i); f.A2 = (const uint4*)(W + sc.w2 + sc.w2_one * i);
-      f.h_in = h_in; f.h_out = (bf16_t*)(S + st.h + st.h_one * (i + 1)); f.h_bs = (long)Lp * C;
-      f.spect = (const bf16_t*)spect_pm_dev; f.sp_bs = (long)Lr * NCOND;
-      f.b1 = b1 + 2 * C * i; f.b2 = wts->rs_b[i];
-      f.acts = (bf16_t*)(S + st.acts + st.acts_one * i); f.ts = (bf16_t*)(S + st.ts + st.ts_one * i); f.skip = (float*)(S + st.skip);
-      f.L = L; f.Lr = Lr; f.B = B; f.d = d; f.first = i == 0; f.last = last;
-      if (int rc = wn_fwd_launch(f, s)) return rc;
-      continue;
-    }
-    BGemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.A = (const uint4*)(W + sc.w1 + sc.w1_one * i); g.KG = K1 / 16; g.M = 2 * C; g.N = L; g.B = B; g.nseg = 4;
-    for (int t = 0; t < 3; ++t) g.seg[t] = Seg{h_in, (long)Lp * C, C, HALO + (t - 1) * d, C};
-    g.seg[3] = Seg{(const bf16_t*)spect_pm_dev, (long)Lr * NCOND, NCOND, 0, NCOND};
-    g.mode = EP_GATE; g.bias = b1 + 2 * C * i; g.Lr = Lr;
-    g.acts = (bf16_t*)(S + st.acts + st.acts_one * i); g.ts = (bf16_t*)(S + st.ts + st.ts_one * i);
-    if (int rc = bgemm_launch(g, s)) return rc;
-    BGemmArgs r;
-    memset(&r, 0, sizeof(r));
-    r.A = (const uint4*)(W + sc.w2 + sc.w2_one * i); r.KG = C / 16; r.M = last ? C : 2 * C; r.N = L; r.B = B; r.nseg = 1;
-    r.seg[0] = Seg{g.acts, (long)Lr * C, C, 0, C};
-    r.mode = EP_RESSKIP; r.bias = wts->rs_b[i]; r.Lr = Lr; r.h_in = h_in; r.h_out = (bf16_t*)(S + st.h + st.h_one * (i + 1));
-    r.h_bs = (long)Lp * C; r.h_row0 = HALO; r.skip = (float*)(S + st.skip); r.first = i == 0; r.last = last;
-    if (int rc = bgemm_launch(r, s)) return rc;
-  }
+  WnPacked pw;
+  memset(&pw, 0, sizeof(pw));
+  pw.w1 = (const uint4*)(W + sc.w1); pw.w1_one = sc.w1_one; pw.w2 = (const uint4*)(W + sc.w2); pw.w2_one = sc.w2_one; pw.b1 = b1;
+  if (int rc = wn_layers_forward(wts, nl, pw, spect_pm_dev, B, L, S, s)) return rc;
   k_t_end<<<dim3((L + 31) / 32, B), 256, 0, s>>>((const float*)(S + st.skip), wts->end_w, wts->end_b, out_dev, 2 * n_in, L, Lr);
   FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+// The data-gradient chain of one stack, from dskip (already formed from d(out) by the end conv's backward) down to dh_0, plus the
+// conditioning gradient of all layers.
+int wn_layers_backward_data(int nl, const WnPacked& pw, const char* S, const WnWork& wk, float* dspect_pm_dev, int accumulate_dspect,
+                            int B, int L, hipStream_t s) {
+  const int Lr = pad_len(L), Lp = HALO + Lr + HALO;
+  const StateLayout st = state_layout(nl, B, Lr);
+  bf16_t* dskip = wk.dskip;
+  const bool fused = fused_bwd_enabled(B, L);
+  auto rst = [&](int i) { return (const uint4*)((const char*)pw.rst + pw.rst_one * i); };
+  auto int_ = [&](int i) { return (const uint4*)((const char*)pw.int_ + pw.int_one * i); };
+  auto gate_bwd_launch = [&](int i) -> int {      // dpre_i = gate'(ts_i) * Wrs_i^T [dh_{i+1} ; dskip]
+    const int last = i == nl - 1;
+    const bf16_t* dh_next = (const bf16_t*)(wk.dh + wk.dh_one * (i + 1));
+    BGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = rst(i); g.KG = (last ? C : 2 * C) / 16; g.M = C; g.N = L; g.B = B;
+    if (last) { g.nseg = 1; g.seg[0] = Seg{dskip, (long)Lr * C, C, 0, C}; }
+    else { g.nseg = 2; g.seg[0] = Seg{dh_next, (long)Lr * C, C, 0, C}; g.seg[1] = Seg{dskip, (long)Lr * C, C, 0, C}; }
+    g.mode = EP_BWD_GATE; g.Lr = Lr; g.ts = (bf16_t*)(S + st.ts + st.ts_one * i); g.dpre = (bf16_t*)(wk.dpre + wk.dpre_one * i);
+    g.dpre_bs = (long)Lp * 2 * C;
+    return bgemm_launch(g, s);
+  };
+  auto conv_bwd_launch = [&](int i) -> int {      // dh_i = dh_{i+1} + sum_tap Win_i^T dpre_i(shifted)
+    const int last = i == nl - 1, d = 1 << i;
+    const bf16_t* dpre = (const bf16_t*)(wk.dpre + wk.dpre_one * i);
+    BGemmArgs t;
+    memset(&t, 0, sizeof(t));
+    t.A = int_(i); t.KG = 3 * 2 * C / 16; t.M = C; t.N = L; t.B = B; t.nseg = 3;
+    for (int tp = 0; tp < 3; ++tp) t.seg[tp] = Seg{dpre, (long)Lp * 2 * C, 2 * C, HALO - (tp - 1) * d, 2 * C};
+    t.mode = EP_BWD_CONV; t.Lr = Lr; t.dh_next = last ? nullptr : (const bf16_t*)(wk.dh + wk.dh_one * (i + 1));
+    t.dh_out = (bf16_t*)(wk.dh + wk.dh_one * i);
+    return bgemm_launch(t, s);
+  };
+  if (fused && nl > 1) {
+    if (int rc = gate_bwd_launch(nl - 1)) return rc;
+    for (int i = nl - 1; i >= 1; --i) {           // conv backward of layer i + gate backward of layer i-1 in one launch
+      WnBwdArgs f;
+      memset(&f, 0, sizeof(f));
+      f.A1 = int_(i); f.A2 = rst(i - 1);
+      f.dpre_i = (const bf16_t*)(wk.dpre + wk.dpre_one * i); f.dpre_bs = (long)Lp * 2 * C;
+      f.dh_next = i == nl - 1 ? nullptr : (const bf16_t*)(wk.dh + wk.dh_one * (i + 1));
+      f.dh_out = (bf16_t*)(wk.dh + wk.dh_one * i); f.dskip = dskip;
+      f.ts = (const bf16_t*)(S + st.ts + st.ts_one * (i - 1)); f.dpre_out = (bf16_t*)(wk.dpre + wk.dpre_one * (i - 1));
+      f.L = L; f.Lr = Lr; f.B = B; f.d = 1 << i;
+      if (int rc = wn_bwd_launch(f, s)) return rc;
+    }
+    if (int rc = conv_bwd_launch(0)) return rc;
+  } else {
+    for (int i = nl - 1; i >= 0; --i) {
+      if (int rc = gate_bwd_launch(i)) return rc;
+      if (int rc = conv_bwd_launch(i)) return rc;
+    }
+  }
+  const char* e_ds = getenv("FACPPG_TRAIN_DSPECT_BGEMM");     // =1: the k_bgemm<EP_ACC_F32> launch (bit-equality test, A/B timing)
+  if (!(e_ds && e_ds[0] == '1')) {  // dspect over all layers at once
+    DspectArgs c;
+    memset(&c, 0, sizeof(c));
+    c.A = pw.condt; c.dpre = (const bf16_t*)wk.dpre; c.dpre_one = (long)(wk.dpre_one / 2); c.dpre_bs = (long)Lp * 2 * C;
+    c.out = dspect_pm_dev; c.nl = nl; c.L = L; c.Lr = Lr; c.B = B; c.accumulate = accumulate_dspect != 0;
+    if (int rc = dspect_launch(c, s)) return rc;
+  } else {
+    BGemmArgs c;
+    memset(&c, 0, sizeof(c));
+    c.A = pw.condt; c.KG = nl * 2 * C / 16; c.M = NCOND; c.N = L; c.B = B; c.nseg = nl;
+    for (int i = 0; i < nl; ++i) c.seg[i] = Seg{(const bf16_t*)(wk.dpre + wk.dpre_one * i), (long)Lp * 2 * C, 2 * C, HALO, 2 * C};
+    c.mode = EP_ACC_F32; c.Lr = Lr; c.outf = dspect_pm_dev; c.ldo = NCOND; c.accumulate = accumulate_dspect != 0;
+    if (int rc = bgemm_launch(c, s)) return rc;
+  }
+  return FACPPG_OK;
+}
+
+// Weight and bias gradients of the three convs of every layer: NT products over positions, batched over layers (x taps); bias
+// gradients as column sums.
+int wn_layers_backward_weights(const facppg_wn_grads* gr, int nl, const char* S, const WnWork& wk, const void* spect_pm_dev, int B, int L,
+                               hipStream_t s) {
+  const int Lr = pad_len(L), Lp = HALO + Lr + HALO;
+  const StateLayout st = state_layout(nl, B, Lr);
+  bf16_t* dskip = wk.dskip;
+  {
+    WgradArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    wa.B = B; wa.L = L; wa.Lr = Lr;
+    for (int i = 0; i < nl; ++i)
+      for (int tp = 0; tp < 3; ++tp) {
+        WgradProb& p = wa.prob[i * 3 + tp];
+        p.dy0 = (const bf16_t*)(wk.dpre + wk.dpre_one * i); p.dy1 = nullptr; p.dy_bs = (long)Lp * 2 * C; p.ldy = 2 * C; p.dy_row0 = HALO; p.msplit = 0;
+        p.x = (const bf16_t*)(S + st.h + st.h_one * i); p.x_bs = (long)Lp * C; p.ldx = C; p.x_row0 = HALO + (tp - 1) * (1 << i);
+        p.out = gr->in_w[i] + tp; p.o_sm = (long)C * 3; p.o_sk = 3; p.M = 2 * C; p.K = C;
+      }
+    ReduceSet rs;
+    ReduceSet* defer = wk.wgpart_regions >= 3 ? &rs : nullptr;
+    float* region[3];
+    for (int r = 0; r < 3; ++r) region[r] = defer ? (float*)((char*)wk.wgpart + wk.wgpart_bytes * r) : wk.wgpart;
+    if (int rc = wgrad_launch(wa, nl * 3, 2 * C, C, region[0], wk.wgpart_bytes, s, defer)) return rc;
+    memset(&wa.prob, 0, sizeof(wa.prob));
+    for (int i = 0; i < nl; ++i) {
+      WgradProb& p = wa.prob[i];
+      p.dy0 = (const bf16_t*)(wk.dpre + wk.dpre_one * i); p.dy_bs = (long)Lp * 2 * C; p.ldy = 2 * C; p.dy_row0 = HALO;
+      p.x = (const bf16_t*)spect_pm_dev; p.x_bs = (long)Lr * NCOND; p.ldx = NCOND; p.x_row0 = 0;
+      p.out = gr->cond_w[i]; p.o_sm = NCOND; p.o_sk = 1; p.M = 2 * C; p.K = NCOND;
+    }
+    if (int rc = wgrad_launch(wa, nl, 2 * C, NCOND, region[1], wk.wgpart_bytes, s, defer)) return rc;
+    memset(&wa.prob, 0, sizeof(wa.prob));
+    for (int i = 0; i < nl; ++i) {
+      const int last = i == nl - 1;
+      WgradProb& p = wa.prob[i];
+      if (last) { p.dy0 = dskip; p.dy1 = nullptr; p.msplit = 0; p.M = C; }
+      else { p.dy0 = (const bf16_t*)(wk.dh + wk.dh_one * (i + 1)); p.dy1 = dskip; p.msplit = C; p.M = 2 * C; }
+      p.dy_bs = (long)Lr * C; p.ldy = C; p.dy_row0 = 0;
+      p.x = (const bf16_t*)(S + st.acts + st.acts_one * i); p.x_bs = (long)Lr * C; p.ldx = C; p.x_row0 = 0;
+      p.out = gr->rs_w[i]; p.o_sm = C; p.o_sk = 1; p.K = C;
+    }
+    if (int rc = wgrad_launch(wa, nl, 2 * C, C, region[2], wk.wgpart_bytes, s, defer)) return rc;
+    if (defer)
+      if (int rc = reduce_launch(rs, s)) return rc;
+  }
+  {  // bias gradients: column sums of dpre_i (in + cond biases share them) and of [dh_{i+1} | dskip], ONE pair of launches for the 2 nl
+     // problems.  The skip half of every rs_b[i] is the column sum of the SAME dskip: summed once, written to every layer.  (Round 3
+     // also tried leaving per-tile partial sums behind in the two backward GEMMs' epilogues instead of re-reading dpre / dh: the
+     // 32-lane reductions cost those latency-bound launches 3-4 us each, more than the second pass they saved.)
+    ColsumArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.B = B; ca.L = L; ca.part = wk.cspart;
+    int np = 0;
+    // (the conditioning conv's bias sees the same pre-activations: its gradient is the same sums, written by the same launch)
+    for (int i = 0; i < nl; ++i) ca.prob[np++] = ColsumProb{wk.dpre + wk.dpre_one * i, (long)Lp * 2 * C, 2 * C, HALO, 2 * C, gr->in_b[i], gr->cond_b[i]};
+    for (int i = 0; i + 1 < nl; ++i) ca.prob[np++] = ColsumProb{wk.dh + wk.dh_one * (i + 1), (long)Lr * C, C, 0, C, gr->rs_b[i], nullptr};
+    ca.bc_prob = np;
+    ca.prob[np++] = ColsumProb{dskip, (long)Lr * C, C, 0, C, gr->rs_b[nl - 1], nullptr};
+    for (int i = 0; i + 1 < nl; ++i) ca.bc[ca.nbc++] = gr->rs_b[i] + C;
+    if (int rc = colsum_launch<false>(ca, np, 2 * C, 1, s)) return rc;
+  }
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+int check_wn_grads(const facppg_wn_grads* gr, int nl) {
+  FACPPG_REQUIRE(gr && gr->start_w && gr->start_b && gr->end_w && gr->end_b, FACPPG_EINVAL, "NULL gradient pointer");
+  for (int i = 0; i < nl; ++i)
+    FACPPG_REQUIRE(gr->in_w[i] && gr->in_b[i] && gr->cond_w[i] && gr->cond_b[i] && gr->rs_w[i] && gr->rs_b[i], FACPPG_EINVAL,
+                   "NULL gradient pointer (layer %d)", i);
   return FACPPG_OK;
 }
 
@@ -2166,10 +2406,7 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
                                        size_t scratch_bytes, void* stream_) {
   if (int rc = check_wn(wts, n_in, nl, B, L)) return rc;
   FACPPG_REQUIRE(gr && a0_dev && spect_pm_dev && dout_dev && state_dev && da0_dev && dspect_pm_dev && scratch_dev, FACPPG_EINVAL, "NULL argument");
-  FACPPG_REQUIRE(gr->start_w && gr->start_b && gr->end_w && gr->end_b, FACPPG_EINVAL, "NULL gradient pointer");
-  for (int i = 0; i < nl; ++i)
-    FACPPG_REQUIRE(gr->in_w[i] && gr->in_b[i] && gr->cond_w[i] && gr->cond_b[i] && gr->rs_w[i] && gr->rs_b[i], FACPPG_EINVAL,
-                   "NULL gradient pointer (layer %d)", i);
+  if (int rc = check_wn_grads(gr, nl)) return rc;
   const int Lr = pad_len(L), Lp = HALO + Lr + HALO;
   const StateLayout st = state_layout(nl, B, Lr);
   const ScratchLayout sc = scratch_layout(nl, B, Lr);
@@ -2179,19 +2416,10 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
   const char* S = (const char*)state_dev;
   char* W = (char*)scratch_dev;
   const int nout = 2 * n_in;
-  // transposed operand images
   uint4* condt = (uint4*)(W + sc.condt);
   {
     Packer pk;
-    for (int i = 0; i < nl; ++i) {
-      const int last = i == nl - 1;
-      // dacts[c] = sum_r Wrs[r][c] * [dh_next (res rows) | dskip (skip rows)][r]; last layer: skip rows only
-      pk.add(wts->rs_w[i], (uint4*)(W + sc.rst + sc.rst_one * i), C, (last ? C : 2 * C) / 16, 0, last ? C : 2 * C, 1, 1, C, 0, 0, 0);
-      // dh[m] += sum_{tap,o} Win[o][m][tap] * dpre[n - (tap-1) d][o]
-      pk.add(wts->in_w[i], (uint4*)(W + sc.int_ + sc.int_one * i), C, 3 * 2 * C / 16, 0, 2 * C, 3, 3, (long)C * 3, 1, 0, 0);
-      // dspect[j] = sum_{i,o} Wcond_i[o][j] * dpre_i[o]: one image, K = nl * 512
-      pk.add(wts->cond_w[i], condt, NCOND, nl * 2 * C / 16, i * 2 * C, 2 * C, 1, 1, NCOND, 0, 0, 0);
-    }
+    add_backward_images(pk, wts, nl, W + sc.rst, sc.rst_one, W + sc.int_, sc.int_one, condt);
     if (int rc = pk.launch(s)) return rc;
   }
   bf16_t* dskip = (bf16_t*)(W + sc.dskip);
@@ -2209,65 +2437,13 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
     k_small_wgrad_sum<<<dim3(C / 16, 9), 256, 0, s>>>(part, SMALL_PARTS, nout, gr->end_w, C, 1, nullptr);
     k_small_rowsum<<<nout, 256, 0, s>>>(dout_dev, gr->end_b, nout, B, L);
   }
-  const bool fused = fused_bwd_enabled(B, L);
-  auto gate_bwd_launch = [&](int i) -> int {      // dpre_i = gate'(ts_i) * Wrs_i^T [dh_{i+1} ; dskip]
-    const int last = i == nl - 1;
-    const bf16_t* dh_next = (const bf16_t*)(W + sc.dh + sc.dh_one * (i + 1));
-    BGemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.A = (const uint4*)(W + sc.rst + sc.rst_one * i); g.KG = (last ? C : 2 * C) / 16; g.M = C; g.N = L; g.B = B;
-    if (last) { g.nseg = 1; g.seg[0] = Seg{dskip, (long)Lr * C, C, 0, C}; }
-    else { g.nseg = 2; g.seg[0] = Seg{dh_next, (long)Lr * C, C, 0, C}; g.seg[1] = Seg{dskip, (long)Lr * C, C, 0, C}; }
-    g.mode = EP_BWD_GATE; g.Lr = Lr; g.ts = (bf16_t*)(S + st.ts + st.ts_one * i); g.dpre = (bf16_t*)(W + sc.dpre + sc.dpre_one * i);
-    g.dpre_bs = (long)Lp * 2 * C;
-    return bgemm_launch(g, s);
-  };
-  auto conv_bwd_launch = [&](int i) -> int {      // dh_i = dh_{i+1} + sum_tap Win_i^T dpre_i(shifted)
-    const int last = i == nl - 1, d = 1 << i;
-    const bf16_t* dpre = (const bf16_t*)(W + sc.dpre + sc.dpre_one * i);
-    BGemmArgs t;
-    memset(&t, 0, sizeof(t));
-    t.A = (const uint4*)(W + sc.int_ + sc.int_one * i); t.KG = 3 * 2 * C / 16; t.M = C; t.N = L; t.B = B; t.nseg = 3;
-    for (int tp = 0; tp < 3; ++tp) t.seg[tp] = Seg{dpre, (long)Lp * 2 * C, 2 * C, HALO - (tp - 1) * d, 2 * C};
-    t.mode = EP_BWD_CONV; t.Lr = Lr; t.dh_next = last ? nullptr : (const bf16_t*)(W + sc.dh + sc.dh_one * (i + 1));
-    t.dh_out = (bf16_t*)(W + sc.dh + sc.dh_one * i);
-    return bgemm_launch(t, s);
-  };
-  if (fused && nl > 1) {
-    if (int rc = gate_bwd_launch(nl - 1)) return rc;
-    for (int i = nl - 1; i >= 1; --i) {           // conv backward of layer i + gate backward of layer i-1 in one launch
-      WnBwdArgs f;
-      memset(&f, 0, sizeof(f));
-      f.A1 = (const uint4*)(W + sc.int_ + sc.int_one * i); f.A2 = (const uint4*)(W + sc.rst + sc.rst_one * (i - 1));
-      f.dpre_i = (const bf16_t*)(W + sc.dpre + sc.dpre_one * i); f.dpre_bs = (long)Lp * 2 * C;
-      f.dh_next = i == nl - 1 ? nullptr : (const bf16_t*)(W + sc.dh + sc.dh_one * (i + 1));
-      f.dh_out = (bf16_t*)(W + sc.dh + sc.dh_one * i); f.dskip = dskip;
-      f.ts = (const bf16_t*)(S + st.ts + st.ts_one * (i - 1)); f.dpre_out = (bf16_t*)(W + sc.dpre + sc.dpre_one * (i - 1));
-      f.L = L; f.Lr = Lr; f.B = B; f.d = 1 << i;
-      if (int rc = wn_bwd_launch(f, s)) return rc;
-    }
-    if (int rc = conv_bwd_launch(0)) return rc;
-  } else {
-    for (int i = nl - 1; i >= 0; --i) {
-      if (int rc = gate_bwd_launch(i)) return rc;
-      if (int rc = conv_bwd_launch(i)) return rc;
-    }
-  }
-  const char* e_ds = getenv("FACPPG_TRAIN_DSPECT_BGEMM");     // =1: the k_bgemm<EP_ACC_F32> launch (bit-equality test, A/B timing)
-  if (!(e_ds && e_ds[0] == '1')) {  // dspect over all layers at once
-    DspectArgs c;
-    memset(&c, 0, sizeof(c));
-    c.A = condt; c.dpre = (const bf16_t*)(W + sc.dpre); c.dpre_one = (long)(sc.dpre_one / 2); c.dpre_bs = (long)Lp * 2 * C;
-    c.out = dspect_pm_dev; c.nl = nl; c.L = L; c.Lr = Lr; c.B = B; c.accumulate = accumulate_dspect != 0;
-    if (int rc = dspect_launch(c, s)) return rc;
-  } else {
-    BGemmArgs c;
-    memset(&c, 0, sizeof(c));
-    c.A = condt; c.KG = nl * 2 * C / 16; c.M = NCOND; c.N = L; c.B = B; c.nseg = nl;
-    for (int i = 0; i < nl; ++i) c.seg[i] = Seg{(const bf16_t*)(W + sc.dpre + sc.dpre_one * i), (long)Lp * 2 * C, 2 * C, HALO, 2 * C};
-    c.mode = EP_ACC_F32; c.Lr = Lr; c.outf = dspect_pm_dev; c.ldo = NCOND; c.accumulate = accumulate_dspect != 0;
-    if (int rc = bgemm_launch(c, s)) return rc;
-  }
+  WnPacked pw;
+  memset(&pw, 0, sizeof(pw));
+  pw.rst = (const uint4*)(W + sc.rst); pw.rst_one = sc.rst_one; pw.int_ = (const uint4*)(W + sc.int_); pw.int_one = sc.int_one; pw.condt = condt;
+  WnWork wk;
+  wk.dpre = W + sc.dpre; wk.dpre_one = sc.dpre_one; wk.dh = W + sc.dh; wk.dh_one = sc.dh_one; wk.dskip = dskip;
+  wk.cspart = (float*)(W + sc.cspart); wk.wgpart = (float*)(W + sc.wgpart); wk.wgpart_bytes = sc.wgpart_bytes; wk.wgpart_regions = 1;
+  if (int rc = wn_layers_backward_data(nl, pw, S, wk, dspect_pm_dev, accumulate_dspect, B, L, s)) return rc;
   const bf16_t* dh0 = (const bf16_t*)(W + sc.dh);
   k_t_start_bwd<<<dim3((L + 31) / 32, B), 256, 0, s>>>(dh0, wts->start_w, da0_dev, n_in, L, Lr);
   {  // start conv: weight [256][n_in] and bias [256] gradients
@@ -2275,61 +2451,614 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
     k_small_wgrad_part<true><<<SMALL_PARTS, 256, 0, s>>>(a0_dev, dh0, (long)Lr * C, 0, part, n_in, B, L, SMALL_PARTS);
     k_small_wgrad_sum<<<dim3(C / 16, 9), 256, 0, s>>>(part, SMALL_PARTS, n_in, gr->start_w, 1, n_in, gr->start_b);
   }
-  // weight gradients of the three convs of every layer: NT products over positions, batched over layers (x taps)
-  {
-    WgradArgs wa;
-    memset(&wa, 0, sizeof(wa));
-    wa.B = B; wa.L = L; wa.Lr = Lr;
-    for (int i = 0; i < nl; ++i)
-      for (int tp = 0; tp < 3; ++tp) {
-        WgradProb& p = wa.prob[i * 3 + tp];
-        p.dy0 = (const bf16_t*)(W + sc.dpre + sc.dpre_one * i); p.dy1 = nullptr; p.dy_bs = (long)Lp * 2 * C; p.ldy = 2 * C; p.dy_row0 = HALO; p.msplit = 0;
-        p.x = (const bf16_t*)(S + st.h + st.h_one * i); p.x_bs = (long)Lp * C; p.ldx = C; p.x_row0 = HALO + (tp - 1) * (1 << i);
-        p.out = gr->in_w[i] + tp; p.o_sm = (long)C * 3; p.o_sk = 3; p.M = 2 * C; p.K = C;
+  return wn_layers_backward_weights(gr, nl, S, wk, spect_pm_dev, B, L, s);
+}
+
+// ================================================================================================================
+// The whole model's training direction (glow.py:208-250) on the bf16 stack: GROUPS of consecutive flows per call.
+//
+// Between two stacks everything is per-position arithmetic on <= 8 channels: flow k-1's end conv + affine coupling
+// (glow.py:175, 240-245), the early-output split (glow.py:231-233), flow k's 1x1 mixing conv (glow.py:98-102) and the start
+// conv of its stack (glow.py:156).  Until round 5 that was ~13 launches per flow forward and ~25 backward (HIP and torch
+// kernels of 5-15 us each: a third of the step at batch 12, most of it at batch 3).  k_edge_fwd / k_edge_bwd do one flow
+// boundary per launch -- tail of the flow below, head of the flow above -- and the backward one also leaves per-workgroup
+// partial sums of the <= 8-channel weight / bias gradients (end conv, start conv, mixing matrix), which one k_edge_sum
+// launch per group adds up in a fixed order.  The packed bf16 weight images, the zeroed margins of every flow's saved
+// state and the summed gate biases are prepared ONCE per step for all flows (facppg_glow_bf16_begin).
+// ================================================================================================================
+namespace {
+
+constexpr int MAXGF = FACPPG_GLOW_MAX_FLOWS;
+constexpr int EPART = FACPPG_GLOW_PART_FLOATS;          // end_w [8][256] | start_w^T [4][256] | start_b [256] | dW [8][8] | end_b [8]
+constexpr int EP_START = 8 * C, EP_W = EP_START + 5 * C, EP_EB = EP_W + 64;
+static_assert(EPART == EP_EB + 8, "FACPPG_GLOW_PART_FLOATS");
+
+struct EdgeFlow {
+  const float* conv_w;                            // [c][c]
+  const float* start_w; const float* start_b;     // [256][c/2], [256]
+  const float* end_w; const float* end_b;         // [c][256], [c]
+  float* u; float* z; float* wn; float* dzp;      // [B][c][L]: conv input, conv output, stack output (b | log_s), backward temp (dy0 | dx1)
+  float* early; long early_bs;                    // [B][early_n][L] with batch stride early_bs: early output (forward) / its gradient (backward)
+  float* part;                                    // [nparts][EPART]
+  bf16_t* h0;                                     // [B][Lp][256]: h_0 of the stack
+  const float* skip;                              // [B][Lr][256] fp32: the stack's skip sum
+  const float* dlogs; long dl_b, dl_j, dl_n;      // gradient of log_s (element strides; NULL: none)
+  int c, early_n;
+};
+struct EdgeFwdArgs { EdgeFlow lo, hi; const float* audio_in; float* audio_out; long in_bs, out_bs; int has_lo, has_hi, L, Lr, Lp; };   // (batch strides in floats)
+struct EdgeBwdArgs {
+  EdgeFlow lo, hi;
+  const bf16_t* dh0;      // [B][Lr][256]: gradient w.r.t. hi's h_0 (its stack's backward has run)
+  bf16_t* dskip;          // [B][Lr][256]: gradient w.r.t. lo's skip sum (its stack's backward runs next)
+  const float* d_out;     // !has_hi: gradient of the group's output audio [B][lo.c][L], batch stride d_out_bs
+  float* d_in;            // !has_lo: gradient of the group's input audio [B][hi.c + hi.early_n][L], batch stride d_in_bs
+  long d_out_bs, d_in_bs;
+  int has_lo, has_hi, L, Lr, nchunk;
+};
+
+// lo: end conv of the stack that just ran + affine coupling; hi: early split + mixing conv + start conv of the next stack.
+// A workgroup takes 32 positions of one batch item.
+__global__ __launch_bounds__(256) void k_edge_fwd(EdgeFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float sw[C * 8];
+  __shared__ float s_wn[32][9];
+  __shared__ float s_y[32][9];
+  __shared__ float s_a0[32][5];
+  const int tid = threadIdx.x, b = blockIdx.y, n0 = blockIdx.x * 32, L = a.L;
+  if (a.has_lo) {
+    // end conv (glow.py:175) as in k_t_end: a wave takes 8 positions, lane = (position, slice of 32 channels)
+    const int cl = a.lo.c;
+    for (int i = tid; i < C * 8; i += 256) sw[i] = (i & 7) < cl ? a.lo.end_w[(i & 7) * C + (i >> 3)] : 0.0f;
+    __syncthreads();
+    const int lane = tid & 63, ps = lane >> 3, sl = lane & 7, r = (tid >> 6) * 8 + ps, n = n0 + r;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (n < L) {
+      const float4* row = reinterpret_cast<const float4*>(a.lo.skip + ((size_t)b * a.Lr + n) * C + 32 * sl);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 x = row[q];
+        const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float4 w0 = *reinterpret_cast<const float4*>(sw + (32 * sl + 4 * q + e) * 8), w1 = *reinterpret_cast<const float4*>(sw + (32 * sl + 4 * q + e) * 8 + 4);
+          v[0] = fmaf(w0.x, xv[e], v[0]); v[1] = fmaf(w0.y, xv[e], v[1]); v[2] = fmaf(w0.z, xv[e], v[2]); v[3] = fmaf(w0.w, xv[e], v[3]);
+          v[4] = fmaf(w1.x, xv[e], v[4]); v[5] = fmaf(w1.y, xv[e], v[5]); v[6] = fmaf(w1.z, xv[e], v[6]); v[7] = fmaf(w1.w, xv[e], v[7]);
+        }
       }
-    float* wgpart = (float*)(W + sc.wgpart);
-    if (int rc = wgrad_launch(wa, nl * 3, 2 * C, C, wgpart, sc.wgpart_bytes, s)) return rc;
-    memset(&wa.prob, 0, sizeof(wa.prob));
-    for (int i = 0; i < nl; ++i) {
-      WgradProb& p = wa.prob[i];
-      p.dy0 = (const bf16_t*)(W + sc.dpre + sc.dpre_one * i); p.dy_bs = (long)Lp * 2 * C; p.ldy = 2 * C; p.dy_row0 = HALO;
-      p.x = (const bf16_t*)spect_pm_dev; p.x_bs = (long)Lr * NCOND; p.ldx = NCOND; p.x_row0 = 0;
-      p.out = gr->cond_w[i]; p.o_sm = NCOND; p.o_sk = 1; p.M = 2 * C; p.K = NCOND;
     }
-    if (int rc = wgrad_launch(wa, nl, 2 * C, NCOND, wgpart, sc.wgpart_bytes, s)) return rc;
-    memset(&wa.prob, 0, sizeof(wa.prob));
-    for (int i = 0; i < nl; ++i) {
-      const int last = i == nl - 1;
-      WgradProb& p = wa.prob[i];
-      if (last) { p.dy0 = dskip; p.dy1 = nullptr; p.msplit = 0; p.M = C; }
-      else { p.dy0 = (const bf16_t*)(W + sc.dh + sc.dh_one * (i + 1)); p.dy1 = dskip; p.msplit = C; p.M = 2 * C; }
-      p.dy_bs = (long)Lr * C; p.ldy = C; p.dy_row0 = 0;
-      p.x = (const bf16_t*)(S + st.acts + st.acts_one * i); p.x_bs = (long)Lr * C; p.ldx = C; p.x_row0 = 0;
-      p.out = gr->rs_w[i]; p.o_sm = C; p.o_sk = 1; p.K = C;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int off = 1; off < 8; off <<= 1) v[j] += __shfl_xor(v[j], off, 64);
+    if (sl == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s_wn[r][j] = j < cl ? v[j] + a.lo.end_b[j] : 0.0f;
     }
-    if (int rc = wgrad_launch(wa, nl, 2 * C, C, wgpart, sc.wgpart_bytes, s)) return rc;
+    __syncthreads();
   }
-  {  // bias gradients: column sums of dpre_i (in + cond biases share them) and of [dh_{i+1} | dskip].  The skip half of every
-     // rs_b[i] is the column sum of the SAME dskip: summed once, copied to the other layers.  (Round 3 also tried leaving
-     // per-tile partial sums behind in the two backward GEMMs' epilogues instead of re-reading dpre / dh: the 32-lane
-     // reductions cost those latency-bound launches 3-4 us each, more than the second pass they saved.)
-    ColsumArgs ca;
-    memset(&ca, 0, sizeof(ca));
-    ca.B = B; ca.L = L; ca.part = (float*)(W + sc.cspart);
-    // (the conditioning conv's bias sees the same pre-activations: its gradient is the same sums, written by the same launch)
-    for (int i = 0; i < nl; ++i) ca.prob[i] = ColsumProb{W + sc.dpre + sc.dpre_one * i, (long)Lp * 2 * C, 2 * C, HALO, 2 * C, gr->in_b[i], gr->cond_b[i]};
-    if (int rc = colsum_launch<false>(ca, nl, 2 * C, 1, s)) return rc;
-    memset(&ca.prob, 0, sizeof(ca.prob));
-    int np = 0;
-    for (int i = 0; i + 1 < nl; ++i) ca.prob[np++] = ColsumProb{W + sc.dh + sc.dh_one * (i + 1), (long)Lr * C, C, 0, C, gr->rs_b[i], nullptr};
-    ca.prob[np++] = ColsumProb{dskip, (long)Lr * C, C, 0, C, gr->rs_b[nl - 1], nullptr};
-    if (int rc = colsum_launch<false>(ca, np, C, 1, s)) return rc;
-    if (nl > 1) {
-      SkipBiasCopy cp;
-      cp.src = gr->rs_b[nl - 1]; cp.n = nl - 1;
-      for (int i = 0; i + 1 < nl; ++i) cp.dst[i] = gr->rs_b[i] + C;
-      k_copy_skip_bias<<<dim3(1, nl - 1), C, 0, s>>>(cp);
+  if (tid < 32 && n0 + tid < L) {
+    // one thread per position; its <= 8 channel values live in its own LDS row (run-time channel counts index them)
+    const int n = n0 + tid;
+    float* y = s_y[tid];
+    int cy;
+    if (a.has_lo) {       // affine coupling (glow.py:240-245): y = [x0 | exp(log_s) * x1 + b], (b | log_s) = the stack's output
+      const int cl = a.lo.c, hl = cl >> 1;
+      cy = cl;
+      for (int j = 0; j < cl; ++j) a.lo.wn[((size_t)b * cl + j) * L + n] = s_wn[tid][j];
+      for (int j = 0; j < hl; ++j) {
+        const float x0 = a.lo.z[((size_t)b * cl + j) * L + n], x1 = a.lo.z[((size_t)b * cl + hl + j) * L + n];
+        y[j] = x0;
+        y[hl + j] = fmaf(expf(s_wn[tid][hl + j]), x1, s_wn[tid][j]);
+      }
+    } else {
+      cy = a.hi.c + a.hi.early_n;
+      for (int j = 0; j < cy; ++j) y[j] = a.audio_in[(size_t)b * a.in_bs + (size_t)j * L + n];
     }
+    if (a.has_hi) {       // early output (glow.py:231-233), mixing conv (glow.py:98-102); a0 = the first half of its output
+      const int e = a.hi.early_n, ch = a.hi.c, hh = ch >> 1;
+      for (int j = 0; j < e; ++j) a.hi.early[(size_t)b * a.hi.early_bs + (size_t)j * L + n] = y[j];
+      for (int j = 0; j < ch; ++j) a.hi.u[((size_t)b * ch + j) * L + n] = y[e + j];
+      for (int i = 0; i < ch; ++i) {
+        float zv = 0.0f;
+        for (int j = 0; j < ch; ++j) zv = fmaf(a.hi.conv_w[i * ch + j], y[e + j], zv);
+        a.hi.z[((size_t)b * ch + i) * L + n] = zv;
+        if (i < hh) s_a0[tid][i] = zv;
+      }
+    } else {
+      for (int j = 0; j < cy; ++j) a.audio_out[(size_t)b * a.out_bs + (size_t)j * L + n] = y[j];
+    }
+  }
+  if (!a.has_hi) return;
+  __syncthreads();
+  {   // start conv (glow.py:156) as in k_t_start: a thread owns 4 channels and walks 8 positions
+    const int c4 = (tid & 63) * 4, r0 = (tid >> 6) * 8, nin = a.hi.c >> 1;
+    float wr[4][4], bv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      bv[t] = a.hi.start_b[c4 + t];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wr[t][j] = j < nin ? a.hi.start_w[(c4 + t) * nin + j] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int n = n0 + r0 + i;
+      if (n >= L) break;
+      float v[4] = {bv[0], bv[1], bv[2], bv[3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < nin) {
+          const float av = s_a0[r0 + i][j];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = fmaf(wr[t][j], av, v[t]);
+        }
+      *reinterpret_cast<uint2*>(a.hi.h0 + ((size_t)b * a.Lp + HALO + n) * C + c4) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+    }
+  }
+}
+
+// Backward of one flow boundary.  hi: the flow whose stack's backward has just produced dh_0 -- start conv backward (da0), the
+// mixing conv's backward (du = W^T dz) and the early split's; lo: the flow below -- affine coupling backward and the end conv's
+// (dskip), after which lo's stack can run backward.  Also per-workgroup partial sums (fixed order, no atomics) of hi's start conv
+// weight / bias and mixing-matrix gradients and of lo's end conv weight / bias gradients.  A workgroup walks `nchunk` chunks of 32
+// positions of one batch item.
+__global__ __launch_bounds__(256) void k_edge_bwd(EdgeBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float sw_s[C * 4];
+  __shared__ float s_da0[32][5], s_a0[32][5], s_dwn[32][9], s_v[32][9], s_dz[32][9];
+  __shared__ float red[3][13][C];
+  const int tid = threadIdx.x, b = blockIdx.y, L = a.L;
+  const int c4 = (tid & 63) * 4, rl = tid >> 6;
+  const size_t wg = (size_t)b * gridDim.x + blockIdx.x;
+  const int chh = a.has_hi ? a.hi.c : 0, hh = chh >> 1, eh = a.has_hi ? a.hi.early_n : 0;
+  const int cl = a.has_lo ? a.lo.c : 0, hl = cl >> 1;
+  for (int i = tid; i < C * 4; i += 256) sw_s[i] = (i & 3) < hh ? a.hi.start_w[(i >> 2) * hh + (i & 3)] : 0.0f;
+  for (int i = tid; i < 32 * 9; i += 256) (&s_dwn[0][0])[i] = 0.0f;
+  for (int i = tid; i < 32 * 5; i += 256) (&s_a0[0][0])[i] = 0.0f;
+  float we[8][4];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) we[j][t] = j < cl ? a.lo.end_w[j * C + c4 + t] : 0.0f;
+  float acc_e[8][4], acc_s[5][4], accW[64], acc_eb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    acc_eb[j] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc_e[j][t] = 0.0f;
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc_s[j][t] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 64; ++k) accW[k] = 0.0f;
+  __syncthreads();
+  for (int ck = 0; ck < a.nchunk; ++ck) {
+    const int n0 = (blockIdx.x * a.nchunk + ck) * 32;
+    if (n0 >= L) break;
+    if (a.has_hi) {   // da0[j] = sum_c Ws[c][j] dh0[c] as in k_t_start_bwd: a wave takes 8 positions, lane = (position, 32 channels)
+      const int lane = tid & 63, ps = lane >> 3, sl = lane & 7, r = (tid >> 6) * 8 + ps, n = n0 + r;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (n < L) {
+        const uint4* row = reinterpret_cast<const uint4*>(a.dh0 + ((size_t)b * a.Lr + n) * C + 32 * sl);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint4 d = row[q];
+          const float dv[8] = {lo2f(d.x), hi2f(d.x), lo2f(d.y), hi2f(d.y), lo2f(d.z), hi2f(d.z), lo2f(d.w), hi2f(d.w)};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float4 ww = *reinterpret_cast<const float4*>(sw_s + (32 * sl + 8 * q + e) * 4);
+            v[0] = fmaf(ww.x, dv[e], v[0]); v[1] = fmaf(ww.y, dv[e], v[1]); v[2] = fmaf(ww.z, dv[e], v[2]); v[3] = fmaf(ww.w, dv[e], v[3]);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) v[j] += __shfl_xor(v[j], off, 64);
+      if (sl == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s_da0[r][j] = v[j];
+      }
+    }
+    __syncthreads();
+    if (tid < 32 && n0 + tid < L) {   // one thread per position; its channel vectors live in its own LDS rows
+      const int n = n0 + tid;
+      float* dy = s_v[tid];
+      int cy;
+      if (a.has_hi) {
+        float* dz = s_dz[tid];
+        for (int j = 0; j < hh; ++j) {
+          dz[j] = a.hi.dzp[((size_t)b * chh + j) * L + n] + s_da0[tid][j];
+          dz[hh + j] = a.hi.dzp[((size_t)b * chh + hh + j) * L + n];
+          s_a0[tid][j] = a.hi.z[((size_t)b * chh + j) * L + n];
+        }
+        for (int j = chh; j < 8; ++j) dz[j] = 0.0f;
+        float uu[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) uu[j] = j < chh ? a.hi.u[((size_t)b * chh + j) * L + n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {   // dW[i][j] += dz[i] u[j]
+          const float dzi = dz[i];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) accW[i * 8 + j] = fmaf(dzi, uu[j], accW[i * 8 + j]);
+        }
+        for (int j = 0; j < eh; ++j) dy[j] = a.hi.early[(size_t)b * a.hi.early_bs + (size_t)j * L + n];
+        for (int j = 0; j < chh; ++j) {  // du[j] = sum_i W[i][j] dz[i]
+          float v = 0.0f;
+          for (int i = 0; i < chh; ++i) v = fmaf(a.hi.conv_w[i * chh + j], dz[i], v);
+          dy[eh + j] = v;
+        }
+        cy = chh + eh;
+      } else {
+        cy = cl;
+        for (int j = 0; j < cy; ++j) dy[j] = a.d_out[(size_t)b * a.d_out_bs + (size_t)j * L + n];
+      }
+      if (a.has_lo) {   // y = [x0 | exp(log_s) x1 + b]: d b = dy1, d log_s = dy1 x1 exp(log_s) (+ the loss's), dx1 = dy1 exp(log_s), dx0 = dy0 (+ da0 later)
+        for (int j = 0; j < hl; ++j) {
+          const float x1 = a.lo.z[((size_t)b * cl + hl + j) * L + n], ev = expf(a.lo.wn[((size_t)b * cl + hl + j) * L + n]);
+          const float d1 = dy[hl + j];
+          float dls = d1 * x1 * ev;
+          if (a.lo.dlogs) dls += a.lo.dlogs[(size_t)b * a.lo.dl_b + (size_t)j * a.lo.dl_j + (size_t)n * a.lo.dl_n];
+          s_dwn[tid][j] = d1;
+          s_dwn[tid][hl + j] = dls;
+          a.lo.dzp[((size_t)b * cl + j) * L + n] = dy[j];
+          a.lo.dzp[((size_t)b * cl + hl + j) * L + n] = d1 * ev;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc_eb[j] += j < cl ? s_dwn[tid][j] : 0.0f;
+      } else {
+        for (int j = 0; j < cy; ++j) a.d_in[(size_t)b * a.d_in_bs + (size_t)j * L + n] = dy[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {   // a thread owns 4 of the 256 channels and walks 8 positions
+      const int r = rl * 8 + i, n = n0 + r;
+      if (n >= L) break;
+      if (a.has_lo) {   // dskip = We^T dwn (bf16); end conv weight gradient += dwn skip^T
+        float dwn[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dwn[j] = s_dwn[r][j];
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = fmaf(we[j][t], dwn[j], v[t]);
+        *reinterpret_cast<uint2*>(a.dskip + ((size_t)b * a.Lr + n) * C + c4) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+        const float4 sk = *reinterpret_cast<const float4*>(a.lo.skip + ((size_t)b * a.Lr + n) * C + c4);
+        const float sv[4] = {sk.x, sk.y, sk.z, sk.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc_e[j][t] = fmaf(dwn[j], sv[t], acc_e[j][t]);
+      }
+      if (a.has_hi) {   // start conv weight gradient += dh0 a0^T, bias gradient += dh0
+        const uint2 d = *reinterpret_cast<const uint2*>(a.dh0 + ((size_t)b * a.Lr + n) * C + c4);
+        const float dv[4] = {lo2f(d.x), hi2f(d.x), lo2f(d.y), hi2f(d.y)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float av = s_a0[r][j];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc_s[j][t] = fmaf(av, dv[t], acc_s[j][t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc_s[4][t] += dv[t];
+      }
+    }
+    __syncthreads();
+  }
+  // the four row lanes meet in lane order
+  if (rl) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) red[rl - 1][j][c4 + t] = acc_e[j][t];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) red[rl - 1][8 + j][c4 + t] = acc_s[j][t];
+  }
+  __syncthreads();
+  if (rl == 0) {
+#pragma unroll
+    for (int j = 0; j < 13; ++j) {
+      float4 v = j < 8 ? make_float4(acc_e[j][0], acc_e[j][1], acc_e[j][2], acc_e[j][3])
+                       : make_float4(acc_s[j - 8 < 0 ? 0 : j - 8][0], acc_s[j - 8 < 0 ? 0 : j - 8][1], acc_s[j - 8 < 0 ? 0 : j - 8][2], acc_s[j - 8 < 0 ? 0 : j - 8][3]);
+#pragma unroll
+      for (int l = 0; l < 3; ++l) { v.x += red[l][j][c4]; v.y += red[l][j][c4 + 1]; v.z += red[l][j][c4 + 2]; v.w += red[l][j][c4 + 3]; }
+      if (j < 8) { if (a.has_lo) *reinterpret_cast<float4*>(a.lo.part + wg * EPART + j * C + c4) = v; }
+      else if (a.has_hi) *reinterpret_cast<float4*>(a.hi.part + wg * EPART + EP_START + (j - 8) * C + c4) = v;
+    }
+  }
+  __syncthreads();
+  float* sW = &red[0][0][0];     // [32][65] mixing-matrix sums | [32][9] end-bias sums of the position threads
+  if (tid < 32) {
+#pragma unroll
+    for (int k = 0; k < 64; ++k) sW[tid * 65 + k] = accW[k];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sW[32 * 65 + tid * 9 + j] = acc_eb[j];
+  }
+  __syncthreads();
+  if (tid < 64 && a.has_hi) {
+    float v = 0.0f;
+    for (int t = 0; t < 32; ++t) v += sW[t * 65 + tid];
+    a.hi.part[wg * EPART + EP_W + tid] = v;
+  } else if (tid >= 64 && tid < 72 && a.has_lo) {
+    float v = 0.0f;
+    for (int t = 0; t < 32; ++t) v += sW[32 * 65 + t * 9 + (tid - 64)];
+    a.lo.part[wg * EPART + EP_EB + (tid - 64)] = v;
+  }
+}
+
+// Fixed-order sums of the per-workgroup partials of a group's flows -> the <= 8-channel gradients; the mixing matrix also gets its
+// log-determinant term g * B * L * W^-T (glow.py:100).  Workgroup = 16 outputs x 16 groups of partials.
+struct EdgeSumFlow {
+  const float* part; float* end_w; float* end_b; float* start_w; float* start_b; float* d_conv_w;
+  const float* winv_t; const float* g_logdet; float ld_scale; int c;
+};
+struct EdgeSumArgs { EdgeSumFlow f[MAXGF]; int nparts; };
+__global__ __launch_bounds__(256) void k_edge_sum(EdgeSumArgs a) {
+  const EdgeSumFlow& f = a.f[blockIdx.y];
+  __shared__ float red[16][16];
+  const int el = threadIdx.x & 15, q = threadIdx.x >> 4, e = blockIdx.x * 16 + el;
+  const int p0 = a.nparts * q / 16, p1 = a.nparts * (q + 1) / 16;
+  float v4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (e < EPART)
+    for (int p = p0; p < p1; p += 4)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (p + u < p1) v4[u] += f.part[(size_t)(p + u) * EPART + e];
+  red[q][el] = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+  __syncthreads();
+  if (q || e >= EPART) return;
+  float v = red[0][el];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) v += red[k][el];
+  const int c = f.c, h = c >> 1;
+  if (e < EP_START) {
+    const int j = e >> 8, cc = e & 255;
+    if (j < c) f.end_w[j * C + cc] = v;
+  } else if (e < EP_W) {
+    const int j = (e - EP_START) >> 8, cc = (e - EP_START) & 255;
+    if (j < h) f.start_w[cc * h + j] = v;
+    else if (j == 4) f.start_b[cc] = v;
+  } else if (e < EP_EB) {
+    const int i = (e - EP_W) >> 3, j = (e - EP_W) & 7;
+    if (i < c && j < c) f.d_conv_w[i * c + j] = v + (f.g_logdet ? f.g_logdet[0] * f.ld_scale * f.winv_t[i * c + j] : 0.0f);
+  } else if (e - EP_EB < c) {
+    f.end_b[e - EP_EB] = v;
+  }
+}
+
+// out[0] = scale * log|det W| (glow.py:100: log_det_W = B * L * logdet(W)), out[1..] = W^-T
+struct LogdetBatch { const float* w[MAXGF]; float* out[MAXGF]; int c[MAXGF]; float scale[MAXGF]; };
+__global__ __launch_bounds__(64) void k_logdet_batch(LogdetBatch lb) {
+  logdet_wave(lb.w[blockIdx.x], lb.c[blockIdx.x], lb.out[blockIdx.x], lb.out[blockIdx.x] + 1);
+  if (threadIdx.x == 0) lb.out[blockIdx.x][0] *= lb.scale[blockIdx.x];
+}
+
+// what one flow's stack keeps packed for a whole step: both directions' bf16 operand images and the summed gate biases
+struct PackedLayout { size_t w1, w2, rst, int_, condt, b1, total; size_t w1_one, w2_one, rst_one, int_one; };
+PackedLayout packed_layout(int nl) {
+  PackedLayout s;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  s.w1_one = (size_t)16 * (K1 / 16) * 64 * 16; s.w2_one = (size_t)16 * (C / 16) * 64 * 16;
+  s.rst_one = (size_t)8 * (2 * C / 16) * 64 * 16; s.int_one = (size_t)8 * (3 * 2 * C / 16) * 64 * 16;
+  s.w1 = take(s.w1_one * nl); s.w2 = take(s.w2_one * nl); s.rst = take(s.rst_one * nl); s.int_ = take(s.int_one * nl);
+  s.condt = take((size_t)(NCOND / 32) * (nl * 2 * C / 16) * 64 * 16);
+  s.b1 = take((size_t)nl * 2 * C * 4);
+  s.total = off;
+  return s;
+}
+// gradients in flight of ONE flow's backward (the flows of a step take turns on it) + the reductions' partial buffers
+struct WorkLayout { size_t dpre, dh, dskip, cspart, wgpart, wgpart_bytes, total; size_t dpre_one, dh_one; };
+WorkLayout work_layout(int nl, int B, int Lr) {
+  WorkLayout s;
+  const int Lp = HALO + Lr + HALO;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  s.dpre_one = (size_t)B * Lp * 2 * C * 2; s.dh_one = (size_t)B * Lr * C * 2;
+  s.dpre = take(s.dpre_one * nl); s.dh = take(s.dh_one * (nl + 1)); s.dskip = take(s.dh_one);
+  s.cspart = take((size_t)MAXCS * CS_SLICES * 1024 * 4);
+  s.wgpart_bytes = (size_t)3 * nl * 5 * (2 * C) * C * 4;      // per weight-gradient launch of a flow (three regions: one ordered reduce)
+  s.wgpart = take(s.wgpart_bytes * 3);
+  s.total = off;
+  return s;
+}
+// When the bf16 operand images of a flow's stack are formed.  Measured (round 6): all flows at the start of the step (one launch per
+// flow, 12 instead of 24) leaves every layer launch fetching its 2 - 3 MB of weights from HBM milliseconds after they were written
+// (k_wn_fwd 38.6 -> 42.7 us, k_wn_bwd 30.1 -> 32.4 at batch 12; 18.1 -> 22.6 at batch 3: +0.5 ms per step); packed right in front of
+// the flow's stack, per direction, they are still in the L2s / the Infinity Cache when the layers read them.  FACPPG_TRAIN_PACK=step: the former.
+bool pack_per_step() {
+  const char* e = getenv("FACPPG_TRAIN_PACK");
+  return e && !strcmp(e, "step");
+}
+int edge_chunks(int B, int L) {   // chunks of 32 positions a backward edge workgroup walks: at most ~256 workgroups
+  const int nblk = (L + 31) / 32;
+  return std::max(1, (B * nblk + 255) / 256);
+}
+WnPacked packed_view(const char* P, const PackedLayout& pl) {
+  WnPacked pw;
+  pw.w1 = (const uint4*)(P + pl.w1); pw.w1_one = pl.w1_one; pw.w2 = (const uint4*)(P + pl.w2); pw.w2_one = pl.w2_one;
+  pw.rst = (const uint4*)(P + pl.rst); pw.rst_one = pl.rst_one; pw.int_ = (const uint4*)(P + pl.int_); pw.int_one = pl.int_one;
+  pw.condt = (const uint4*)(P + pl.condt); pw.b1 = (const float*)(P + pl.b1);
+  return pw;
+}
+int check_glow_flows(const facppg_glow_flow* f, int n, int nl, int B, int L, bool backward) {
+  FACPPG_REQUIRE(f && n >= 1 && n <= MAXGF, FACPPG_EINVAL, "1..%d flows per group call (got %d)", MAXGF, n);
+  for (int k = 0; k < n; ++k) {
+    FACPPG_REQUIRE(f[k].c >= 2 && f[k].c <= 8 && f[k].c % 2 == 0 && f[k].early >= 0 && f[k].c + f[k].early <= 8, FACPPG_EUNSUPPORTED,
+                   "flow %d: %d channels after an early split of %d (even, <= 8 in all)", k, f[k].c, f[k].early);
+    if (int rc = check_wn(f[k].w, f[k].c / 2, nl, B, L)) return rc;
+    FACPPG_REQUIRE(f[k].conv_w && f[k].logdet && f[k].u && f[k].z && f[k].wn_out && f[k].packed && f[k].state && (f[k].early == 0 || f[k].early_io),
+                   FACPPG_EINVAL, "flow %d: NULL buffer", k);
+    if (k) FACPPG_REQUIRE(f[k].c + f[k].early == f[k - 1].c, FACPPG_EINVAL, "flow %d takes %d + %d channels, flow %d leaves %d", k, f[k].c,
+                          f[k].early, k - 1, f[k - 1].c);
+    if (backward) {
+      if (int rc = check_wn_grads(f[k].g, nl)) return rc;
+      FACPPG_REQUIRE(f[k].d_conv_w && f[k].dzp && f[k].part, FACPPG_EINVAL, "flow %d: NULL gradient buffer", k);
+    }
+  }
+  return FACPPG_OK;
+}
+EdgeFlow edge_flow(const facppg_glow_flow& f, int nl, int B, int Lr) {
+  const StateLayout st = state_layout(nl, B, Lr);
+  EdgeFlow e;
+  memset(&e, 0, sizeof(e));
+  e.conv_w = f.conv_w; e.start_w = f.w->start_w; e.start_b = f.w->start_b; e.end_w = f.w->end_w; e.end_b = f.w->end_b;
+  e.u = f.u; e.z = f.z; e.wn = f.wn_out; e.dzp = f.dzp; e.early = f.early_io; e.early_bs = f.early_bs; e.part = f.part;
+  e.h0 = (bf16_t*)((char*)f.state + st.h); e.skip = (const float*)((const char*)f.state + st.skip);
+  e.dlogs = f.dlog_s; e.dl_b = f.dls_b; e.dl_j = f.dls_j; e.dl_n = f.dls_n;
+  e.c = f.c; e.early_n = f.early;
+  return e;
+}
+
+}  // namespace
+
+extern "C" int facppg_glow_bf16_layout(int n_layers, int B, int L, facppg_glow_bf16_sizes* out) {
+  FACPPG_REQUIRE(out && n_layers >= 1 && n_layers <= 8 && B > 0 && B <= 65535 && L > 0, FACPPG_EINVAL, "bad argument");
+  const int Lr = pad_len(L);
+  out->packed_bytes_per_flow = packed_layout(n_layers).total;
+  out->state_bytes_per_flow = (state_layout(n_layers, B, Lr).total + 255) / 256 * 256;
+  out->work_bytes = work_layout(n_layers, B, Lr).total;
+  const int nchunk = edge_chunks(B, L);
+  out->n_parts = B * (((L + 31) / 32 + nchunk - 1) / nchunk);
+  out->part_floats = EPART;
+  return FACPPG_OK;
+}
+
+// Once per step, for ALL flows: both directions' bf16 operand images of every stack, the summed gate biases, and the zero rows of
+// every flow's saved state (the conv padding margins, the rows between L and the padded length) and of the backward's buffers.
+extern "C" int facppg_glow_bf16_begin(const facppg_wn_weights* wts, int n_flows, int nl, int B, int L, void* packed_dev, void* states_dev,
+                                      void* work_dev, void* stream_) {
+  FACPPG_REQUIRE(wts && packed_dev && states_dev && work_dev && n_flows >= 1 && n_flows <= 64, FACPPG_EINVAL, "bad argument");
+  for (int k = 0; k < n_flows; ++k)
+    if (int rc = check_wn(&wts[k], 1, nl, B, L)) return rc;
+  hipStream_t s = (hipStream_t)stream_;
+  const int Lr = pad_len(L), Lp = HALO + Lr + HALO;
+  const PackedLayout pl = packed_layout(nl);
+  const StateLayout st = state_layout(nl, B, Lr);
+  const size_t st_stride = (st.total + 255) / 256 * 256;
+  const WorkLayout wl = work_layout(nl, B, Lr);
+  if (pack_per_step())
+    for (int k = 0; k < n_flows; ++k) {
+      char* P = (char*)packed_dev + pl.total * k;
+      Packer pk;
+      add_forward_images(pk, &wts[k], nl, P + pl.w1, pl.w1_one, P + pl.w2, pl.w2_one);
+      add_backward_images(pk, &wts[k], nl, P + pl.rst, pl.rst_one, P + pl.int_, pl.int_one, (uint4*)(P + pl.condt));
+      if (int rc = pk.launch(s)) return rc;
+    }
+  for (int k0 = 0; k0 < n_flows; k0 += ADD_FLOWS) {
+    AddBatchN ab;
+    const int nf = std::min(ADD_FLOWS, n_flows - k0);
+    for (int k = 0; k < nf; ++k)
+      for (int i = 0; i < nl; ++i) { ab.a[k * 8 + i] = wts[k0 + k].in_b[i]; ab.b[k * 8 + i] = wts[k0 + k].cond_b[i]; }
+    ab.out = (float*)((char*)packed_dev + pl.total * k0 + pl.b1); ab.out_stride = (long)(pl.total / 4);
+    k_add2_flows<<<dim3(2, nl, nf), 256, 0, s>>>(ab, 2 * C);
+  }
+  {
+    char* S = (char*)states_dev;
+    ZeroRows z;
+    z.add(S + st.h, (long)(nl + 1) * B, (long)Lp * C * 2, C * 2, HALO, HALO + L, Lp, n_flows, (long)st_stride);
+    z.add(S + st.ts, (long)nl * B, (long)Lr * 2 * C * 2, 2 * C * 2, 0, L, Lr, n_flows, (long)st_stride);
+    z.add(S + st.acts, (long)nl * B, (long)Lr * C * 2, C * 2, 0, L, Lr, n_flows, (long)st_stride);
+    z.launch(s);
+    char* W = (char*)work_dev;
+    ZeroRows zb;
+    zb.add(W + wl.dpre, (long)nl * B, (long)Lp * 2 * C * 2, 2 * C * 2, HALO, HALO + L, Lp);
+    zb.add(W + wl.dh, (long)(nl + 1) * B, (long)Lr * C * 2, C * 2, 0, L, Lr);
+    zb.add(W + wl.dskip, B, (long)Lr * C * 2, C * 2, 0, L, Lr);
+    zb.launch(s);
+  }
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+// Forward of n consecutive flows (glow.py:228-247): audio_in [B][flows[0].c + flows[0].early][L] -> audio_out [B][flows[n-1].c][L];
+// per flow its early output (if it splits one off), u / z / wn_out (kept for the backward; log_s = wn_out[:, c/2:]) and
+// logdet[0] = log|det W|, logdet[1..] = W^-T.
+extern "C" int facppg_glow_bf16_group_forward(const facppg_glow_flow* flows, int n, int nl, const float* audio_in_dev, long in_bs,
+                                              float* audio_out_dev, long out_bs, const void* spect_pm_dev, int B, int L, void* stream_) {
+  if (int rc = check_glow_flows(flows, n, nl, B, L, false)) return rc;
+  FACPPG_REQUIRE(audio_in_dev && audio_out_dev && spect_pm_dev, FACPPG_EINVAL, "NULL argument");
+  hipStream_t s = (hipStream_t)stream_;
+  const int Lr = pad_len(L), Lp = HALO + Lr + HALO;
+  const PackedLayout pl = packed_layout(nl);
+  {
+    LogdetBatch lb;
+    for (int k = 0; k < n; ++k) { lb.w[k] = flows[k].conv_w; lb.out[k] = flows[k].logdet; lb.c[k] = flows[k].c; lb.scale[k] = flows[k].ld_scale; }
+    k_logdet_batch<<<n, 64, 0, s>>>(lb);
+  }
+  for (int k = 0; k <= n; ++k) {
+    EdgeFwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.has_lo = k > 0; a.has_hi = k < n; a.L = L; a.Lr = Lr; a.Lp = Lp;
+    if (a.has_lo) a.lo = edge_flow(flows[k - 1], nl, B, Lr);
+    if (a.has_hi) a.hi = edge_flow(flows[k], nl, B, Lr);
+    a.audio_in = audio_in_dev; a.audio_out = audio_out_dev; a.in_bs = in_bs; a.out_bs = out_bs;
+    k_edge_fwd<<<dim3((L + 31) / 32, B), 256, 0, s>>>(a);
+    if (k < n) {
+      if (!pack_per_step()) {
+        char* P = (char*)flows[k].packed;
+        Packer pk;
+        add_forward_images(pk, flows[k].w, nl, P + pl.w1, pl.w1_one, P + pl.w2, pl.w2_one);
+        if (int rc = pk.launch(s)) return rc;
+      }
+      if (int rc = wn_layers_forward(flows[k].w, nl, packed_view((const char*)flows[k].packed, pl), spect_pm_dev, B, L, (char*)flows[k].state, s))
+        return rc;
+    }
+  }
+  FACPPG_HIP_CHECK(hipGetLastError());
+  return FACPPG_OK;
+}
+
+// Backward of the same n flows: d_audio_out -> d_audio_in, every weight / bias gradient of the stacks (flows[k].g), the mixing
+// matrices' gradients incl. the log-determinant term (d_conv_w), the conditioning gradient added to dspect_pm (overwritten by the
+// first flow that runs when !accumulate_dspect).  flows[k].early_io = gradient of the early output, dlog_s = gradient of log_s.
+extern "C" int facppg_glow_bf16_group_backward(const facppg_glow_flow* flows, int n, int nl, const float* d_audio_out_dev, long d_out_bs,
+                                               float* d_audio_in_dev, long d_in_bs, const void* spect_pm_dev, float* dspect_pm_dev, int accumulate_dspect, void* work_dev, int B,
+                                               int L, void* stream_) {
+  if (int rc = check_glow_flows(flows, n, nl, B, L, true)) return rc;
+  FACPPG_REQUIRE(d_audio_out_dev && d_audio_in_dev && spect_pm_dev && dspect_pm_dev && work_dev, FACPPG_EINVAL, "NULL argument");
+  hipStream_t s = (hipStream_t)stream_;
+  const int Lr = pad_len(L);
+  const PackedLayout pl = packed_layout(nl);
+  const WorkLayout wl = work_layout(nl, B, Lr);
+  char* W = (char*)work_dev;
+  WnWork wk;
+  wk.dpre = W + wl.dpre; wk.dpre_one = wl.dpre_one; wk.dh = W + wl.dh; wk.dh_one = wl.dh_one; wk.dskip = (bf16_t*)(W + wl.dskip);
+  wk.cspart = (float*)(W + wl.cspart); wk.wgpart = (float*)(W + wl.wgpart); wk.wgpart_bytes = wl.wgpart_bytes; wk.wgpart_regions = 3;
+  const int nchunk = edge_chunks(B, L), gx = ((L + 31) / 32 + nchunk - 1) / nchunk;
+  for (int k = n; k >= 0; --k) {
+    EdgeBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.has_hi = k < n; a.has_lo = k > 0; a.L = L; a.Lr = Lr; a.nchunk = nchunk;
+    if (a.has_hi) a.hi = edge_flow(flows[k], nl, B, Lr);
+    if (a.has_lo) a.lo = edge_flow(flows[k - 1], nl, B, Lr);
+    a.dh0 = (const bf16_t*)(W + wl.dh); a.dskip = wk.dskip; a.d_out = d_audio_out_dev; a.d_in = d_audio_in_dev; a.d_out_bs = d_out_bs; a.d_in_bs = d_in_bs;
+    k_edge_bwd<<<dim3(gx, B), 256, 0, s>>>(a);
+    if (k > 0) {
+      const facppg_glow_flow& f = flows[k - 1];
+      if (!pack_per_step()) {
+        char* P = (char*)f.packed;
+        Packer pk;
+        add_backward_images(pk, f.w, nl, P + pl.rst, pl.rst_one, P + pl.int_, pl.int_one, (uint4*)(P + pl.condt));
+        if (int rc = pk.launch(s)) return rc;
+      }
+      const WnPacked pw = packed_view((const char*)f.packed, pl);
+      if (int rc = wn_layers_backward_data(nl, pw, (const char*)f.state, wk, dspect_pm_dev, accumulate_dspect || k < n, B, L, s)) return rc;
+      if (int rc = wn_layers_backward_weights(f.g, nl, (const char*)f.state, wk, spect_pm_dev, B, L, s)) return rc;
+    }
+  }
+  {
+    EdgeSumArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.nparts = B * gx;
+    for (int k = 0; k < n; ++k) {
+      const facppg_glow_flow& f = flows[k];
+      sa.f[k] = EdgeSumFlow{f.part, f.g->end_w, f.g->end_b, f.g->start_w, f.g->start_b, f.d_conv_w, f.logdet + 1, f.g_logdet, f.ld_scale, f.c};
+    }
+    k_edge_sum<<<dim3((EPART + 15) / 16, n), 256, 0, s>>>(sa);
   }
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;

@@ -52,6 +52,23 @@ class WnGrads(ctypes.Structure):
     _fields_ = WnWeights._fields_
 
 
+class GlowBf16Sizes(ctypes.Structure):
+    """facppg_glow_bf16_sizes (include/facppg.h)."""
+    _fields_ = [("packed_bytes_per_flow", ctypes.c_size_t), ("state_bytes_per_flow", ctypes.c_size_t), ("work_bytes", ctypes.c_size_t),
+                ("n_parts", ctypes.c_int), ("part_floats", ctypes.c_int)]
+
+
+class GlowFlow(ctypes.Structure):
+    """facppg_glow_flow (include/facppg.h): one flow of a group call of the bf16 training direction."""
+    _fields_ = [("w", ctypes.POINTER(WnWeights)), ("g", ctypes.POINTER(WnGrads)),
+                ("conv_w", ctypes.c_void_p), ("d_conv_w", ctypes.c_void_p), ("logdet", ctypes.c_void_p), ("g_logdet", ctypes.c_void_p),
+                ("ld_scale", ctypes.c_float), ("c", ctypes.c_int), ("early", ctypes.c_int),
+                ("early_io", ctypes.c_void_p), ("early_bs", ctypes.c_long),
+                ("u", ctypes.c_void_p), ("z", ctypes.c_void_p), ("wn_out", ctypes.c_void_p), ("dzp", ctypes.c_void_p),
+                ("dlog_s", ctypes.c_void_p), ("dls_b", ctypes.c_long), ("dls_j", ctypes.c_long), ("dls_n", ctypes.c_long),
+                ("part", ctypes.c_void_p), ("packed", ctypes.c_void_p), ("state", ctypes.c_void_p)]
+
+
 class TdnnLayer(ctypes.Structure):
     """facppg_tdnn_layer (include/facppg.h)."""
     _fields_ = [(n, ctypes.c_int32) for n in ("out_dim", "in_dim", "taps", "dil", "first", "relu")] + [("renorm_target_rms", ctypes.c_float)]
@@ -97,6 +114,11 @@ def _declare(lib):
         "facppg_wn_forward_bf16": (c.c_int, [c.POINTER(WnWeights), c.c_int, c.c_int, vp, vp, c.c_int, c.c_int, vp, vp, sz, vp, sz, vp]),
         "facppg_wn_backward_bf16": (c.c_int, [c.POINTER(WnWeights), c.POINTER(WnGrads), c.c_int, c.c_int, vp, vp, vp, c.c_int, c.c_int,
                                               vp, sz, vp, vp, c.c_int, vp, sz, vp]),
+        "facppg_glow_bf16_layout": (c.c_int, [c.c_int, c.c_int, c.c_int, c.POINTER(GlowBf16Sizes)]),
+        "facppg_glow_bf16_begin": (c.c_int, [c.POINTER(WnWeights), c.c_int, c.c_int, c.c_int, c.c_int, vp, vp, vp, vp]),
+        "facppg_glow_bf16_group_forward": (c.c_int, [c.POINTER(GlowFlow), c.c_int, c.c_int, vp, c.c_long, vp, c.c_long, vp, c.c_int, c.c_int, vp]),
+        "facppg_glow_bf16_group_backward": (c.c_int, [c.POINTER(GlowFlow), c.c_int, c.c_int, vp, c.c_long, vp, c.c_long, vp, vp, c.c_int, vp,
+                                                      c.c_int, c.c_int, vp]),
         "facppg_upsample_regroup_bf16": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, vp, vp]),
         "facppg_upsample_backward_workspace_bytes": (sz, []),
         "facppg_upsample_regroup_backward": (c.c_int, [vp, vp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, vp, vp, vp, sz, vp]),

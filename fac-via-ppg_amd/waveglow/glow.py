@@ -16,6 +16,8 @@ Extensions over the reference signature (all optional, defaults = reference beha
     utterance_seeds  B integers: the noise of utterance b depends on utterance_seeds[b] alone
              (facppg_wg_draw_noise), so the batch reproduces B batch-1 calls with the same seeds
 """
+import os
+
 import torch
 
 from facppg import lib as _lib
@@ -119,9 +121,9 @@ class _WNFunction(torch.autograd.Function):
     (in.w, in.b, cond.w, cond.b, res_skip.w, res_skip.b), end.w, end.b -- plain effective weights."""
 
     @staticmethod
-    def _weights_struct(ws, struct=None):
+    def _weights_struct(ws, struct=None, into=None):
         n_layers = (len(ws) - 4) // 6
-        st = (struct or _lib.WnWeights)()
+        st = into if into is not None else (struct or _lib.WnWeights)()
         st.start_w, st.start_b = ws[0].data_ptr(), ws[1].data_ptr()
         for i in range(n_layers):
             q = ws[2 + 6 * i: 8 + 6 * i]
@@ -231,6 +233,7 @@ class _UpsampleBf16Function(torch.autograd.Function):
                                                       _lib.ptr(spect_pm), _lib.current_stream(dev)))
         ctx.save_for_backward(mel)
         ctx.shared, ctx.hop, ctx.Lg, ctx.wshape = shared, hop, Lg, tuple(w.shape)
+        ctx.set_materialize_grads(False)                  # (the link's gradient is None: it only orders this node behind the flows)
         ctx.mark_non_differentiable(spect_pm)
         return spect_pm, torch.zeros(1, device=dev)
 
@@ -311,6 +314,191 @@ class _WNFunctionBf16(torch.autograd.Function):
             if shared is None:
                 _lib.check(L.facppg_posmajor_to_f32(_lib.ptr(dspect_pm), B, droute.shape[1], Lg, _lib.ptr(droute), droute.shape[2], s))
         return (da0, droute, None, None, *grads)
+
+
+class _GlowStepBf16(object):
+    """What the flows of ONE bf16 training step share (train_waveglow.py:126-133 on the HIP kernels): both directions' packed bf16
+    operand images of every flow's stack and the summed gate biases (formed ONCE per step: facppg_glow_bf16_begin), every flow's
+    saved activations (their zero margins written by the same call), the one set of gradient buffers the flows' backward passes
+    take turns on, the <= 8-channel tensors at the flow boundaries, and the output z the early outputs are written straight into.
+    Held by the group nodes' contexts: it lives exactly as long as the step's autograd graph."""
+
+    def __init__(self, model, flow_weights, B, Lg, dev, shared):
+        L = _lib.load()
+        c = _lib.ctypes
+        self.shared = shared                                # (_StepShared: the conditioning gradient the upsampler's backward consumes)
+        self.n_flows, self.nl, self.B, self.Lg, self.dev = model.n_flows, model.WN[0].n_layers, B, Lg, dev
+        self.sizes = _lib.GlowBf16Sizes()
+        _lib.check(L.facppg_glow_bf16_layout(self.nl, B, Lg, c.byref(self.sizes)))
+        nf = self.n_flows
+        self.packed = torch.empty(nf * self.sizes.packed_bytes_per_flow, dtype=torch.uint8, device=dev)
+        self.states = torch.empty(nf * self.sizes.state_bytes_per_flow, dtype=torch.uint8, device=dev)
+        self.work = torch.empty(self.sizes.work_bytes, dtype=torch.uint8, device=dev)
+        # channels through every flow and what is split off in front of it (glow.py:231-233)
+        self.plan, ch = [], model.n_group
+        for k in range(nf):
+            early = model.n_early_size if (k % model.n_early_every == 0 and k > 0) else 0
+            ch -= early
+            self.plan.append((ch, early))
+        # the boundary tensors of all flows in ONE allocation: u | z | wn_out | dzp [B, c, Lg] each, logdet [1 + c*c]
+        offs, tot = [], 0
+        for ch, _ in self.plan:
+            offs.append(tot)
+            tot += 4 * B * ch * Lg + 1 + ch * ch
+        self.small = torch.empty(tot, dtype=torch.float32, device=dev)
+        self.flow_small = []
+        for (ch, _), o in zip(self.plan, offs):
+            n = B * ch * Lg
+            u, z, wn, dzp = (self.small[o + i * n:o + (i + 1) * n].view(B, ch, Lg) for i in range(4))
+            self.flow_small.append((u, z, wn, dzp, self.small[o + 4 * n:o + 4 * n + 1 + ch * ch]))
+        self.z = torch.empty(B, model.n_group, Lg, dtype=torch.float32, device=dev)     # [early outputs ... | last flow's output]
+        self.parts = None                                   # backward partial sums, allocated by the first group that runs backward
+        self.wts_t = [[w.detach().float().contiguous() for w in fw] for fw in flow_weights]
+        self.wts = (_lib.WnWeights * nf)()
+        for k in range(nf):
+            _WNFunction._weights_struct(self.wts_t[k], into=self.wts[k])
+        with torch.cuda.device(dev):
+            _lib.check(L.facppg_glow_bf16_begin(self.wts, nf, self.nl, B, Lg, _lib.ptr(self.packed), _lib.ptr(self.states), _lib.ptr(self.work),
+                                                _lib.current_stream(dev)))
+
+    def flow_struct(self, k, conv_w):
+        f = _lib.GlowFlow()
+        ch, early = self.plan[k]
+        u, z, wn, dzp, ld = self.flow_small[k]
+        f.w = _lib.ctypes.pointer(self.wts[k])
+        f.conv_w, f.logdet, f.ld_scale, f.c, f.early = conv_w.data_ptr(), ld.data_ptr(), float(self.B * self.Lg), ch, early
+        f.u, f.z, f.wn_out, f.dzp = u.data_ptr(), z.data_ptr(), wn.data_ptr(), dzp.data_ptr()
+        f.packed = self.packed.data_ptr() + k * self.sizes.packed_bytes_per_flow
+        f.state = self.states.data_ptr() + k * self.sizes.state_bytes_per_flow
+        return f
+
+
+class _FlowGroupBf16Function(torch.autograd.Function):
+    """A GROUP of consecutive flows of the training direction (glow.py:228-247) as one autograd node on HIP kernels
+    (facppg_glow_bf16_group_forward / _backward): per flow boundary ONE launch forward (end conv + affine coupling of the flow
+    below, early split, 1x1 mixing conv and start conv of the flow above) and one backward (which also leaves the partial sums
+    of the <= 8-channel weight gradients), the WN layers in between.  The groups are the weight-norm groups = the gradient buckets
+    of the data-parallel exchange: a group's weight gradients are complete when its node's backward returns.
+    Inputs: audio [B, c_in, L] (contiguous), the upsampler's link, then per flow the mixing matrix [c, c] and the stack's
+    effective weights.  Outputs: audio_out, the early outputs of the group's flows, log_s per flow (views of the saved stack
+    outputs), B * L * log|det W| per flow."""
+
+    @staticmethod
+    def forward(ctx, audio, link, step, k0, nfl, spect_pm, last, *tensors):
+        L = _lib.load()
+        dev = audio.device
+        B, Lg = step.B, step.Lg
+        audio = audio.detach().float().contiguous()
+        convs = [t.detach().float().contiguous() for t in tensors[:nfl]]
+        flows = (_lib.GlowFlow * nfl)()
+        c_in = audio.shape[1]
+        assert c_in == step.plan[k0][0] + step.plan[k0][1], (c_in, step.plan[k0])
+        zc, zoff = step.z, sum(e for _, e in step.plan[:k0])      # early outputs go straight into the model's output z
+        earlies = []
+        for i in range(nfl):
+            flows[i] = step.flow_struct(k0 + i, convs[i])
+            ch, early = step.plan[k0 + i]
+            if early:
+                ev = zc[:, zoff:zoff + early, :]
+                flows[i].early_io, flows[i].early_bs = ev.data_ptr(), zc.stride(0)
+                earlies.append(ev)
+                zoff += early
+        c_out = step.plan[k0 + nfl - 1][0]
+        if last:       # the last flow's output is the rest of z
+            out = zc[:, zoff:zoff + c_out, :]
+        else:
+            out = torch.empty(B, c_out, Lg, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.facppg_glow_bf16_group_forward(flows, nfl, step.nl, _lib.ptr(audio), audio.stride(0), out.data_ptr(), out.stride(0),
+                                                        _lib.ptr(spect_pm), B, Lg, _lib.current_stream(dev)))
+        ctx.step, ctx.k0, ctx.nfl, ctx.convs, ctx.spect_pm, ctx.n_early = step, k0, nfl, convs, spect_pm, len(earlies)
+        ctx.in_shape, ctx.link_shape = tuple(audio.shape), tuple(link.shape)
+        log_s = [step.flow_small[k0 + i][2][:, step.plan[k0 + i][0] // 2:, :] for i in range(nfl)]
+        log_det = [step.flow_small[k0 + i][4][0] for i in range(nfl)]        # (the kernel stores B * L * log|det W|, glow.py:100)
+        return (out, *earlies, *log_s, *log_det)
+
+    @staticmethod
+    def backward(ctx, d_out, *rest):
+        L = _lib.load()
+        step, k0, nfl = ctx.step, ctx.k0, ctx.nfl
+        dev = d_out.device
+        B, Lg = step.B, step.Lg
+        d_early, d_log_s, d_log_det = rest[:ctx.n_early], rest[ctx.n_early:ctx.n_early + nfl], rest[ctx.n_early + nfl:]
+        d_out = d_out.float()
+        if d_out.stride(2) != 1 or d_out.stride(1) != Lg:
+            d_out = d_out.contiguous()
+        if step.parts is None:
+            step.parts = torch.empty(step.n_flows * step.sizes.n_parts * step.sizes.part_floats, dtype=torch.float32, device=dev)
+        per = step.sizes.n_parts * step.sizes.part_floats
+        flows = (_lib.GlowFlow * nfl)()
+        keep, grads, gstructs, dconvs = [], [], (_lib.WnGrads * nfl)(), []
+        ei = 0
+        for i in range(nfl):
+            k = k0 + i
+            f = step.flow_struct(k, ctx.convs[i])
+            ch, early = step.plan[k]
+            g = [torch.empty_like(w) for w in step.wts_t[k]]
+            _WNFunction._weights_struct(g, into=gstructs[i])
+            f.g = _lib.ctypes.pointer(gstructs[i])
+            dW = torch.empty(ch, ch, dtype=torch.float32, device=dev)
+            f.d_conv_w = dW.data_ptr()
+            f.part = step.parts.data_ptr() + 4 * per * k
+            if early:
+                de = d_early[ei]
+                ei += 1
+                if de is None:
+                    de = torch.zeros(B, early, Lg, dtype=torch.float32, device=dev)
+                elif de.stride(2) != 1 or de.stride(1) != Lg:
+                    de = de.contiguous()
+                f.early_io, f.early_bs = de.data_ptr(), de.stride(0)
+                keep.append(de)
+            dl = d_log_s[i]
+            if dl is not None:
+                dl = dl.float()
+                f.dlog_s, f.dls_b, f.dls_j, f.dls_n = dl.data_ptr(), dl.stride(0), dl.stride(1), dl.stride(2)
+                keep.append(dl)
+            gd = d_log_det[i]
+            if gd is not None:
+                gd = gd.float()
+                f.g_logdet = gd.data_ptr()
+                keep.append(gd)
+            flows[i] = f
+            grads.append(g)
+            dconvs.append(dW)
+        d_in = torch.empty(ctx.in_shape, dtype=torch.float32, device=dev)
+        shared = step.shared
+        accumulate = shared.dspect_pm is not None
+        if not accumulate:
+            shared.dspect_pm = torch.empty(ctx.spect_pm.shape, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.facppg_glow_bf16_group_backward(flows, nfl, step.nl, d_out.data_ptr(), d_out.stride(0), _lib.ptr(d_in), d_in.stride(0),
+                                                         _lib.ptr(ctx.spect_pm), _lib.ptr(shared.dspect_pm), 1 if accumulate else 0,
+                                                         _lib.ptr(step.work), B, Lg, _lib.current_stream(dev)))
+        flat = []
+        for dW, g in zip(dconvs, grads):
+            flat.append(dW)
+        for g in grads:
+            flat.extend(g)
+        return (d_in, None, None, None, None, None, None, *flat)
+
+
+class _AssembleZFunction(torch.autograd.Function):
+    """torch.cat(output_audio, 1) (glow.py:249) without a copy: the group nodes wrote the early outputs and the last flow's output
+    straight into the step's z buffer, of which the inputs here are channel slices; forward hands out that buffer, backward the
+    matching slices of its gradient."""
+
+    @staticmethod
+    def forward(ctx, step, *pieces):
+        ctx.widths = [p.shape[1] for p in pieces]
+        return step.z
+
+    @staticmethod
+    def backward(ctx, dz):
+        out, o = [], 0
+        for w in ctx.widths:
+            out.append(dz[:, o:o + w, :])
+            o += w
+        return (None, *out)
 
 
 def _conv1x1(W, z, transpose=False):
@@ -835,6 +1023,20 @@ class WaveGlow(torch.nn.Module):
             for j, k in enumerate(ks):
                 flow_weights[k] = self.WN[k]._plain_weights(eff[j * per:(j + 1) * per])
         output_audio, log_s_list, log_det_W_list = [], [], []
+        if bf16 and os.environ.get("FACPPG_TRAIN_FLOW_NODES", "0") != "1":
+            # one autograd node per weight-norm group of flows; the early outputs and the last flow's output land in ONE buffer (z)
+            groups = [[k for k in range(self.n_flows) if k * ngr // self.n_flows == gi] for gi in range(ngr)]
+            step = _GlowStepBf16(self, flow_weights, audio.size(0), Lg, audio.device, shared)
+            for gi, ks in enumerate(groups):
+                tensors = [self.convinv[k].conv.weight.squeeze(-1) for k in ks] + [w for k in ks for w in flow_weights[k]]
+                outs = _FlowGroupBf16Function.apply(audio, link, step, ks[0], len(ks), spect_pm, gi == ngr - 1, *tensors)
+                ne = sum(1 for k in ks if step.plan[k][1])
+                audio = outs[0]
+                output_audio += outs[1:1 + ne]
+                log_s_list += outs[1 + ne:1 + ne + len(ks)]
+                log_det_W_list += outs[1 + ne + len(ks):]
+            output_audio.append(audio)
+            return _AssembleZFunction.apply(step, *output_audio), log_s_list, log_det_W_list
         for k in range(self.n_flows):
             if k % self.n_early_every == 0 and k > 0:
                 output_audio.append(audio[:, :self.n_early_size, :])

@@ -224,6 +224,47 @@ typedef struct facppg_wn_grads {   /* fp32 outputs, same shapes as facppg_wn_wei
   float* end_w; float* end_b;
 } facppg_wn_grads;
 int facppg_wn_bf16_padded_len(int L);
+/* ---- the whole model's training direction on the bf16 stack, GROUPS of consecutive flows per call (src/waveglow/glow.py:228-247 and
+ * its autograd backward; src/script/train_waveglow.py:126-133).  Between two WN stacks everything is per-position arithmetic on <= 8
+ * channels -- the end conv + affine coupling of the flow below (glow.py:175, 240-245), the early-output split (glow.py:231-233), the
+ * 1x1 mixing conv (glow.py:98-102) and the start conv (glow.py:156) of the flow above: one launch per flow boundary and direction.
+ * Per step: facppg_glow_bf16_begin once (packed bf16 weight images of every stack, zeroed margins of every flow's saved state), then
+ * facppg_glow_bf16_group_forward per group in flow order, facppg_glow_bf16_group_backward per group in reverse order. */
+#define FACPPG_GLOW_MAX_FLOWS 12
+#define FACPPG_GLOW_PART_FLOATS 3400
+typedef struct facppg_glow_bf16_sizes {
+  size_t packed_bytes_per_flow;  /* bf16 operand images + summed gate biases of one flow's stack */
+  size_t state_bytes_per_flow;   /* saved activations of one flow's stack (stride between flows in `states`) */
+  size_t work_bytes;             /* gradients in flight of one flow's backward + reduction partials (shared by all flows) */
+  int n_parts;                   /* workgroups of a backward edge launch: facppg_glow_flow.part is [n_parts][part_floats] */
+  int part_floats;
+} facppg_glow_bf16_sizes;
+typedef struct facppg_glow_flow {
+  const facppg_wn_weights* w;    /* effective (weight-normed) fp32 weights of the flow's WN, n_in = c / 2 */
+  const facppg_wn_grads* g;      /* backward: where their gradients go */
+  const float* conv_w;           /* [c][c] mixing matrix (Invertible1x1Conv, glow.py:62-102) */
+  float* d_conv_w;               /* backward: its gradient, data term + g_logdet * ld_scale * W^-T */
+  float* logdet;                 /* [1 + c*c]: ld_scale * log|det W| and W^-T, written by the forward, read by the backward */
+  const float* g_logdet;         /* backward: upstream gradient of the flow's log_det_W output (one float), or NULL */
+  float ld_scale;                /* B * L (glow.py:100) */
+  int c;                         /* channels through the flow */
+  int early;                     /* channels split off in front of it as an early output (glow.py:231-233), 0 if none */
+  float* early_io; long early_bs; /* [B][early][L], batch stride early_bs floats: forward = the early output, backward = its gradient */
+  float* u; float* z; float* wn_out; float* dzp;   /* [B][c][L] each: conv input, conv output, stack output (b | log_s), backward temp */
+  const float* dlog_s; long dls_b, dls_j, dls_n;   /* backward: gradient of log_s = wn_out[:, c/2:] and its element strides (NULL: none) */
+  float* part;                   /* backward: [n_parts][part_floats] partial sums */
+  void* packed; void* state;                       /* this flow's slices of the step's `packed` and `states` buffers */
+} facppg_glow_flow;
+int facppg_glow_bf16_layout(int n_layers, int B, int L, facppg_glow_bf16_sizes* out);
+int facppg_glow_bf16_begin(const facppg_wn_weights* wts /* [n_flows] */, int n_flows, int n_layers, int B, int L, void* packed_dev,
+                           void* states_dev, void* work_dev, void* stream);
+/* audio_in [B][flows[0].c + flows[0].early][L] -> audio_out [B][flows[n-1].c][L]; *_bs: batch strides in floats (rows are L apart) */
+int facppg_glow_bf16_group_forward(const facppg_glow_flow* flows, int n, int n_layers, const float* audio_in_dev, long in_bs,
+                                   float* audio_out_dev, long out_bs, const void* spect_pm_dev, int B, int L, void* stream);
+int facppg_glow_bf16_group_backward(const facppg_glow_flow* flows, int n, int n_layers, const float* d_audio_out_dev, long d_out_bs,
+                                    float* d_audio_in_dev, long d_in_bs, const void* spect_pm_dev, float* dspect_pm_dev, int accumulate_dspect,
+                                    void* work_dev, int B, int L, void* stream);
+
 size_t facppg_wn_bf16_state_bytes(int n_layers, int B, int L);    /* saved activations of one stack (forward -> backward) */
 size_t facppg_wn_bf16_scratch_bytes(int n_layers, int B, int L);  /* per-call scratch (packed bf16 weight images, gradients in flight) */
 /* Which launches facppg_wn_forward_bf16 / facppg_wn_backward_bf16 use for B items of L positions (glow.py:154-175 and its autograd
