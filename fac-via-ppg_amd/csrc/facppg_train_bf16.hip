@@ -1367,22 +1367,36 @@ struct ReduceSet {
     }
   }
 };
-struct ReduceArgs { ReduceProb p[MAXRED]; };
-__global__ void k_wgrad_reduce_multi(ReduceArgs ra) {
-  const ReduceProb& p = ra.p[blockIdx.y];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// blk0[i]: first workgroup of problem i (a workgroup = 1024 consecutive outputs, four per thread: 16-byte loads of the partials)
+struct ReduceArgs { ReduceProb p[MAXRED]; int blk0[MAXRED + 1]; int n; };
+__global__ __launch_bounds__(256) void k_wgrad_reduce_multi(ReduceArgs ra) {
+  int pi = 0;
+  while (pi + 1 < ra.n && (int)blockIdx.x >= ra.blk0[pi + 1]) ++pi;
+  const ReduceProb& p = ra.p[pi];
+  const int i = ((blockIdx.x - ra.blk0[pi]) * 256 + threadIdx.x) * 4;
   if (i >= p.M * p.K) return;
   const float* part = p.part + i;
-  float v = 0.0f;
-  for (int s = 0; s < p.nsplit; ++s) v += part[(size_t)s * p.pstride];
-  const int m = i / p.K, k = i - m * p.K;
-  p.out[m * p.o_sm + k * p.o_sk] = v;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < p.nsplit; ++s) {
+    const float4 x = *reinterpret_cast<const float4*>(part + (size_t)s * p.pstride);
+    v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+  }
+  const int m = i / p.K, k = i - m * p.K;      // (K is a multiple of 4: the four outputs share the row)
+  float* o = p.out + m * p.o_sm + k * p.o_sk;
+  o[0] = v.x; o[p.o_sk] = v.y; o[2 * p.o_sk] = v.z; o[3 * p.o_sk] = v.w;
 }
 int reduce_launch(ReduceSet& rs, hipStream_t s) {
   if (!rs.n) return FACPPG_OK;
   ReduceArgs ra;
   memcpy(ra.p, rs.p, sizeof(ReduceProb) * rs.n);
-  k_wgrad_reduce_multi<<<dim3((rs.max_mk + 255) / 256, rs.n), 256, 0, s>>>(ra);
+  int blocks = 0;
+  for (int i = 0; i < rs.n; ++i) {
+    FACPPG_REQUIRE(rs.p[i].K % 4 == 0 && rs.p[i].pstride % 4 == 0, FACPPG_EINVAL, "weight-gradient reduce: K must be a multiple of 4");
+    ra.blk0[i] = blocks;
+    blocks += (rs.p[i].M * rs.p[i].K + 1023) / 1024;
+  }
+  ra.blk0[rs.n] = blocks; ra.n = rs.n;
+  k_wgrad_reduce_multi<<<blocks, 256, 0, s>>>(ra);
   FACPPG_HIP_CHECK(hipGetLastError());
   rs.n = 0; rs.max_mk = 0;
   return FACPPG_OK;
@@ -2497,16 +2511,20 @@ struct EdgeBwdArgs {
 };
 
 // lo: end conv of the stack that just ran + affine coupling; hi: early split + mixing conv + start conv of the next stack.
-// A workgroup takes 32 positions of one batch item.
+// A workgroup takes 32 positions of one batch item.  The <= 8-channel tensors are [B][c][L]: thread (j = tid / 32, r = tid % 32) moves
+// channel j of position r between HBM and LDS (32 consecutive floats per channel), the per-position arithmetic -- one thread per
+// position -- reads and writes LDS only.
 __global__ __launch_bounds__(256) void k_edge_fwd(EdgeFwdArgs a) {
   __shared__ __attribute__((aligned(16))) float sw[C * 8];
-  __shared__ float s_wn[32][9];
-  __shared__ float s_y[32][9];
-  __shared__ float s_a0[32][5];
+  __shared__ float s_wn[32][9], s_y[32][9], s_in[32][9], s_z[32][9];
   const int tid = threadIdx.x, b = blockIdx.y, n0 = blockIdx.x * 32, L = a.L;
+  const int cj = tid >> 5, cr = tid & 31, cn = n0 + cr;      // the cooperative (channel, position) of this thread
+  const int cl = a.has_lo ? a.lo.c : 0, hl = cl >> 1;
+  const int ch = a.has_hi ? a.hi.c : 0, hh = ch >> 1, e = a.has_hi ? a.hi.early_n : 0;
+  const int cy = a.has_lo ? cl : ch + e;
+  if (cn < L && cj < cy) s_in[cr][cj] = a.has_lo ? a.lo.z[((size_t)b * cl + cj) * L + cn] : a.audio_in[(size_t)b * a.in_bs + (size_t)cj * L + cn];
   if (a.has_lo) {
     // end conv (glow.py:175) as in k_t_end: a wave takes 8 positions, lane = (position, slice of 32 channels)
-    const int cl = a.lo.c;
     for (int i = tid; i < C * 8; i += 256) sw[i] = (i & 7) < cl ? a.lo.end_w[(i & 7) * C + (i >> 3)] : 0.0f;
     __syncthreads();
     const int lane = tid & 63, ps = lane >> 3, sl = lane & 7, r = (tid >> 6) * 8 + ps, n = n0 + r;
@@ -2518,10 +2536,10 @@ __global__ __launch_bounds__(256) void k_edge_fwd(EdgeFwdArgs a) {
         const float4 x = row[q];
         const float xv[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float4 w0 = *reinterpret_cast<const float4*>(sw + (32 * sl + 4 * q + e) * 8), w1 = *reinterpret_cast<const float4*>(sw + (32 * sl + 4 * q + e) * 8 + 4);
-          v[0] = fmaf(w0.x, xv[e], v[0]); v[1] = fmaf(w0.y, xv[e], v[1]); v[2] = fmaf(w0.z, xv[e], v[2]); v[3] = fmaf(w0.w, xv[e], v[3]);
-          v[4] = fmaf(w1.x, xv[e], v[4]); v[5] = fmaf(w1.y, xv[e], v[5]); v[6] = fmaf(w1.z, xv[e], v[6]); v[7] = fmaf(w1.w, xv[e], v[7]);
+        for (int t = 0; t < 4; ++t) {
+          const float4 w0 = *reinterpret_cast<const float4*>(sw + (32 * sl + 4 * q + t) * 8), w1 = *reinterpret_cast<const float4*>(sw + (32 * sl + 4 * q + t) * 8 + 4);
+          v[0] = fmaf(w0.x, xv[t], v[0]); v[1] = fmaf(w0.y, xv[t], v[1]); v[2] = fmaf(w0.z, xv[t], v[2]); v[3] = fmaf(w0.w, xv[t], v[3]);
+          v[4] = fmaf(w1.x, xv[t], v[4]); v[5] = fmaf(w1.y, xv[t], v[5]); v[6] = fmaf(w1.z, xv[t], v[6]); v[7] = fmaf(w1.w, xv[t], v[7]);
         }
       }
     }
@@ -2533,50 +2551,47 @@ __global__ __launch_bounds__(256) void k_edge_fwd(EdgeFwdArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) s_wn[r][j] = j < cl ? v[j] + a.lo.end_b[j] : 0.0f;
     }
-    __syncthreads();
   }
+  __syncthreads();
   if (tid < 32 && n0 + tid < L) {
-    // one thread per position; its <= 8 channel values live in its own LDS row (run-time channel counts index them)
-    const int n = n0 + tid;
     float* y = s_y[tid];
-    int cy;
     if (a.has_lo) {       // affine coupling (glow.py:240-245): y = [x0 | exp(log_s) * x1 + b], (b | log_s) = the stack's output
-      const int cl = a.lo.c, hl = cl >> 1;
-      cy = cl;
-      for (int j = 0; j < cl; ++j) a.lo.wn[((size_t)b * cl + j) * L + n] = s_wn[tid][j];
       for (int j = 0; j < hl; ++j) {
-        const float x0 = a.lo.z[((size_t)b * cl + j) * L + n], x1 = a.lo.z[((size_t)b * cl + hl + j) * L + n];
-        y[j] = x0;
-        y[hl + j] = fmaf(expf(s_wn[tid][hl + j]), x1, s_wn[tid][j]);
+        y[j] = s_in[tid][j];
+        y[hl + j] = fmaf(expf(s_wn[tid][hl + j]), s_in[tid][hl + j], s_wn[tid][j]);
       }
     } else {
-      cy = a.hi.c + a.hi.early_n;
-      for (int j = 0; j < cy; ++j) y[j] = a.audio_in[(size_t)b * a.in_bs + (size_t)j * L + n];
+      for (int j = 0; j < cy; ++j) y[j] = s_in[tid][j];
     }
-    if (a.has_hi) {       // early output (glow.py:231-233), mixing conv (glow.py:98-102); a0 = the first half of its output
-      const int e = a.hi.early_n, ch = a.hi.c, hh = ch >> 1;
-      for (int j = 0; j < e; ++j) a.hi.early[(size_t)b * a.hi.early_bs + (size_t)j * L + n] = y[j];
-      for (int j = 0; j < ch; ++j) a.hi.u[((size_t)b * ch + j) * L + n] = y[e + j];
+    if (a.has_hi)         // mixing conv (glow.py:98-102) of what the early split (glow.py:231-233) leaves; a0 = the first half of its output
       for (int i = 0; i < ch; ++i) {
         float zv = 0.0f;
         for (int j = 0; j < ch; ++j) zv = fmaf(a.hi.conv_w[i * ch + j], y[e + j], zv);
-        a.hi.z[((size_t)b * ch + i) * L + n] = zv;
-        if (i < hh) s_a0[tid][i] = zv;
+        s_z[tid][i] = zv;
       }
-    } else {
-      for (int j = 0; j < cy; ++j) a.audio_out[(size_t)b * a.out_bs + (size_t)j * L + n] = y[j];
+  }
+  __syncthreads();
+  if (cn < L) {           // cooperative stores: lo's stack output, hi's early output / conv input / conv output, or the group's output
+    if (a.has_lo && cj < cl) a.lo.wn[((size_t)b * cl + cj) * L + cn] = s_wn[cr][cj];
+    if (a.has_hi) {
+      if (cj < e) a.hi.early[(size_t)b * a.hi.early_bs + (size_t)cj * L + cn] = s_y[cr][cj];
+      if (cj < ch) {
+        a.hi.u[((size_t)b * ch + cj) * L + cn] = s_y[cr][e + cj];
+        a.hi.z[((size_t)b * ch + cj) * L + cn] = s_z[cr][cj];
+      }
+    } else if (cj < cy) {
+      a.audio_out[(size_t)b * a.out_bs + (size_t)cj * L + cn] = s_y[cr][cj];
     }
   }
   if (!a.has_hi) return;
-  __syncthreads();
   {   // start conv (glow.py:156) as in k_t_start: a thread owns 4 channels and walks 8 positions
-    const int c4 = (tid & 63) * 4, r0 = (tid >> 6) * 8, nin = a.hi.c >> 1;
+    const int c4 = (tid & 63) * 4, r0 = (tid >> 6) * 8;
     float wr[4][4], bv[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       bv[t] = a.hi.start_b[c4 + t];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wr[t][j] = j < nin ? a.hi.start_w[(c4 + t) * nin + j] : 0.0f;
+      for (int j = 0; j < 4; ++j) wr[t][j] = j < hh ? a.hi.start_w[(c4 + t) * hh + j] : 0.0f;
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -2585,8 +2600,8 @@ __global__ __launch_bounds__(256) void k_edge_fwd(EdgeFwdArgs a) {
       float v[4] = {bv[0], bv[1], bv[2], bv[3]};
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (j < nin) {
-          const float av = s_a0[r0 + i][j];
+        if (j < hh) {
+          const float av = s_z[r0 + i][j];
 #pragma unroll
           for (int t = 0; t < 4; ++t) v[t] = fmaf(wr[t][j], av, v[t]);
         }
@@ -2599,16 +2614,19 @@ __global__ __launch_bounds__(256) void k_edge_fwd(EdgeFwdArgs a) {
 // mixing conv's backward (du = W^T dz) and the early split's; lo: the flow below -- affine coupling backward and the end conv's
 // (dskip), after which lo's stack can run backward.  Also per-workgroup partial sums (fixed order, no atomics) of hi's start conv
 // weight / bias and mixing-matrix gradients and of lo's end conv weight / bias gradients.  A workgroup walks `nchunk` chunks of 32
-// positions of one batch item.
+// positions of one batch item; HBM <-> LDS traffic of the <= 8-channel tensors is cooperative as in k_edge_fwd.
 __global__ __launch_bounds__(256) void k_edge_bwd(EdgeBwdArgs a) {
   __shared__ __attribute__((aligned(16))) float sw_s[C * 4];
   __shared__ float s_da0[32][5], s_a0[32][5], s_dwn[32][9], s_v[32][9], s_dz[32][9];
+  __shared__ float s_u[32][9], s_dzph[32][9], s_zl[32][9], s_wnl[32][9], s_dl[32][5], s_out[32][9];
   __shared__ float red[3][13][C];
   const int tid = threadIdx.x, b = blockIdx.y, L = a.L;
   const int c4 = (tid & 63) * 4, rl = tid >> 6;
+  const int cj = tid >> 5, cr = tid & 31;
   const size_t wg = (size_t)b * gridDim.x + blockIdx.x;
   const int chh = a.has_hi ? a.hi.c : 0, hh = chh >> 1, eh = a.has_hi ? a.hi.early_n : 0;
   const int cl = a.has_lo ? a.lo.c : 0, hl = cl >> 1;
+  const int cy = a.has_hi ? chh + eh : cl;
   for (int i = tid; i < C * 4; i += 256) sw_s[i] = (i & 3) < hh ? a.hi.start_w[(i >> 2) * hh + (i & 3)] : 0.0f;
   for (int i = tid; i < 32 * 9; i += 256) (&s_dwn[0][0])[i] = 0.0f;
   for (int i = tid; i < 32 * 5; i += 256) (&s_a0[0][0])[i] = 0.0f;
@@ -2634,6 +2652,24 @@ __global__ __launch_bounds__(256) void k_edge_bwd(EdgeBwdArgs a) {
   for (int ck = 0; ck < a.nchunk; ++ck) {
     const int n0 = (blockIdx.x * a.nchunk + ck) * 32;
     if (n0 >= L) break;
+    const int cn = n0 + cr;
+    if (cn < L) {   // cooperative loads of the <= 8-channel tensors of this chunk
+      if (a.has_hi) {
+        if (cj < chh) {
+          s_u[cr][cj] = a.hi.u[((size_t)b * chh + cj) * L + cn];
+          s_dzph[cr][cj] = a.hi.dzp[((size_t)b * chh + cj) * L + cn];
+          if (cj < hh) s_a0[cr][cj] = a.hi.z[((size_t)b * chh + cj) * L + cn];
+        }
+        if (cj < eh) s_v[cr][cj] = a.hi.early[(size_t)b * a.hi.early_bs + (size_t)cj * L + cn];
+      } else if (cj < cl) {
+        s_v[cr][cj] = a.d_out[(size_t)b * a.d_out_bs + (size_t)cj * L + cn];
+      }
+      if (a.has_lo && cj < cl) {
+        s_zl[cr][cj] = a.lo.z[((size_t)b * cl + cj) * L + cn];
+        s_wnl[cr][cj] = a.lo.wn[((size_t)b * cl + cj) * L + cn];
+        if (cj < hl) s_dl[cr][cj] = a.lo.dlogs ? a.lo.dlogs[(size_t)b * a.lo.dl_b + (size_t)cj * a.lo.dl_j + (size_t)cn * a.lo.dl_n] : 0.0f;
+      }
+    }
     if (a.has_hi) {   // da0[j] = sum_c Ws[c][j] dh0[c] as in k_t_start_bwd: a wave takes 8 positions, lane = (position, 32 channels)
       const int lane = tid & 63, ps = lane >> 3, sl = lane & 7, r = (tid >> 6) * 8 + ps, n = n0 + r;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -2644,9 +2680,9 @@ __global__ __launch_bounds__(256) void k_edge_bwd(EdgeBwdArgs a) {
           const uint4 d = row[q];
           const float dv[8] = {lo2f(d.x), hi2f(d.x), lo2f(d.y), hi2f(d.y), lo2f(d.z), hi2f(d.z), lo2f(d.w), hi2f(d.w)};
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float4 ww = *reinterpret_cast<const float4*>(sw_s + (32 * sl + 8 * q + e) * 4);
-            v[0] = fmaf(ww.x, dv[e], v[0]); v[1] = fmaf(ww.y, dv[e], v[1]); v[2] = fmaf(ww.z, dv[e], v[2]); v[3] = fmaf(ww.w, dv[e], v[3]);
+          for (int t = 0; t < 8; ++t) {
+            const float4 ww = *reinterpret_cast<const float4*>(sw_s + (32 * sl + 8 * q + t) * 4);
+            v[0] = fmaf(ww.x, dv[t], v[0]); v[1] = fmaf(ww.y, dv[t], v[1]); v[2] = fmaf(ww.z, dv[t], v[2]); v[3] = fmaf(ww.w, dv[t], v[3]);
           }
         }
       }
@@ -2660,88 +2696,94 @@ __global__ __launch_bounds__(256) void k_edge_bwd(EdgeBwdArgs a) {
       }
     }
     __syncthreads();
-    if (tid < 32 && n0 + tid < L) {   // one thread per position; its channel vectors live in its own LDS rows
-      const int n = n0 + tid;
+    if (tid < 32 && n0 + tid < L) {   // one thread per position, LDS operands only
       float* dy = s_v[tid];
-      int cy;
       if (a.has_hi) {
         float* dz = s_dz[tid];
         for (int j = 0; j < hh; ++j) {
-          dz[j] = a.hi.dzp[((size_t)b * chh + j) * L + n] + s_da0[tid][j];
-          dz[hh + j] = a.hi.dzp[((size_t)b * chh + hh + j) * L + n];
-          s_a0[tid][j] = a.hi.z[((size_t)b * chh + j) * L + n];
+          dz[j] = s_dzph[tid][j] + s_da0[tid][j];
+          dz[hh + j] = s_dzph[tid][hh + j];
         }
         for (int j = chh; j < 8; ++j) dz[j] = 0.0f;
         float uu[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) uu[j] = j < chh ? a.hi.u[((size_t)b * chh + j) * L + n] : 0.0f;
+        for (int j = 0; j < 8; ++j) uu[j] = j < chh ? s_u[tid][j] : 0.0f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {   // dW[i][j] += dz[i] u[j]
           const float dzi = dz[i];
 #pragma unroll
           for (int j = 0; j < 8; ++j) accW[i * 8 + j] = fmaf(dzi, uu[j], accW[i * 8 + j]);
         }
-        for (int j = 0; j < eh; ++j) dy[j] = a.hi.early[(size_t)b * a.hi.early_bs + (size_t)j * L + n];
         for (int j = 0; j < chh; ++j) {  // du[j] = sum_i W[i][j] dz[i]
           float v = 0.0f;
           for (int i = 0; i < chh; ++i) v = fmaf(a.hi.conv_w[i * chh + j], dz[i], v);
           dy[eh + j] = v;
         }
-        cy = chh + eh;
-      } else {
-        cy = cl;
-        for (int j = 0; j < cy; ++j) dy[j] = a.d_out[(size_t)b * a.d_out_bs + (size_t)j * L + n];
       }
       if (a.has_lo) {   // y = [x0 | exp(log_s) x1 + b]: d b = dy1, d log_s = dy1 x1 exp(log_s) (+ the loss's), dx1 = dy1 exp(log_s), dx0 = dy0 (+ da0 later)
         for (int j = 0; j < hl; ++j) {
-          const float x1 = a.lo.z[((size_t)b * cl + hl + j) * L + n], ev = expf(a.lo.wn[((size_t)b * cl + hl + j) * L + n]);
+          const float x1 = s_zl[tid][hl + j], ev = expf(s_wnl[tid][hl + j]);
           const float d1 = dy[hl + j];
-          float dls = d1 * x1 * ev;
-          if (a.lo.dlogs) dls += a.lo.dlogs[(size_t)b * a.lo.dl_b + (size_t)j * a.lo.dl_j + (size_t)n * a.lo.dl_n];
           s_dwn[tid][j] = d1;
-          s_dwn[tid][hl + j] = dls;
-          a.lo.dzp[((size_t)b * cl + j) * L + n] = dy[j];
-          a.lo.dzp[((size_t)b * cl + hl + j) * L + n] = d1 * ev;
+          s_dwn[tid][hl + j] = d1 * x1 * ev + s_dl[tid][j];
+          s_out[tid][j] = dy[j];
+          s_out[tid][hl + j] = d1 * ev;
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc_eb[j] += j < cl ? s_dwn[tid][j] : 0.0f;
       } else {
-        for (int j = 0; j < cy; ++j) a.d_in[(size_t)b * a.d_in_bs + (size_t)j * L + n] = dy[j];
+        for (int j = 0; j < cy; ++j) s_out[tid][j] = dy[j];
       }
     }
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {   // a thread owns 4 of the 256 channels and walks 8 positions
-      const int r = rl * 8 + i, n = n0 + r;
-      if (n >= L) break;
-      if (a.has_lo) {   // dskip = We^T dwn (bf16); end conv weight gradient += dwn skip^T
-        float dwn[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dwn[j] = s_dwn[r][j];
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) v[t] = fmaf(we[j][t], dwn[j], v[t]);
-        *reinterpret_cast<uint2*>(a.dskip + ((size_t)b * a.Lr + n) * C + c4) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
-        const float4 sk = *reinterpret_cast<const float4*>(a.lo.skip + ((size_t)b * a.Lr + n) * C + c4);
-        const float sv[4] = {sk.x, sk.y, sk.z, sk.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) acc_e[j][t] = fmaf(dwn[j], sv[t], acc_e[j][t]);
+    if (cn < L) {   // cooperative stores: lo's (dy0 | dx1), or the gradient of the group's input
+      if (a.has_lo) {
+        if (cj < cl) a.lo.dzp[((size_t)b * cl + cj) * L + cn] = s_out[cr][cj];
+      } else if (cj < cy) {
+        a.d_in[(size_t)b * a.d_in_bs + (size_t)cj * L + cn] = s_out[cr][cj];
       }
-      if (a.has_hi) {   // start conv weight gradient += dh0 a0^T, bias gradient += dh0
-        const uint2 d = *reinterpret_cast<const uint2*>(a.dh0 + ((size_t)b * a.Lr + n) * C + c4);
-        const float dv[4] = {lo2f(d.x), hi2f(d.x), lo2f(d.y), hi2f(d.y)};
+    }
+    {   // a thread owns 4 of the 256 channels and walks 8 positions; every row's loads are issued before the first FMA (rows >= L read
+        // row L - 1 and contribute nothing)
+      float4 sk[8];
+      uint2 dd[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float av = s_a0[r][j];
+      for (int i = 0; i < 8; ++i) {
+        const int n = min(n0 + rl * 8 + i, L - 1);
+        if (a.has_lo) sk[i] = *reinterpret_cast<const float4*>(a.lo.skip + ((size_t)b * a.Lr + n) * C + c4);
+        if (a.has_hi) dd[i] = *reinterpret_cast<const uint2*>(a.dh0 + ((size_t)b * a.Lr + n) * C + c4);
+      }
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc_s[j][t] = fmaf(av, dv[t], acc_s[j][t]);
+      for (int i = 0; i < 8; ++i) {
+        const int r = rl * 8 + i, n = n0 + r;
+        const bool live = n < L;
+        if (a.has_lo) {   // dskip = We^T dwn (bf16); end conv weight gradient += dwn skip^T
+          float dwn[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dwn[j] = live ? s_dwn[r][j] : 0.0f;
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = fmaf(we[j][t], dwn[j], v[t]);
+          if (live) *reinterpret_cast<uint2*>(a.dskip + ((size_t)b * a.Lr + n) * C + c4) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+          const float sv[4] = {sk[i].x, sk[i].y, sk[i].z, sk[i].w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc_e[j][t] = fmaf(dwn[j], sv[t], acc_e[j][t]);
         }
+        if (a.has_hi) {   // start conv weight gradient += dh0 a0^T, bias gradient += dh0
+          const float dv[4] = {live ? lo2f(dd[i].x) : 0.0f, live ? hi2f(dd[i].x) : 0.0f, live ? lo2f(dd[i].y) : 0.0f, live ? hi2f(dd[i].y) : 0.0f};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc_s[4][t] += dv[t];
+          for (int j = 0; j < 4; ++j) {
+            const float av = s_a0[r][j];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc_s[j][t] = fmaf(av, dv[t], acc_s[j][t]);
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc_s[4][t] += dv[t];
+        }
       }
     }
     __syncthreads();
@@ -2873,9 +2915,11 @@ bool pack_per_step() {
   const char* e = getenv("FACPPG_TRAIN_PACK");
   return e && !strcmp(e, "step");
 }
-int edge_chunks(int B, int L) {   // chunks of 32 positions a backward edge workgroup walks: at most ~256 workgroups
+int edge_chunks(int B, int L) {   // chunks of 32 positions a backward edge workgroup walks: at most ~512 workgroups (two per CU)
   const int nblk = (L + 31) / 32;
-  return std::max(1, (B * nblk + 255) / 256);
+  const char* e = getenv("FACPPG_EDGE_WGS");
+  const int target = e && atoi(e) > 0 ? atoi(e) : 512;
+  return std::max(1, (B * nblk + target - 1) / target);
 }
 WnPacked packed_view(const char* P, const PackedLayout& pl) {
   WnPacked pw;
