@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "facppg_common.h"
+#include "facppg_gemm.h"
 
 namespace facppg {
 namespace {
@@ -2069,40 +2070,181 @@ extern "C" int facppg_posmajor_to_f32(const float* src_dev, int B, int channels,
   return FACPPG_OK;
 }
 
+// ---- the upsampler as exact-fp32 MFMA GEMMs (round 6) ----------------------------------------------------------------------------
+// ConvTranspose1d(80, 80, K, stride hop): sample n = q hop + pp of channel m is sum_{j, m'} mel[m'][q - j] Wu[m'][m][pp + j hop], i.e.
+//   out[(b, q)][(m, pp)] = sum_{k = (j, m')} melshift[(b, q)][k] * Wfold[k][(m, pp)],    nj = ceil(K / hop) taps,
+// a [B Tq x 80 nj] x [80 nj x 80 hop] matrix product (k_gemm, facppg_gemm.h), and its weight gradient the product with the roles of
+// the position and the tap axis exchanged.  k_up_fwd / k_up_wgrad (scalar fp32 FMA loops, 377 + 335 us at batch 12) stay as the
+// FACPPG_UPSAMPLE_GEMM=0 path and the parity reference of the tests.
+struct UpDims { int B, T, Tq, nm, hop, ksize, nj, K, N, rows, L, Lr; };
+// Wfold[k = j nm + m'][n = m hop + pp] = Wu[m'][m][pp + j hop] (0 beyond the kernel)
+__global__ void k_up_fold(const float* __restrict__ W, float* __restrict__ out, UpDims d) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)d.K * d.N) return;
+  const int k = (int)(i / d.N), n = (int)(i - (size_t)k * d.N);
+  const int j = k / d.nm, mp = k - j * d.nm, m = n / d.hop, pp = n - m * d.hop, t = pp + j * d.hop;
+  out[i] = t < d.ksize ? W[((size_t)mp * d.nm + m) * d.ksize + t] : 0.0f;
+}
+// A-operand image (pack_a's layout) of melshift: rows (b, q), entries k = j nm + m': mel[b][m'][q - j]; TRANSPOSED: rows k, entries (b, q)
+template <bool TRANSPOSED>
+__global__ void k_up_pack_mel(const float* __restrict__ mel, float4* __restrict__ dst, UpDims d, int M, int K, int KG) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int MB = (M + 31) / 32;
+  if (idx >= MB * (KG + 1) * 64) return;
+  const int lane = idx & 63, g = (idx >> 6) % (KG + 1), mb = (idx >> 6) / (KG + 1);
+  const int row = mb * 32 + (lane & 31);
+  float v[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int col = 8 * g + 4 * (lane >> 5) + t;
+    const int r = TRANSPOSED ? col : row, k = TRANSPOSED ? row : col;      // r = (b, q), k = (j, m')
+    float x = 0.0f;
+    if (row < M && col < K && g < KG) {
+      const int bb = r / d.Tq, q = r - bb * d.Tq, j = k / d.nm, mp = k - j * d.nm;
+      if (q - j >= 0) x = mel[((size_t)bb * d.nm + mp) * d.T + q - j];
+    }
+    v[t] = x;
+  }
+  dst[idx] = make_float4(v[0], v[1], v[2], v[3]);
+}
+// out[(b, q)][m hop + pp] (+ bias[m]) -> spect bf16 [b][(q hop + pp) / 8][8 m + (q hop + pp) % 8]: 8-sample pieces (l', m) of frame q.
+// One workgroup per (b, q): rows of `out` in, whole spect rows out (through LDS).
+__global__ __launch_bounds__(256) void k_up_regroup(const float* __restrict__ out, const float* __restrict__ bias, bf16_t* __restrict__ spect, UpDims d) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];       // [N]
+  const int r = blockIdx.x, b = r / d.Tq, q = r - b * d.Tq, P = d.hop / 8;
+  const float4* src = reinterpret_cast<const float4*>(out + (size_t)r * d.N);
+  for (int i = threadIdx.x; i < d.N / 4; i += blockDim.x) reinterpret_cast<float4*>(sm)[i] = src[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < P * d.nm; i += blockDim.x) {     // piece (l', m), m fastest: consecutive threads write consecutive 16 bytes
+    const int lp = i / d.nm, m = i - lp * d.nm;
+    const int l = q * P + lp;
+    if (l >= d.L) continue;
+    const float* x = sm + m * d.hop + 8 * lp;
+    const float bv = bias[m];
+    *reinterpret_cast<uint4*>(spect + ((size_t)b * d.Lr + l) * (d.nm * 8) + m * 8) =
+        make_uint4(pack2(x[0] + bv, x[1] + bv), pack2(x[2] + bv, x[3] + bv), pack2(x[4] + bv, x[5] + bv), pack2(x[6] + bv, x[7] + bv));
+  }
+}
+// dup[(b, q)][m hop + pp] = dspect[b][(q hop + pp) / 8][8 m + (q hop + pp) % 8] (0 for samples >= 8 L): the inverse regrouping
+__global__ __launch_bounds__(256) void k_up_ungroup(const float* __restrict__ dspect, float* __restrict__ out, UpDims d) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];       // [N] as [m][pp]
+  const int r = blockIdx.x, b = r / d.Tq, q = r - b * d.Tq, P = d.hop / 8;
+  for (int i = threadIdx.x; i < P * d.nm * 2; i += blockDim.x) {  // half pieces (l', m, half): 16-byte loads along a dspect row
+    const int hf = i & 1, pm = i >> 1, lp = pm / d.nm, m = pm - lp * d.nm;
+    const int l = q * P + lp;
+    const float4 v = l < d.L ? *reinterpret_cast<const float4*>(dspect + ((size_t)b * d.Lr + l) * (d.nm * 8) + m * 8 + 4 * hf) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(sm + m * d.hop + 8 * lp + 4 * hf) = v;
+  }
+  __syncthreads();
+  float4* dst = reinterpret_cast<float4*>(out + (size_t)r * d.N);
+  for (int i = threadIdx.x; i < d.N / 4; i += blockDim.x) dst[i] = reinterpret_cast<const float4*>(sm)[i];
+}
+// dWu[m'][m][k] = dWfold[(k / hop) nm + m'][m hop + k % hop]
+__global__ void k_up_unfold(const float* __restrict__ fold, float* __restrict__ dW, UpDims d) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)d.nm * d.nm * d.ksize) return;
+  const int t = (int)(i % d.ksize), m = (int)((i / d.ksize) % d.nm), mp = (int)(i / ((size_t)d.ksize * d.nm));
+  const int j = t / d.hop, pp = t - j * d.hop;
+  dW[i] = fold[(size_t)(j * d.nm + mp) * d.N + m * d.hop + pp];
+}
+UpDims up_dims(int B, int T, int nm, int hop, int ksize, int L) {
+  UpDims d;
+  d.B = B; d.T = T; d.nm = nm; d.hop = hop; d.ksize = ksize; d.L = L; d.Lr = pad_len(L);
+  d.Tq = std::min(T, (L * 8 + hop - 1) / hop);     // frames q with q*hop < N produce samples < N
+  d.nj = (ksize + hop - 1) / hop; d.K = d.nj * nm; d.N = nm * hop; d.rows = B * d.Tq;
+  return d;
+}
+struct UpWs { size_t fold, aimg, out, total; };
+UpWs up_ws(const UpDims& d, bool backward) {   // forward: Wfold | A(melshift) | out;  backward: dWfold | A(melshift^T) | dup
+  UpWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  w.fold = take((size_t)round_up(d.K, 32) * d.N * 4);
+  w.aimg = take(packed_a_float4s(backward ? d.K : d.rows, backward ? d.rows : d.K) * 16);
+  w.out = take((size_t)d.rows * d.N * 4);
+  w.total = off;
+  return w;
+}
+bool upsample_gemm() {
+  const char* e = getenv("FACPPG_UPSAMPLE_GEMM");
+  return !(e && e[0] == '0');
+}
+
+extern "C" size_t facppg_upsample_forward_workspace_bytes(int B, int T, int n_mel, int hop, int ksize, int L) {
+  if (B <= 0 || T <= 0 || n_mel <= 0 || hop <= 0 || ksize <= 0 || L <= 0) return 0;
+  return up_ws(up_dims(B, T, n_mel, hop, ksize, L), false).total;
+}
+
 extern "C" int facppg_upsample_regroup_bf16(const float* mel_dev, const float* up_w_dev, const float* up_b_dev, int B, int T, int n_mel,
-                                            int hop, int ksize, int L, void* spect_pm_dev, void* stream_) {
+                                            int hop, int ksize, int L, void* spect_pm_dev, void* ws_dev, size_t ws_bytes, void* stream_) {
   FACPPG_REQUIRE(mel_dev && up_w_dev && up_b_dev && spect_pm_dev, FACPPG_EINVAL, "NULL argument");
   FACPPG_REQUIRE(B > 0 && T > 0 && L > 0 && n_mel == 80 && hop % 8 == 0 && hop > 0 && (ksize + hop - 1) / hop <= UMAXJ, FACPPG_EUNSUPPORTED,
                  "upsample: n_mel must be 80, hop a multiple of 8, kernel/hop <= %d", UMAXJ);
   FACPPG_REQUIRE((long)(T - 1) * hop + ksize >= (long)L * 8, FACPPG_EINVAL, "upsampled mel is shorter than the audio (glow.py:216)");
   hipStream_t s = (hipStream_t)stream_;
-  const int Lr = pad_len(L);
-  FACPPG_HIP_CHECK(hipMemsetAsync(spect_pm_dev, 0, (size_t)B * Lr * n_mel * 8 * 2, s));   // rows >= L (and samples no frame reaches) are zero
-  const int Tq = std::min(T, (L * 8 + hop - 1) / hop);     // frames q with q*hop < N produce samples < N
-  k_up_fwd<<<dim3((Tq + UQ - 1) / UQ, n_mel, B), 256, (size_t)n_mel * (UQ + UMAXJ) * 4, s>>>(mel_dev, up_w_dev, up_b_dev, (bf16_t*)spect_pm_dev, T,
-                                                                                          n_mel, hop, ksize, Lr, L * 8);
+  const UpDims d = up_dims(B, T, n_mel, hop, ksize, L);
+  FACPPG_HIP_CHECK(hipMemsetAsync(spect_pm_dev, 0, (size_t)B * d.Lr * n_mel * 8 * 2, s));   // rows >= L (and samples no frame reaches) are zero
+  if (!upsample_gemm() || !ws_dev) {
+    k_up_fwd<<<dim3((d.Tq + UQ - 1) / UQ, n_mel, B), 256, (size_t)n_mel * (UQ + UMAXJ) * 4, s>>>(mel_dev, up_w_dev, up_b_dev, (bf16_t*)spect_pm_dev, T,
+                                                                                              n_mel, hop, ksize, d.Lr, L * 8);
+    FACPPG_HIP_CHECK(hipGetLastError());
+    return FACPPG_OK;
+  }
+  const UpWs w = up_ws(d, false);
+  FACPPG_REQUIRE(ws_bytes >= w.total, FACPPG_EWORKSPACE, "upsample workspace has %zu bytes, need %zu", ws_bytes, w.total);
+  char* Wk = (char*)ws_dev;
+  float* fold = (float*)(Wk + w.fold);
+  float4* aimg = (float4*)(Wk + w.aimg);
+  float* out = (float*)(Wk + w.out);
+  k_up_fold<<<(unsigned)(((size_t)d.K * d.N + 255) / 256), 256, 0, s>>>(up_w_dev, fold, d);
+  const int KG = gemm_kpad(d.K) / 8;
+  k_up_pack_mel<false><<<((d.rows + 31) / 32 * (KG + 1) * 64 + 255) / 256, 256, 0, s>>>(mel_dev, aimg, d, d.rows, d.K, KG);
+  GemmArgs g;
+  g.A = aimg; g.M = d.rows; g.Cin = d.K; g.taps = 1; g.X = fold; g.x_bs = 0; g.ldx = d.N; g.N = d.N; g.C = out; g.c_bs = 0; g.ldc = d.N; g.B = 1;
+  if (int rc = gemm_launch(g, s)) return rc;
+  k_up_regroup<<<d.rows, 256, (size_t)d.N * 4, s>>>(out, up_b_dev, (bf16_t*)spect_pm_dev, d);
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
 }
 
-extern "C" size_t facppg_upsample_backward_workspace_bytes(void) { return (size_t)MAXCS * CS_SLICES * 1024 * 4; }
+extern "C" size_t facppg_upsample_backward_workspace_bytes(int B, int T, int n_mel, int hop, int ksize, int L) {
+  const size_t cs = (size_t)MAXCS * CS_SLICES * 1024 * 4;
+  if (B <= 0 || T <= 0 || n_mel <= 0 || hop <= 0 || ksize <= 0 || L <= 0) return cs;
+  return cs + up_ws(up_dims(B, T, n_mel, hop, ksize, L), true).total;
+}
 
 extern "C" int facppg_upsample_regroup_backward(const float* mel_dev, const float* dspect_pm_dev, int B, int T, int n_mel, int hop, int ksize,
                                                 int L, float* d_up_w_dev, float* d_up_b_dev, void* ws_dev, size_t ws_bytes, void* stream_) {
   FACPPG_REQUIRE(mel_dev && dspect_pm_dev && d_up_w_dev && d_up_b_dev && ws_dev, FACPPG_EINVAL, "NULL argument");
   FACPPG_REQUIRE(B > 0 && T > 0 && L > 0 && n_mel == 80 && hop % 8 == 0 && hop > 0, FACPPG_EUNSUPPORTED, "upsample backward: n_mel must be 80, hop a multiple of 8");
-  FACPPG_REQUIRE(ws_bytes >= facppg_upsample_backward_workspace_bytes(), FACPPG_EWORKSPACE, "workspace too small");
+  const size_t cs = (size_t)MAXCS * CS_SLICES * 1024 * 4;
+  FACPPG_REQUIRE(ws_bytes >= cs, FACPPG_EWORKSPACE, "workspace too small");
   hipStream_t s = (hipStream_t)stream_;
-  const int Lr = pad_len(L);
-  k_up_wgrad<80><<<dim3((ksize + 255) / 256, n_mel), 256, 0, s>>>(mel_dev, dspect_pm_dev, d_up_w_dev, B, T, hop, ksize, Lr, L * 8);
+  const UpDims d = up_dims(B, T, n_mel, hop, ksize, L);
+  const UpWs w = up_ws(d, true);
+  if (upsample_gemm() && ws_bytes >= cs + w.total && (ksize + hop - 1) / hop <= UMAXJ) {
+    char* Wk = (char*)ws_dev + cs;
+    float* fold = (float*)(Wk + w.fold);
+    float4* aimg = (float4*)(Wk + w.aimg);
+    float* dup = (float*)(Wk + w.out);
+    k_up_ungroup<<<d.rows, 256, (size_t)d.N * 4, s>>>(dspect_pm_dev, dup, d);
+    const int KG = gemm_kpad(d.rows) / 8;
+    k_up_pack_mel<true><<<((d.K + 31) / 32 * (KG + 1) * 64 + 255) / 256, 256, 0, s>>>(mel_dev, aimg, d, d.K, d.rows, KG);
+    GemmArgs g;
+    g.A = aimg; g.M = d.K; g.Cin = d.rows; g.taps = 1; g.X = dup; g.x_bs = 0; g.ldx = d.N; g.N = d.N; g.C = fold; g.c_bs = 0; g.ldc = d.N; g.B = 1;
+    if (int rc = gemm_launch(g, s)) return rc;
+    k_up_unfold<<<(unsigned)(((size_t)n_mel * n_mel * ksize + 255) / 256), 256, 0, s>>>(fold, d_up_w_dev, d);
+  } else {
+    k_up_wgrad<80><<<dim3((ksize + 255) / 256, n_mel), 256, 0, s>>>(mel_dev, dspect_pm_dev, d_up_w_dev, B, T, hop, ksize, d.Lr, L * 8);
+  }
   // d bias[m] = sum over every produced sample of channel m = column sums of dspect over its 8 regrouped channels
   ColsumArgs ca;
   memset(&ca, 0, sizeof(ca));
   ca.B = B; ca.L = L; ca.part = (float*)ws_dev;
   // 640 channels as two problems of 320 (k_colsum_part covers <= 512 channels per problem)
   const int half = n_mel * 4;
-  ca.prob[0] = ColsumProb{dspect_pm_dev, (long)Lr * n_mel * 8, n_mel * 8, 0, half, d_up_b_dev};
-  ca.prob[1] = ColsumProb{dspect_pm_dev + half, (long)Lr * n_mel * 8, n_mel * 8, 0, half, d_up_b_dev + half / 8};
+  ca.prob[0] = ColsumProb{dspect_pm_dev, (long)d.Lr * n_mel * 8, n_mel * 8, 0, half, d_up_b_dev};
+  ca.prob[1] = ColsumProb{dspect_pm_dev + half, (long)d.Lr * n_mel * 8, n_mel * 8, 0, half, d_up_b_dev + half / 8};
   return colsum_launch<true>(ca, 2, half, 8, s);
 }
 

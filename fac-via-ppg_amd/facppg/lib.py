@@ -119,8 +119,9 @@ def _declare(lib):
         "facppg_glow_bf16_group_forward": (c.c_int, [c.POINTER(GlowFlow), c.c_int, c.c_int, vp, c.c_long, vp, c.c_long, vp, c.c_int, c.c_int, vp]),
         "facppg_glow_bf16_group_backward": (c.c_int, [c.POINTER(GlowFlow), c.c_int, c.c_int, vp, c.c_long, vp, c.c_long, vp, vp, c.c_int, vp,
                                                       c.c_int, c.c_int, vp]),
-        "facppg_upsample_regroup_bf16": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, vp, vp]),
-        "facppg_upsample_backward_workspace_bytes": (sz, []),
+        "facppg_upsample_forward_workspace_bytes": (sz, [c.c_int] * 6),
+        "facppg_upsample_regroup_bf16": (c.c_int, [vp, vp, vp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, vp, vp, sz, vp]),
+        "facppg_upsample_backward_workspace_bytes": (sz, [c.c_int] * 6),
         "facppg_upsample_regroup_backward": (c.c_int, [vp, vp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, vp, vp, vp, sz, vp]),
         "facppg_weight_norm_forward": (c.c_int, [vp, c.c_int, c.c_long, vp]),
         "facppg_weight_norm_backward": (c.c_int, [vp, vp, c.c_int, c.c_long, vp]),

@@ -228,9 +228,10 @@ class _UpsampleBf16Function(torch.autograd.Function):
         B, nm, T = mel.shape
         Lr = L.facppg_wn_bf16_padded_len(Lg)
         spect_pm = torch.empty(B, Lr, nm * 8, dtype=torch.bfloat16, device=dev)
+        ws = torch.empty(L.facppg_upsample_forward_workspace_bytes(B, T, nm, hop, w.shape[2], Lg), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             _lib.check(L.facppg_upsample_regroup_bf16(_lib.ptr(mel), _lib.ptr(w), _lib.ptr(b), B, T, nm, hop, w.shape[2], Lg,
-                                                      _lib.ptr(spect_pm), _lib.current_stream(dev)))
+                                                      _lib.ptr(spect_pm), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)))
         ctx.save_for_backward(mel)
         ctx.shared, ctx.hop, ctx.Lg, ctx.wshape = shared, hop, Lg, tuple(w.shape)
         ctx.set_materialize_grads(False)                  # (the link's gradient is None: it only orders this node behind the flows)
@@ -248,7 +249,7 @@ class _UpsampleBf16Function(torch.autograd.Function):
         d = ctx.shared.dspect_pm
         if d is None:                                     # no flow contributed (cannot happen in WaveGlow.forward)
             return None, torch.zeros_like(dw), torch.zeros_like(db), None, None, None
-        ws = torch.empty(L.facppg_upsample_backward_workspace_bytes(), dtype=torch.uint8, device=dev)
+        ws = torch.empty(L.facppg_upsample_backward_workspace_bytes(B, T, nm, ctx.hop, ctx.wshape[2], ctx.Lg), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             _lib.check(L.facppg_upsample_regroup_backward(_lib.ptr(mel), _lib.ptr(d), B, T, nm, ctx.hop, ctx.wshape[2], ctx.Lg, _lib.ptr(dw),
                                                           _lib.ptr(db), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)))

@@ -290,12 +290,14 @@ int facppg_wn_backward_bf16(const facppg_wn_weights* w, const facppg_wn_grads* g
 /* Replaces WaveGlow.upsample + crop + regroup in the training direction (glow.py:184-186, 214-222), straight into
  * the bf16 position-major conditioning operand: mel [B][80][T] fp32, up_w [80][80][ksize], up_b [80] ->
  * spect_pm bf16 [B][Lr][640] for L = N/8 group positions (rows >= L zero). */
+size_t facppg_upsample_forward_workspace_bytes(int B, int T, int n_mel, int hop, int ksize, int L);
+/* workspace (may be NULL: the scalar kernels run): the transposed convolution as an exact-fp32 MFMA matrix product */
 int facppg_upsample_regroup_bf16(const float* mel_dev, const float* up_w_dev, const float* up_b_dev, int B,
                                  int T, int n_mel, int hop, int ksize, int L, void* spect_pm_dev,
-                                 void* stream);
+                                 void* workspace_dev, size_t workspace_bytes, void* stream);
 /* Its backward w.r.t. the parameters from the accumulated conditioning gradient dspect_pm fp32 [B][Lr][640]:
  * d_up_w [80][80][ksize], d_up_b [80]. */
-size_t facppg_upsample_backward_workspace_bytes(void);
+size_t facppg_upsample_backward_workspace_bytes(int B, int T, int n_mel, int hop, int ksize, int L);
 int facppg_upsample_regroup_backward(const float* mel_dev, const float* dspect_pm_dev, int B, int T, int n_mel,
                                      int hop, int ksize, int L, float* d_up_w_dev, float* d_up_b_dev,
                                      void* workspace_dev, size_t workspace_bytes, void* stream);
