@@ -2410,10 +2410,8 @@ extern "C" int facppg_wn_forward_bf16(const facppg_wn_weights* wts, int n_in, in
   return FACPPG_OK;
 }
 
-// The data-gradient chain of one stack, from dskip (already formed from d(out) by the end conv's backward) down to dh_0, plus the
-// conditioning gradient of all layers.
-int wn_layers_backward_data(int nl, const WnPacked& pw, const char* S, const WnWork& wk, float* dspect_pm_dev, int accumulate_dspect,
-                            int B, int L, hipStream_t s) {
+// The data-gradient chain of one stack, from dskip (already formed from d(out) by the end conv's backward) down to dh_0.
+int wn_layers_backward_data(int nl, const WnPacked& pw, const char* S, const WnWork& wk, int B, int L, hipStream_t s) {
   const int Lr = pad_len(L), Lp = HALO + Lr + HALO;
   const StateLayout st = state_layout(nl, B, Lr);
   bf16_t* dskip = wk.dskip;
@@ -2463,6 +2461,13 @@ int wn_layers_backward_data(int nl, const WnPacked& pw, const char* S, const WnW
       if (int rc = conv_bwd_launch(i)) return rc;
     }
   }
+  return FACPPG_OK;
+}
+
+// the conditioning gradient of all layers of one stack: dspect (+)= [Wcond_0^T | ... ] [dpre_0; ...]
+int wn_layers_backward_dspect(int nl, const WnPacked& pw, const WnWork& wk, float* dspect_pm_dev, int accumulate_dspect, int B, int L,
+                              hipStream_t s) {
+  const int Lr = pad_len(L), Lp = HALO + Lr + HALO;
   const char* e_ds = getenv("FACPPG_TRAIN_DSPECT_BGEMM");     // =1: the k_bgemm<EP_ACC_F32> launch (bit-equality test, A/B timing)
   if (!(e_ds && e_ds[0] == '1')) {  // dspect over all layers at once
     DspectArgs c;
@@ -2483,8 +2488,9 @@ int wn_layers_backward_data(int nl, const WnPacked& pw, const char* S, const WnW
 
 // Weight and bias gradients of the three convs of every layer: NT products over positions, batched over layers (x taps); bias
 // gradients as column sums.
+// (s: the NT products and their ordered reduce; s_bias: the column sums -- the same stream, or a parallel branch)
 int wn_layers_backward_weights(const facppg_wn_grads* gr, int nl, const char* S, const WnWork& wk, const void* spect_pm_dev, int B, int L,
-                               hipStream_t s) {
+                               hipStream_t s, hipStream_t s_bias) {
   const int Lr = pad_len(L), Lp = HALO + Lr + HALO;
   const StateLayout st = state_layout(nl, B, Lr);
   bf16_t* dskip = wk.dskip;
@@ -2540,7 +2546,7 @@ int wn_layers_backward_weights(const facppg_wn_grads* gr, int nl, const char* S,
     ca.bc_prob = np;
     ca.prob[np++] = ColsumProb{dskip, (long)Lr * C, C, 0, C, gr->rs_b[nl - 1], nullptr};
     for (int i = 0; i + 1 < nl; ++i) ca.bc[ca.nbc++] = gr->rs_b[i] + C;
-    if (int rc = colsum_launch<false>(ca, np, 2 * C, 1, s)) return rc;
+    if (int rc = colsum_launch<false>(ca, np, 2 * C, 1, s_bias)) return rc;
   }
   FACPPG_HIP_CHECK(hipGetLastError());
   return FACPPG_OK;
@@ -2599,7 +2605,8 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
   WnWork wk;
   wk.dpre = W + sc.dpre; wk.dpre_one = sc.dpre_one; wk.dh = W + sc.dh; wk.dh_one = sc.dh_one; wk.dskip = dskip;
   wk.cspart = (float*)(W + sc.cspart); wk.wgpart = (float*)(W + sc.wgpart); wk.wgpart_bytes = sc.wgpart_bytes; wk.wgpart_regions = 1;
-  if (int rc = wn_layers_backward_data(nl, pw, S, wk, dspect_pm_dev, accumulate_dspect, B, L, s)) return rc;
+  if (int rc = wn_layers_backward_data(nl, pw, S, wk, B, L, s)) return rc;
+  if (int rc = wn_layers_backward_dspect(nl, pw, wk, dspect_pm_dev, accumulate_dspect, B, L, s)) return rc;
   const bf16_t* dh0 = (const bf16_t*)(W + sc.dh);
   k_t_start_bwd<<<dim3((L + 31) / 32, B), 256, 0, s>>>(dh0, wts->start_w, da0_dev, n_in, L, Lr);
   {  // start conv: weight [256][n_in] and bias [256] gradients
@@ -2607,7 +2614,7 @@ extern "C" int facppg_wn_backward_bf16(const facppg_wn_weights* wts, const facpp
     k_small_wgrad_part<true><<<SMALL_PARTS, 256, 0, s>>>(a0_dev, dh0, (long)Lr * C, 0, part, n_in, B, L, SMALL_PARTS);
     k_small_wgrad_sum<<<dim3(C / 16, 9), 256, 0, s>>>(part, SMALL_PARTS, n_in, gr->start_w, 1, n_in, gr->start_b);
   }
-  return wn_layers_backward_weights(gr, nl, S, wk, spect_pm_dev, B, L, s);
+  return wn_layers_backward_weights(gr, nl, S, wk, spect_pm_dev, B, L, s, s);
 }
 
 // ================================================================================================================
@@ -3232,8 +3239,12 @@ extern "C" int facppg_glow_bf16_group_backward(const facppg_glow_flow* flows, in
         if (int rc = pk.launch(s)) return rc;
       }
       const WnPacked pw = packed_view((const char*)f.packed, pl);
-      if (int rc = wn_layers_backward_data(nl, pw, (const char*)f.state, wk, dspect_pm_dev, accumulate_dspect || k < n, B, L, s)) return rc;
-      if (int rc = wn_layers_backward_weights(f.g, nl, (const char*)f.state, wk, spect_pm_dev, B, L, s)) return rc;
+      if (int rc = wn_layers_backward_data(nl, pw, (const char*)f.state, wk, B, L, s)) return rc;
+      // (Round 6 experiment: the conditioning gradient, the weight-gradient products and the bias column sums as three parallel
+      // branches -- side streams forked / joined by events, parallel branches of the captured graph -- measured SLOWER: 8.63 -> 9.50 ms
+      // at batch 3, 15.0 -> 15.6 at batch 12; a fork + two joins per flow cost more cross-queue latency than the overlap returns.)
+      if (int rc = wn_layers_backward_dspect(nl, pw, wk, dspect_pm_dev, accumulate_dspect || k < n, B, L, s)) return rc;
+      if (int rc = wn_layers_backward_weights(f.g, nl, (const char*)f.state, wk, spect_pm_dev, B, L, s, s)) return rc;
     }
   }
   {
