@@ -129,6 +129,41 @@ __global__ void k_pack_bf16(PackBatch pb) {
   p.dst[((size_t)mb * p.KG + p.k_base / 16 + gl) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// The same images for sources whose rows are contiguous along the reduction (sc == taps, st == 1: the forward images).  k_pack_bf16
+// gives a lane one ROW, i.e. 64 lanes read 64 different cache lines per load; here consecutive threads take consecutive 8-channel
+// groups of one row -- a thread reads 8 * taps contiguous floats (16-byte loads) and writes one 16-byte piece per tap.
+__global__ void k_pack_rows_bf16(PackBatch pb) {
+  const PackArgs& p = pb.e[blockIdx.y];
+  const int c8n = p.Cin / 8, MB = (p.M + 31) / 32;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= MB * 32 * c8n) return;
+  const int c8 = idx % c8n, rr = idx / c8n, mb = rr >> 5, rho = rr & 31;
+  const int m = p.gate_rows ? gate_row_src(mb, rho) : mb * 32 + rho;
+  float v[24];
+  const int nf = 8 * p.taps;            // taps <= 3
+  if (m < p.M) {
+    const float4* src = reinterpret_cast<const float4*>(p.src + p.off + (size_t)m * p.sm + (size_t)c8 * nf);
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+      if (q * 4 < nf) {
+        const float4 x = src[q];
+        v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+      }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 24; ++q) v[q] = 0.0f;
+  }
+#pragma unroll
+  for (int tap = 0; tap < 3; ++tap)
+    if (tap < p.taps) {
+      float e[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) e[i] = p.taps == 1 ? v[i] : (p.taps == 3 ? v[(3 * i + tap) % 24] : v[(2 * i + tap) % 24]);
+      const int k = p.k_base + tap * p.Cin + c8 * 8;
+      p.dst[((size_t)mb * p.KG + (k >> 4)) * 64 + rho + 32 * ((k >> 3) & 1)] = make_uint4(pack2(e[0], e[1]), pack2(e[2], e[3]), pack2(e[4], e[5]), pack2(e[6], e[7]));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // k_bgemm: out[b][n][m] = epilogue( sum_k A[m][k] * X[b][n + shift(k)][c(k)] ), the reduction being a list of
 // segments (each a multiple of 64 channels of one position-major tensor at one row shift).
@@ -2007,7 +2042,18 @@ struct Packer {
   }
   int launch(hipStream_t s) {
     if (!n) return FACPPG_OK;
-    k_pack_bf16<<<dim3((max_total + 255) / 256, n), 256, 0, s>>>(pb);
+    bool rows = true;       // every job row-contiguous along the reduction (16-byte aligned rows): the coalesced kernel
+    for (int i = 0; i < n && rows; ++i) {
+      const PackArgs& e = pb.e[i];
+      rows = (e.taps == 1 || e.st == 1) && e.sc == e.taps && e.taps <= 3 && e.Cin % 8 == 0 && e.sm % 4 == 0 && e.off % 4 == 0 && ((size_t)e.src & 15) == 0;
+    }
+    if (rows) {
+      int mt = 0;
+      for (int i = 0; i < n; ++i) mt = std::max(mt, (pb.e[i].M + 31) / 32 * 32 * (pb.e[i].Cin / 8));
+      k_pack_rows_bf16<<<dim3((mt + 255) / 256, n), 256, 0, s>>>(pb);
+    } else {
+      k_pack_bf16<<<dim3((max_total + 255) / 256, n), 256, 0, s>>>(pb);
+    }
     n = 0; max_total = 0;
     FACPPG_HIP_CHECK(hipGetLastError());
     return FACPPG_OK;
