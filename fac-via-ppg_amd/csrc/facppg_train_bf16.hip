@@ -452,6 +452,10 @@ int dump_stamps(const char* path, const char* what, const unsigned long long* de
 constexpr int FKC = 128, FLDB = FKC + 8, FLDA = C + 8, FLDT = 2 * C + 8, FLDO = 2 * C + 4;
 // LDS of k_wn_fwd: TN * FLDO * 4 bytes: staging (TN * 544) -> gated + tanh|sigmoid tiles (TN * 1568) -> fp32 res/skip tile (TN * 2064)
 constexpr int FNCH = (3 * C + NCOND) / FKC;   // 11 chunks
+#ifndef FACPPG_FWD_RING
+#define FACPPG_FWD_RING 8
+#endif
+constexpr int FRD = FACPPG_FWD_RING;          // A-fragment ring of k_wn_fwd, in 16-entry steps
 struct WnFwdArgs {
   const uint4* A1;          // gate image, KG = 88, gate-interleaved rows
   const uint4* A2;          // res/skip image, KG = 16, M2 rows
@@ -519,10 +523,13 @@ __global__ __launch_bounds__(512) void k_wn_fwd(WnFwdArgs p) {
       *reinterpret_cast<uint4*>(lds + buf * (TN * FLDB) + (e >> 4) * FLDB + (e & 15) * 8) = stg[j];
     }
   };
-  uint4 st[2][NCB], ar[8][2];     // activation chunks are requested TWO chunks ahead (register ring st[chunk & 1])
+  // activation chunks are requested TWO chunks ahead (register ring st[chunk & 1]); the A fragments FRD 16-entry steps ahead (ring
+  // ar[step % FRD]: 8 = one chunk -- the fragment of step t is requested 0.85 us of MFMA work before its use, less than an L2 round trip
+  // under load, and half of every wave's time was s_waitcnt -- 12 / 16 = one and a half / two chunks)
+  uint4 st[2][NCB], ar[FRD][2];
   stage_load(0, st[0]);
 #pragma unroll
-  for (int s = 0; s < 8; ++s) { ar[s][0] = ap0[(size_t)s * 64]; ar[s][1] = ap1[(size_t)s * 64]; }
+  for (int s = 0; s < FRD; ++s) { ar[s][0] = ap0[(size_t)s * 64]; ar[s][1] = ap1[(size_t)s * 64]; }
   stage_load(1, st[1]);
   stage_write(0, st[0]);
   stage_load(2, st[0]);
@@ -534,7 +541,6 @@ __global__ __launch_bounds__(512) void k_wn_fwd(WnFwdArgs p) {
     stage_load(c + 3, st[(c + 1) & 1]);
     __builtin_amdgcn_sched_barrier(0);   // requests stay where they are written (hipcc otherwise sinks them to the end of the iteration, next to their use)
     const bf16_t* lb = lds + (c & 1) * (TN * FLDB) + li * FLDB + 8 * kh;
-    const size_t gnext = (size_t)(min(c + 1, FNCH - 1) * 8) * 64;
     uint4 bc[NCB], bn[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) bc[cb] = *reinterpret_cast<const uint4*>(lb + cb * 32 * FLDB);
@@ -543,12 +549,14 @@ __global__ __launch_bounds__(512) void k_wn_fwd(WnFwdArgs p) {
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb)   // fragments of the next step requested before this step's MFMAs
         bn[cb] = s < 7 ? *reinterpret_cast<const uint4*>(lb + cb * 32 * FLDB + 16 * (s + 1)) : bc[cb];
+      const int t = c * 8 + s;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) acc[i][cb] = mfma_bf16(ar[s][i], bc[cb], acc[i][cb]);
-      ar[s][0] = ap0[gnext + (size_t)s * 64];
-      ar[s][1] = ap1[gnext + (size_t)s * 64];
+        for (int cb = 0; cb < NCB; ++cb) acc[i][cb] = mfma_bf16(ar[t % FRD][i], bc[cb], acc[i][cb]);
+      const size_t gnext = (size_t)min(t + FRD, FNCH * 8 - 1) * 64;     // (the last steps re-request the last fragment: unconditional requests)
+      ar[t % FRD][0] = ap0[gnext];
+      ar[t % FRD][1] = ap1[gnext];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) bc[cb] = bn[cb];
