@@ -337,13 +337,16 @@ def train_worker():
     print(json.dumps(out))
 
 
-def stage_rooflines(stages, frames_in, frames_out, batch, hop):
+def stage_rooflines(stages, frames_in, frames_out, batch, hop, seeded_frames=0):
     """Per-stage achieved rates next to the roofline that bounds each (SURVEY.md 8d per-unit figures): the MFMA
     stages in TFLOP/s of the fp32 MFMA peak, the streaming denoiser in GB/s of HBM peak, the autoregressive decoder as
-    microseconds per frame (latency-bound: neither roofline applies)."""
+    microseconds per frame (latency-bound: neither roofline applies).
+    seeded_frames: frames of the (single, streamed) utterance whose conditioning chunks k_cond_seed executed under the decoder
+    -- those FLOPs did not run in the vocoder stage and are not credited to it."""
     out = {}
-    pos = frames_out * hop // 8
-    flop = {"encoder": 22.8e6 * frames_in, "postnet": 8.68e6 * frames_out, "waveglow": 96 * layer_flops_per_position(hop=hop) * pos}
+    P = hop // 8
+    wg_flops = 96 * P * (seeded_frames * layer_flops_per_position(ncond=0, hop=hop) + (frames_out - seeded_frames) * layer_flops_per_position(hop=hop))
+    flop = {"encoder": 22.8e6 * frames_in, "postnet": 8.68e6 * frames_out, "waveglow": wg_flops}
     for k, f in flop.items():
         if stages.get(k):
             t = f / (stages[k] * 1e-3) / 1e12
@@ -775,7 +778,12 @@ class E2EWorkload(object):
                          "per_gpu_batch": len(self.e.lens), "global_batch": len(self.e.lens) * self.world, "parallelism": "dp%d" % self.world}
         out["stage_ms"] = {k: v for k, v in st.items() if k != "total"}
         out["stage_ms_total"] = st["total"]
-        out["stage_roofline"] = stage_rooflines(st, sum(self.e.lens), sum(self.e.lens), len(self.e.lens), HOP)
+        cs = self.e.waveglow.__dict__.get("_facppg_cond_stream") if b1 else None
+        seeded_now = min(int(getattr(cs, "seeded", 0)), self.e.lens[0]) if cs is not None and os.environ.get("FACPPG_STREAM", "1") != "0" else 0
+        out["stage_roofline"] = stage_rooflines(st, sum(self.e.lens), sum(self.e.lens), len(self.e.lens), HOP, seeded_frames=seeded_now)
+        if seeded_now:
+            out["stage_roofline"]["waveglow"]["executed"] = ("%d of %d frames start from seeds: their conditioning chunks ran in k_cond_seed under "
+                                                             "the decoder and are not counted here" % (seeded_now, self.e.lens[0]))
 
 
 class CorpusWorkload(object):

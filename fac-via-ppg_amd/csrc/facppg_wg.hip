@@ -866,7 +866,7 @@ __global__ __launch_bounds__(256, 2) void k_wn_layer(WnArgs p) {
 // FACPPG_WN8_PROF: phase stamps of k_wn_layer8 (workgroup 0, thread 0; clock64 ticks summed over launches), read back with
 // facppg_debug_wn8_prof -- where a narrow launch spends its time outside the K loop (tools/prof_wn8.py)
 #ifdef FACPPG_WN8_PROF
-__device__ unsigned long long g_wn8_prof[12];   // 0-5 phases, 6 launches, 7 k_wn_flow8's wait, 8 its hand-off
+__device__ unsigned long long g_wn8_prof[12];   // 0-5 phases, 6 launches
 #define WN8_STAMP_DECL long long wn8_t = clock64()
 #define WN8_STAMP(i)                                                                           \
   do {                                                                                         \
@@ -890,17 +890,8 @@ __device__ unsigned long long g_wn8_prof[12];   // 0-5 phases, 6 launches, 7 k_w
 // NCB = 4 (128-frame tiles, ONE workgroup per CU, 256 VGPRs): each weight load then feeds four column blocks -- 2 global
 // loads per 32 MFMAs instead of k_wn_layer's 4.  tools/probes/mfma_probe.hip: with 2 waves per SIMD the fp32 MFMA stream
 // runs at 0.95 of peak next to 2 global_load_dwordx4 per 32 MFMAs and at 0.85 next to 4.
-// FUSED (k_wn_flow8: all layers of a flow in one launch, see there): what a tile waits for before it touches the previous
-// layer's output, and how long it may wait.  Stores are then write-through (sc1) so that a tile of the next layer, on any CU
-// of any XCD, reads them behind one agent-scope acquire.
-struct FlowWait {
-  const unsigned* ctr;             // completed-tile counter of the previous layer (null: nothing to wait for)
-  unsigned target;                 // its value once every tile of that layer is done
-  unsigned long long poll_limit;   // wall-clock ticks before the wait traps (0: unbounded)
-  int flags;                       // experiments: 1 = wait before the prologue (no overlap), 2 = no acquire behind the wait (racy)
-};
 typedef float f32x4s __attribute__((ext_vector_type(4)));
-// a load that is a global_load whatever hipcc knows about the pointer: pointers that come out of a device table (k_wn_flow8's
+// a load that is a global_load whatever hipcc knows about the pointer: pointers that come out of a device table (k_cond_seed's
 // per-layer operands) or out of integer arithmetic are "generic" to it, and every access through them a flat_load -- which
 // counts on the LDS counter too, so that the K loop's ds_read waits would wait for the weight loads as well
 // (built-in vector types only: a class type such as float4 is copied through a generic reference again)
@@ -912,44 +903,15 @@ __device__ __forceinline__ float4 gld(const float4* q) {
 }
 __device__ __forceinline__ f4u gld(const f4u* q) { return *(const FACPPG_AS1 f4u*)q; }
 __device__ __forceinline__ float gld(const float* q) { return *(const FACPPG_AS1 float*)q; }
-template <bool SC1>
 __device__ __forceinline__ void store_f4(float* g, const float4 v) {
-  if constexpr (SC1) {
-    const f32x4s x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(g), "v"(x) : "memory");
-  } else {
-    const f32x4s x = {v.x, v.y, v.z, v.w};
-    *(FACPPG_AS1 f32x4s*)g = x;
-  }
+  const f32x4s x = {v.x, v.y, v.z, v.w};
+  *(FACPPG_AS1 f32x4s*)g = x;
 }
-template <bool SC1>
-__device__ __forceinline__ void store_f1(float* g, const float v) {
-  if constexpr (SC1) __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *(__attribute__((address_space(1))) float*)g = v;
-}
-__device__ __forceinline__ void flow_wait(const FlowWait& fw) {
-  // ONE wave polls (1 800 waves would hammer one address; a scalar s_load glc poll, which would leave the vector memory pipeline
-  // alone, sees the counter ~300 us late on this stack); the others meet it at the barrier
-  if (threadIdx.x < 64) {
-    unsigned long long t0 = 0;
-    unsigned spins = 0;
-    for (;;) {
-      if (__hip_atomic_load(fw.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= fw.target) break;
-      __builtin_amdgcn_s_sleep(16);
-      if ((++spins & 1023u) == 0 && fw.poll_limit) {
-        const unsigned long long now = wall_clock64();
-        if (!t0) t0 = now;
-        else if (now - t0 > fw.poll_limit) __builtin_trap();
-      }
-    }
-  }
-  __syncthreads();
-  if (!(fw.flags & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU's L1 may hold the buffer's lines of two layers ago
-}
+__device__ __forceinline__ void store_f1(float* g, const float v) { *(__attribute__((address_space(1))) float*)g = v; }
 
-template <bool LAST, int NCB, bool EF, bool FUSED, bool SC1 = FUSED, bool SEED = false>
-__device__ __forceinline__ void wn_layer8_tile(const WnArgs& p, const int lin, float* __restrict__ smem, const FlowWait fw) {
-  static_assert(!SEED || (NCB == 1 && !FUSED), "seeded tiles: 32 frames, one launch per layer");
+template <bool LAST, int NCB, bool EF, bool SEED = false>
+__device__ __forceinline__ void wn_layer8_tile(const WnArgs& p, const int lin, float* __restrict__ smem) {
+  static_assert(!SEED || NCB == 1, "seeded tiles: 32 frames");
   constexpr int TNt = 32 * NCB;
   WN8_STAMP_DECL;
   const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, wq = w8 >> 1, sub = w8 & 1;
@@ -999,9 +961,6 @@ __device__ __forceinline__ void wn_layer8_tile(const WnArgs& p, const int lin, f
   const bool folded_first = EF && p.nconv == 1;
   const float* hb4 = folded_first ? p.xa + (size_t)b * 8 * p.Lp : p.h_in + (size_t)b * C * p.Lp;
   const float* sb4 = p.melp + (size_t)b * NMEL * p.Tqp + in_off - ph * p.Tqp;
-  if constexpr (FUSED) {
-    if (fw.ctr && (fw.flags & 1)) flow_wait(fw);
-  }
   float4 stg[NSTG4];
   auto stage_load = [&](int c) __attribute__((always_inline)) {
     const bool conv = c >= ncc;
@@ -1074,18 +1033,6 @@ __device__ __forceinline__ void wn_layer8_tile(const WnArgs& p, const int lin, f
   __syncthreads();
   WN8_STAMP(0);   // prologue
   for (int c = 0; c < nch; ++c) {
-    if constexpr (FUSED) {
-      // the conditioning chunks behind us needed nothing of the previous layer; the first convolution chunk is requested next
-      if (c == ncc - 1 && fw.ctr && !(fw.flags & 1)) {
-#ifdef FACPPG_WN8_PROF
-        const long long w0 = clock64();
-#endif
-        flow_wait(fw);
-#ifdef FACPPG_WN8_PROF
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_wn8_prof[7], (unsigned long long)(clock64() - w0));
-#endif
-      }
-    }
     stage_load(c + 1 < nch ? c + 1 : c);
     const float* lb = smem + (c & 1) * (KCH * TNt) + (kh * TNt + li) * 4;
 #pragma unroll
@@ -1223,9 +1170,9 @@ __device__ __forceinline__ void wn_layer8_tile(const WnArgs& p, const int lin, f
       if (nvalid >= 4) {
         float4 x = make_float4(bias, bias, bias, bias);
         if (!p.first) x = *reinterpret_cast<const float4*>(g);
-        store_f4<SC1>(g, make_float4(x.x + vv[0], x.y + vv[1], x.z + vv[2], x.w + vv[3]));
+        store_f4(g, make_float4(x.x + vv[0], x.y + vv[1], x.z + vv[2], x.w + vv[3]));
       } else {
-        for (int k = 0; k < nvalid; ++k) store_f1<SC1>(g + k, (p.first ? bias : g[k]) + vv[k]);
+        for (int k = 0; k < nvalid; ++k) store_f1(g + k, (p.first ? bias : g[k]) + vv[k]);
       }
     }
   }
@@ -1255,10 +1202,10 @@ __device__ __forceinline__ void wn_layer8_tile(const WnArgs& p, const int lin, f
           else x = gld(reinterpret_cast<const float4*>(rbase + o));
           v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
         }
-        store_f4<SC1>(gbase + o, v);
+        store_f4(gbase + o, v);
       } else {
         const float vv[4] = {v.x, v.y, v.z, v.w};
-        for (int k = 0; k < nv; ++k) store_f1<SC1>(gbase + o + k, vv[k] + (add ? gld(rbase + o + k) : 0.0f));
+        for (int k = 0; k < nv; ++k) store_f1(gbase + o + k, vv[k] + (add ? gld(rbase + o + k) : 0.0f));
       }
     }
   }
@@ -1268,28 +1215,10 @@ __device__ __forceinline__ void wn_layer8_tile(const WnArgs& p, const int lin, f
 template <bool LAST, int NCB, bool EF = false, bool SEED = false>
 __global__ __launch_bounds__(512, NCB == 4 ? 2 : 4) void k_wn_layer8(WnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  wn_layer8_tile<LAST, NCB, EF, false, false, SEED>(p, (int)blockIdx.x, smem, FlowWait{nullptr, 0u, 0ull, 0});
+  wn_layer8_tile<LAST, NCB, EF, SEED>(p, (int)blockIdx.x, smem);
 }
 
 
-// ------------------------------------------------------------------------------------------
-// k_wn_flow8: ALL layers of one flow in ONE launch, for launches that do not fill the chip (one short utterance:
-// 32 phases x 7 tiles of 32 frames = 224 workgroups of k_wn_layer8<NCB = 1>, each bound by its own MFMA stream, 65 us, on
-// 224 of 256 CUs -- and ~13 us of launch ramp, prologue, gate, epilogue and drain around it per layer).
-// Every tile of every layer runs exactly k_wn_layer8's code (same K order, same bits); what changes is who runs it when:
-//   * grid = 2 x tiles: workgroup (w, t) runs tile t of the layers l = w, w + 2, ...  The dispatcher places the first
-//     `tiles` workgroups one per CU and the second `tiles` next to them (VGPRs allow two 8-wave workgroups per CU), so a CU
-//     holds the two workers of (about) one tile: while one is in its prologue / gate / epilogue / hand-off, the other one's
-//     MFMAs run -- the matrix pipe has no kernel boundary to idle through.  Any other placement is correct as well.
-//   * layer l + 1 needs layer l complete (its taps reach into neighbouring tiles' columns and other phases' rows): a tile
-//     of layer l counts itself done on a per-layer counter (write-through stores, s_waitcnt, workgroup barrier, one relaxed
-//     agent atomic); a tile of layer l + 1 runs its CONDITIONING chunks first -- a quarter of its K loop that reads nothing
-//     of layer l -- and only then waits for the counter (one agent-scope acquire behind it).  By then the counter is
-//     usually there.  The h buffers alternate as in the per-layer launches; the same wait covers the write-after-read side
-//     (layer l + 1 writes the buffer layer l read only after every tile of layer l is done).
-// Co-residency of all 2 x tiles workgroups is required (a waiting tile must not keep a producer off the chip): the host
-// uses this launch only while 2 x tiles <= 2 x CUs; a wait that lasts longer than the poll limit traps instead of hanging.
-// ------------------------------------------------------------------------------------------
 struct WnLayerPtrs {   // the per-layer operands of one flow (device table, built once per handle)
   const float4* w1;
   const float4* wc;
@@ -1298,50 +1227,6 @@ struct WnLayerPtrs {   // the per-layer operands of one flow (device table, buil
   const float* b2;
   const float* we;
 };
-struct FlowArgs {
-  WnArgs a;                  // what all layers share; h_in / h_out = layer 0's
-  const WnLayerPtrs* layers;
-  unsigned* done;            // [n_layers] completed-tile counters, zero at launch
-  int n_layers, tiles, workers;
-  int l0;                    // first layer of this launch (0; the timing experiments launch the layers one by one)
-  int flags;                 // FlowWait::flags
-  unsigned long long poll_limit;
-};
-
-__device__ unsigned g_flow_ids[1024];   // FACPPG_WN_FUSED_DEBUG & 16: (XCC_ID << 16 | HW_ID[15:8]) of every workgroup of the last launch
-
-template <bool EF, bool SC1 = true>
-__global__ __launch_bounds__(512, 4) void k_wn_flow8(FlowArgs f) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  if ((f.flags & 4) && threadIdx.x == 0 && blockIdx.x < 1024)
-    g_flow_ids[blockIdx.x] = (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 16) | __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));
-  const int worker = (int)blockIdx.x / f.tiles, lin = (int)blockIdx.x - worker * f.tiles;
-  for (int l = f.l0 + worker; l < f.n_layers; l += f.workers) {
-    WnArgs p = f.a;
-    const WnLayerPtrs lp = f.layers[l];
-    const uintptr_t hx = (uintptr_t)f.a.h_in ^ (uintptr_t)f.a.h_out, odd = (uintptr_t)0 - (uintptr_t)(l & 1);
-    p.h_in = (const float*)((uintptr_t)f.a.h_in ^ (hx & odd));
-    p.h_out = (float*)((uintptr_t)f.a.h_out ^ (hx & odd));
-    p.w1 = lp.w1; p.wc = lp.wc; p.b1 = lp.b1; p.w2 = lp.w2; p.b2 = lp.b2;
-    p.we = lp.we;
-    p.dil = 1 << l; p.first = (l == 0);
-    p.nconv = (EF && l == 0) ? 1 : NCHH;
-    p.nch = p.nconv + f.a.nch;   // (f.a.nch: the conditioning chunks)
-    const FlowWait fw{l > 0 ? f.done + (l - 1) : nullptr, (unsigned)f.tiles, f.poll_limit, f.flags};
-    if (p.dil == 128) wn_layer8_tile<true, 1, EF, true, SC1>(p, lin, smem, fw);   // (the flow's last layer; n_layers = 8 whenever this launch is used)
-    else wn_layer8_tile<false, 1, EF, true, SC1>(p, lin, smem, fw);
-    // this tile of layer l is done once its write-through stores have left the CU
-#ifdef FACPPG_WN8_PROF
-    const long long s0 = clock64();
-#endif
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // (also: the next layer's prologue rewrites the LDS the epilogue read)
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(f.done + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef FACPPG_WN8_PROF
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_wn8_prof[8], (unsigned long long)(clock64() - s0));
-#endif
-  }
-}
 
 // ------------------------------------------------------------------------------------------
 // k_cond_seed: the conditioning part of every WN layer's gate GEMM, ahead of the layers themselves.
@@ -1772,7 +1657,7 @@ __global__ __launch_bounds__(512, 4) void k_wn_layer_mixed(WnArgs p32, WnArgs p1
   if (p32.xcd_map == 1) { const int r = lin >> 3; ph = (r / nt) * 8 + (lin & 7); tile = r % nt; }
   else { ph = lin / nt; tile = lin % nt; }
   if (ph >= p32.P) return;
-  if (tile < n32) wn_layer8_tile<LAST, 1, true, false, false, true>(p32, lin, smem, FlowWait{nullptr, 0u, 0ull, 0});
+  if (tile < n32) wn_layer8_tile<LAST, 1, true, true>(p32, lin, smem);
   else wn_layer16_tile<LAST, true>(p16, ph, 0, 32 * n32 + (tile - n32) * TN16, smem);
 }
 
@@ -2512,7 +2397,7 @@ extern "C" int facppg_wg_create(const facppg_wg_config* cfg, const float* weight
     h->wfwd[k] = F(fo[k].wfwd);
     WG_TRY(cpy(h->wfwd[k], src, cc * cc)); src += cc * cc;
   }
-  // k_wn_flow8's operand tables (32-frame tiles, folded flow edges), its poll limit, the CUs its workgroups must all fit on
+  // per-layer operand tables of a flow (32-frame tiles, folded flow edges: k_cond_seed walks them), the poll limit of in-launch waits, the CU count
   for (int k = 0; k < cfg->n_flows; ++k) {
     WnLayerPtrs t[8];
     memset(t, 0, sizeof(t));
@@ -2612,7 +2497,6 @@ PmLayout pm_layout(const facppg_wg_config& c, int B, int T) {
   w.h0 = take((size_t)B * C * w.P * w.Tqp);
   w.h1 = take((size_t)B * C * w.P * w.Tqp);
   w.xa = take((size_t)B * 8 * w.P * w.Tqp);     // right behind h0 | h1: one memset zeroes the margins of all three
-  w.sync = take(MAXF * 8);                      // ... and k_wn_flow8's completed-tile counters, one per (flow, layer)
   w.skip = take((size_t)B * C * w.P * w.Tr);
   w.melp = take((size_t)B * NMEL * w.Tqp);
   w.aud0 = take((size_t)B * 8 * w.La);
@@ -2630,11 +2514,6 @@ extern "C" size_t facppg_wg_workspace_bytes(const facppg_wg* h, int B, int T) {
   if (!h || B <= 0 || T <= 0) return 0;
   const size_t a = ws_layout(h->cfg, B, T).total, b = pm_layout(h->cfg, B, T).total, c = wgp_workspace_bytes(h, B, T);
   return std::max(a, std::max(b, c));
-}
-
-extern "C" int facppg_debug_flow_ids(unsigned* out1024) {
-  FACPPG_HIP_CHECK(hipMemcpyFromSymbol(out1024, HIP_SYMBOL(g_flow_ids), 1024 * sizeof(unsigned)));
-  return FACPPG_OK;
 }
 
 #ifdef FACPPG_WN8_PROF
@@ -2675,7 +2554,6 @@ extern "C" int facppg_wg_last_layer_ms(facppg_wg* h, float* avg_ms, int* n_launc
     FACPPG_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
     tot += ms;
   }
-  // (k_wn_flow8: a pair brackets a whole flow; reported per layer all the same)
   *n_launches = h->ev_used / 2 * std::max(1, h->ev_layers);
   *avg_ms = *n_launches ? (float)(tot / *n_launches) : 0.0f;
   return FACPPG_OK;
@@ -2838,41 +2716,11 @@ static int wg_infer_pm(facppg_wg* h, const float* mel_dev, const int32_t* T_vali
   a.seed_nt = w.Tr / 32;
   h->last_tile = tn; h->last_tiles = (int)lgrid;
   h->last_waves = (wide128 || tile16 || (narrow && w8mode != 0) || (!narrow && w8mode == 2)) ? 8 : 4;
-  // A launch that leaves CUs empty can run all layers of a flow in ONE launch (k_wn_flow8): FACPPG_WN_FUSED = 1 one worker per
-  // tile, 2 two workers per tile taking turns on the layers.  Same bits, but MEASURED SLOWER than one launch per layer (T = 200:
-  // 7.69 ms per layer launches, 9.07 / 10.74 ms fused with 1 / 2 workers -- profiles/r04_experiments.txt section 2), so it is
-  // off unless asked for.
-  const char* fenv = getenv("FACPPG_WN_FUSED");
-  const int fworkers = fenv ? atoi(fenv) : 0;
-  FACPPG_REQUIRE(fworkers >= 0 && fworkers <= 2, FACPPG_EINVAL, "FACPPG_WN_FUSED=%s: expected 0, 1 or 2", fenv);
-  const bool fused = !seeds && fold && narrow && w8mode != 0 && fworkers > 0 && h->n_cu > 0 && (long)lgrid <= h->n_cu && c.wn_layers == 8;
   h->ev_layers = c.wn_layers;
   for (int k = nf - 1; k >= 0; --k) {
-    if (fused) {
-      FlowArgs f;
-      a.h_in = hbuf[hi]; a.h_out = hbuf[hi ^ 1];
-      a.endb = h->endb[k]; a.nch = h->kcp / KCH;
-      f.a = a; f.layers = (const WnLayerPtrs*)h->ltab[k]; f.done = (unsigned*)(ws + w.sync) + (size_t)k * 8;
-      f.n_layers = c.wn_layers; f.tiles = (int)lgrid; f.workers = fworkers; f.poll_limit = h->poll_limit;
-      if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
-      f.l0 = 0;
-      const char* fdbg = getenv("FACPPG_WN_FUSED_DEBUG");   // timing experiments: 1 = plain stores (racy), 2 = one launch per layer
-      const int dbg = fdbg ? atoi(fdbg) : 0;
-      f.flags = (dbg >> 2) & 7;   // 4 = wait before the prologue, 8 = no acquire behind the wait
-      if (dbg & 2) {
-        for (int l = 0; l < c.wn_layers; ++l) {
-          f.l0 = l; f.n_layers = l + 1; f.workers = 1;
-          if (dbg & 1) k_wn_flow8<true, false><<<lgrid, 512, 32768 + 8 * 1024, s>>>(f);
-          else k_wn_flow8<true, true><<<lgrid, 512, 32768 + 8 * 1024, s>>>(f);
-        }
-      } else if (dbg & 1) k_wn_flow8<true, false><<<lgrid * fworkers, 512, 32768 + 8 * 1024, s>>>(f);
-      else k_wn_flow8<true><<<lgrid * fworkers, 512, 32768 + 8 * 1024, s>>>(f);
-      if (h->profiling) FACPPG_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
-      if ((c.wn_layers - 1) & 1) hi ^= 1;
-    }
     // (streamed utterance: the seeds of this flow come from a pass that may still be running on another stream)
     if (flow_events && flow_events[k]) FACPPG_HIP_CHECK(hipStreamWaitEvent(s, (hipEvent_t)flow_events[k], 0));
-    for (int i = 0; i < (fused ? 0 : c.wn_layers); ++i) {
+    for (int i = 0; i < c.wn_layers; ++i) {
       a.h_in = hbuf[hi]; a.h_out = hbuf[hi ^ 1];
       a.w1 = h->w1pm[k][i]; a.wc = h->wcpm[k][i]; a.b1 = h->b1pm[k][i]; a.w2 = h->w2[k][i]; a.b2 = h->b2[k][i];
       if (tile16) { a.w1 = h->w1_16[k][i]; a.wc = h->wc_16[k][i]; a.w2 = h->w2_16[k][i]; }

@@ -64,8 +64,8 @@ struct facppg_wg {
   int profiling;
   std::vector<hipEvent_t> ev;  // pairs around each k_wn_layer launch
   int ev_used;
-  int ev_layers;               // layers one pair brackets (k_wn_flow8: a whole flow)
-  void* ltab[facppg::MAXF];    // device tables of k_wn_flow8's per-layer operands (WnLayerPtrs[8] per flow)
+  int ev_layers;               // layers one event pair brackets (a flow's back-to-back layer launches)
+  void* ltab[facppg::MAXF];    // device tables of a flow's per-layer operands (WnLayerPtrs[8] per flow; k_cond_seed)
   unsigned long long poll_limit;   // wall-clock ticks an in-launch wait may last before it traps
   int n_cu;
   facppg::WgpState* wgp;   // persistent small-launch path (facppg_wgp.hip), or null

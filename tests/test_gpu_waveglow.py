@@ -487,28 +487,6 @@ def test_persistent_launch_equals_layer_launches_bit_for_bit(T, model256, monkey
     assert (m.last_launch_shape()[1:] == (8, 256) and m.last_launch_shape()[0] % 16 == 0 and m.last_launch_shape()[0] > 64) == (128 < T <= 192)
 
 
-@pytest.mark.parametrize("T,workers", [(200, 1), (200, 2), (144, 2), (256, 2), (161, 1)])
-def test_flow_launch_equals_layer_launches_bit_for_bit(T, workers, model256, monkeypatch):
-    """FACPPG_WN_FUSED=1|2 (off by default: measured slower, profiles/r04_experiments.txt): all eight layers of a flow in ONE
-    launch (k_wn_flow8) -- every tile runs k_wn_layer8's code, the layers are ordered by per-layer completed-tile counters
-    (write-through stores, one agent-scope acquire behind the wait) instead of kernel boundaries, with one or two workgroups
-    per tile taking turns on the layers.  Same sums in the same order: the audio must agree bit for bit, call after call
-    (the counters live in the workspace and are zeroed per call)."""
-    m, cfg = model256
-    hop = 256
-    mel = synth.synthetic_mel(1, T, seed=700 + T).cuda()
-    zs = synth.synthetic_z(1, T * hop // 8, cfg, seed=701 + T)
-    monkeypatch.setenv("FACPPG_WG_PERSIST", "0")
-    monkeypatch.setenv("FACPPG_POLL_LIMIT", "5")
-    monkeypatch.setenv("FACPPG_WN_FUSED", "0")
-    ref = m.infer(mel, sigma=0.6, z=zs)
-    ref_seed = m.infer(mel, sigma=0.6, seed=5)
-    assert m.last_launch_shape()[:2] == (32, 8)
-    monkeypatch.setenv("FACPPG_WN_FUSED", str(workers))
-    for _ in range(2):
-        got = m.infer(mel, sigma=0.6, z=zs)
-        assert torch.equal(got, ref), "flow launch vs per-layer launches differ: max abs %.3e" % (got - ref).abs().max().item()
-    assert torch.equal(m.infer(mel, sigma=0.6, seed=5), ref_seed)
 
 
 def test_persistent_launch_matches_oracle_hop256(model256, monkeypatch):
