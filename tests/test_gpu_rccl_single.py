@@ -16,7 +16,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench(args, port):
-    e = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    # FACPPG_COOP_PLAIN=1: this pytest process has made cooperative launches (the streamed-utterance tests) and stays alive while the
+    # child runs.  Two live processes that have EACH made a cooperative launch on a device are time-sliced against each other by the
+    # hardware scheduler (one global-wave-sync resource per device) even while one of them is idle: bench.py's batch-1 step then takes
+    # 27 ms instead of 12 (profiles/r06_insuite_slowdown_probe.txt, tools/insuite_probe.py).  The child therefore launches the same
+    # kernels with the same grids as ordinary launches -- what a deployment with two such processes on one GPU must do as well.
+    e = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FACPPG_COOP_PLAIN="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         e.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist"] + args, capture_output=True, text=True, env=e, timeout=900)
@@ -41,11 +46,9 @@ def test_corpus_and_infer_extras_through_rccl_world1():
     assert d["collective_backend"].startswith("RCCL") and d["config"]["utterances"] == 48 and d["value"] > 0
     d = _bench(["--steps", "3", "--warmup", "2", "--utterances", "32"], 29524)
     assert d["train_dp"] is not None and d["corpus_dp"] is not None
-    # the default run is the batch-1 utterance: ~0.55 of the fp32 MFMA peak when bench.py runs on its own.  As a subprocess of
-    # the whole GPU suite its 3 timed steps have been measured at 0.23 (avg launch 0.20 ms instead of 0.08; the stages of the
-    # following step at full speed); in isolation the same test gives ~0.5 every time.  The cause was not established -- only
-    # the plumbing is asserted here, the figure itself is the driver's bench run
-    assert 0.05 < d["roofline"]["frac"] < 1.0, (d["roofline"], d["ms_per_step"], d.get("stage_ms"))
+    # the default run is the batch-1 utterance: ~0.55 - 0.57 of the fp32 MFMA peak (executed FLOPs of k_wn_layer_mixed), also as a
+    # subprocess of the whole suite now that the child does not contend for the cooperative queue (see _bench)
+    assert 0.45 <= d["roofline"]["frac"] < 1.0, (d["roofline"], d["ms_per_step"], d.get("stage_ms"))
 
 
 _CAPTURED_EXCHANGE = r'''
