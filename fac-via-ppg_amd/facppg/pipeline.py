@@ -134,12 +134,15 @@ class ConditioningStream(object):
         self.counters = self.words[steps * self.NF:].view(torch.int32)[512:]              # one per bounded seed launch
         self.melp = self.zeroed[nw:].view(torch.float32)[:self.NF * self.tqp].view(self.NF, self.tqp)
         self.mel = grown("mel", self.NF * steps, torch.float32, zero=True).view(self.NF, steps)   # collected frames, channel-major
+        if "void_host" not in self.store:
+            self.store["void_host"] = torch.zeros(512, dtype=torch.int32).pin_memory()
+        self.void_host = self.store["void_host"]
         self.seeds = grown("seeds", seed_bytes // 4, torch.float32)
         self.post_ws = grown("post_ws", L.facppg_taco_postnet_stream_workspace_bytes(self.tacotron._handle(dev), cap), torch.uint8)
 
     def footprint_bytes(self):
         """Device memory the stream holds on to between utterances."""
-        return sum(t.numel() * t.element_size() for t in getattr(self, "store", {}).values())
+        return sum(t.numel() * t.element_size() for t in getattr(self, "store", {}).values() if t.is_cuda)
 
     def plan(self, steps, Tin):
         """[(frames of mel needed, first seeded frame, end of seeded frames)] -- blocks that can be formed before the utterance ends
@@ -242,6 +245,10 @@ class ConditioningStream(object):
                     _lib.check(L.facppg_taco_postnet_range(self.taco_handle, _lib.ptr(self.mel), steps, f_prev, f_new, 0,
                                                            self.melp.data_ptr() + 4 * self.margin, self.tqp, _lib.ptr(self.post_ws),
                                                            self.post_ws.numel(), self.cap, _lib.ptr(void), st))
+                    # (the block's void flag travels to pinned host memory behind its collector, on this stream: when the decoder has
+                    #  ended the flags of the blocks it covered have been on the host for milliseconds -- finish() reads them there
+                    #  instead of spending a second device->host round trip between the decoder and the vocoder)
+                    self.void_host[k:k + 1].copy_(void, non_blocking=True)
                     final = torch.cuda.Event()
                     final.record(self.post)
                     self.last_final = final
@@ -279,9 +286,8 @@ class ConditioningStream(object):
         n_cov = sum(1 for f_new, _, _ in self.cuts if f_new <= Tout)
         self.void_blocks = 0
         if n_cov:
-            self.finals[n_cov - 1].synchronize()          # (block k's flag is written ahead of its event)
-            void_host = self.void[:n_cov].cpu()
-            first_void = next((k for k in range(n_cov) if int(void_host[k])), n_cov)
+            self.finals[n_cov - 1].synchronize()          # (block k's flag is copied to the host ahead of its event)
+            first_void = next((k for k in range(n_cov) if int(self.void_host[k])), n_cov)
             self.void_blocks, n_cov = n_cov - first_void, first_void
         f_done = s_done = 0
         for f_new, s_a, s_b in self.cuts[:n_cov]:
