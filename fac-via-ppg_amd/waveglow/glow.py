@@ -491,7 +491,10 @@ class _AssembleZFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, step, *pieces):
         ctx.widths = [p.shape[1] for p in pieces]
-        return step.z
+        # (a NEW tensor object over the buffer: returning step.z itself would hang this node -- and through it the whole step's graph,
+        #  whose contexts hold `step` -- on an attribute of `step`: a reference cycle that only the cyclic collector breaks, i.e. every
+        #  step's saved activations alive until then)
+        return step.z.view(step.z.shape)
 
     @staticmethod
     def backward(ctx, dz):
