@@ -163,7 +163,7 @@ class ConditioningStream(object):
                 w = max(32, min(widths.pop(0), rest))
             cuts.append((s + w + self.lag, s, s + w))
             s += w
-        s_lim = (min(steps, self.cap) - self.lag) // 32 * 32      # the decoder may run on towards its step limit: a few more blocks
+        s_lim = (min(steps, getattr(self, "cap", steps)) - self.lag) // 32 * 32   # the decoder may run on towards its step limit: a few more blocks (inside the layout)
         extra = 0
         while s < s_lim and extra < 2 and len(cuts) < 120:
             w = min(chunk, s_lim - s)

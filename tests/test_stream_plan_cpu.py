@@ -18,13 +18,14 @@ def test_block_plan_invariants(steps, Tin, monkeypatch):
     for var in ("FACPPG_STREAM_CHUNK", "FACPPG_STREAM_LAST", "FACPPG_STREAM_PLAN"):
         monkeypatch.delenv(var, raising=False)
     cs = planner()
+    cs.cap = min(steps, -(-(Tin + ConditioningStream.SLACK) // 32) * 32)      # what begin() lays the vocoder-side buffers out for
     cuts = cs.plan(steps, Tin)
     assert len(cuts) <= 120
     prev_end = 0
     for f_new, s_a, s_b in cuts:
         assert s_a == prev_end and s_b > s_a and s_a % 32 == 0 and s_b % 32 == 0      # consecutive blocks of whole 32-frame tiles
         assert f_new == s_b + cs.lag                                                   # mel_post[q] is final once frame q + lag exists
-        assert f_new <= steps                                                          # never waits for a frame past the step limit
+        assert f_new <= min(steps, cs.cap)                                             # never waits for a frame past the step limit or the layout
         assert s_b - s_a <= 128                                                        # k_cond_seed takes at most 4 tiles per pass
         prev_end = s_b
     end = min(steps, Tin)
