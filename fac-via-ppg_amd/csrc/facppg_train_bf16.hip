@@ -3179,6 +3179,7 @@ extern "C" int facppg_glow_bf16_layout(int n_layers, int B, int L, facppg_glow_b
 extern "C" int facppg_glow_bf16_begin(const facppg_wn_weights* wts, int n_flows, int nl, int B, int L, void* packed_dev, void* states_dev,
                                       void* work_dev, void* stream_) {
   FACPPG_REQUIRE(wts && packed_dev && states_dev && work_dev && n_flows >= 1 && n_flows <= 64, FACPPG_EINVAL, "bad argument");
+  FACPPG_REQUIRE((long)n_flows * (nl + 1) * B <= 65535, FACPPG_EUNSUPPORTED, "%d flows x %d layers x batch %d: more state images than one launch zeroes", n_flows, nl, B);
   for (int k = 0; k < n_flows; ++k)
     if (int rc = check_wn(&wts[k], 1, nl, B, L)) return rc;
   hipStream_t s = (hipStream_t)stream_;
