@@ -362,15 +362,18 @@ class _GlowStepBf16(object):
             _lib.check(L.facppg_glow_bf16_begin(self.wts, nf, self.nl, B, Lg, _lib.ptr(self.packed), _lib.ptr(self.states), _lib.ptr(self.work),
                                                 _lib.current_stream(dev)))
 
-    def flow_struct(self, k, conv_w):
+    def flow_struct(self, k, conv_w, packed=None, states=None):
+        """facppg_glow_flow of flow k over the step's buffers (forward: the step's own; backward: the node's saved tensors)."""
+        packed = self.packed if packed is None else packed
+        states = self.states if states is None else states
         f = _lib.GlowFlow()
         ch, early = self.plan[k]
         u, z, wn, dzp, ld = self.flow_small[k]
         f.w = _lib.ctypes.pointer(self.wts[k])
         f.conv_w, f.logdet, f.ld_scale, f.c, f.early = conv_w.data_ptr(), ld.data_ptr(), float(self.B * self.Lg), ch, early
         f.u, f.z, f.wn_out, f.dzp = u.data_ptr(), z.data_ptr(), wn.data_ptr(), dzp.data_ptr()
-        f.packed = self.packed.data_ptr() + k * self.sizes.packed_bytes_per_flow
-        f.state = self.states.data_ptr() + k * self.sizes.state_bytes_per_flow
+        f.packed = packed.data_ptr() + k * self.sizes.packed_bytes_per_flow
+        f.state = states.data_ptr() + k * self.sizes.state_bytes_per_flow
         return f
 
 
@@ -412,6 +415,12 @@ class _FlowGroupBf16Function(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(L.facppg_glow_bf16_group_forward(flows, nfl, step.nl, _lib.ptr(audio), audio.stride(0), out.data_ptr(), out.stride(0),
                                                         _lib.ptr(spect_pm), B, Lg, _lib.current_stream(dev)))
+        # The GBs of saved activations / weight images / gradient buffers belong to the graph like any saved tensor: released by the
+        # backward pass (unless the graph is retained), not when the last reference to the loss goes.  Every group node saves the
+        # same three tensors; the step object itself lets go of them once its last group has run forward.
+        ctx.save_for_backward(step.packed, step.states, step.work)
+        if last:
+            step.packed = step.states = step.work = None
         ctx.step, ctx.k0, ctx.nfl, ctx.convs, ctx.spect_pm, ctx.n_early = step, k0, nfl, convs, spect_pm, len(earlies)
         ctx.in_shape, ctx.link_shape = tuple(audio.shape), tuple(link.shape)
         log_s = [step.flow_small[k0 + i][2][:, step.plan[k0 + i][0] // 2:, :] for i in range(nfl)]
@@ -422,6 +431,7 @@ class _FlowGroupBf16Function(torch.autograd.Function):
     def backward(ctx, d_out, *rest):
         L = _lib.load()
         step, k0, nfl = ctx.step, ctx.k0, ctx.nfl
+        packed, states, work = ctx.saved_tensors
         dev = d_out.device
         B, Lg = step.B, step.Lg
         d_early, d_log_s, d_log_det = rest[:ctx.n_early], rest[ctx.n_early:ctx.n_early + nfl], rest[ctx.n_early + nfl:]
@@ -436,7 +446,7 @@ class _FlowGroupBf16Function(torch.autograd.Function):
         ei = 0
         for i in range(nfl):
             k = k0 + i
-            f = step.flow_struct(k, ctx.convs[i])
+            f = step.flow_struct(k, ctx.convs[i], packed, states)
             ch, early = step.plan[k]
             g = [torch.empty_like(w) for w in step.wts_t[k]]
             _WNFunction._weights_struct(g, into=gstructs[i])
@@ -474,7 +484,9 @@ class _FlowGroupBf16Function(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(L.facppg_glow_bf16_group_backward(flows, nfl, step.nl, d_out.data_ptr(), d_out.stride(0), _lib.ptr(d_in), d_in.stride(0),
                                                          _lib.ptr(ctx.spect_pm), _lib.ptr(shared.dspect_pm), 1 if accumulate else 0,
-                                                         _lib.ptr(step.work), B, Lg, _lib.current_stream(dev)))
+                                                         _lib.ptr(work), B, Lg, _lib.current_stream(dev)))
+        if k0 == 0:
+            step.parts = None          # (the first group's node runs backward last)
         flat = []
         for dW, g in zip(dconvs, grads):
             flat.append(dW)
