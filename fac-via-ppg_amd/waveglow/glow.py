@@ -322,7 +322,8 @@ class _GlowStepBf16(object):
     operand images of every flow's stack and the summed gate biases (formed ONCE per step: facppg_glow_bf16_begin), every flow's
     saved activations (their zero margins written by the same call), the one set of gradient buffers the flows' backward passes
     take turns on, the <= 8-channel tensors at the flow boundaries, and the output z the early outputs are written straight into.
-    Held by the group nodes' contexts: it lives exactly as long as the step's autograd graph."""
+    The object is held by the group nodes' contexts; the large buffers (packed, states, work) become the nodes' SAVED TENSORS as the
+    groups run forward (released by the backward pass like any saved tensor) and the object lets go of them after its last group."""
 
     def __init__(self, model, flow_weights, B, Lg, dev, shared):
         L = _lib.load()
